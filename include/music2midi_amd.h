@@ -1,0 +1,206 @@
+/*
+ * music2midi_amd — C ABI of the MI355X (gfx950) Music2MIDI inference hot path.
+ *
+ * The reference (ytinyui/music2midi) is pure Python with no FFI of its own; its
+ * hot path is two Python call sites into third-party libraries:
+ *
+ *   ref: music2midi/input.py:33-41      LogMelSpectrogram.forward  (torchaudio MelSpectrogram)
+ *   ref: music2midi/input.py:50-59      Conditioning.forward       (2 embedding rows prepended)
+ *   ref: music2midi/transformer.py:28-39 T5Transformer.forward     (HF T5 teacher-forced forward)
+ *   ref: music2midi/transformer.py:41-45 T5Transformer.generate    (HF T5 encoder + greedy generate)
+ *
+ * Each entry point below names the call site it replaces.  INTEGRATION.md shows
+ * the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - Every function returns 0 on success or a negative M2M_ERR_* code; it never
+ *    throws or aborts.  m2m_last_error() returns a thread-local message.
+ *  - "dev" pointers are device (HBM) addresses, "host" pointers are host
+ *    addresses.  The caller owns every input, output and workspace buffer; the
+ *    library owns only what *_create() returns (plans, repacked weights,
+ *    sessions) until the matching *_destroy().
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *    All work is enqueued asynchronously on it unless stated otherwise.
+ *  - No function allocates or frees device memory except the *_create /
+ *    *_destroy pairs.
+ */
+#ifndef MUSIC2MIDI_AMD_H
+#define MUSIC2MIDI_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define M2M_ABI_VERSION 1
+
+enum {
+  M2M_OK = 0,
+  M2M_ERR_INVALID = -1,     /* bad argument / unsupported geometry */
+  M2M_ERR_HIP = -2,         /* a HIP runtime call failed */
+  M2M_ERR_NOMEM = -3,       /* workspace too small / allocation failed */
+  M2M_ERR_STATE = -4        /* call order violated (e.g. generate before encode) */
+};
+
+enum {
+  M2M_PREC_FP32 = 0,        /* fp32 weights / KV / GEMM inputs (f32 MFMA): parity mode */
+  M2M_PREC_BF16 = 1         /* bf16 weights / KV / GEMM inputs, fp32 accumulate: throughput mode */
+};
+
+int m2m_abi_version(void);
+const char* m2m_last_error(void);
+
+/* Number of visible HIP devices (0 when none; never fails). */
+int m2m_device_count(void);
+
+/* ------------------------------------------------------------------------- *
+ * Frontend: framed STFT -> |X|^2 -> mel filterbank -> log(clamp(., 1e-6))
+ * replaces ref: music2midi/input.py:25-41 (torchaudio MelSpectrogram + log).
+ * ------------------------------------------------------------------------- */
+typedef struct m2m_frontend m2m_frontend;
+
+typedef struct {
+  int n_fft;                /* must be 2048 (ref: config.yaml:12) */
+  int hop_length;           /* 1..n_fft/2 (reference: 256) */
+  int n_freqs;              /* n_fft/2 + 1 */
+  int n_mels;               /* = d_model (ref: music2midi/transformer.py:20) */
+  const float* window_host; /* [n_fft] analysis window (Hann, periodic) */
+  const float* fb_host;     /* [n_freqs, n_mels] row-major mel filterbank (dense) */
+} m2m_frontend_desc;
+
+int  m2m_frontend_create(const m2m_frontend_desc* desc, m2m_frontend** out);
+void m2m_frontend_destroy(m2m_frontend* fe);
+/* frames = 1 + n_samples / hop (center=True), or a negative error. */
+int  m2m_frontend_num_frames(const m2m_frontend* fe, int n_samples);
+/* non-zero taps the sparse filterbank keeps (diagnostic). */
+int  m2m_frontend_fb_nnz(const m2m_frontend* fe);
+
+/*
+ * wav_dev  [B, T] fp32 row-major.
+ * out_dev  row f of clip b is written at out_dev + b*out_batch_stride + (row_offset + f)*n_mels
+ *          (fp32).  With row_offset = n_cond and out_batch_stride = (n_cond+frames)*n_mels the
+ *          kernel writes straight into the encoder input, leaving rows [0, n_cond) for
+ *          m2m_cond_rows_f32 — the reference's torch.cat copy (input.py:59) never happens.
+ * T >= n_fft/2 + 1 (reflect padding needs it, as torch.stft does).
+ */
+int m2m_logmel_f32(const m2m_frontend* fe, const float* wav_dev, int B, int T,
+                   float* out_dev, int64_t out_batch_stride, int row_offset, void* stream);
+
+/*
+ * Conditioning rows, replaces ref: music2midi/input.py:57-59.
+ * tables_dev_host: host array of n_tables device pointers, table i is [n_i, n_dim] fp32.
+ * table_rows_host: host array with n_i (indices are range-checked on device: an
+ *                  out-of-range index writes NaNs into that row rather than faulting).
+ * idx_dev [B, n_tables] int64.  Row i of clip b lands at out_dev + b*out_batch_stride + i*n_dim.
+ */
+int m2m_cond_rows_f32(const float* const* tables_dev_host, const int* table_rows_host, int n_tables,
+                      int n_dim, const int64_t* idx_dev, int B, float* out_dev,
+                      int64_t out_batch_stride, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * T5 encoder-decoder weights, replaces what ref: music2midi/transformer.py:14-16
+ * builds (T5Config + T5ForConditionalGeneration) once a state dict is loaded.
+ * ------------------------------------------------------------------------- */
+typedef struct {
+  int d_model, d_ff, num_layers, num_decoder_layers, num_heads, d_kv;
+  int vocab_size, num_buckets, max_distance;
+  int pad_token_id, eos_token_id, decoder_start_token_id;
+  float layer_norm_eps;
+} m2m_t5_geometry;
+
+/* All pointers: DEVICE, fp32, HuggingFace layout ([out_features, in_features]). */
+typedef struct {
+  const float *ln0, *q, *k, *v, *o;             /* layer.0.layer_norm, SelfAttention.{q,k,v,o} */
+  const float *ln1, *wi0, *wi1, *wo;            /* layer.1.layer_norm, DenseReluDense.{wi_0,wi_1,wo} */
+} m2m_enc_layer_weights;
+
+typedef struct {
+  const float *ln0, *q, *k, *v, *o;             /* layer.0: self attention */
+  const float *ln1, *cq, *ck, *cv, *co;         /* layer.1: EncDecAttention.{q,k,v,o} */
+  const float *ln2, *wi0, *wi1, *wo;            /* layer.2: DenseReluDense */
+} m2m_dec_layer_weights;
+
+typedef struct {
+  const float* shared;            /* [V, d_model] token embedding */
+  const float* lm_head;           /* [V, d_model] separate tensor (transformers 4.34 untied head) */
+  const float* enc_rel_bias;      /* [num_buckets, H] encoder.block.0 relative_attention_bias */
+  const float* dec_rel_bias;      /* [num_buckets, H] decoder.block.0 relative_attention_bias */
+  const float* enc_final_ln;      /* [d_model] */
+  const float* dec_final_ln;      /* [d_model] */
+  const m2m_enc_layer_weights* enc;  /* host array [num_layers] */
+  const m2m_dec_layer_weights* dec;  /* host array [num_decoder_layers] */
+} m2m_t5_weights;
+
+typedef struct m2m_model m2m_model;
+
+/* Repacks the weights into kernel layouts (device-side kernels on `stream`,
+ * synchronised before returning); the source tensors may be freed afterwards. */
+int  m2m_model_create(const m2m_t5_geometry* geom, const m2m_t5_weights* w, int precision,
+                      void* stream, m2m_model** out);
+void m2m_model_destroy(m2m_model* m);
+int  m2m_model_precision(const m2m_model* m);
+int64_t m2m_model_param_bytes(const m2m_model* m);   /* bytes of repacked weights held */
+
+/* T5 relative-position bucket (hf: models/t5/modeling_t5.py:217-262), host-side,
+ * exported so the integer table can be tested without a GPU. rel = key_pos - query_pos. */
+int m2m_rel_bucket(int rel, int bidirectional, int num_buckets, int max_distance);
+
+/* ------------------------------------------------------------------------- *
+ * Session: workspace + captured decode-step graph for up to (max_batch,
+ * max_enc_len, max_dec_len).  One session per concurrent call; a session is
+ * not re-entrant.  The workspace is caller-owned device memory.
+ * ------------------------------------------------------------------------- */
+typedef struct m2m_session m2m_session;
+
+int64_t m2m_session_workspace_bytes(const m2m_model* m, int max_batch, int max_enc_len, int max_dec_len);
+int  m2m_session_create(const m2m_model* m, int max_batch, int max_enc_len, int max_dec_len,
+                        void* workspace_dev, int64_t workspace_bytes, m2m_session** out);
+void m2m_session_destroy(m2m_session* s);
+
+/*
+ * Encoder stack + cross-attention K/V projection for every decoder layer,
+ * replaces the encoder half of ref: music2midi/transformer.py:44 (HF generate
+ * runs the encoder once, hf: generation/utils.py:809-848) and of :35-37.
+ * inputs_embeds_dev [B, S, d_model] fp32 (cond rows + log-mel rows).
+ * enc_out_dev: optional [B, S, d_model] fp32 copy of the final encoder states (NULL to skip).
+ */
+int m2m_encode(m2m_session* s, const float* inputs_embeds_dev, int B, int S, float* enc_out_dev, void* stream);
+
+/*
+ * KV-cached greedy decode, replaces the decode half of
+ * ref: music2midi/transformer.py:44 (hf: generation/utils.py:2783-2973, do_sample=False):
+ * start token decoder_start_token_id, argmax, rows that emitted EOS keep emitting
+ * pad, stop when every row has finished or the length reaches max_length.
+ * tokens_out_dev [B, max_length] int64 (columns >= *out_len_host are pad).
+ * *out_len_host: number of valid columns L <= max_length.  This call synchronises `stream`.
+ */
+int m2m_generate_greedy(m2m_session* s, int max_length, int64_t* tokens_out_dev, int* out_len_host, void* stream);
+
+/*
+ * Teacher-forced decoder pass, replaces the decoder half of
+ * ref: music2midi/transformer.py:35-37 (logits only; the loss is a host-side reduction).
+ * dec_input_ids_dev [B, Ld] int64 (= shift_right(labels)), logits_out_dev [B, Ld, V] fp32.
+ */
+int m2m_decode_forced(m2m_session* s, const int64_t* dec_input_ids_dev, int Ld, float* logits_out_dev, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Measurement hooks (bench.py): time one kernel of the decode step in isolation
+ * with hipEvents on `stream`, cycling through all decoder layers so the working
+ * set matches the real loop.  Requires a prior m2m_encode on the session.
+ * ------------------------------------------------------------------------- */
+enum {
+  M2M_KERNEL_DEC_CROSS_ATTN = 0,
+  M2M_KERNEL_DEC_SELF_ATTN = 1,
+  M2M_KERNEL_DEC_STEP = 2        /* the whole captured step graph */
+};
+/* self_len: number of cached self-attention keys to assume (1..max_dec_len).
+ * avg_us_host: mean duration of one launch in microseconds.
+ * bytes_host: algorithmic HBM bytes one launch moves (K/V streamed + q read + o written). */
+int m2m_bench_kernel(m2m_session* s, int which, int self_len, int iters, float* avg_us_host,
+                     int64_t* bytes_host, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MUSIC2MIDI_AMD_H */

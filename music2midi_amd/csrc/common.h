@@ -1,0 +1,101 @@
+// Shared host/device helpers for the music2midi_amd HIP library (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/music2midi_amd.h"
+
+namespace m2m {
+
+// ---------------------------------------------------------------- errors ---
+void set_error(const char* fmt, ...);
+
+#define M2M_CHECK_HIP(expr)                                                        \
+  do {                                                                             \
+    hipError_t _e = (expr);                                                        \
+    if (_e != hipSuccess) {                                                        \
+      ::m2m::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),     \
+                       __FILE__, __LINE__);                                        \
+      return M2M_ERR_HIP;                                                          \
+    }                                                                              \
+  } while (0)
+
+#define M2M_REQUIRE(cond, ...)                                                     \
+  do {                                                                             \
+    if (!(cond)) {                                                                 \
+      ::m2m::set_error(__VA_ARGS__);                                               \
+      return M2M_ERR_INVALID;                                                      \
+    }                                                                              \
+  } while (0)
+
+// ------------------------------------------------------------ bf16 / f32 ---
+// Storage element types: float (parity mode) or bf16_t (throughput mode).
+struct bf16_t {
+  uint16_t bits;
+};
+
+__host__ __device__ inline float bf16_to_f32(bf16_t v) {
+  union { uint32_t u; float f; } c;
+  c.u = (uint32_t)v.bits << 16;
+  return c.f;
+}
+
+// round-to-nearest-even; a plain cast keeps NaNs NaN (v_cvt_pk_bf16_f32 on gfx950).
+__device__ inline bf16_t f32_to_bf16(float f) {
+  __hip_bfloat16 h = __float2bfloat16(f);
+  bf16_t r;
+  r.bits = *reinterpret_cast<uint16_t*>(&h);
+  return r;
+}
+
+template <typename T> __device__ inline T from_f32(float f);
+template <> __device__ inline float from_f32<float>(float f) { return f; }
+template <> __device__ inline bf16_t from_f32<bf16_t>(float f) { return f32_to_bf16(f); }
+
+__device__ inline float to_f32(float v) { return v; }
+__device__ inline float to_f32(bf16_t v) { return bf16_to_f32(v); }
+
+// 16-byte vectors of storage elements.
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+  static constexpr int N = 4;
+  float4 v;
+  __device__ inline float get(int i) const { return reinterpret_cast<const float*>(&v)[i]; }
+};
+template <> struct Vec16<bf16_t> {
+  static constexpr int N = 8;
+  uint4 v;
+  __device__ inline float get(int i) const {
+    uint32_t w = reinterpret_cast<const uint32_t*>(&v)[i >> 1];
+    union { uint32_t u; float f; } c;
+    c.u = (i & 1) ? (w & 0xFFFF0000u) : (w << 16);
+    return c.f;
+  }
+};
+
+// ------------------------------------------------------------- wave ops ---
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// gelu_new (hf: activations.py NewGELUActivation), fp32, accurate tanhf.
+__device__ inline float gelu_new(float x) {
+  const float k = 0.7978845608028654f;  // sqrt(2/pi)
+  return 0.5f * x * (1.0f + tanhf(k * (x + 0.044715f * x * x * x)));
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace m2m

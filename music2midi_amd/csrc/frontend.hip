@@ -1,0 +1,405 @@
+// Fused log-mel frontend for gfx950: reflect-pad + framing + Hann window + real FFT-2048
+// + |X|^2 + sparse mel filterbank + clamp(1e-6) + log, one kernel, power spectrum never
+// leaves the CU.  Replaces ref: music2midi/input.py:25-41 (torchaudio MelSpectrogram, i.e.
+// torch.stft -> |.|^2 -> dense [1025 x n_mels] matmul -> transpose -> clamp -> log).
+//
+// Work decomposition
+//   grid  = (ceil(frames / FR), B);   block = 256 threads = 4 waves.
+//   A workgroup stages the (FR-1)*hop + 2048 padded samples its FR frames cover in LDS once
+//   (frames overlap 8x at hop 256, so the waveform is re-used from LDS, not re-read), then
+//   each WAVE transforms one frame at a time:
+//     real FFT-2048 = complex FFT-1024 of z[n] = x[2n] + i x[2n+1], 1024 = 16 x 16 x 4:
+//       radix-16 in registers (lane l holds n = 64*n1 + l)      -> twiddle W1024^(l*k1)
+//       transpose through LDS (per-wave buffer, conflict-free pitch 68)
+//       radix-16 in registers (lane = (k1, m2))                  -> twiddle W64^(m2*q1)
+//       radix-4 ACROSS the 4 lanes of a quad with two DPP quad_perm exchanges (no LDS)
+//     split/post-process pairs (k, 1024-k) into the 1025 real-FFT power bins in LDS.
+//   The 4 frames' power spectra are then reduced by all 256 threads through the sparse
+//   (contiguous-tap) mel filterbank, clamped, logged, and stored coalesced (n_mels floats/row).
+//
+// Roofline: algorithmic HBM bytes/clip = 4*T + 4*frames*n_mels; arithmetic ~56.8 MFLOP/clip
+// (~26 flop/B, at the fp32-vector ridge) — see DESIGN.md.
+#include "common.h"
+
+#include <math.h>
+#include <string.h>
+#include <vector>
+
+namespace m2m {
+
+constexpr int NFFT = 2048;
+constexpr int HALF = 1024;            // complex FFT length
+constexpr int FE_THREADS = 256;
+constexpr int FE_WAVES = 4;
+constexpr int T_PITCH = 68;           // float2 per k1 row of the transpose buffer
+constexpr int WAVE_C2 = 16 * T_PITCH; // float2 per wave (transpose buffer, aliased by Z)
+constexpr int P_PITCH = 1032;         // floats per wave (1025 power bins, padded)
+
+struct FrontendDev {
+  const float* window;    // [2048]
+  const float2* tw1024;   // [1024]  exp(-2 pi i k / 1024)
+  const float2* tw2048;   // [1024]  exp(-2 pi i k / 2048)
+  const int* fb_start;    // [n_mels] first frequency bin with a tap
+  const int* fb_count;    // [n_mels] number of contiguous taps
+  const int* fb_off;      // [n_mels] offset of the first tap weight in fb_w
+  const float* fb_w;      // [nnz]
+  int n_mels;
+  int hop;
+};
+
+__device__ inline float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ inline float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ inline float2 cmul(float2 a, float2 b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+// multiply by -i : (x + iy)(-i) = y - ix
+__device__ inline float2 mul_negi(float2 a) { return make_float2(a.y, -a.x); }
+
+// forward 4-point DFT, natural order in and out
+__device__ inline void fft4(float2& x0, float2& x1, float2& x2, float2& x3) {
+  float2 s02 = cadd(x0, x2), d02 = csub(x0, x2);
+  float2 s13 = cadd(x1, x3), d13 = mul_negi(csub(x1, x3));  // -i (x1 - x3)
+  x0 = cadd(s02, s13);
+  x1 = cadd(d02, d13);
+  x2 = csub(s02, s13);
+  x3 = csub(d02, d13);
+}
+
+// forward 16-point DFT in registers: n = 4 n1 + n2, k = k1 + 4 k2.
+__device__ inline void fft16(float2 (&z)[16]) {
+  const float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R = 0.70710678118654752f;
+  float2 a[16];
+#pragma unroll
+  for (int n2 = 0; n2 < 4; ++n2) {
+    float2 y0 = z[n2], y1 = z[4 + n2], y2 = z[8 + n2], y3 = z[12 + n2];
+    fft4(y0, y1, y2, y3);
+    a[n2 * 4 + 0] = y0; a[n2 * 4 + 1] = y1; a[n2 * 4 + 2] = y2; a[n2 * 4 + 3] = y3;
+  }
+  // twiddles W16^(n2*k1)
+  a[1 * 4 + 1] = cmul(a[1 * 4 + 1], make_float2(C1, -S1));   // W^1
+  a[1 * 4 + 2] = cmul(a[1 * 4 + 2], make_float2(R, -R));     // W^2
+  a[1 * 4 + 3] = cmul(a[1 * 4 + 3], make_float2(S1, -C1));   // W^3
+  a[2 * 4 + 1] = cmul(a[2 * 4 + 1], make_float2(R, -R));     // W^2
+  a[2 * 4 + 2] = mul_negi(a[2 * 4 + 2]);                     // W^4 = -i
+  a[2 * 4 + 3] = cmul(a[2 * 4 + 3], make_float2(-R, -R));    // W^6
+  a[3 * 4 + 1] = cmul(a[3 * 4 + 1], make_float2(S1, -C1));   // W^3
+  a[3 * 4 + 2] = cmul(a[3 * 4 + 2], make_float2(-R, -R));    // W^6
+  a[3 * 4 + 3] = cmul(a[3 * 4 + 3], make_float2(-C1, S1));   // W^9
+#pragma unroll
+  for (int k1 = 0; k1 < 4; ++k1) {
+    float2 y0 = a[0 * 4 + k1], y1 = a[1 * 4 + k1], y2 = a[2 * 4 + k1], y3 = a[3 * 4 + k1];
+    fft4(y0, y1, y2, y3);
+    z[k1] = y0; z[k1 + 4] = y1; z[k1 + 8] = y2; z[k1 + 12] = y3;
+  }
+}
+
+template <int CTRL>
+__device__ inline float dpp_quad(float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+constexpr int DPP_XOR1 = 0xB1;  // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;  // quad_perm [2,3,0,1]
+
+__device__ inline int zidx(int k) { return k + 4 * (k >> 8); }  // bank-spread layout of Z[0..1023]
+
+__global__ __launch_bounds__(FE_THREADS) void logmel_kernel(
+    const float* __restrict__ wav, int T, int F, FrontendDev fe, float* __restrict__ out,
+    int64_t out_bstride, int row_offset, int FR) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int hop = fe.hop;
+  const int span_max = (FR - 1) * hop + NFFT;
+
+  float* samples = reinterpret_cast<float*>(smem_raw);
+  float2* cbuf = reinterpret_cast<float2*>(smem_raw + (size_t)((span_max + 3) & ~3) * sizeof(float)) + wave * WAVE_C2;
+  float* pbase = reinterpret_cast<float*>(reinterpret_cast<float2*>(smem_raw + (size_t)((span_max + 3) & ~3) * sizeof(float)) +
+                                          FE_WAVES * WAVE_C2);
+  float* pbuf = pbase + wave * P_PITCH;
+
+  const int b = blockIdx.y;
+  const int f0 = blockIdx.x * FR;
+  const int nfr = min(FR, F - f0);
+  const int span = (nfr - 1) * hop + NFFT;
+
+  // ---- stage the padded samples (reflect, as torch.stft center=True pad_mode="reflect") ----
+  {
+    const float* w = wav + (int64_t)b * T;
+    const int base = f0 * hop - NFFT / 2;
+    for (int i = tid; i < span; i += FE_THREADS) {
+      int j = base + i;
+      if (j < 0) j = -j;
+      else if (j >= T) j = 2 * (T - 1) - j;
+      samples[i] = w[j];
+    }
+  }
+
+  // ---- per-lane constants, loaded once ----
+  float2 win[16];   // window[2n], window[2n+1] for n = 64*n1 + lane
+  float2 tw_a[16];  // W1024^(lane*k1)
+  float2 tw_b[16];  // W64^(m2*q1) = W1024^(16*m2*q1)
+  float2 tw_p[8];   // W2048^(lane + 64 i)
+  const int k1_lane = lane >> 2, m2 = lane & 3;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    win[j] = *reinterpret_cast<const float2*>(fe.window + 2 * (64 * j + lane));
+    tw_a[j] = fe.tw1024[lane * j];
+    tw_b[j] = fe.tw1024[16 * m2 * j];
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) tw_p[i] = fe.tw2048[lane + 64 * i];
+
+  __syncthreads();
+
+  const int rounds = (nfr + FE_WAVES - 1) / FE_WAVES;
+  for (int r = 0; r < rounds; ++r) {
+    const int fl = r * FE_WAVES + wave;
+    if (fl < nfr) {  // wave-uniform
+      const float* fs = samples + fl * hop;
+      float2 z[16];
+      // stage 1: lane holds n = 64*n1 + lane
+#pragma unroll
+      for (int n1 = 0; n1 < 16; ++n1) {
+        const int n = 64 * n1 + lane;
+        z[n1] = make_float2(fs[2 * n] * win[n1].x, fs[2 * n + 1] * win[n1].y);
+      }
+      fft16(z);
+#pragma unroll
+      for (int k1 = 0; k1 < 16; ++k1) {
+        float2 v = (k1 == 0) ? z[0] : cmul(z[k1], tw_a[k1]);
+        cbuf[k1 * T_PITCH + lane] = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // stage 2: lane = (k1, m2) holds l = 4*m1 + m2
+#pragma unroll
+      for (int m1 = 0; m1 < 16; ++m1) z[m1] = cbuf[k1_lane * T_PITCH + 4 * m1 + m2];
+      __builtin_amdgcn_wave_barrier();
+      fft16(z);
+#pragma unroll
+      for (int q1 = 1; q1 < 16; ++q1) z[q1] = cmul(z[q1], tw_b[q1]);
+      // stage 3: radix-4 across the quad (m2 = lane&3) by two DPP exchanges.
+      //   after: lane m2 holds Y[q1 + 16*q2] with q2 = bitrev2(m2)
+#pragma unroll
+      for (int q1 = 0; q1 < 16; ++q1) {
+        float2 v = z[q1];
+        float2 p = make_float2(dpp_quad<DPP_XOR2>(v.x), dpp_quad<DPP_XOR2>(v.y));
+        v = (m2 & 2) ? csub(p, v) : cadd(v, p);
+        if (m2 == 3) v = mul_negi(v);
+        p = make_float2(dpp_quad<DPP_XOR1>(v.x), dpp_quad<DPP_XOR1>(v.y));
+        v = (m2 & 1) ? csub(p, v) : cadd(v, p);
+        z[q1] = v;
+      }
+      {
+        const int q2 = ((m2 & 1) << 1) | (m2 >> 1);
+#pragma unroll
+        for (int q1 = 0; q1 < 16; ++q1) cbuf[zidx(k1_lane + 16 * q1 + 256 * q2)] = z[q1];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // post-process pairs (k, 1024-k): X[k] = E + W2048^k O, X[1024-k] = conj(E - W2048^k O)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = lane + 64 * i;
+        float2 zk = cbuf[zidx(k)];
+        float2 zn = cbuf[zidx((HALF - k) & (HALF - 1))];
+        zn.y = -zn.y;  // conj
+        float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y + zn.y));
+        float2 d = make_float2(0.5f * (zk.x - zn.x), 0.5f * (zk.y - zn.y));
+        float2 o = make_float2(d.y, -d.x);  // d / i
+        float2 t = cmul(tw_p[i], o);
+        float2 xp = cadd(e, t), xm = csub(e, t);
+        pbuf[k] = xp.x * xp.x + xp.y * xp.y;
+        pbuf[HALF - k] = xm.x * xm.x + xm.y * xm.y;
+      }
+      if (lane == 0) {  // k = 512: E = Re Z, O = Im Z, W2048^512 = -i
+        float2 zk = cbuf[zidx(512)];
+        pbuf[512] = zk.x * zk.x + zk.y * zk.y;
+      }
+    }
+    __syncthreads();
+    // ---- mel filterbank + clamp + log for the frames of this round ----
+    {
+      const int nround = min(FE_WAVES, nfr - r * FE_WAVES);
+      const int n_mels = fe.n_mels;
+      const int total = nround * n_mels;
+      for (int idx = tid; idx < total; idx += FE_THREADS) {
+        const int w = idx / n_mels;
+        const int m = idx - w * n_mels;
+        const float* p = pbase + w * P_PITCH + fe.fb_start[m];
+        const float* fw = fe.fb_w + fe.fb_off[m];
+        const int cnt = fe.fb_count[m];
+        float acc = 0.f;
+        for (int c = 0; c < cnt; ++c) acc = fmaf(p[c], fw[c], acc);
+        const int f = f0 + r * FE_WAVES + w;
+        // clamp(min=1e-6).log(): the floor is the correctly rounded fp32 ln(1e-6f), so silent
+        // (zero-padded) regions are bit-identical to the reference's constant.
+        out[(int64_t)b * out_bstride + (int64_t)(row_offset + f) * n_mels + m] =
+            (acc > 1e-6f) ? logf(acc) : -13.815510749816895f;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+struct CondArgs {
+  const float* tables[8];
+  int rows[8];
+};
+
+__global__ void cond_rows_kernel(CondArgs a, int n_tables, int n_dim, const int64_t* __restrict__ idx,
+                                 float* __restrict__ out, int64_t out_bstride) {
+  const int b = blockIdx.x / n_tables;
+  const int i = blockIdx.x - b * n_tables;
+  const int64_t id = idx[(int64_t)b * n_tables + i];
+  const bool ok = id >= 0 && id < a.rows[i];
+  const float* src = a.tables[i] + (ok ? id : 0) * n_dim;
+  float* dst = out + (int64_t)b * out_bstride + (int64_t)i * n_dim;
+  for (int d = threadIdx.x; d < n_dim; d += blockDim.x) dst[d] = ok ? src[d] : __builtin_nanf("");
+}
+
+}  // namespace m2m
+
+// ------------------------------------------------------------------ C ABI ---
+using namespace m2m;
+
+struct m2m_frontend {
+  int n_fft, hop, n_freqs, n_mels, nnz;
+  void* dev_blob = nullptr;  // one allocation holding every table
+  FrontendDev dev;
+};
+
+extern "C" int m2m_frontend_create(const m2m_frontend_desc* d, m2m_frontend** out) {
+  M2M_REQUIRE(d && out, "m2m_frontend_create: null argument");
+  M2M_REQUIRE(d->n_fft == NFFT, "m2m_frontend_create: n_fft=%d unsupported (kernel is specialised for 2048, ref config.yaml:12)", d->n_fft);
+  M2M_REQUIRE(d->n_freqs == NFFT / 2 + 1, "m2m_frontend_create: n_freqs must be n_fft/2+1");
+  M2M_REQUIRE(d->hop_length >= 1 && d->hop_length <= NFFT / 2, "m2m_frontend_create: hop_length out of range");
+  M2M_REQUIRE(d->n_mels >= 1 && d->window_host && d->fb_host, "m2m_frontend_create: bad n_mels / null tables");
+
+  const int n_mels = d->n_mels, n_freqs = d->n_freqs;
+  std::vector<int> start(n_mels), count(n_mels), off(n_mels);
+  std::vector<float> w;
+  for (int m = 0; m < n_mels; ++m) {
+    int lo = -1, hi = -1;
+    for (int k = 0; k < n_freqs; ++k)
+      if (d->fb_host[(size_t)k * n_mels + m] != 0.0f) { if (lo < 0) lo = k; hi = k; }
+    start[m] = lo < 0 ? 0 : lo;
+    count[m] = lo < 0 ? 0 : hi - lo + 1;
+    off[m] = (int)w.size();
+    for (int k = 0; k < count[m]; ++k) w.push_back(d->fb_host[(size_t)(lo + k) * n_mels + m]);
+  }
+  std::vector<float2> tw1(HALF), tw2(HALF);
+  for (int k = 0; k < HALF; ++k) {
+    double a1 = -2.0 * M_PI * k / 1024.0, a2 = -2.0 * M_PI * k / 2048.0;
+    tw1[k] = make_float2((float)cos(a1), (float)sin(a1));
+    tw2[k] = make_float2((float)cos(a2), (float)sin(a2));
+  }
+  // one blob: window | tw1024 | tw2048 | start | count | off | weights
+  size_t o_win = 0;
+  size_t o_tw1 = o_win + NFFT * sizeof(float);
+  size_t o_tw2 = o_tw1 + HALF * sizeof(float2);
+  size_t o_st = o_tw2 + HALF * sizeof(float2);
+  size_t o_ct = o_st + (size_t)n_mels * sizeof(int);
+  size_t o_of = o_ct + (size_t)n_mels * sizeof(int);
+  size_t o_w = (size_t)align_up((int64_t)(o_of + (size_t)n_mels * sizeof(int)), 16);
+  size_t total = o_w + (w.size() + 4) * sizeof(float);
+  std::vector<unsigned char> host(total, 0);
+  memcpy(host.data() + o_win, d->window_host, NFFT * sizeof(float));
+  memcpy(host.data() + o_tw1, tw1.data(), HALF * sizeof(float2));
+  memcpy(host.data() + o_tw2, tw2.data(), HALF * sizeof(float2));
+  memcpy(host.data() + o_st, start.data(), (size_t)n_mels * sizeof(int));
+  memcpy(host.data() + o_ct, count.data(), (size_t)n_mels * sizeof(int));
+  memcpy(host.data() + o_of, off.data(), (size_t)n_mels * sizeof(int));
+  if (!w.empty()) memcpy(host.data() + o_w, w.data(), w.size() * sizeof(float));
+
+  m2m_frontend* fe = new m2m_frontend();
+  fe->n_fft = d->n_fft; fe->hop = d->hop_length; fe->n_freqs = n_freqs; fe->n_mels = n_mels;
+  fe->nnz = (int)w.size();
+  hipError_t e = hipMalloc(&fe->dev_blob, total);
+  if (e == hipSuccess) e = hipMemcpy(fe->dev_blob, host.data(), total, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    set_error("m2m_frontend_create: device allocation/copy failed: %s", hipGetErrorString(e));
+    if (fe->dev_blob) (void)hipFree(fe->dev_blob);
+    delete fe;
+    return M2M_ERR_HIP;
+  }
+  unsigned char* base = (unsigned char*)fe->dev_blob;
+  fe->dev.window = (const float*)(base + o_win);
+  fe->dev.tw1024 = (const float2*)(base + o_tw1);
+  fe->dev.tw2048 = (const float2*)(base + o_tw2);
+  fe->dev.fb_start = (const int*)(base + o_st);
+  fe->dev.fb_count = (const int*)(base + o_ct);
+  fe->dev.fb_off = (const int*)(base + o_of);
+  fe->dev.fb_w = (const float*)(base + o_w);
+  fe->dev.n_mels = n_mels;
+  fe->dev.hop = d->hop_length;
+  *out = fe;
+  return M2M_OK;
+}
+
+extern "C" void m2m_frontend_destroy(m2m_frontend* fe) {
+  if (!fe) return;
+  if (fe->dev_blob) (void)hipFree(fe->dev_blob);
+  delete fe;
+}
+
+extern "C" int m2m_frontend_num_frames(const m2m_frontend* fe, int n_samples) {
+  M2M_REQUIRE(fe, "m2m_frontend_num_frames: null frontend");
+  M2M_REQUIRE(n_samples >= fe->n_fft / 2 + 1,
+              "m2m_frontend_num_frames: n_samples=%d too short for reflect padding (need > n_fft/2 = %d)",
+              n_samples, fe->n_fft / 2);
+  return 1 + n_samples / fe->hop;
+}
+
+extern "C" int m2m_frontend_fb_nnz(const m2m_frontend* fe) { return fe ? fe->nnz : M2M_ERR_INVALID; }
+
+static size_t frontend_smem_bytes(int FR, int hop) {
+  size_t span = (size_t)(FR - 1) * hop + NFFT;
+  span = (span + 3) & ~(size_t)3;
+  return span * sizeof(float) + (size_t)FE_WAVES * WAVE_C2 * sizeof(float2) + (size_t)FE_WAVES * P_PITCH * sizeof(float);
+}
+
+extern "C" int m2m_logmel_f32(const m2m_frontend* fe, const float* wav_dev, int B, int T, float* out_dev,
+                              int64_t out_batch_stride, int row_offset, void* stream) {
+  M2M_REQUIRE(fe && wav_dev && out_dev, "m2m_logmel_f32: null argument");
+  M2M_REQUIRE(B >= 1 && B <= 65535, "m2m_logmel_f32: batch %d out of range", B);
+  M2M_REQUIRE(T >= fe->n_fft / 2 + 1, "m2m_logmel_f32: T=%d too short for reflect padding (need > %d)", T, fe->n_fft / 2);
+  M2M_REQUIRE(row_offset >= 0, "m2m_logmel_f32: negative row_offset");
+  const int F = 1 + T / fe->hop;
+  M2M_REQUIRE(out_batch_stride >= (int64_t)(row_offset + F) * fe->n_mels,
+              "m2m_logmel_f32: out_batch_stride %lld smaller than (row_offset+frames)*n_mels", (long long)out_batch_stride);
+  // 16 frames per workgroup: waveform re-read factor 1.44 at hop 256, two workgroups per CU.
+  int FR = 16;
+  while (FR > 4 && frontend_smem_bytes(FR, fe->hop) > 78 * 1024) FR -= 4;
+  const size_t smem = frontend_smem_bytes(FR, fe->hop);
+  dim3 grid((unsigned)ceil_div(F, FR), (unsigned)B);
+  static bool attr_set = false;
+  if (!attr_set) {
+    M2M_CHECK_HIP(hipFuncSetAttribute((const void*)logmel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(logmel_kernel, grid, dim3(FE_THREADS), smem, (hipStream_t)stream, wav_dev, T, F, fe->dev,
+                     out_dev, out_batch_stride, row_offset, FR);
+  M2M_CHECK_HIP(hipGetLastError());
+  return M2M_OK;
+}
+
+extern "C" int m2m_cond_rows_f32(const float* const* tables_dev_host, const int* table_rows_host, int n_tables,
+                                 int n_dim, const int64_t* idx_dev, int B, float* out_dev,
+                                 int64_t out_batch_stride, void* stream) {
+  M2M_REQUIRE(tables_dev_host && table_rows_host && idx_dev && out_dev, "m2m_cond_rows_f32: null argument");
+  M2M_REQUIRE(n_tables >= 1 && n_tables <= 8, "m2m_cond_rows_f32: n_tables %d out of range (1..8)", n_tables);
+  M2M_REQUIRE(B >= 1 && n_dim >= 1, "m2m_cond_rows_f32: bad B / n_dim");
+  CondArgs a{};
+  for (int i = 0; i < n_tables; ++i) {
+    M2M_REQUIRE(tables_dev_host[i] && table_rows_host[i] >= 1, "m2m_cond_rows_f32: table %d is null/empty", i);
+    a.tables[i] = tables_dev_host[i];
+    a.rows[i] = table_rows_host[i];
+  }
+  hipLaunchKernelGGL(cond_rows_kernel, dim3((unsigned)(B * n_tables)), dim3(128), 0, (hipStream_t)stream, a,
+                     n_tables, n_dim, idx_dev, out_dev, out_batch_stride);
+  M2M_CHECK_HIP(hipGetLastError());
+  return M2M_OK;
+}

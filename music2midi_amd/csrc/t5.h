@@ -1,0 +1,139 @@
+// Internal structures of the T5 encoder/decoder path (not part of the C ABI).
+#pragma once
+
+#include "common.h"
+
+namespace m2m {
+
+constexpr int DK = 64;  // d_kv: the attention kernels are specialised for 64 (HF default the reference uses)
+
+// ------------------------------------------------------------------ model ---
+struct EncLayerPacked {
+  const float* ln0;   // [d]
+  const void* wqkv;   // [3*inner, d]      rows: q | k | v
+  const void* wo;     // [d, inner]
+  const float* ln1;   // [d]
+  const void* wi;     // [2*dff, d]        64-row chunks: 32 rows of wi_0 then the matching 32 rows of wi_1
+  const void* wo_ff;  // [d, dff]
+};
+
+struct DecLayerPacked {
+  const float* ln0;
+  const void* wqkv;   // [3*inner, d]
+  const void* wo;     // [d, inner]
+  const float* ln1;
+  const void* wcq;    // [inner, d]
+  const void* wco;    // [d, inner]
+  const float* ln2;
+  const void* wi;     // [2*dff, d]        32-row chunks: 16 rows of wi_0 then the matching 16 rows of wi_1
+  const void* wo_ff;  // [d, dff]
+};
+
+}  // namespace m2m
+
+struct m2m_model {
+  m2m_t5_geometry g;
+  int precision;
+  int inner;            // num_heads * d_kv
+  int vocab_pad;        // vocab rounded up to 32 (lm_head rows beyond vocab are zero)
+  size_t esize;         // sizeof storage element (4 or 2)
+  void* blob = nullptr; // one device allocation holding every packed tensor
+  int64_t blob_bytes = 0;
+  std::vector<m2m::EncLayerPacked> enc;
+  std::vector<m2m::DecLayerPacked> dec;
+  const float* enc_final_ln = nullptr;
+  const float* dec_final_ln = nullptr;
+  const float* shared = nullptr;     // [V, d] fp32 (feeds the fp32 residual stream)
+  const void* lm_head = nullptr;     // [vocab_pad, d]
+  const void* wckv = nullptr;        // [L_dec * 2 * inner, d]  per layer: ck rows then cv rows
+  std::vector<float> enc_rel_bias_host;  // [num_buckets, H]
+  std::vector<float> dec_rel_bias_host;  // [num_buckets, H]
+};
+
+namespace m2m {
+
+// device-resident decode loop state
+struct DecState {
+  int t;             // position of the token being fed this step (0-based)
+  int done;          // every row has emitted EOS
+  int out_len;       // valid columns of the token matrix once done
+  int n_unfinished;
+  int max_steps;     // steps after which the loop must stop (max_length - 1)
+  int pad[3];
+};
+
+}  // namespace m2m
+
+struct m2m_session {
+  const m2m_model* m;
+  int max_batch, max_enc, max_dec;
+  unsigned char* ws;       // caller-owned workspace
+  int64_t ws_bytes;
+  // carved buffers
+  float* x_enc;            // [B*S, d] fp32 residual stream
+  void* h_enc;             // [B*S, d] T normalised activations
+  void* qkv_enc;           // [3][B][H][S][64] T
+  void* attn_enc;          // [B*S, inner] T
+  void* mid_enc;           // [B*S, dff] T
+  float* enc_bias_tab;     // [H][2*max_enc-1]
+  float* dec_bias_tab;     // [H][max_dec]
+  void* cross_kv;          // [L][2][B][H][S][64] T
+  void* self_k;            // [L][B][H][max_dec][64] T
+  void* self_v;
+  float* x_dec;            // [32-row padded B, d]
+  float* q_dec;            // [B, inner]
+  float* o_dec;            // [B, inner]
+  float* g_dec;            // [B, dff]
+  float* logits;           // [B, vocab_pad]
+  int64_t* tokens;         // [B, max_dec]
+  int* finished;           // [B]
+  m2m::DecState* state;    // device
+  int64_t* forced_ids;     // [B, max_dec]
+  // current problem
+  int B = 0, S = 0;
+  bool encoded = false;
+  // graph
+  hipStream_t stream = nullptr;   // session-owned stream the decode loop runs on
+  hipEvent_t ev_in = nullptr, ev_out = nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  int graph_B = -1, graph_S = -1;
+  m2m::DecState* state_host = nullptr;  // pinned
+};
+
+namespace m2m {
+
+// -------------------------------------------------------- launch helpers ---
+// encoder-side (enc_kernels.hip)
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_GATED = 2, EPI_HEADS = 3 };
+
+struct GemmArgs {
+  const void* A;     // [M, K] T row-major
+  const void* W;     // [N, K] T row-major (HF [out, in])
+  int M, N, K;
+  void* out;         // EPI_STORE / EPI_GATED / EPI_HEADS: T ; EPI_RESID: float (in-place +=)
+  int ldo;           // leading dimension of out (STORE/RESID/GATED)
+  // EPI_HEADS: out[(which*B + b)*H + h][s][64], which = n / inner
+  int Bsz, S, H, inner;
+};
+
+int launch_gemm(int precision, int epi, const GemmArgs& a, hipStream_t st);
+int launch_rmsnorm(int precision, const float* x, const float* w, void* out, int M, int d, float eps, hipStream_t st);
+int launch_enc_attn(int precision, const void* qkv, const float* bias_tab, int tab_stride, int tab_center,
+                    void* out, int B, int H, int S, hipStream_t st);
+int launch_final_norm_f32(const float* x, const float* w, float* out_f32, void* out_T, int precision, int M, int d,
+                          float eps, hipStream_t st);
+
+// repack (repack.hip)
+int launch_convert(int precision, const float* src, void* dst, int64_t n, hipStream_t st);
+int launch_interleave(int precision, const float* wi0, const float* wi1, void* dst, int dff, int d, int half,
+                      hipStream_t st);
+int launch_copy_f32(const float* src, float* dst, int64_t n, hipStream_t st);
+int launch_fill_zero(void* dst, int64_t bytes, hipStream_t st);
+
+// decoder-side (decode.hip)
+int decode_init(m2m_session* s, int max_steps, bool forced, hipStream_t st);
+int decode_launch_step(m2m_session* s, bool forced, float* logits_out, int Ld, hipStream_t st);
+int decode_launch_attn(m2m_session* s, bool self, int layer, int self_len, hipStream_t st);
+
+}  // namespace m2m
