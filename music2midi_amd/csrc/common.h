@@ -95,7 +95,7 @@ __device__ inline float gelu_new(float x) {
   return 0.5f * x * (1.0f + tanhf(k * (x + 0.044715f * x * x * x)));
 }
 
-static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
 }  // namespace m2m

@@ -1,0 +1,364 @@
+// Encoder-side kernels (one shot per clip batch): RMSNorm, MFMA GEMM with fused epilogues,
+// flash-style self-attention with the T5 relative-position bias.
+// Replaces the HF T5 encoder stack that ref: music2midi/transformer.py:44 runs once per
+// generate() (hf: models/t5/modeling_t5.py:663-750), and the cross-attention K/V projections
+// (hf: :319-332) for all decoder layers in one GEMM.
+//
+// All three are templated on the storage type T of the precision mode: float (f32-input MFMA,
+// exact fp32 FMA chains: parity mode) or bf16 (bf16 MFMA, fp32 accumulate: throughput mode).
+#include "mma.h"
+#include "t5.h"
+
+namespace m2m {
+
+// ============================================================== RMSNorm ====
+// One wave per row: y = x * rsqrt(mean(x^2) + eps) * w   (hf: modeling_t5.py:59-72), fp32 math,
+// output in storage type T (GEMM input) and/or fp32.
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                      T* __restrict__ outT, float* __restrict__ outF, int M, int d,
+                                                      float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (int64_t)row * d;
+  float ss = 0.f;
+  for (int c = lane * 4; c < d; c += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(xr + c);
+    ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  ss = wave_sum(ss);
+  const float rstd = rsqrtf(ss / (float)d + eps);
+  for (int c = lane * 4; c < d; c += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(xr + c);
+    const float4 g = *reinterpret_cast<const float4*>(w + c);
+    const float y0 = g.x * (v.x * rstd), y1 = g.y * (v.y * rstd), y2 = g.z * (v.z * rstd), y3 = g.w * (v.w * rstd);
+    if (outT) {
+      T* o = outT + (int64_t)row * d + c;
+      o[0] = from_f32<T>(y0); o[1] = from_f32<T>(y1); o[2] = from_f32<T>(y2); o[3] = from_f32<T>(y3);
+    }
+    if (outF) *reinterpret_cast<float4*>(outF + (int64_t)row * d + c) = make_float4(y0, y1, y2, y3);
+  }
+}
+
+int launch_rmsnorm(int precision, const float* x, const float* w, void* out, int M, int d, float eps, hipStream_t st) {
+  M2M_REQUIRE(d % 4 == 0, "rmsnorm: d_model must be a multiple of 4");
+  dim3 grid((unsigned)ceil_div(M, 4));
+  if (precision == M2M_PREC_BF16)
+    hipLaunchKernelGGL(rmsnorm_kernel<bf16_t>, grid, dim3(256), 0, st, x, w, (bf16_t*)out, (float*)nullptr, M, d, eps);
+  else
+    hipLaunchKernelGGL(rmsnorm_kernel<float>, grid, dim3(256), 0, st, x, w, (float*)out, (float*)nullptr, M, d, eps);
+  M2M_CHECK_HIP(hipGetLastError());
+  return M2M_OK;
+}
+
+int launch_final_norm_f32(const float* x, const float* w, float* out_f32, void* out_T, int precision, int M, int d,
+                          float eps, hipStream_t st) {
+  dim3 grid((unsigned)ceil_div(M, 4));
+  if (precision == M2M_PREC_BF16)
+    hipLaunchKernelGGL(rmsnorm_kernel<bf16_t>, grid, dim3(256), 0, st, x, w, (bf16_t*)out_T, out_f32, M, d, eps);
+  else
+    hipLaunchKernelGGL(rmsnorm_kernel<float>, grid, dim3(256), 0, st, x, w, (float*)out_T, out_f32, M, d, eps);
+  M2M_CHECK_HIP(hipGetLastError());
+  return M2M_OK;
+}
+
+// ================================================================= GEMM ====
+// C[M,N] = A[M,K] * W[N,K]^T.  128x128 output tile per 256-thread workgroup, BK = 32,
+// 2x2 waves each owning 64x64 (2x2 MFMA 32x32 tiles), register-prefetched LDS staging.
+constexpr int BM = 128, BN = 128, BK = 32;
+
+template <typename T> struct TileCfg;
+template <> struct TileCfg<bf16_t> {
+  static constexpr int PITCH = BK + 8;                       // elements per LDS row (80 B)
+  static constexpr int CPR = BK * 2 / 16;                    // 16-byte chunks per row = 4
+};
+template <> struct TileCfg<float> {
+  static constexpr int PITCH = BK + 4;                       // 144 B
+  static constexpr int CPR = BK * 4 / 16;                    // 8
+};
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  using Cfg = TileCfg<T>;
+  constexpr int EPC = 16 / sizeof(T);                          // elements per 16-byte chunk
+  constexpr int CHUNKS = BM * Cfg::CPR;                        // per operand tile
+  constexpr int PER_THREAD = CHUNKS / 256;
+  __shared__ __align__(16) T As[BM * Cfg::PITCH];
+  __shared__ __align__(16) T Bs[BN * Cfg::PITCH];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const T* A = reinterpret_cast<const T*>(g.A);
+  const T* W = reinterpret_cast<const T*>(g.W);
+  const int K = g.K;
+
+  uint4 ra[PER_THREAD], rb[PER_THREAD];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i) {
+      const int c = tid + i * 256;
+      const int row = c / Cfg::CPR, cc = c % Cfg::CPR;
+      const int ar = min(m0 + row, g.M - 1), br = min(n0 + row, g.N - 1);
+      ra[i] = *reinterpret_cast<const uint4*>(A + (int64_t)ar * K + k0 + cc * EPC);
+      rb[i] = *reinterpret_cast<const uint4*>(W + (int64_t)br * K + k0 + cc * EPC);
+    }
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i) {
+      const int c = tid + i * 256;
+      const int row = c / Cfg::CPR, cc = c % Cfg::CPR;
+      *reinterpret_cast<uint4*>(As + row * Cfg::PITCH + cc * EPC) = ra[i];
+      *reinterpret_cast<uint4*>(Bs + row * Cfg::PITCH + cc * EPC) = rb[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = zero_acc();
+
+  const int r = lane & 31, h = lane >> 5;
+  const int nk = K / BK;
+  gload(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    sstore();
+    __syncthreads();
+    if (kt + 1 < nk) gload((kt + 1) * BK);
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      Frag<T> fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[i] = load_frag(As + (wm * 64 + i * 32 + r) * Cfg::PITCH + s * 16 + 8 * h);
+        fb[i] = load_frag(Bs + (wn * 64 + i * 32 + r) * Cfg::PITCH + s * 16 + 8 * h);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mma16(acc[i][j], fa[i], fb[j]);
+    }
+  }
+
+  // ---- epilogue ----
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = m0 + wm * 64 + mi * 32 + acc_row(e, lane);
+      if (row >= g.M) continue;
+      if constexpr (EPI == EPI_GATED) {
+        // the wave's 64 columns are [32 of wi_0 | the matching 32 of wi_1]
+        const int col = (n0 + wn * 64) / 2 + r;
+        if (n0 + wn * 64 < g.N) {
+          const float v = gelu_new(acc[mi][0][e]) * acc[mi][1][e];
+          reinterpret_cast<T*>(g.out)[(int64_t)row * g.ldo + col] = from_f32<T>(v);
+        }
+      } else {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const int col = n0 + wn * 64 + ni * 32 + r;
+          if (col >= g.N) continue;
+          const float v = acc[mi][ni][e];
+          if constexpr (EPI == EPI_STORE) {
+            reinterpret_cast<T*>(g.out)[(int64_t)row * g.ldo + col] = from_f32<T>(v);
+          } else if constexpr (EPI == EPI_RESID) {
+            float* p = reinterpret_cast<float*>(g.out) + (int64_t)row * g.ldo + col;
+            *p += v;
+          } else {  // EPI_HEADS
+            const int which = col / g.inner, rem = col - which * g.inner;
+            const int hh = rem / DK, dd = rem - hh * DK;
+            const int b = row / g.S, s = row - b * g.S;
+            reinterpret_cast<T*>(g.out)[((((int64_t)which * g.Bsz + b) * g.H + hh) * g.S + s) * DK + dd] = from_f32<T>(v);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <typename T>
+static int launch_gemm_t(int epi, const GemmArgs& a, hipStream_t st) {
+  dim3 grid((unsigned)ceil_div(a.N, BN), (unsigned)ceil_div(a.M, BM));
+  switch (epi) {
+    case EPI_STORE: hipLaunchKernelGGL((gemm_kernel<T, EPI_STORE>), grid, dim3(256), 0, st, a); break;
+    case EPI_RESID: hipLaunchKernelGGL((gemm_kernel<T, EPI_RESID>), grid, dim3(256), 0, st, a); break;
+    case EPI_GATED: hipLaunchKernelGGL((gemm_kernel<T, EPI_GATED>), grid, dim3(256), 0, st, a); break;
+    case EPI_HEADS: hipLaunchKernelGGL((gemm_kernel<T, EPI_HEADS>), grid, dim3(256), 0, st, a); break;
+    default: set_error("launch_gemm: bad epilogue %d", epi); return M2M_ERR_INVALID;
+  }
+  M2M_CHECK_HIP(hipGetLastError());
+  return M2M_OK;
+}
+
+int launch_gemm(int precision, int epi, const GemmArgs& a, hipStream_t st) {
+  M2M_REQUIRE(a.K % BK == 0, "gemm: K=%d must be a multiple of %d", a.K, BK);
+  M2M_REQUIRE(a.M >= 1 && a.N >= 1, "gemm: empty problem");
+  if (epi == EPI_GATED) M2M_REQUIRE(a.N % 64 == 0, "gemm: gated epilogue needs N %% 64 == 0 (d_ff %% 32 == 0)");
+  return precision == M2M_PREC_BF16 ? launch_gemm_t<bf16_t>(epi, a, st) : launch_gemm_t<float>(epi, a, st);
+}
+
+// =========================================================== attention ====
+// Flash-style bidirectional self-attention with T5's additive relative-position bias and NO
+// 1/sqrt(d) scaling (hf: modeling_t5.py:159-170,197).  Workgroup = 4 waves = 128 query rows
+// of one (clip, head); keys/values stream through LDS in 64-key tiles.
+//
+// Orientation: S^T = K * Q^T, so a lane owns ONE query column and 16 keys in registers
+// (row-softmax is 15 in-lane ops + one cross-half exchange) and the running rescale factor
+// is a per-lane scalar.  P^T then feeds O^T = V^T * P^T directly as the MFMA B operand with
+// no lane movement; V^T is staged in LDS with key slots permuted to match (vt_pos).
+constexpr int AQ = 128, AK = 64;
+
+template <typename T> struct AttnCfg;
+template <> struct AttnCfg<bf16_t> { static constexpr int KP = DK + 8, VP = AK + 8; };
+template <> struct AttnCfg<float> { static constexpr int KP = DK + 4, VP = AK + 4; };
+
+// slot of key kk (0..31) inside a 32-key group of the V^T image: swap bits 2 and 3, so that
+// the 8 contiguous slots [16s + 8h, +8) hold keys 16s + 8(j>>2) + 4h + (j&3), j = 0..7 —
+// the k-order in which accumulator registers 8s..8s+7 of S^T present P^T (see mma.h).
+__device__ inline int vt_pos(int kk) { return (kk & ~0xC) | ((kk & 4) << 1) | ((kk & 8) >> 1); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void enc_attn_kernel(const T* __restrict__ qkv, const float* __restrict__ bias_tab,
+                                                       int tab_stride, int tab_center, T* __restrict__ out, int B,
+                                                       int H, int S) {
+  using Cfg = AttnCfg<T>;
+  constexpr int EPC = 16 / sizeof(T);
+  extern __shared__ __align__(16) unsigned char smem[];
+  T* Ks = reinterpret_cast<T*>(smem);                       // [AK][KP]
+  T* Vt = Ks + AK * Cfg::KP;                                // [DK][VP]  (transposed, permuted key slots)
+  float* tb = reinterpret_cast<float*>(Vt + DK * Cfg::VP);  // [2S-1] bias by (key - q) + S - 1
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / H, hh = bh - b * H;
+  const int q0 = blockIdx.x * AQ + wave * 32;
+  const int64_t head_stride = (int64_t)S * DK;
+  const T* Q = qkv + ((int64_t)(0 * B + b) * H + hh) * head_stride;
+  const T* Kg = qkv + ((int64_t)(1 * B + b) * H + hh) * head_stride;
+  const T* Vg = qkv + ((int64_t)(2 * B + b) * H + hh) * head_stride;
+
+  for (int i = tid; i < 2 * S - 1; i += 256) tb[i] = bias_tab[(int64_t)hh * tab_stride + tab_center - (S - 1) + i];
+
+  // Q fragments (B operand): lane (r,h) holds Q[q0 + r][16 s + 8 h + j]
+  const int qrow = min(q0 + r, S - 1);
+  Frag<T> qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) qf[s] = load_frag(Q + (int64_t)qrow * DK + s * 16 + 8 * h);
+
+  f32x16 o[2] = {zero_acc(), zero_acc()};
+  float m_run = -1e30f, l_run = 0.f;
+  const int my_q = q0 + r;
+
+  const int ntiles = ceil_div(S, AK);
+  for (int kt = 0; kt < ntiles; ++kt) {
+    __syncthreads();
+    // ---- stage K (row-major) and V (transposed + slot-permuted) ----
+    for (int c = tid; c < AK * (DK / EPC); c += 256) {
+      const int key = c / (DK / EPC), dc = c % (DK / EPC);
+      const int gk = min(kt * AK + key, S - 1);
+      *reinterpret_cast<uint4*>(Ks + key * Cfg::KP + dc * EPC) =
+          *reinterpret_cast<const uint4*>(Kg + (int64_t)gk * DK + dc * EPC);
+      uint4 vv = *reinterpret_cast<const uint4*>(Vg + (int64_t)gk * DK + dc * EPC);
+      const T* ve = reinterpret_cast<const T*>(&vv);
+      const int slot = (key & 32) + vt_pos(key & 31);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) Vt[(dc * EPC + e) * Cfg::VP + slot] = ve[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const int kbase = kt * AK + sub * 32;
+      if (kbase >= S) break;  // uniform
+      f32x16 st = zero_acc();
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        Frag<T> kf = load_frag(Ks + (sub * 32 + r) * Cfg::KP + s * 16 + 8 * h);
+        mma16(st, kf, qf[s]);
+      }
+      // scores for query my_q: element i is key kbase + acc_row(i, lane)
+      float p[16];
+      float mx = -1e30f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int key = kbase + acc_row(i, lane);
+        float sc = -1e30f;
+        if (key < S) {
+          int rel = key - my_q + (S - 1);
+          rel = min(max(rel, 0), 2 * S - 2);  // rows beyond S (clamped q) are discarded later
+          sc = st[i] + tb[rel];
+        }
+        p[i] = sc;
+        mx = fmaxf(mx, sc);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __expf(m_run - m_new);
+      float psum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        p[i] = __expf(p[i] - m_new);
+        psum += p[i];
+      }
+      psum += __shfl_xor(psum, 32, 64);
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        o[0][i] *= alpha;
+        o[1][i] *= alpha;
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        float pp[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pp[j] = p[8 * s2 + j];
+        const Frag<T> pf = pack_frag<T>(pp);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          Frag<T> vf = load_frag(Vt + (db * 32 + r) * Cfg::VP + sub * 32 + s2 * 16 + 8 * h);
+          mma16(o[db], vf, pf);
+        }
+      }
+    }
+  }
+  // ---- normalise and store: O^T element i of block db is d = db*32 + acc_row(i), query my_q ----
+  if (my_q < S) {
+    const float inv = 1.0f / l_run;
+    T* orow = out + ((int64_t)b * S + my_q) * (H * DK) + hh * DK;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) orow[db * 32 + acc_row(i, lane)] = from_f32<T>(o[db][i] * inv);
+  }
+}
+
+template <typename T>
+static int launch_enc_attn_t(const void* qkv, const float* bias_tab, int tab_stride, int tab_center, void* out, int B,
+                             int H, int S, hipStream_t st) {
+  using Cfg = AttnCfg<T>;
+  const size_t smem = (size_t)(AK * Cfg::KP + DK * Cfg::VP) * sizeof(T) + (size_t)(2 * S - 1) * sizeof(float);
+  M2M_REQUIRE(smem <= 150 * 1024, "enc_attn: S=%d too long for the LDS bias table", S);
+  static bool attr_set = false;
+  if (!attr_set) {
+    M2M_CHECK_HIP(hipFuncSetAttribute((const void*)enc_attn_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  dim3 grid((unsigned)ceil_div(S, AQ), (unsigned)(B * H));
+  hipLaunchKernelGGL(enc_attn_kernel<T>, grid, dim3(256), smem, st, (const T*)qkv, bias_tab, tab_stride, tab_center,
+                     (T*)out, B, H, S);
+  M2M_CHECK_HIP(hipGetLastError());
+  return M2M_OK;
+}
+
+int launch_enc_attn(int precision, const void* qkv, const float* bias_tab, int tab_stride, int tab_center, void* out,
+                    int B, int H, int S, hipStream_t st) {
+  return precision == M2M_PREC_BF16 ? launch_enc_attn_t<bf16_t>(qkv, bias_tab, tab_stride, tab_center, out, B, H, S, st)
+                                    : launch_enc_attn_t<float>(qkv, bias_tab, tab_stride, tab_center, out, B, H, S, st);
+}
+
+}  // namespace m2m

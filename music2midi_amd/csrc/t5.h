@@ -3,6 +3,8 @@
 
 #include "common.h"
 
+#include <vector>
+
 namespace m2m {
 
 constexpr int DK = 64;  // d_kv: the attention kernels are specialised for 64 (HF default the reference uses)

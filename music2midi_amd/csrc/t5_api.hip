@@ -1,0 +1,441 @@
+// C ABI of the T5 encoder/decoder path: model (repacked weights), session (workspace +
+// captured decode-step graph), encode, greedy generate, teacher-forced decode, bench hooks.
+#include "t5.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+using namespace m2m;
+
+// ---------------------------------------------------------------- buckets ---
+// T5 relative-position bucket (hf: models/t5/modeling_t5.py:217-262).  HF evaluates the log
+// branch in float32 and truncates; the same float32 expression is used here and the result
+// is pinned against the integer table of SURVEY.md §8a-A6 by tests/test_host_logic.py.
+extern "C" int m2m_rel_bucket(int rel, int bidirectional, int num_buckets, int max_distance) {
+  int bucket = 0;
+  int nb = num_buckets;
+  int n;
+  if (bidirectional) {
+    nb /= 2;
+    if (rel > 0) bucket += nb;
+    n = rel < 0 ? -rel : rel;
+  } else {
+    n = rel < 0 ? -rel : 0;
+  }
+  const int max_exact = nb / 2;
+  if (n < max_exact) return bucket + n;
+  const float ratio = logf((float)n / (float)max_exact) / (float)log((double)max_distance / (double)max_exact);
+  int large = max_exact + (int)(ratio * (float)(nb - max_exact));
+  if (large > nb - 1) large = nb - 1;
+  return bucket + large;
+}
+
+// ------------------------------------------------------------------ model ---
+extern "C" int m2m_model_create(const m2m_t5_geometry* geom, const m2m_t5_weights* w, int precision, void* stream,
+                                m2m_model** out) {
+  M2M_REQUIRE(geom && w && out, "m2m_model_create: null argument");
+  M2M_REQUIRE(precision == M2M_PREC_FP32 || precision == M2M_PREC_BF16, "m2m_model_create: bad precision %d", precision);
+  const m2m_t5_geometry& g = *geom;
+  M2M_REQUIRE(g.d_kv == DK, "m2m_model_create: d_kv=%d unsupported (attention kernels are specialised for 64)", g.d_kv);
+  M2M_REQUIRE(g.d_model >= 64 && g.d_model % 64 == 0, "m2m_model_create: d_model=%d must be a multiple of 64", g.d_model);
+  M2M_REQUIRE(g.d_ff >= 64 && g.d_ff % 64 == 0, "m2m_model_create: d_ff=%d must be a multiple of 64", g.d_ff);
+  M2M_REQUIRE(g.num_heads >= 1 && g.num_layers >= 1 && g.num_decoder_layers >= 1 && g.vocab_size >= 2,
+              "m2m_model_create: bad geometry");
+  M2M_REQUIRE(g.num_buckets >= 4 && g.num_buckets % 2 == 0 && g.max_distance > g.num_buckets / 2,
+              "m2m_model_create: bad relative-attention geometry");
+  M2M_REQUIRE(w->shared && w->lm_head && w->enc_rel_bias && w->dec_rel_bias && w->enc_final_ln && w->dec_final_ln &&
+                  w->enc && w->dec, "m2m_model_create: null weight pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int d = g.d_model, dff = g.d_ff, inner = g.num_heads * g.d_kv, V = g.vocab_size;
+  const int Le = g.num_layers, Ld = g.num_decoder_layers;
+  const size_t es = precision == M2M_PREC_BF16 ? 2 : 4;
+  const int vocab_pad = ceil_div(V, 32) * 32;
+
+  // ---- carve one blob ----
+  int64_t off = 0;
+  auto take = [&](int64_t bytes) { int64_t o = off; off = align_up(off + bytes, 256); return o; };
+  struct EncOff { int64_t ln0, wqkv, wo, ln1, wi, wo_ff; };
+  struct DecOff { int64_t ln0, wqkv, wo, ln1, wcq, wco, ln2, wi, wo_ff; };
+  std::vector<EncOff> eo(Le);
+  std::vector<DecOff> dof(Ld);
+  for (int l = 0; l < Le; ++l) {
+    eo[l].ln0 = take(d * 4); eo[l].wqkv = take((int64_t)3 * inner * d * es); eo[l].wo = take((int64_t)d * inner * es);
+    eo[l].ln1 = take(d * 4); eo[l].wi = take((int64_t)2 * dff * d * es); eo[l].wo_ff = take((int64_t)d * dff * es);
+  }
+  for (int l = 0; l < Ld; ++l) {
+    dof[l].ln0 = take(d * 4); dof[l].wqkv = take((int64_t)3 * inner * d * es); dof[l].wo = take((int64_t)d * inner * es);
+    dof[l].ln1 = take(d * 4); dof[l].wcq = take((int64_t)inner * d * es); dof[l].wco = take((int64_t)d * inner * es);
+    dof[l].ln2 = take(d * 4); dof[l].wi = take((int64_t)2 * dff * d * es); dof[l].wo_ff = take((int64_t)d * dff * es);
+  }
+  const int64_t o_eln = take(d * 4), o_dln = take(d * 4);
+  const int64_t o_shared = take((int64_t)V * d * 4);
+  const int64_t o_head = take((int64_t)vocab_pad * d * es);
+  const int64_t o_ckv = take((int64_t)Ld * 2 * inner * d * es);
+
+  m2m_model* m = new m2m_model();
+  m->g = g; m->precision = precision; m->inner = inner; m->vocab_pad = vocab_pad; m->esize = es; m->blob_bytes = off;
+  hipError_t e = hipMalloc(&m->blob, (size_t)off);
+  if (e != hipSuccess) {
+    set_error("m2m_model_create: hipMalloc(%lld) failed: %s", (long long)off, hipGetErrorString(e));
+    delete m;
+    return M2M_ERR_NOMEM;
+  }
+  unsigned char* base = (unsigned char*)m->blob;
+  int rc = M2M_OK;
+  auto conv = [&](const float* src, int64_t o, int64_t n) {
+    if (rc == M2M_OK && !src) { set_error("m2m_model_create: null layer weight pointer"); rc = M2M_ERR_INVALID; }
+    if (rc == M2M_OK) rc = launch_convert(precision, src, base + o, n, st);
+  };
+  auto copyf = [&](const float* src, int64_t o, int64_t n) {
+    if (rc == M2M_OK && !src) { set_error("m2m_model_create: null layer weight pointer"); rc = M2M_ERR_INVALID; }
+    if (rc == M2M_OK) rc = launch_copy_f32(src, (float*)(base + o), n, st);
+  };
+  m->enc.resize(Le); m->dec.resize(Ld);
+  for (int l = 0; l < Le && rc == M2M_OK; ++l) {
+    const m2m_enc_layer_weights& s = w->enc[l];
+    copyf(s.ln0, eo[l].ln0, d); copyf(s.ln1, eo[l].ln1, d);
+    conv(s.q, eo[l].wqkv, (int64_t)inner * d);
+    conv(s.k, eo[l].wqkv + (int64_t)inner * d * es, (int64_t)inner * d);
+    conv(s.v, eo[l].wqkv + (int64_t)2 * inner * d * es, (int64_t)inner * d);
+    conv(s.o, eo[l].wo, (int64_t)d * inner);
+    if (rc == M2M_OK && !(s.wi0 && s.wi1)) { set_error("m2m_model_create: null wi pointer"); rc = M2M_ERR_INVALID; }
+    if (rc == M2M_OK) rc = launch_interleave(precision, s.wi0, s.wi1, base + eo[l].wi, dff, d, 32, st);
+    conv(s.wo, eo[l].wo_ff, (int64_t)d * dff);
+    m->enc[l] = {(const float*)(base + eo[l].ln0), base + eo[l].wqkv, base + eo[l].wo, (const float*)(base + eo[l].ln1),
+                 base + eo[l].wi, base + eo[l].wo_ff};
+  }
+  for (int l = 0; l < Ld && rc == M2M_OK; ++l) {
+    const m2m_dec_layer_weights& s = w->dec[l];
+    copyf(s.ln0, dof[l].ln0, d); copyf(s.ln1, dof[l].ln1, d); copyf(s.ln2, dof[l].ln2, d);
+    conv(s.q, dof[l].wqkv, (int64_t)inner * d);
+    conv(s.k, dof[l].wqkv + (int64_t)inner * d * es, (int64_t)inner * d);
+    conv(s.v, dof[l].wqkv + (int64_t)2 * inner * d * es, (int64_t)inner * d);
+    conv(s.o, dof[l].wo, (int64_t)d * inner);
+    conv(s.cq, dof[l].wcq, (int64_t)inner * d);
+    conv(s.co, dof[l].wco, (int64_t)d * inner);
+    if (rc == M2M_OK && !(s.wi0 && s.wi1)) { set_error("m2m_model_create: null wi pointer"); rc = M2M_ERR_INVALID; }
+    if (rc == M2M_OK) rc = launch_interleave(precision, s.wi0, s.wi1, base + dof[l].wi, dff, d, 16, st);
+    conv(s.wo, dof[l].wo_ff, (int64_t)d * dff);
+    conv(s.ck, o_ckv + (int64_t)(l * 2 + 0) * inner * d * es, (int64_t)inner * d);
+    conv(s.cv, o_ckv + (int64_t)(l * 2 + 1) * inner * d * es, (int64_t)inner * d);
+    m->dec[l] = {(const float*)(base + dof[l].ln0), base + dof[l].wqkv, base + dof[l].wo,
+                 (const float*)(base + dof[l].ln1), base + dof[l].wcq, base + dof[l].wco,
+                 (const float*)(base + dof[l].ln2), base + dof[l].wi, base + dof[l].wo_ff};
+  }
+  copyf(w->enc_final_ln, o_eln, d); copyf(w->dec_final_ln, o_dln, d);
+  copyf(w->shared, o_shared, (int64_t)V * d);
+  if (rc == M2M_OK) rc = launch_fill_zero(base + o_head, (int64_t)vocab_pad * d * es, st);
+  conv(w->lm_head, o_head, (int64_t)V * d);
+  m->enc_final_ln = (const float*)(base + o_eln); m->dec_final_ln = (const float*)(base + o_dln);
+  m->shared = (const float*)(base + o_shared); m->lm_head = base + o_head; m->wckv = base + o_ckv;
+  m->enc_rel_bias_host.resize((size_t)g.num_buckets * g.num_heads);
+  m->dec_rel_bias_host.resize((size_t)g.num_buckets * g.num_heads);
+  hipError_t he = hipSuccess;
+  if (rc == M2M_OK) he = hipMemcpyAsync(m->enc_rel_bias_host.data(), w->enc_rel_bias, m->enc_rel_bias_host.size() * 4, hipMemcpyDeviceToHost, st);
+  if (rc == M2M_OK && he == hipSuccess) he = hipMemcpyAsync(m->dec_rel_bias_host.data(), w->dec_rel_bias, m->dec_rel_bias_host.size() * 4, hipMemcpyDeviceToHost, st);
+  if (rc == M2M_OK && he == hipSuccess) he = hipStreamSynchronize(st);
+  if (rc == M2M_OK && he != hipSuccess) { set_error("m2m_model_create: %s", hipGetErrorString(he)); rc = M2M_ERR_HIP; }
+  if (rc != M2M_OK) {
+    (void)hipFree(m->blob);
+    delete m;
+    return rc;
+  }
+  *out = m;
+  return M2M_OK;
+}
+
+extern "C" void m2m_model_destroy(m2m_model* m) {
+  if (!m) return;
+  if (m->blob) (void)hipFree(m->blob);
+  delete m;
+}
+extern "C" int m2m_model_precision(const m2m_model* m) { return m ? m->precision : M2M_ERR_INVALID; }
+extern "C" int64_t m2m_model_param_bytes(const m2m_model* m) { return m ? m->blob_bytes : (int64_t)M2M_ERR_INVALID; }
+
+// ---------------------------------------------------------------- session ---
+namespace {
+struct WsLayout {
+  int64_t x_enc, h_enc, qkv_enc, attn_enc, mid_enc, enc_bias, dec_bias, cross_kv, self_k, self_v;
+  int64_t x_dec, q_dec, o_dec, g_dec, logits, tokens, finished, state, forced, total;
+};
+
+WsLayout ws_layout(const m2m_model* m, int B, int S, int L) {
+  const m2m_t5_geometry& g = m->g;
+  const int64_t es = (int64_t)m->esize, M = (int64_t)B * S, Bp = (int64_t)ceil_div(B, 32) * 32;
+  WsLayout w{};
+  int64_t off = 0;
+  auto take = [&](int64_t bytes) { int64_t o = off; off = align_up(off + bytes, 256); return o; };
+  w.x_enc = take(M * g.d_model * 4);
+  w.h_enc = take(M * g.d_model * es);
+  w.qkv_enc = take(3 * M * m->inner * es);
+  w.attn_enc = take(M * m->inner * es);
+  w.mid_enc = take(M * g.d_ff * es);
+  w.enc_bias = take((int64_t)g.num_heads * (2 * S - 1) * 4);
+  w.dec_bias = take((int64_t)g.num_heads * L * 4);
+  w.cross_kv = take((int64_t)g.num_decoder_layers * 2 * M * m->inner * es);
+  w.self_k = take((int64_t)g.num_decoder_layers * B * m->inner * L * es);
+  w.self_v = take((int64_t)g.num_decoder_layers * B * m->inner * L * es);
+  w.x_dec = take(Bp * g.d_model * 4);
+  w.q_dec = take(Bp * m->inner * 4);
+  w.o_dec = take(Bp * m->inner * 4);
+  w.g_dec = take(Bp * g.d_ff * 4);
+  w.logits = take(Bp * m->vocab_pad * 4);
+  w.tokens = take((int64_t)B * L * 8);
+  w.finished = take((int64_t)B * 4);
+  w.state = take(sizeof(DecState));
+  w.forced = take((int64_t)B * L * 8);
+  w.total = off;
+  return w;
+}
+}  // namespace
+
+extern "C" int64_t m2m_session_workspace_bytes(const m2m_model* m, int max_batch, int max_enc_len, int max_dec_len) {
+  if (!m || max_batch < 1 || max_enc_len < 1 || max_dec_len < 1) {
+    set_error("m2m_session_workspace_bytes: bad argument");
+    return M2M_ERR_INVALID;
+  }
+  return ws_layout(m, max_batch, max_enc_len, max_dec_len).total;
+}
+
+extern "C" int m2m_session_create(const m2m_model* m, int max_batch, int max_enc_len, int max_dec_len,
+                                  void* workspace_dev, int64_t workspace_bytes, m2m_session** out) {
+  M2M_REQUIRE(m && workspace_dev && out, "m2m_session_create: null argument");
+  M2M_REQUIRE(max_batch >= 1 && max_enc_len >= 1 && max_dec_len >= 1, "m2m_session_create: bad geometry");
+  M2M_REQUIRE(((uintptr_t)workspace_dev & 255) == 0, "m2m_session_create: workspace must be 256-byte aligned");
+  const WsLayout w = ws_layout(m, max_batch, max_enc_len, max_dec_len);
+  if (workspace_bytes < w.total) {
+    set_error("m2m_session_create: workspace %lld bytes < required %lld", (long long)workspace_bytes, (long long)w.total);
+    return M2M_ERR_NOMEM;
+  }
+  M2M_REQUIRE((size_t)(2 * max_enc_len - 1) * 4 + 40 * 1024 <= 150 * 1024,
+              "m2m_session_create: max_enc_len=%d too long (attention bias table must fit LDS)", max_enc_len);
+  M2M_REQUIRE((size_t)max_enc_len * 4 <= 60 * 1024 && (size_t)max_dec_len * 4 <= 60 * 1024,
+              "m2m_session_create: sequence too long for the decode attention score buffer");
+  m2m_session* s = new m2m_session();
+  s->m = m; s->max_batch = max_batch; s->max_enc = max_enc_len; s->max_dec = max_dec_len;
+  s->ws = (unsigned char*)workspace_dev; s->ws_bytes = workspace_bytes;
+  unsigned char* b = s->ws;
+  s->x_enc = (float*)(b + w.x_enc); s->h_enc = b + w.h_enc; s->qkv_enc = b + w.qkv_enc; s->attn_enc = b + w.attn_enc;
+  s->mid_enc = b + w.mid_enc; s->enc_bias_tab = (float*)(b + w.enc_bias); s->dec_bias_tab = (float*)(b + w.dec_bias);
+  s->cross_kv = b + w.cross_kv; s->self_k = b + w.self_k; s->self_v = b + w.self_v;
+  s->x_dec = (float*)(b + w.x_dec); s->q_dec = (float*)(b + w.q_dec); s->o_dec = (float*)(b + w.o_dec);
+  s->g_dec = (float*)(b + w.g_dec); s->logits = (float*)(b + w.logits); s->tokens = (int64_t*)(b + w.tokens);
+  s->finished = (int*)(b + w.finished); s->state = (DecState*)(b + w.state); s->forced_ids = (int64_t*)(b + w.forced);
+
+  // relative-position bias tables (fp32), built on the host from the bucket function
+  const m2m_t5_geometry& g = m->g;
+  const int H = g.num_heads, S = max_enc_len, L = max_dec_len;
+  std::vector<float> et((size_t)H * (2 * S - 1)), dt((size_t)H * L);
+  for (int rel = -(S - 1); rel <= S - 1; ++rel) {
+    const int bk = m2m_rel_bucket(rel, 1, g.num_buckets, g.max_distance);
+    for (int h = 0; h < H; ++h) et[(size_t)h * (2 * S - 1) + rel + S - 1] = m->enc_rel_bias_host[(size_t)bk * H + h];
+  }
+  for (int n = 0; n < L; ++n) {
+    const int bk = m2m_rel_bucket(-n, 0, g.num_buckets, g.max_distance);
+    for (int h = 0; h < H; ++h) dt[(size_t)h * L + n] = m->dec_rel_bias_host[(size_t)bk * H + h];
+  }
+  hipError_t e = hipMemcpy(s->enc_bias_tab, et.data(), et.size() * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(s->dec_bias_tab, dt.data(), dt.size() * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemset(s->state, 0, sizeof(DecState));
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&s->state_host, sizeof(DecState), hipHostMallocDefault);
+  if (e != hipSuccess) {
+    set_error("m2m_session_create: %s", hipGetErrorString(e));
+    m2m_session_destroy(s);
+    return M2M_ERR_HIP;
+  }
+  *out = s;
+  return M2M_OK;
+}
+
+extern "C" void m2m_session_destroy(m2m_session* s) {
+  if (!s) return;
+  if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
+  if (s->graph) (void)hipGraphDestroy(s->graph);
+  if (s->ev_in) (void)hipEventDestroy(s->ev_in);
+  if (s->ev_out) (void)hipEventDestroy(s->ev_out);
+  if (s->stream) (void)hipStreamDestroy(s->stream);
+  if (s->state_host) (void)hipHostFree(s->state_host);
+  delete s;
+}
+
+// ----------------------------------------------------------------- encode ---
+extern "C" int m2m_encode(m2m_session* s, const float* inputs_embeds_dev, int B, int S, float* enc_out_dev, void* stream) {
+  M2M_REQUIRE(s && inputs_embeds_dev, "m2m_encode: null argument");
+  M2M_REQUIRE(B >= 1 && B <= s->max_batch, "m2m_encode: batch %d exceeds session max_batch %d", B, s->max_batch);
+  M2M_REQUIRE(S >= 1 && S <= s->max_enc, "m2m_encode: S=%d exceeds session max_enc_len %d", S, s->max_enc);
+  const m2m_model* m = s->m;
+  const m2m_t5_geometry& g = m->g;
+  const int P = m->precision;
+  hipStream_t st = (hipStream_t)stream;
+  const int M = B * S, d = g.d_model;
+  s->encoded = false;
+  M2M_CHECK_HIP(hipMemcpyAsync(s->x_enc, inputs_embeds_dev, (size_t)M * d * 4, hipMemcpyDeviceToDevice, st));
+  int rc;
+  for (int l = 0; l < g.num_layers; ++l) {
+    const EncLayerPacked& L = m->enc[l];
+    if ((rc = launch_rmsnorm(P, s->x_enc, L.ln0, s->h_enc, M, d, g.layer_norm_eps, st))) return rc;
+    GemmArgs a{};
+    a.A = s->h_enc; a.W = L.wqkv; a.M = M; a.N = 3 * m->inner; a.K = d; a.out = s->qkv_enc;
+    a.Bsz = B; a.S = S; a.H = g.num_heads; a.inner = m->inner;
+    if ((rc = launch_gemm(P, EPI_HEADS, a, st))) return rc;
+    if ((rc = launch_enc_attn(P, s->qkv_enc, s->enc_bias_tab, 2 * s->max_enc - 1, s->max_enc - 1, s->attn_enc, B,
+                              g.num_heads, S, st))) return rc;
+    a = GemmArgs{};
+    a.A = s->attn_enc; a.W = L.wo; a.M = M; a.N = d; a.K = m->inner; a.out = s->x_enc; a.ldo = d;
+    if ((rc = launch_gemm(P, EPI_RESID, a, st))) return rc;
+    if ((rc = launch_rmsnorm(P, s->x_enc, L.ln1, s->h_enc, M, d, g.layer_norm_eps, st))) return rc;
+    a = GemmArgs{};
+    a.A = s->h_enc; a.W = L.wi; a.M = M; a.N = 2 * g.d_ff; a.K = d; a.out = s->mid_enc; a.ldo = g.d_ff;
+    if ((rc = launch_gemm(P, EPI_GATED, a, st))) return rc;
+    a = GemmArgs{};
+    a.A = s->mid_enc; a.W = L.wo_ff; a.M = M; a.N = d; a.K = g.d_ff; a.out = s->x_enc; a.ldo = d;
+    if ((rc = launch_gemm(P, EPI_RESID, a, st))) return rc;
+  }
+  // final norm -> GEMM input (T) and, if asked, the fp32 encoder states
+  if ((rc = launch_final_norm_f32(s->x_enc, m->enc_final_ln, enc_out_dev, s->h_enc, P, M, d, g.layer_norm_eps, st))) return rc;
+  // cross-attention K/V of every decoder layer in one GEMM, written in decode layout
+  GemmArgs a{};
+  a.A = s->h_enc; a.W = m->wckv; a.M = M; a.N = g.num_decoder_layers * 2 * m->inner; a.K = d; a.out = s->cross_kv;
+  a.Bsz = B; a.S = S; a.H = g.num_heads; a.inner = m->inner;
+  if ((rc = launch_gemm(P, EPI_HEADS, a, st))) return rc;
+  s->B = B; s->S = S; s->encoded = true;
+  return M2M_OK;
+}
+
+// ----------------------------------------------------------------- decode ---
+static int ensure_graph(m2m_session* s) {
+  if (s->graph_exec && s->graph_B == s->B && s->graph_S == s->S) return M2M_OK;
+  if (s->graph_exec) { (void)hipGraphExecDestroy(s->graph_exec); s->graph_exec = nullptr; }
+  if (s->graph) { (void)hipGraphDestroy(s->graph); s->graph = nullptr; }
+  M2M_CHECK_HIP(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+  int rc = decode_launch_step(s, false, nullptr, 0, s->stream);
+  hipGraph_t gph = nullptr;
+  hipError_t e = hipStreamEndCapture(s->stream, &gph);
+  if (rc != M2M_OK) { if (gph) (void)hipGraphDestroy(gph); return rc; }
+  if (e != hipSuccess) { set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return M2M_ERR_HIP; }
+  s->graph = gph;
+  M2M_CHECK_HIP(hipGraphInstantiate(&s->graph_exec, s->graph, nullptr, nullptr, 0));
+  s->graph_B = s->B; s->graph_S = s->S;
+  return M2M_OK;
+}
+
+static bool use_graph() {
+  const char* v = getenv("M2M_NO_GRAPH");
+  return !(v && v[0] == '1');
+}
+
+extern "C" int m2m_generate_greedy(m2m_session* s, int max_length, int64_t* tokens_out_dev, int* out_len_host, void* stream) {
+  M2M_REQUIRE(s && tokens_out_dev && out_len_host, "m2m_generate_greedy: null argument");
+  if (!s->encoded) { set_error("m2m_generate_greedy: call m2m_encode first"); return M2M_ERR_STATE; }
+  M2M_REQUIRE(max_length >= 1 && max_length <= s->max_dec, "m2m_generate_greedy: max_length %d outside [1, %d]", max_length, s->max_dec);
+  hipStream_t caller = (hipStream_t)stream;
+  const int steps = max_length - 1;
+  // order the session stream after whatever the caller enqueued (encode ran on the caller's stream)
+  M2M_CHECK_HIP(hipEventRecord(s->ev_in, caller));
+  M2M_CHECK_HIP(hipStreamWaitEvent(s->stream, s->ev_in, 0));
+  int rc;
+  if ((rc = decode_init(s, steps, false, s->stream))) return rc;
+  const bool graph = use_graph();
+  if (graph && (rc = ensure_graph(s))) return rc;
+  // Launch in chunks; after each chunk fetch the loop state so a batch whose rows have all
+  // emitted EOS stops early (the kernels themselves turn into no-ops once state.done is set).
+  const int CHUNK = 64;
+  int launched = 0;
+  bool done = steps == 0;
+  while (!done && launched < steps) {
+    const int n = steps - launched < CHUNK ? steps - launched : CHUNK;
+    for (int i = 0; i < n; ++i) {
+      if (graph) M2M_CHECK_HIP(hipGraphLaunch(s->graph_exec, s->stream));
+      else if ((rc = decode_launch_step(s, false, nullptr, 0, s->stream))) return rc;
+    }
+    launched += n;
+    M2M_CHECK_HIP(hipMemcpyAsync(s->state_host, s->state, sizeof(DecState), hipMemcpyDeviceToHost, s->stream));
+    M2M_CHECK_HIP(hipStreamSynchronize(s->stream));
+    done = s->state_host->done != 0;
+  }
+  M2M_CHECK_HIP(hipMemcpyAsync(s->state_host, s->state, sizeof(DecState), hipMemcpyDeviceToHost, s->stream));
+  // pack [B, max_dec] -> caller's [B, max_length]
+  M2M_CHECK_HIP(hipMemcpy2DAsync(tokens_out_dev, (size_t)max_length * 8, s->tokens, (size_t)s->max_dec * 8,
+                                 (size_t)max_length * 8, (size_t)s->B, hipMemcpyDeviceToDevice, s->stream));
+  M2M_CHECK_HIP(hipEventRecord(s->ev_out, s->stream));
+  M2M_CHECK_HIP(hipStreamWaitEvent(caller, s->ev_out, 0));
+  M2M_CHECK_HIP(hipStreamSynchronize(s->stream));
+  *out_len_host = steps == 0 ? 1 : s->state_host->out_len;
+  return M2M_OK;
+}
+
+extern "C" int m2m_decode_forced(m2m_session* s, const int64_t* dec_input_ids_dev, int Ld, float* logits_out_dev, void* stream) {
+  M2M_REQUIRE(s && dec_input_ids_dev && logits_out_dev, "m2m_decode_forced: null argument");
+  if (!s->encoded) { set_error("m2m_decode_forced: call m2m_encode first"); return M2M_ERR_STATE; }
+  M2M_REQUIRE(Ld >= 1 && Ld <= s->max_dec, "m2m_decode_forced: Ld %d outside [1, %d]", Ld, s->max_dec);
+  hipStream_t st = (hipStream_t)stream;
+  M2M_CHECK_HIP(hipMemcpyAsync(s->forced_ids, dec_input_ids_dev, (size_t)s->B * Ld * 8, hipMemcpyDeviceToDevice, st));
+  int rc;
+  if ((rc = decode_init(s, Ld, true, st))) return rc;
+  for (int t = 0; t < Ld; ++t)
+    if ((rc = decode_launch_step(s, true, logits_out_dev, Ld, st))) return rc;
+  return M2M_OK;
+}
+
+// ------------------------------------------------------------------ bench ---
+extern "C" int m2m_bench_kernel(m2m_session* s, int which, int self_len, int iters, float* avg_us_host,
+                                int64_t* bytes_host, void* stream) {
+  M2M_REQUIRE(s && avg_us_host && bytes_host && iters >= 1, "m2m_bench_kernel: bad argument");
+  if (!s->encoded) { set_error("m2m_bench_kernel: call m2m_encode first"); return M2M_ERR_STATE; }
+  M2M_REQUIRE(self_len >= 1 && self_len <= s->max_dec, "m2m_bench_kernel: self_len out of range");
+  const m2m_model* m = s->m;
+  const int Ld = m->g.num_decoder_layers;
+  hipStream_t st = s->stream;
+  hipStream_t caller = (hipStream_t)stream;
+  M2M_CHECK_HIP(hipEventRecord(s->ev_in, caller));
+  M2M_CHECK_HIP(hipStreamWaitEvent(st, s->ev_in, 0));
+  int rc;
+  // state.t = self_len - 1, not done: the kernels see a live loop in its (self_len)-th step
+  DecState hs{}; hs.t = self_len - 1; hs.done = 0; hs.out_len = 1; hs.n_unfinished = s->B; hs.max_steps = s->max_dec;
+  M2M_CHECK_HIP(hipMemcpyAsync(s->state, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
+  M2M_CHECK_HIP(hipStreamSynchronize(st));
+  hipEvent_t e0, e1;
+  M2M_CHECK_HIP(hipEventCreate(&e0));
+  M2M_CHECK_HIP(hipEventCreate(&e1));
+  const int64_t qo = (int64_t)s->B * m->inner * 4 * 2;
+  auto run = [&](int n) -> int {
+    for (int i = 0; i < n; ++i) {
+      if (which == M2M_KERNEL_DEC_CROSS_ATTN) { if ((rc = decode_launch_attn(s, false, i % Ld, 0, st))) return rc; }
+      else if (which == M2M_KERNEL_DEC_SELF_ATTN) { if ((rc = decode_launch_attn(s, true, i % Ld, self_len, st))) return rc; }
+      else {
+        // whole step: re-pin t so every replay does the same amount of work
+        M2M_CHECK_HIP(hipMemcpyAsync(s->state, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
+        if (use_graph()) { if ((rc = ensure_graph(s))) return rc; M2M_CHECK_HIP(hipGraphLaunch(s->graph_exec, st)); }
+        else if ((rc = decode_launch_step(s, false, nullptr, 0, st))) return rc;
+      }
+    }
+    return M2M_OK;
+  };
+  if (which != M2M_KERNEL_DEC_CROSS_ATTN && which != M2M_KERNEL_DEC_SELF_ATTN && which != M2M_KERNEL_DEC_STEP) {
+    set_error("m2m_bench_kernel: unknown kernel id %d", which);
+    return M2M_ERR_INVALID;
+  }
+  if ((rc = run(Ld))) return rc;  // warm-up
+  M2M_CHECK_HIP(hipEventRecord(e0, st));
+  if ((rc = run(iters))) return rc;
+  M2M_CHECK_HIP(hipEventRecord(e1, st));
+  M2M_CHECK_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  M2M_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *avg_us_host = ms * 1000.0f / (float)iters;
+  const int64_t kv_cross = (int64_t)s->B * m->inner * s->S * 2 * (int64_t)m->esize;
+  const int64_t kv_self = (int64_t)s->B * m->inner * self_len * 2 * (int64_t)m->esize;
+  if (which == M2M_KERNEL_DEC_CROSS_ATTN) *bytes_host = kv_cross + qo;
+  else if (which == M2M_KERNEL_DEC_SELF_ATTN) *bytes_host = kv_self + qo;
+  else *bytes_host = (int64_t)Ld * (kv_cross + kv_self);  // + weights: reported by the caller
+  M2M_CHECK_HIP(hipEventRecord(s->ev_out, st));
+  M2M_CHECK_HIP(hipStreamWaitEvent(caller, s->ev_out, 0));
+  return M2M_OK;
+}
