@@ -1,0 +1,129 @@
+"""Multi-GPU plumbing: one process per GPU, clips sharded by contiguous blocks.
+
+The path shards naturally — every clip has its own encoder pass, KV cache and
+EOS state (ref: music2midi/model.py:115-135 already treats chunks
+independently) — so there is no collective inside the decode loop.  Two
+collectives exist, both outside it:
+
+* a one-time broadcast of the weights from rank 0 as ONE flat buffer (RCCL
+  broadcast over xGMI; a single large message instead of ~150 small ones), and
+* one all-gather of the decoded token matrix per batch (<= 2 MiB in total), so
+  every rank returns all rows in original clip order.
+
+``backend="nccl"`` is RCCL on ROCm; ``gloo`` runs the same code on CPU tensors
+(tests/test_distributed.py, world_size 2).
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def env_world() -> Tuple[int, int, int]:
+    """(rank, local_rank, world_size) from the torchrun environment (1 process if unset)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init_process_group(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+    return rank, local_rank, world
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block partition: rank r owns [lo, hi); sizes differ by at most one."""
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def broadcast_module_state(module: torch.nn.Module, src: int = 0) -> int:
+    """Broadcast every parameter and buffer of ``module`` from ``src`` as one flat fp32 buffer.
+
+    Returns the number of bytes sent.  No-op without an initialised process group.
+    """
+    tensors = [t for t in list(module.parameters()) + list(module.buffers())]
+    seen, uniq = set(), []
+    for t in tensors:   # shared tensors (embed_tokens aliases) travel once
+        if t.data_ptr() not in seen:
+            seen.add(t.data_ptr())
+            uniq.append(t)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0
+    dev = uniq[0].device
+    flat = torch.cat([t.detach().reshape(-1).to(torch.float32) for t in uniq]).to(dev)
+    dist.broadcast(flat, src=src)
+    off = 0
+    with torch.no_grad():
+        for t in uniq:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t).to(t.dtype))
+            off += n
+    return flat.numel() * 4
+
+
+def all_gather_tokens(tokens: torch.Tensor, max_length: int, pad_id: int = 0) -> torch.Tensor:
+    """Local [B_local, L_local] ids -> global [sum B_local, L_global] in rank (= clip) order.
+
+    Rows are right-padded with ``pad_id`` to ``max_length`` for the collective, then trimmed to
+    the longest valid length over all ranks — the shape one process decoding the whole batch
+    would have returned (generation stops when EVERY row has finished).
+    """
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return tokens
+    world = dist.get_world_size()
+    B, L = tokens.shape
+    send = torch.full((B, max_length + 1), pad_id, dtype=torch.long, device=tokens.device)
+    send[:, :L] = tokens
+    send[:, max_length] = L              # carry the local valid length in the last column
+    counts = [torch.zeros(1, dtype=torch.long, device=tokens.device) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([B], dtype=torch.long, device=tokens.device))
+    sizes = [int(c.item()) for c in counts]
+    if len(set(sizes)) == 1:
+        out = torch.empty((world * B, max_length + 1), dtype=torch.long, device=tokens.device)
+        dist.all_gather_into_tensor(out, send)
+    else:                                # ragged last shard: pad to the largest block
+        bmax = max(sizes)
+        padded = torch.full((bmax, max_length + 1), pad_id, dtype=torch.long, device=tokens.device)
+        padded[:B] = send
+        parts = [torch.empty_like(padded) for _ in range(world)]
+        dist.all_gather(parts, padded)
+        out = torch.cat([p[:n] for p, n in zip(parts, sizes)], dim=0)
+    L_global = int(out[:, max_length].max().item())
+    return out[:, :L_global].contiguous()
+
+
+def barrier() -> None:
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def all_reduce_max(value: float, device) -> float:
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def all_reduce_sum(value: float, device) -> float:
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())

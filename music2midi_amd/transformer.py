@@ -330,6 +330,20 @@ class T5Transformer(nn.Module):
                                                              native.stream_handle(x.device)), "m2m_decode_forced")
             return logits
 
+    def bench_kernel(self, which: int, self_len: int, iters: int):
+        """Time one decode kernel in isolation on the current session (after an encode):
+        returns (avg microseconds per launch, algorithmic bytes per launch)."""
+        with self._lock:
+            if self._session is None:
+                raise native.NativeError("bench_kernel needs a prior generate/encode on this model")
+            us, nbytes = C.c_float(0), C.c_int64(0)
+            dev = self.transformer.device
+            with torch.cuda.device(dev):
+                native.check(native.load().m2m_bench_kernel(self._session, which, self_len, iters, C.byref(us),
+                                                            C.byref(nbytes), native.stream_handle(dev)),
+                             "m2m_bench_kernel")
+            return float(us.value), int(nbytes.value)
+
     # -- reference API -------------------------------------------------------
     def forward(self, inputs: ModelInputs, **kwargs):
         """Teacher-forced pass (ref transformer.py:28-39): labels from the tokenizer, pad -> -100,
