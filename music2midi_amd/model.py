@@ -1,0 +1,147 @@
+"""Music2MIDI — the task wrapper callers use (ref: music2midi/model.py:20-140),
+without pytorch-lightning: same constructor, ``load_from_checkpoint``,
+``generate(audio_path|audio_y, sr, cond_index)``, ``sample_tokens`` and
+``evaluate_batch``; segmentation, zero padding, chunking by
+``inference.batch_size``, conditioning broadcast, ``max_length=1024`` and the
+sequential token decode follow the reference line by line in behaviour.
+Training hooks are out of scope for the inference hot path and raise.
+"""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import Optional, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .checkpoint import load_t5_state, read_checkpoint
+from .config import load_config
+from .evaluation import evaluate_batch
+from .input import ModelInputs
+from .transformer import T5Transformer
+from .utils import numpy_to_midi
+
+
+def _load_audio(path, sr: int) -> np.ndarray:
+    """Mono float32 at ``sr``.  librosa when present (what the reference uses, model.py:84);
+    otherwise PCM WAV through the stdlib with polyphase resampling."""
+    try:
+        import librosa  # type: ignore
+        y, _ = librosa.load(str(path), sr=sr)
+        return y
+    except ImportError:
+        pass
+    import wave
+    with wave.open(str(path), "rb") as w:
+        n_ch, width, rate, n = w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()
+        raw = w.readframes(n)
+    if width == 2:
+        y = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
+    elif width == 4:
+        y = np.frombuffer(raw, dtype="<i4").astype(np.float32) / 2147483648.0
+    elif width == 1:
+        y = (np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
+    else:
+        raise ValueError(f"unsupported WAV sample width {width}")
+    y = y.reshape(-1, n_ch).mean(axis=1)
+    if rate != sr:
+        from math import gcd
+        from scipy.signal import resample_poly
+        g = gcd(int(rate), int(sr))
+        y = resample_poly(y, sr // g, rate // g).astype(np.float32)
+    return y.astype(np.float32)
+
+
+class Music2MIDI(nn.Module):
+    def __init__(self, config_path: str, precision: Optional[str] = None):
+        super().__init__()
+        self.config = load_config(config_path)
+        self.model = T5Transformer(config_path, precision=precision)
+        self.hparams = {"config_path": config_path}
+
+    # -- checkpoint ----------------------------------------------------------
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, config_path: Optional[str] = None, map_location=None,
+                             strict: bool = True, **kwargs) -> "Music2MIDI":
+        """Lightning-format ``.ckpt`` -> model (ref: evaluate.py:27, webui.py:90)."""
+        ckpt = read_checkpoint(checkpoint_path)
+        if config_path is None:
+            config_path = (ckpt.get("hyper_parameters") or {}).get("config_path", "config.yaml")
+        obj = cls(config_path, **kwargs)
+        state = ckpt["state_dict"] if "state_dict" in ckpt else ckpt
+        prefix = "model."
+        inner = {k[len(prefix):]: v for k, v in state.items() if k.startswith(prefix)}
+        load_t5_state(obj.model, inner if inner else state, strict=strict)
+        return obj
+
+    @property
+    def device(self) -> torch.device:
+        return self.model.transformer.device
+
+    # -- training surface (out of scope: SURVEY.md §8f rank 1) ----------------
+    def configure_optimizers(self):
+        raise NotImplementedError("training is not part of the MI355X inference hot path (SURVEY.md §8f)")
+
+    def training_step(self, inputs, batch_idx):
+        raise NotImplementedError("training is not part of the MI355X inference hot path (SURVEY.md §8f)")
+
+    def validation_step(self, inputs: ModelInputs, batch_idx):
+        outputs = self.model(inputs)
+        score, _, _ = self.evaluate_batch(inputs)
+        return outputs.loss, score
+
+    # -- inference -----------------------------------------------------------
+    @torch.no_grad()
+    def evaluate_batch(self, inputs: ModelInputs):
+        max_num_notes = max(len(notes) for notes in inputs.notes_batch)
+        generated_outputs = self.model.generate(inputs, max_length=max_num_notes * 4)
+        decoded_notes = self.model.tokenizer.decode(generated_outputs, mode="batched")
+        label_midi = [numpy_to_midi(notes) for notes in inputs.notes_batch]
+        output_midi = [numpy_to_midi(notes) for notes in decoded_notes]
+        metrics = evaluate_batch(label_midi, output_midi)
+        return metrics, output_midi, label_midi
+
+    def generate(self, audio_path: Optional[Union[str, Path]] = None, audio_y: Optional[np.ndarray] = None,
+                 sr: Optional[int] = None, cond_index: Optional[list] = None):
+        """Specify either audio_path or audio_y as input; returns a MIDI object."""
+        return numpy_to_midi(self.generate_notes(audio_path, audio_y, sr, cond_index))
+
+    def generate_notes(self, audio_path=None, audio_y=None, sr=None, cond_index=None) -> np.ndarray:
+        if audio_path is None and audio_y is None:
+            raise ValueError("Either audio_path or audio_y should be specified")
+        if sr is None:
+            sr = self.config.model.sample_rate
+        else:
+            assert sr == self.config.model.sample_rate
+        if audio_y is None:
+            audio_y = _load_audio(audio_path, sr)
+        # pad with zeros to a whole number of segments (ref model.py:86-90)
+        split_size = int(sr * self.config.dataset.segment_duration)
+        n_seg = int(np.ceil(len(audio_y) / split_size))
+        audio_y = np.pad(np.asarray(audio_y, dtype=np.float32), (0, n_seg * split_size - len(audio_y)), "constant")
+        waveform = torch.from_numpy(audio_y).to(self.device)
+        return self.sample_tokens(waveform, split_size, split_duration=self.config.dataset.segment_duration,
+                                  cond_index=cond_index)
+
+    @torch.no_grad()
+    def sample_tokens(self, waveform: torch.Tensor, split_size: int, split_duration: float,
+                      cond_index: Optional[list] = None) -> np.ndarray:
+        """Segments -> chunks of inference.batch_size -> generate(max_length=1024) -> notes."""
+        n_embeds = len(self.model.conditioning.embeds)
+        segments = torch.split(waveform, split_size)
+        chunk = int(self.config.inference.batch_size)
+        tokens_list = []
+        for i in range(0, len(segments), chunk):
+            batch = segments[i:i + chunk]
+            width = max(len(s) for s in batch)
+            input_wav = torch.zeros((len(batch), width), dtype=waveform.dtype, device=self.device)
+            for r, s in enumerate(batch):
+                input_wav[r, : len(s)] = s
+            cond = torch.zeros((len(batch), n_embeds))
+            if cond_index is not None:
+                cond = cond + torch.Tensor(cond_index)
+            cond = cond.long().to(self.device)
+            tokens = self.model.generate(ModelInputs(input_waveform=input_wav, cond_index=cond), max_length=1024)
+            tokens_list += [*tokens]
+        return self.model.tokenizer.decode(tokens_list, mode="sequential", duration_per_batch=split_duration)

@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ (run in the BUILD container only).
+
+    python tests/golden/make_golden.py
+
+The reference has no tests or fixtures of its own, so the vectors
+are produced here by the real third-party code the reference calls, as far as it
+is importable in this container:
+
+* HuggingFace ``T5ForConditionalGeneration`` (transformers 5.15.0) forced to
+  eager attention with an untied ``lm_head`` (= the pinned 4.34.0 semantics,
+  SURVEY.md §0.3), built from the reference's own ``config.yaml`` ``model.t5``
+  section  -> encoder states, teacher-forced logits, greedy ids.
+* ``torch.stft`` for the STFT half of the frontend; the mel filterbank half is the
+  restated torchaudio formula (torchaudio is absent: "filterbank parity unpinned").
+* The reference's ``music2midi/tokenizer.py`` itself, imported from
+  /root/reference under three shims (numba.njit -> identity, omegaconf.DictConfig
+  -> dict, np.float_ -> np.float64) with bytecode writing disabled.
+
+Only inputs/outputs are stored (weights and waveforms are regenerated from
+music2midi_amd.synth seeds); no reference source text is copied.
+"""
+from __future__ import annotations
+
+import importlib.util
+import json
+import sys
+import types
+from pathlib import Path
+
+sys.dont_write_bytecode = True
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parents[1]
+sys.path.insert(0, str(ROOT))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import yaml  # noqa: E402
+
+from music2midi_amd import synth  # noqa: E402
+from music2midi_amd.config import ConfigNode, T5Geometry  # noqa: E402
+from oracle.logmel import LogMelOracle, melscale_fbanks  # noqa: E402
+from oracle.t5 import T5Oracle  # noqa: E402
+
+REF = Path("/root/reference")
+
+
+# ------------------------------------------------------------------ helpers
+def ref_config() -> dict:
+    return yaml.safe_load((REF / "config.yaml").read_text())
+
+
+def tiny_t5(cfg: dict) -> dict:
+    t5 = dict(cfg["model"]["t5"])
+    t5.update(d_model=128, d_ff=256, num_layers=2, num_decoder_layers=2, num_heads=2)
+    return t5
+
+
+def build_hf(t5cfg: dict, sd: dict):
+    from transformers import T5Config, T5ForConditionalGeneration
+    cfg = T5Config(**t5cfg)
+    cfg._attn_implementation = "eager"
+    m = T5ForConditionalGeneration(cfg)
+    m.config.tie_word_embeddings = False
+    m.lm_head.weight = torch.nn.Parameter(torch.zeros_like(m.lm_head.weight))   # untie (4.34.0)
+    hf_sd = {k[len("transformer."):]: torch.from_numpy(v) for k, v in sd.items() if k.startswith("transformer.")}
+    hf_sd["encoder.embed_tokens.weight"] = hf_sd["shared.weight"]
+    hf_sd["decoder.embed_tokens.weight"] = hf_sd["shared.weight"]
+    missing, unexpected = m.load_state_dict(hf_sd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    assert m.lm_head.weight.data_ptr() != m.shared.weight.data_ptr()
+    assert getattr(m.config, "scale_decoder_outputs", False) is False
+    return m.eval()
+
+
+def import_reference_tokenizer():
+    numba = types.ModuleType("numba")
+    numba.njit = lambda f=None, **k: (f if f is not None else (lambda g: g))
+    omegaconf = types.ModuleType("omegaconf")
+    omegaconf.DictConfig = dict
+    sys.modules.setdefault("numba", numba)
+    sys.modules.setdefault("omegaconf", omegaconf)
+    if not hasattr(np, "float_"):
+        np.float_ = np.float64
+    spec = importlib.util.spec_from_file_location("ref_tokenizer", REF / "music2midi" / "tokenizer.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def embeds(B, S, d, seed=7):
+    return torch.from_numpy(synth.normal(seed, "embeds", (B, S, d), 3.0))
+
+
+# ------------------------------------------------------------------ T5 goldens
+def t5_case(name, t5cfg, B, S, L, Ld, eos, out):
+    geom = T5Geometry(t5cfg)
+    sd = synth.t5_state_dict(geom, seed=0)
+    synth.perturb_layer_norms(sd, 0)
+    if eos:
+        synth.force_eos_head(sd, geom)
+    hf = build_hf(t5cfg, sd)
+    orc = T5Oracle(geom, sd)
+    x = embeds(B, S, geom.d_model)
+    with torch.no_grad():
+        enc = hf.encoder(inputs_embeds=x).last_hidden_state
+        ids = hf.generate(inputs_embeds=x, max_length=L, do_sample=False)
+        labels = torch.from_numpy((synth.uniform01(3, "labels", B * Ld) * 330).astype(np.int64).reshape(B, Ld)) + 3
+        labels[0, Ld - 3:] = -100   # exercise ignore_index
+        fw = hf(inputs_embeds=x, labels=labels)
+    # pin the oracle against HF right here
+    o_enc = orc.encode(x)
+    o_ids, margins = orc.generate(x, L, return_margins=True)
+    o_loss, o_logits = orc.forward(x, labels)
+    assert torch.equal(ids, o_ids), f"{name}: oracle greedy ids differ from HF"
+    assert (enc - o_enc).abs().max() < 1e-4
+    assert (fw.logits - o_logits).abs().max() < 2e-3 and abs(fw.loss.item() - o_loss.item()) < 1e-4
+    print(f"[{name}] ids {tuple(ids.shape)} min margin {margins.min():.4f} | enc diff {(enc - o_enc).abs().max():.2e} "
+          f"| logits diff {(fw.logits - o_logits).abs().max():.2e}")
+    rows = sorted({0, 1, S // 2, S - 1})
+    out[name] = dict(
+        ids=ids.numpy().astype(np.int16), margins=margins.numpy().astype(np.float32),
+        enc_rows=np.asarray(rows, dtype=np.int32), enc_sample=enc[:, rows].numpy().astype(np.float32),
+        enc_abs_sum=np.float64(enc.double().abs().sum().item()),
+        labels=labels.numpy().astype(np.int16), loss=np.float32(fw.loss.item()),
+        logits_sample=fw.logits[:, :: max(1, Ld // 4)].numpy().astype(np.float32),
+        meta=np.asarray([B, S, L, Ld, int(eos)], dtype=np.int32))
+
+
+def make_t5(out_path):
+    cfg = ref_config()
+    full, tiny = dict(cfg["model"]["t5"]), tiny_t5(cfg)
+    cases = {}
+    t5_case("tiny", tiny, 3, 19, 40, 12, False, cases)
+    t5_case("tiny_eos", tiny, 5, 30, 64, 8, True, cases)
+    t5_case("full_s190", full, 2, 190, 128, 24, False, cases)
+    t5_case("full_eos", full, 4, 60, 96, 8, True, cases)
+    t5_case("full_s864", full, 2, 864, 1024, 8, False, cases)
+    flat = {f"{c}/{k}": v for c, d in cases.items() for k, v in d.items()}
+    np.savez_compressed(out_path, **flat)
+
+
+# ------------------------------------------------------------------ frontend goldens
+def make_frontend(out_path):
+    cfg = ref_config()
+    sr, n_mels = cfg["model"]["sample_rate"], cfg["model"]["t5"]["d_model"]
+    sp = cfg["spectrogram"]
+    fb = melscale_fbanks(sp["n_fft"] // 2 + 1, sp["f_min"], float(sr // 2), n_mels, sr).numpy()
+    r, c = np.nonzero(fb)
+    orc = LogMelOracle(sr, sp["n_fft"], sp["hop_length"], sp["f_min"], n_mels)
+    data = dict(fb_rows=r.astype(np.int16), fb_cols=c.astype(np.int16), fb_vals=fb[r, c].astype(np.float32),
+                fb_shape=np.asarray(fb.shape, dtype=np.int32))
+    for kind in ("noise", "tones", "zeros"):
+        wav = torch.from_numpy(synth.waveform_batch(0, 2, 4096, kind))
+        data[f"logmel_{kind}"] = orc(wav).numpy().astype(np.float32)             # [2, 17, 384]
+        data[f"logmel64_{kind}"] = orc(wav, dtype=torch.float64).numpy().astype(np.float32)
+    wav = torch.from_numpy(synth.waveform_batch(5, 1, 48000, "noise"))
+    full = orc(wav)
+    data["logmel_noise_48000_frames"] = np.asarray([0, 1, 94, 187], dtype=np.int32)
+    data["logmel_noise_48000"] = full[:, [0, 1, 94, 187]].numpy().astype(np.float32)
+    print(f"[frontend] fb nnz {len(r)} taps/filter min {np.bincount(c).min()} max {np.bincount(c).max()}")
+    np.savez_compressed(out_path, **data)
+
+
+# ------------------------------------------------------------------ tokenizer goldens
+def random_notes(seed, n, max_t=9.5):
+    u = synth.uniform01(seed, "notes", n * 4).reshape(n, 4)
+    onset = np.sort(u[:, 0] * max_t)
+    dur = u[:, 1] * 1.2
+    dur[u[:, 3] < 0.15] = 0.0          # zero-length notes -> min one step
+    pitch = np.floor(21 + u[:, 2] * 88)
+    return np.stack([onset, onset + dur, pitch, np.full(n, 80.0)], axis=1)
+
+
+def make_tokenizer(out_path):
+    ref = import_reference_tokenizer()
+    cfg = ref_config()
+    tok = ref.MidiTokenizer(ConfigNode(cfg))
+    cases = []
+    note_sets = {
+        "empty": np.zeros((0, 4)),
+        "single": np.array([[0.0, 0.5, 60, 80]]),
+        "chord": np.array([[0.0, 0.5, 60, 80], [0.0, 0.5, 64, 80], [0.0, 1.0, 67, 80]]),
+        "tie_half_step": np.array([[0.025, 0.075, 60, 80], [0.125, 0.175, 61, 80]]),
+        "clip_late": np.array([[9.9, 10.5, 72, 80], [11.0, 12.0, 73, 80]]),
+        "zero_len": np.array([[1.0, 1.0, 50, 80], [1.0, 0.9, 51, 80]]),
+        "rand12": random_notes(1, 12), "rand40": random_notes(2, 40), "rand90": random_notes(3, 90, 2.9),
+    }
+    for name, notes in note_sets.items():
+        for cutoff in (None, 3):
+            ids = tok._tokenize(notes, cutoff).numpy().tolist()
+            cases.append(dict(kind="encode", name=name, cutoff=cutoff, notes=notes.tolist(), ids=ids))
+    batch = [note_sets["rand12"], note_sets["empty"], note_sets["chord"]]
+    cases.append(dict(kind="encode_batch", notes=[b.tolist() for b in batch], ids=tok(batch).numpy().tolist()))
+    # decode vectors: valid streams, streams with garbage, unmatched onsets, ids in the unused 333..399 range
+    streams = [tok._tokenize(note_sets[k]).numpy() for k in ("rand12", "rand40", "chord", "zero_len", "empty")]
+    rnd = (synth.uniform01(9, "stream", 3 * 200).reshape(3, 200) * 400).astype(np.int64)
+    rnd[0, 150] = 2
+    streams += [rnd[0], rnd[1], rnd[2], np.array([1, 133, 3, 65, 66, 140, 4, 65, 0, 0, 2, 150, 3, 70])]
+    for i, s in enumerate(streams):
+        for cutoff in (None, 3):
+            notes = tok._decode(np.array(s), 0, cutoff)
+            cases.append(dict(kind="decode", name=f"s{i}", cutoff=cutoff, ids=np.asarray(s).tolist(), notes=notes.tolist()))
+    seq = tok.decode([streams[0], streams[2], streams[5]], mode="sequential", duration_per_batch=3)
+    cases.append(dict(kind="decode_sequential", duration=3, ids=[np.asarray(s).tolist() for s in (streams[0], streams[2], streams[5])],
+                      notes=seq.tolist()))
+    bat = tok.decode(torch.tensor(tok(batch)), mode="batched")
+    cases.append(dict(kind="decode_batched", ids=tok(batch).numpy().tolist(), notes=[b.tolist() for b in bat]))
+    cases.append(dict(kind="to_string", ids=[0, 1, 2, 3, 4, 5, 132, 133, 332], names=tok.to_string(np.array([0, 1, 2, 3, 4, 5, 132, 133, 332]))))
+    out_path.write_text(json.dumps(cases))
+    print(f"[tokenizer] {len(cases)} cases")
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    make_tokenizer(HERE / "tokenizer_cases.json")
+    make_frontend(HERE / "frontend.npz")
+    make_t5(HERE / "t5.npz")
+    for p in sorted(HERE.glob("*.npz")) + sorted(HERE.glob("*.json")):
+        print(p.name, p.stat().st_size, "bytes")
+    # never leave bytecode in the read-only reference tree
+    assert not (REF / "music2midi" / "__pycache__").exists()

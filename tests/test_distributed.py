@@ -1,0 +1,72 @@
+"""CPU: the N>1 path (shard -> broadcast -> all-gather -> original order) with gloo, world_size 2."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from music2midi_amd import distributed as D
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, ragged, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    r, _, w = D.init_process_group("gloo")
+    assert (r, w) == (rank, world)
+    # 1. weight broadcast: rank 0's values win, aliases travel once
+    torch.manual_seed(100 + rank)
+    emb = torch.nn.Embedding(7, 4)
+    mod = torch.nn.ModuleDict({"a": emb, "alias": emb, "l": torch.nn.Linear(4, 3)})
+    mod.register_buffer("buf", torch.full((5,), float(rank)))
+    nbytes = D.broadcast_module_state(mod, src=0)
+    torch.manual_seed(100)
+    ref_emb = torch.nn.Embedding(7, 4)
+    ref_lin = torch.nn.Linear(4, 3)
+    assert torch.equal(mod["a"].weight, ref_emb.weight) and torch.equal(mod["l"].weight, ref_lin.weight)
+    assert torch.equal(mod.buf, torch.zeros(5)) and nbytes == (28 + 12 + 3 + 5) * 4
+    # 2. clip sharding + token all-gather back into clip order
+    n_clips, max_len = (7 if ragged else 8), 12
+    lo, hi = D.shard_range(n_clips, rank, world)
+    L_local = 5 + 3 * rank                      # ranks stop at different lengths
+    toks = torch.zeros((hi - lo, L_local), dtype=torch.long)
+    for i, clip in enumerate(range(lo, hi)):
+        toks[i] = torch.arange(L_local) + 100 * clip
+    out = D.all_gather_tokens(toks, max_len, pad_id=0)
+    assert out.shape == (n_clips, 5 + 3 * (world - 1))
+    for clip in range(n_clips):
+        owner = next(r_ for r_ in range(world) if D.shard_range(n_clips, r_, world)[0] <= clip < D.shard_range(n_clips, r_, world)[1])
+        L = 5 + 3 * owner
+        assert torch.equal(out[clip, :L], torch.arange(L) + 100 * clip) and (out[clip, L:] == 0).all()
+    assert D.all_reduce_max(float(rank), "cpu") == world - 1 and D.all_reduce_sum(1.0, "cpu") == world
+    D.barrier()
+    dist.destroy_process_group()
+    q.put(rank)
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_gloo_world2_broadcast_and_token_gather(ragged):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ragged, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]
+
+
+def test_single_process_paths_are_noops():
+    t = torch.arange(6).reshape(2, 3)
+    assert D.all_gather_tokens(t, 8) is t
+    assert D.broadcast_module_state(torch.nn.Linear(2, 2)) == 0
+    assert D.all_reduce_max(3.0, "cpu") == 3.0
