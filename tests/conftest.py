@@ -12,6 +12,13 @@ GOLDEN = ROOT / "tests" / "golden"
 
 
 def pytest_configure(config):
+    # the oracle's matmuls are tiny: on a 256-core host the default 128 intra-op threads are
+    # ~5x slower than 16 (thread fan-out dominates); results do not depend on the thread count.
+    try:
+        import torch
+        torch.set_num_threads(min(16, torch.get_num_threads()))
+    except Exception:
+        pass
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 
