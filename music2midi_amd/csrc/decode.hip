@@ -2,10 +2,15 @@
 // generate() that ref: music2midi/transformer.py:44 drives (hf: generation/utils.py:2876-2937,
 // one T5 decoder forward hf: models/t5/modeling_t5.py:448-509,1031-1047 per token, ~60 vendor
 // kernel launches and a host sync each).  Here a step is a fixed sequence of kernels that read
-// the step index from device memory, so the whole loop replays one captured hipGraph with no
+// the step index from device memory, so the whole loop replays captured hipGraphs with no
 // host round trip; finished-row bookkeeping (pad after EOS) lives in device memory.
 //
-//   dec_gemm_kernel  skinny projection  out[B<=32 rows, 32 cols] per workgroup, 4 waves split K,
+// Clips are independent, so a batch is decoded as several independent CHAINS ("views": a
+// contiguous range of clips with its own step counter, stream and graph).  One chain's kernels
+// are latency-bound (12..72 workgroups each); running several chains side by side fills the
+// 256 CUs and overlaps one chain's HBM-bound attention with another chain's projections.
+//
+//   dec_gemm_kernel  skinny projection  out[<=32 rows, 32 cols] per workgroup, 8 waves split K,
 //                    MFMA 32x32 tiles; optional fused RMSNorm on the input rows; epilogues:
 //                    QKV (+KV-cache append), plain, residual-add, gated-GELU, logits.
 //   dec_attn_kernel  one (clip, head) per 1024-thread workgroup streams K then V straight from
@@ -21,90 +26,118 @@ namespace m2m {
 enum { DEPI_QKV = 0, DEPI_PLAIN = 1, DEPI_RESID = 2, DEPI_GATED = 3 };
 
 struct DecGemmArgs {
-  const float* x;        // [rows, K] fp32 input activations
+  const void* x;         // [rows, K] input activations: fp32 (normed epilogues) or T (DEPI_RESID)
   int ldx;
-  const float* ln_w;     // [K] RMSNorm weight, or nullptr (no norm)
+  const float* ln_w;     // [K] RMSNorm weight (QKV / PLAIN / GATED), unused for RESID
   float eps;
   const void* W;         // [Npad, K] T
   int K, N, B;
   const DecState* state;
   // outputs
-  float* out;            // PLAIN: [B, N]; RESID: x_res [B, N] (+=); GATED: [B, N/2]; QKV: q [B, inner]
+  void* out;             // PLAIN: float [B, N]; RESID: float x_res [B, N] (+=); GATED: T [B, N/2]; QKV: float q [B, inner]
   int ldo;
   void* kcache;          // QKV: [B][H][Lmax][64] T for this layer
   void* vcache;
   int H, Lmax, inner;
 };
 
+// 512 threads = 8 waves, each owning K/8 of the reduction (<= 9 macro steps of 16).  Every global
+// load of the workgroup (weights, activations, norm weights, loop state) is issued before the
+// first use, so a launch costs about one memory round trip instead of one per k-step; the
+// RMSNorm statistics are reduced across waves through LDS while the weight loads are in flight.
+constexpr int DG_WAVES = 8;
+constexpr int DG_MAXS = 9;   // K <= 8 * 9 * 16 = 1152
+
 template <typename T, int EPI>
-__global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmArgs a) {
-  __shared__ float rstd_s[32];
-  __shared__ float red[4][32 * 33];
-  if (a.state->done) return;
+__global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
+  constexpr bool NORM = (EPI != DEPI_RESID);
+  __shared__ float ss_s[DG_WAVES][32];
+  __shared__ float red[DG_WAVES][32 * 33];
+  const int done = a.state->done;   // consumed only before the stores
+  const int t = a.state->t;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int n0 = blockIdx.x * 32;
   const int b0 = blockIdx.y * 32;
   const int K = a.K;
   const T* W = reinterpret_cast<const T*>(a.W);
-
-  // ---- per-row 1/rms (8 threads per row) ----
-  if (a.ln_w) {
-    const int row = tid >> 3, part = tid & 7;
-    float ss = 0.f;
-    if (b0 + row < a.B) {
-      const float* xr = a.x + (int64_t)(b0 + row) * a.ldx;
-      for (int c = part * 4; c < K; c += 32) {
-        const float4 v = *reinterpret_cast<const float4*>(xr + c);
-        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-      }
-    }
-    ss += __shfl_xor(ss, 1, 64);
-    ss += __shfl_xor(ss, 2, 64);
-    ss += __shfl_xor(ss, 4, 64);
-    if (part == 0) rstd_s[row] = rsqrtf(ss / (float)K + a.eps);
-    __syncthreads();
-  }
-
-  // ---- each wave owns a quarter of K ----
-  const int kq = K / 4;
-  const int kbeg = wave * kq;
+  const int ks = K / DG_WAVES;          // multiple of 16
+  const int ns = ks / 16;               // <= DG_MAXS
+  const int kbeg = wave * ks + 8 * h;
   const bool row_ok = (b0 + r) < a.B;
-  const float* xr = a.x + (int64_t)(b0 + (row_ok ? r : 0)) * a.ldx;
-  const float rs = a.ln_w ? rstd_s[r] : 1.0f;
-  const T* wr = W + (int64_t)(n0 + r) * K;
-  f32x16 acc = zero_acc();
-  for (int k = kbeg; k < kbeg + kq; k += 16) {
-    const int kk = k + 8 * h;
-    Frag<T> fb = load_frag(wr + kk);
-    float xv[8];
-    if (row_ok) {
-      const float4 x0 = *reinterpret_cast<const float4*>(xr + kk);
-      const float4 x1 = *reinterpret_cast<const float4*>(xr + kk + 4);
-      xv[0] = x0.x; xv[1] = x0.y; xv[2] = x0.z; xv[3] = x0.w;
-      xv[4] = x1.x; xv[5] = x1.y; xv[6] = x1.z; xv[7] = x1.w;
-      if (a.ln_w) {
-        const float4 g0 = *reinterpret_cast<const float4*>(a.ln_w + kk);
-        const float4 g1 = *reinterpret_cast<const float4*>(a.ln_w + kk + 4);
-        xv[0] = g0.x * (xv[0] * rs); xv[1] = g0.y * (xv[1] * rs); xv[2] = g0.z * (xv[2] * rs); xv[3] = g0.w * (xv[3] * rs);
-        xv[4] = g1.x * (xv[4] * rs); xv[5] = g1.y * (xv[5] * rs); xv[6] = g1.z * (xv[6] * rs); xv[7] = g1.w * (xv[7] * rs);
-      }
-    } else {
+  const T* wr = W + (int64_t)(n0 + r) * K + kbeg;
+
+  Frag<T> wf[DG_MAXS];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) xv[j] = 0.f;
+  for (int s = 0; s < DG_MAXS; ++s)
+    if (s < ns) wf[s] = load_frag(wr + 16 * s);
+
+  f32x16 acc = zero_acc();
+  if constexpr (NORM) {
+    const float* xr = reinterpret_cast<const float*>(a.x) + (int64_t)(b0 + (row_ok ? r : 0)) * a.ldx + kbeg;
+    float4 x0[DG_MAXS], x1[DG_MAXS], g0[DG_MAXS], g1[DG_MAXS];
+#pragma unroll
+    for (int s = 0; s < DG_MAXS; ++s) {
+      if (s < ns) {
+        if (row_ok) {
+          x0[s] = *reinterpret_cast<const float4*>(xr + 16 * s);
+          x1[s] = *reinterpret_cast<const float4*>(xr + 16 * s + 4);
+        } else {
+          x0[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+          x1[s] = x0[s];
+        }
+        g0[s] = *reinterpret_cast<const float4*>(a.ln_w + kbeg + 16 * s);
+        g1[s] = *reinterpret_cast<const float4*>(a.ln_w + kbeg + 16 * s + 4);
+      }
     }
-    const Frag<T> fa = pack_frag<T>(xv);
-    mma16(acc, fa, fb);
+    float ss = 0.f;
+#pragma unroll
+    for (int s = 0; s < DG_MAXS; ++s)
+      if (s < ns)
+        ss += x0[s].x * x0[s].x + x0[s].y * x0[s].y + x0[s].z * x0[s].z + x0[s].w * x0[s].w +
+              x1[s].x * x1[s].x + x1[s].y * x1[s].y + x1[s].z * x1[s].z + x1[s].w * x1[s].w;
+    ss += __shfl_xor(ss, 32, 64);
+    if (h == 0) ss_s[wave][r] = ss;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < DG_WAVES; ++w) tot += ss_s[w][r];
+    const float rs = rsqrtf(tot / (float)K + a.eps);
+#pragma unroll
+    for (int s = 0; s < DG_MAXS; ++s) {
+      if (s < ns) {
+        const float xv[8] = {g0[s].x * (x0[s].x * rs), g0[s].y * (x0[s].y * rs), g0[s].z * (x0[s].z * rs),
+                             g0[s].w * (x0[s].w * rs), g1[s].x * (x1[s].x * rs), g1[s].y * (x1[s].y * rs),
+                             g1[s].z * (x1[s].z * rs), g1[s].w * (x1[s].w * rs)};
+        const Frag<T> fa = pack_frag<T>(xv);
+        mma16(acc, fa, wf[s]);
+      }
+    }
+  } else {
+    const T* xr = reinterpret_cast<const T*>(a.x) + (int64_t)(b0 + (row_ok ? r : 0)) * a.ldx + kbeg;
+    Frag<T> xf[DG_MAXS];
+#pragma unroll
+    for (int s = 0; s < DG_MAXS; ++s)
+      if (s < ns) xf[s] = row_ok ? load_frag(xr + 16 * s) : zero_frag<T>();
+#pragma unroll
+    for (int s = 0; s < DG_MAXS; ++s)
+      if (s < ns) mma16(acc, xf[s], wf[s]);
   }
   // ---- cross-wave reduction (fixed order: deterministic) ----
 #pragma unroll
   for (int i = 0; i < 16; ++i) red[wave][acc_row(i, lane) * 33 + r] = acc[i];
   __syncthreads();
+  if (done) return;
 
-  const int t = a.state->t;
+  auto rsum = [&](int idx) {
+    float v = red[0][idx];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int e = tid + i * 256;
+    for (int w = 1; w < DG_WAVES; ++w) v += red[w][idx];
+    return v;
+  };
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = tid + i * 512;
     const int row = e >> 5, col = e & 31;
     const int b = b0 + row;
     if (b >= a.B) continue;
@@ -112,24 +145,23 @@ __global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmArgs a) {
     if constexpr (EPI == DEPI_GATED) {
       // tile columns: [16 of wi_0 | the matching 16 of wi_1]
       if (col < 16) {
-        const float v0 = ((red[0][idx] + red[1][idx]) + red[2][idx]) + red[3][idx];
-        const int idx1 = idx + 16;
-        const float v1 = ((red[0][idx1] + red[1][idx1]) + red[2][idx1]) + red[3][idx1];
+        const float v0 = rsum(idx), v1 = rsum(idx + 16);
         const int oc = (n0 >> 1) + col;
-        if (2 * oc < a.N) a.out[(int64_t)b * a.ldo + oc] = gelu_new(v0) * v1;
+        if (2 * oc < a.N) reinterpret_cast<T*>(a.out)[(int64_t)b * a.ldo + oc] = from_f32<T>(gelu_new(v0) * v1);
       }
     } else {
       const int n = n0 + col;
       if (n >= a.N) continue;
-      const float v = ((red[0][idx] + red[1][idx]) + red[2][idx]) + red[3][idx];
+      const float v = rsum(idx);
+      float* outf = reinterpret_cast<float*>(a.out);
       if constexpr (EPI == DEPI_PLAIN) {
-        a.out[(int64_t)b * a.ldo + n] = v;
+        outf[(int64_t)b * a.ldo + n] = v;
       } else if constexpr (EPI == DEPI_RESID) {
-        a.out[(int64_t)b * a.ldo + n] += v;
+        outf[(int64_t)b * a.ldo + n] += v;
       } else {  // DEPI_QKV
         const int which = n / a.inner, rem = n - which * a.inner;
         if (which == 0) {
-          a.out[(int64_t)b * a.ldo + rem] = v;
+          outf[(int64_t)b * a.ldo + rem] = v;
         } else {
           const int hh = rem / DK, dd = rem - hh * DK;
           T* cache = reinterpret_cast<T*>(which == 1 ? a.kcache : a.vcache);
@@ -145,10 +177,10 @@ static int launch_dec_gemm_t(int epi, const DecGemmArgs& a, hipStream_t st) {
   const int npad = ceil_div(a.N, 32) * 32;
   dim3 grid((unsigned)(npad / 32), (unsigned)ceil_div(a.B, 32));
   switch (epi) {
-    case DEPI_QKV: hipLaunchKernelGGL((dec_gemm_kernel<T, DEPI_QKV>), grid, dim3(256), 0, st, a); break;
-    case DEPI_PLAIN: hipLaunchKernelGGL((dec_gemm_kernel<T, DEPI_PLAIN>), grid, dim3(256), 0, st, a); break;
-    case DEPI_RESID: hipLaunchKernelGGL((dec_gemm_kernel<T, DEPI_RESID>), grid, dim3(256), 0, st, a); break;
-    case DEPI_GATED: hipLaunchKernelGGL((dec_gemm_kernel<T, DEPI_GATED>), grid, dim3(256), 0, st, a); break;
+    case DEPI_QKV: hipLaunchKernelGGL((dec_gemm_kernel<T, DEPI_QKV>), grid, dim3(512), 0, st, a); break;
+    case DEPI_PLAIN: hipLaunchKernelGGL((dec_gemm_kernel<T, DEPI_PLAIN>), grid, dim3(512), 0, st, a); break;
+    case DEPI_RESID: hipLaunchKernelGGL((dec_gemm_kernel<T, DEPI_RESID>), grid, dim3(512), 0, st, a); break;
+    case DEPI_GATED: hipLaunchKernelGGL((dec_gemm_kernel<T, DEPI_GATED>), grid, dim3(512), 0, st, a); break;
     default: return M2M_ERR_INVALID;
   }
   M2M_CHECK_HIP(hipGetLastError());
@@ -169,7 +201,7 @@ struct DecAttnArgs {
   int self_len_override; // bench only
   const float* bias;     // self: [H][Lmax] by n = q_pos - k_pos ; cross: nullptr
   int bias_stride;
-  float* out;            // [B, inner] fp32
+  void* out;             // [B, inner] T (input of the output projection)
   int H, inner;
   const DecState* state;
   int is_self;
@@ -295,7 +327,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
     float s = 0.f;
 #pragma unroll
     for (int w = 0; w < 16; ++w) s += redo[w][tid];
-    a.out[(int64_t)b * a.inner + hh * DK + tid] = s / bcast[1];
+    reinterpret_cast<T*>(a.out)[(int64_t)b * a.inner + hh * DK + tid] = from_f32<T>(s / bcast[1]);
   }
 }
 
@@ -337,6 +369,7 @@ __global__ __launch_bounds__(1024) void dec_head_kernel(DecHeadArgs a) {
   __syncthreads();
   for (int b = wave; b < a.B; b += 16) {
     const float* lg = a.logits + (int64_t)b * a.ldl;
+    const int fin = a.forced ? 0 : a.finished[b];
     float best = -INFINITY;
     int bi = 0x7fffffff;
     for (int v = lane; v < a.V; v += 64) {
@@ -356,7 +389,6 @@ __global__ __launch_bounds__(1024) void dec_head_kernel(DecHeadArgs a) {
       next = (t + 1 < a.Ld) ? (int)a.forced[(int64_t)b * a.Ld + t + 1] : a.pad_id;
     } else {
       // hf generation/utils.py:2925-2937: argmax; finished rows emit pad; EOS finishes a row
-      const int fin = a.finished[b];
       next = fin ? a.pad_id : (bi == 0x7fffffff ? 0 : bi);
       if (lane == 0) {
         if (t + 1 < a.max_len) a.tokens[(int64_t)b * a.max_len + t + 1] = next;
@@ -377,8 +409,7 @@ __global__ __launch_bounds__(1024) void dec_head_kernel(DecHeadArgs a) {
       if (nt >= a.Ld) stp->done = 1;
     } else {
       stp->n_unfinished = s_unfinished;
-      if (s_unfinished == 0) { stp->done = 1; stp->out_len = nt + 1; }
-      else if (nt >= stp->max_steps) { stp->done = 1; stp->out_len = nt + 1; }
+      if (s_unfinished == 0 || nt >= stp->max_steps) { stp->done = 1; stp->out_len = nt + 1; }
     }
   }
 }
@@ -402,19 +433,22 @@ __global__ void dec_init_kernel(DecHeadArgs a, int start_id, int max_steps) {
 }
 
 // ============================================================ step driver ====
-static DecHeadArgs head_args(m2m_session* s, bool forced, float* logits_out, int Ld) {
+// All per-clip buffers are [B][...] with the clip index outermost, so a view is a pointer offset.
+static DecHeadArgs head_args(m2m_session* s, const DecView& v, bool forced, float* logits_out, int Ld) {
   const m2m_model* m = s->m;
   DecHeadArgs h{};
-  h.logits = s->logits; h.ldl = m->vocab_pad; h.V = m->g.vocab_size; h.B = s->B; h.d = m->g.d_model;
-  h.shared = m->shared; h.x = s->x_dec; h.tokens = s->tokens; h.max_len = s->max_dec;
-  h.finished = s->finished; h.state = s->state; h.pad_id = m->g.pad_token_id; h.eos_id = m->g.eos_token_id;
-  h.forced = forced ? s->forced_ids : nullptr; h.Ld = Ld; h.logits_out = logits_out;
+  h.logits = s->logits + (int64_t)v.b0 * m->vocab_pad; h.ldl = m->vocab_pad; h.V = m->g.vocab_size; h.B = v.nb;
+  h.d = m->g.d_model; h.shared = m->shared; h.x = s->x_dec + (int64_t)v.b0 * m->g.d_model;
+  h.tokens = s->tokens + (int64_t)v.b0 * s->max_dec; h.max_len = s->max_dec;
+  h.finished = s->finished + v.b0; h.state = v.state; h.pad_id = m->g.pad_token_id; h.eos_id = m->g.eos_token_id;
+  h.forced = forced ? s->forced_ids + (int64_t)v.b0 * Ld : nullptr; h.Ld = Ld;
+  h.logits_out = logits_out ? logits_out + (int64_t)v.b0 * Ld * m->g.vocab_size : nullptr;
   return h;
 }
 
-int decode_init(m2m_session* s, int max_steps, bool forced, hipStream_t st) {
-  DecHeadArgs h = head_args(s, forced, nullptr, forced ? max_steps : 0);
-  hipLaunchKernelGGL(dec_init_kernel, dim3(64), dim3(256), 0, st, h, s->m->g.decoder_start_token_id, max_steps);
+int decode_init(m2m_session* s, const DecView& v, int max_steps, bool forced, hipStream_t st) {
+  DecHeadArgs h = head_args(s, v, forced, nullptr, forced ? max_steps : 0);
+  hipLaunchKernelGGL(dec_init_kernel, dim3(32), dim3(256), 0, st, h, s->m->g.decoder_start_token_id, max_steps);
   M2M_CHECK_HIP(hipGetLastError());
   return M2M_OK;
 }
@@ -423,74 +457,85 @@ static size_t kv_layer_elems(const m2m_session* s, int len) {
   return (size_t)s->max_batch * s->m->g.num_heads * len * DK;
 }
 
-int decode_launch_attn(m2m_session* s, bool self, int layer, int self_len, hipStream_t st) {
+int decode_launch_attn(m2m_session* s, const DecView& v, bool self, int layer, int self_len, hipStream_t st) {
   const m2m_model* m = s->m;
   const size_t es = m->esize;
+  const int H = m->g.num_heads;
   DecAttnArgs a{};
-  a.q = s->q_dec; a.out = s->o_dec; a.H = m->g.num_heads; a.inner = m->inner; a.state = s->state;
+  a.q = s->q_dec + (int64_t)v.b0 * m->inner;
+  a.out = (unsigned char*)s->o_dec + (size_t)v.b0 * m->inner * es;
+  a.H = H; a.inner = m->inner; a.state = v.state;
   if (self) {
-    a.K = (const unsigned char*)s->self_k + (size_t)layer * kv_layer_elems(s, s->max_dec) * es;
-    a.V = (const unsigned char*)s->self_v + (size_t)layer * kv_layer_elems(s, s->max_dec) * es;
+    const size_t off = ((size_t)layer * kv_layer_elems(s, s->max_dec) + (size_t)v.b0 * H * s->max_dec * DK) * es;
+    a.K = (const unsigned char*)s->self_k + off;
+    a.V = (const unsigned char*)s->self_v + off;
     a.kv_stride = s->max_dec; a.n_keys = 0; a.self_len_override = self_len;
     a.bias = s->dec_bias_tab; a.bias_stride = s->max_dec; a.is_self = 1;
-    return launch_dec_attn(m->precision, a, s->B, s->max_dec, st);
+    return launch_dec_attn(m->precision, a, v.nb, s->max_dec, st);
   }
   // cross K/V: [L][2][B][H][S][64] with B, S = the encoded problem
-  const size_t per = (size_t)s->B * m->g.num_heads * s->S * DK;
-  a.K = (const unsigned char*)s->cross_kv + ((size_t)layer * 2 + 0) * per * es;
-  a.V = (const unsigned char*)s->cross_kv + ((size_t)layer * 2 + 1) * per * es;
+  const size_t per = (size_t)s->B * H * s->S * DK;
+  const size_t voff = (size_t)v.b0 * H * s->S * DK;
+  a.K = (const unsigned char*)s->cross_kv + (((size_t)layer * 2 + 0) * per + voff) * es;
+  a.V = (const unsigned char*)s->cross_kv + (((size_t)layer * 2 + 1) * per + voff) * es;
   a.kv_stride = s->S; a.n_keys = s->S; a.self_len_override = 0; a.bias = nullptr; a.bias_stride = 0; a.is_self = 0;
-  return launch_dec_attn(m->precision, a, s->B, s->S, st);
+  return launch_dec_attn(m->precision, a, v.nb, s->S, st);
 }
 
-int decode_launch_step(m2m_session* s, bool forced, float* logits_out, int Ld, hipStream_t st) {
+int decode_launch_step(m2m_session* s, const DecView& v, bool forced, float* logits_out, int Ld, hipStream_t st) {
   const m2m_model* m = s->m;
   const m2m_t5_geometry& g = m->g;
   const int P = m->precision;
   const size_t es = m->esize;
+  const int H = g.num_heads;
+  float* x = s->x_dec + (int64_t)v.b0 * g.d_model;
+  float* q = s->q_dec + (int64_t)v.b0 * m->inner;
+  unsigned char* o = (unsigned char*)s->o_dec + (size_t)v.b0 * m->inner * es;
+  unsigned char* gg = (unsigned char*)s->g_dec + (size_t)v.b0 * g.d_ff * es;
   int rc;
   for (int l = 0; l < g.num_decoder_layers; ++l) {
     const DecLayerPacked& L = m->dec[l];
     DecGemmArgs a{};
-    a.eps = g.layer_norm_eps; a.B = s->B; a.state = s->state; a.H = g.num_heads; a.Lmax = s->max_dec; a.inner = m->inner;
+    a.eps = g.layer_norm_eps; a.B = v.nb; a.state = v.state; a.H = H; a.Lmax = s->max_dec; a.inner = m->inner;
     // 1. RMSNorm + fused QKV projection, K/V appended to the cache at slot t
-    a.x = s->x_dec; a.ldx = g.d_model; a.ln_w = L.ln0; a.W = L.wqkv; a.K = g.d_model; a.N = 3 * m->inner;
-    a.out = s->q_dec; a.ldo = m->inner;
-    a.kcache = (unsigned char*)s->self_k + (size_t)l * kv_layer_elems(s, s->max_dec) * es;
-    a.vcache = (unsigned char*)s->self_v + (size_t)l * kv_layer_elems(s, s->max_dec) * es;
+    a.x = x; a.ldx = g.d_model; a.ln_w = L.ln0; a.W = L.wqkv; a.K = g.d_model; a.N = 3 * m->inner;
+    a.out = q; a.ldo = m->inner;
+    const size_t koff = ((size_t)l * kv_layer_elems(s, s->max_dec) + (size_t)v.b0 * H * s->max_dec * DK) * es;
+    a.kcache = (unsigned char*)s->self_k + koff;
+    a.vcache = (unsigned char*)s->self_v + koff;
     if ((rc = launch_dec_gemm(P, DEPI_QKV, a, st))) return rc;
     // 2. causal self-attention over t+1 cached keys
-    if ((rc = decode_launch_attn(s, true, l, 0, st))) return rc;
+    if ((rc = decode_launch_attn(s, v, true, l, 0, st))) return rc;
     // 3. output projection + residual
-    a.x = s->o_dec; a.ldx = m->inner; a.ln_w = nullptr; a.W = L.wo; a.K = m->inner; a.N = g.d_model;
-    a.out = s->x_dec; a.ldo = g.d_model;
+    a.x = o; a.ldx = m->inner; a.ln_w = nullptr; a.W = L.wo; a.K = m->inner; a.N = g.d_model;
+    a.out = x; a.ldo = g.d_model;
     if ((rc = launch_dec_gemm(P, DEPI_RESID, a, st))) return rc;
     // 4. RMSNorm + cross-attention query projection
-    a.x = s->x_dec; a.ldx = g.d_model; a.ln_w = L.ln1; a.W = L.wcq; a.K = g.d_model; a.N = m->inner;
-    a.out = s->q_dec; a.ldo = m->inner;
+    a.x = x; a.ldx = g.d_model; a.ln_w = L.ln1; a.W = L.wcq; a.K = g.d_model; a.N = m->inner;
+    a.out = q; a.ldo = m->inner;
     if ((rc = launch_dec_gemm(P, DEPI_PLAIN, a, st))) return rc;
     // 5. cross-attention over the S encoder positions (K/V projected once in m2m_encode)
-    if ((rc = decode_launch_attn(s, false, l, 0, st))) return rc;
+    if ((rc = decode_launch_attn(s, v, false, l, 0, st))) return rc;
     // 6. output projection + residual
-    a.x = s->o_dec; a.ldx = m->inner; a.ln_w = nullptr; a.W = L.wco; a.K = m->inner; a.N = g.d_model;
-    a.out = s->x_dec; a.ldo = g.d_model;
+    a.x = o; a.ldx = m->inner; a.ln_w = nullptr; a.W = L.wco; a.K = m->inner; a.N = g.d_model;
+    a.out = x; a.ldo = g.d_model;
     if ((rc = launch_dec_gemm(P, DEPI_RESID, a, st))) return rc;
     // 7. RMSNorm + gated-GELU up projection
-    a.x = s->x_dec; a.ldx = g.d_model; a.ln_w = L.ln2; a.W = L.wi; a.K = g.d_model; a.N = 2 * g.d_ff;
-    a.out = s->g_dec; a.ldo = g.d_ff;
+    a.x = x; a.ldx = g.d_model; a.ln_w = L.ln2; a.W = L.wi; a.K = g.d_model; a.N = 2 * g.d_ff;
+    a.out = gg; a.ldo = g.d_ff;
     if ((rc = launch_dec_gemm(P, DEPI_GATED, a, st))) return rc;
     // 8. down projection + residual
-    a.x = s->g_dec; a.ldx = g.d_ff; a.ln_w = nullptr; a.W = L.wo_ff; a.K = g.d_ff; a.N = g.d_model;
-    a.out = s->x_dec; a.ldo = g.d_model;
+    a.x = gg; a.ldx = g.d_ff; a.ln_w = nullptr; a.W = L.wo_ff; a.K = g.d_ff; a.N = g.d_model;
+    a.out = x; a.ldo = g.d_model;
     if ((rc = launch_dec_gemm(P, DEPI_RESID, a, st))) return rc;
   }
   // final RMSNorm + lm_head (untied, no d_model**-0.5 scaling: transformers 4.34 semantics)
   DecGemmArgs a{};
-  a.eps = g.layer_norm_eps; a.B = s->B; a.state = s->state; a.H = g.num_heads; a.Lmax = s->max_dec; a.inner = m->inner;
-  a.x = s->x_dec; a.ldx = g.d_model; a.ln_w = m->dec_final_ln; a.W = m->lm_head; a.K = g.d_model; a.N = g.vocab_size;
-  a.out = s->logits; a.ldo = m->vocab_pad;
+  a.eps = g.layer_norm_eps; a.B = v.nb; a.state = v.state; a.H = H; a.Lmax = s->max_dec; a.inner = m->inner;
+  a.x = x; a.ldx = g.d_model; a.ln_w = m->dec_final_ln; a.W = m->lm_head; a.K = g.d_model; a.N = g.vocab_size;
+  a.out = s->logits + (int64_t)v.b0 * m->vocab_pad; a.ldo = m->vocab_pad;
   if ((rc = launch_dec_gemm(P, DEPI_PLAIN, a, st))) return rc;
-  DecHeadArgs h = head_args(s, forced, logits_out, Ld);
+  DecHeadArgs h = head_args(s, v, forced, logits_out, Ld);
   hipLaunchKernelGGL(dec_head_kernel, dim3(1), dim3(1024), 0, st, h);
   M2M_CHECK_HIP(hipGetLastError());
   return M2M_OK;

@@ -66,6 +66,26 @@ struct DecState {
 
 }  // namespace m2m
 
+namespace m2m {
+constexpr int MAX_GROUPS = 8;
+
+// A contiguous range of clips decoded as one independent chain (own step counter/stream/graph).
+struct DecView {
+  int b0, nb;
+  DecState* state;          // device
+};
+
+struct DecGroup {
+  DecView view{0, 0, nullptr};
+  DecState* state_host = nullptr;   // pinned
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_done = nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  int graph_key[5] = {-1, -1, -1, -1, -1};   // B, S, b0, nb, steps per graph
+};
+}  // namespace m2m
+
 struct m2m_session {
   const m2m_model* m;
   int max_batch, max_enc, max_dec;
@@ -84,23 +104,19 @@ struct m2m_session {
   void* self_v;
   float* x_dec;            // [32-row padded B, d]
   float* q_dec;            // [B, inner]
-  float* o_dec;            // [B, inner]
-  float* g_dec;            // [B, dff]
+  void* o_dec;             // [B, inner] T (attention output = input of the output projection)
+  void* g_dec;             // [B, dff] T (gated-GELU output = input of the down projection)
   float* logits;           // [B, vocab_pad]
   int64_t* tokens;         // [B, max_dec]
   int* finished;           // [B]
-  m2m::DecState* state;    // device
+  m2m::DecState* states;   // device [MAX_GROUPS]
   int64_t* forced_ids;     // [B, max_dec]
   // current problem
   int B = 0, S = 0;
   bool encoded = false;
-  // graph
-  hipStream_t stream = nullptr;   // session-owned stream the decode loop runs on
-  hipEvent_t ev_in = nullptr, ev_out = nullptr;
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t graph_exec = nullptr;
-  int graph_B = -1, graph_S = -1;
-  m2m::DecState* state_host = nullptr;  // pinned
+  // decode chains
+  hipEvent_t ev_in = nullptr;
+  m2m::DecGroup groups[m2m::MAX_GROUPS];
 };
 
 namespace m2m {
@@ -134,8 +150,8 @@ int launch_copy_f32(const float* src, float* dst, int64_t n, hipStream_t st);
 int launch_fill_zero(void* dst, int64_t bytes, hipStream_t st);
 
 // decoder-side (decode.hip)
-int decode_init(m2m_session* s, int max_steps, bool forced, hipStream_t st);
-int decode_launch_step(m2m_session* s, bool forced, float* logits_out, int Ld, hipStream_t st);
-int decode_launch_attn(m2m_session* s, bool self, int layer, int self_len, hipStream_t st);
+int decode_init(m2m_session* s, const DecView& v, int max_steps, bool forced, hipStream_t st);
+int decode_launch_step(m2m_session* s, const DecView& v, bool forced, float* logits_out, int Ld, hipStream_t st);
+int decode_launch_attn(m2m_session* s, const DecView& v, bool self, int layer, int self_len, hipStream_t st);
 
 }  // namespace m2m

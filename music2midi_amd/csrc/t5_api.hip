@@ -39,8 +39,9 @@ extern "C" int m2m_model_create(const m2m_t5_geometry* geom, const m2m_t5_weight
   M2M_REQUIRE(precision == M2M_PREC_FP32 || precision == M2M_PREC_BF16, "m2m_model_create: bad precision %d", precision);
   const m2m_t5_geometry& g = *geom;
   M2M_REQUIRE(g.d_kv == DK, "m2m_model_create: d_kv=%d unsupported (attention kernels are specialised for 64)", g.d_kv);
-  M2M_REQUIRE(g.d_model >= 64 && g.d_model % 64 == 0, "m2m_model_create: d_model=%d must be a multiple of 64", g.d_model);
-  M2M_REQUIRE(g.d_ff >= 64 && g.d_ff % 64 == 0, "m2m_model_create: d_ff=%d must be a multiple of 64", g.d_ff);
+  M2M_REQUIRE(g.d_model >= 128 && g.d_model % 128 == 0 && g.d_model <= 1152, "m2m_model_create: d_model=%d must be a multiple of 128, <= 1152", g.d_model);
+  M2M_REQUIRE(g.d_ff >= 128 && g.d_ff % 128 == 0 && g.d_ff <= 1152, "m2m_model_create: d_ff=%d must be a multiple of 128, <= 1152", g.d_ff);
+  M2M_REQUIRE((g.num_heads * g.d_kv) % 128 == 0 && g.num_heads * g.d_kv <= 1152, "m2m_model_create: num_heads*d_kv=%d must be a multiple of 128, <= 1152", g.num_heads * g.d_kv);
   M2M_REQUIRE(g.num_heads >= 1 && g.num_layers >= 1 && g.num_decoder_layers >= 1 && g.vocab_size >= 2,
               "m2m_model_create: bad geometry");
   M2M_REQUIRE(g.num_buckets >= 4 && g.num_buckets % 2 == 0 && g.max_distance > g.num_buckets / 2,
@@ -179,12 +180,12 @@ WsLayout ws_layout(const m2m_model* m, int B, int S, int L) {
   w.self_v = take((int64_t)g.num_decoder_layers * B * m->inner * L * es);
   w.x_dec = take(Bp * g.d_model * 4);
   w.q_dec = take(Bp * m->inner * 4);
-  w.o_dec = take(Bp * m->inner * 4);
-  w.g_dec = take(Bp * g.d_ff * 4);
+  w.o_dec = take(Bp * m->inner * es);
+  w.g_dec = take(Bp * g.d_ff * es);
   w.logits = take(Bp * m->vocab_pad * 4);
   w.tokens = take((int64_t)B * L * 8);
   w.finished = take((int64_t)B * 4);
-  w.state = take(sizeof(DecState));
+  w.state = take(sizeof(DecState) * MAX_GROUPS);
   w.forced = take((int64_t)B * L * 8);
   w.total = off;
   return w;
@@ -220,9 +221,9 @@ extern "C" int m2m_session_create(const m2m_model* m, int max_batch, int max_enc
   s->x_enc = (float*)(b + w.x_enc); s->h_enc = b + w.h_enc; s->qkv_enc = b + w.qkv_enc; s->attn_enc = b + w.attn_enc;
   s->mid_enc = b + w.mid_enc; s->enc_bias_tab = (float*)(b + w.enc_bias); s->dec_bias_tab = (float*)(b + w.dec_bias);
   s->cross_kv = b + w.cross_kv; s->self_k = b + w.self_k; s->self_v = b + w.self_v;
-  s->x_dec = (float*)(b + w.x_dec); s->q_dec = (float*)(b + w.q_dec); s->o_dec = (float*)(b + w.o_dec);
-  s->g_dec = (float*)(b + w.g_dec); s->logits = (float*)(b + w.logits); s->tokens = (int64_t*)(b + w.tokens);
-  s->finished = (int*)(b + w.finished); s->state = (DecState*)(b + w.state); s->forced_ids = (int64_t*)(b + w.forced);
+  s->x_dec = (float*)(b + w.x_dec); s->q_dec = (float*)(b + w.q_dec); s->o_dec = b + w.o_dec;
+  s->g_dec = b + w.g_dec; s->logits = (float*)(b + w.logits); s->tokens = (int64_t*)(b + w.tokens);
+  s->finished = (int*)(b + w.finished); s->states = (DecState*)(b + w.state); s->forced_ids = (int64_t*)(b + w.forced);
 
   // relative-position bias tables (fp32), built on the host from the bucket function
   const m2m_t5_geometry& g = m->g;
@@ -238,11 +239,15 @@ extern "C" int m2m_session_create(const m2m_model* m, int max_batch, int max_enc
   }
   hipError_t e = hipMemcpy(s->enc_bias_tab, et.data(), et.size() * 4, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(s->dec_bias_tab, dt.data(), dt.size() * 4, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemset(s->state, 0, sizeof(DecState));
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMemset(s->states, 0, sizeof(DecState) * MAX_GROUPS);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipHostMalloc((void**)&s->state_host, sizeof(DecState), hipHostMallocDefault);
+  for (int i = 0; i < MAX_GROUPS && e == hipSuccess; ++i) {
+    DecGroup& gr = s->groups[i];
+    gr.view.state = s->states + i;
+    e = hipStreamCreateWithFlags(&gr.stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&gr.ev_done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&gr.state_host, sizeof(DecState), hipHostMallocDefault);
+  }
   if (e != hipSuccess) {
     set_error("m2m_session_create: %s", hipGetErrorString(e));
     m2m_session_destroy(s);
@@ -254,12 +259,15 @@ extern "C" int m2m_session_create(const m2m_model* m, int max_batch, int max_enc
 
 extern "C" void m2m_session_destroy(m2m_session* s) {
   if (!s) return;
-  if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
-  if (s->graph) (void)hipGraphDestroy(s->graph);
+  for (int i = 0; i < MAX_GROUPS; ++i) {
+    DecGroup& gr = s->groups[i];
+    if (gr.graph_exec) (void)hipGraphExecDestroy(gr.graph_exec);
+    if (gr.graph) (void)hipGraphDestroy(gr.graph);
+    if (gr.ev_done) (void)hipEventDestroy(gr.ev_done);
+    if (gr.stream) (void)hipStreamDestroy(gr.stream);
+    if (gr.state_host) (void)hipHostFree(gr.state_host);
+  }
   if (s->ev_in) (void)hipEventDestroy(s->ev_in);
-  if (s->ev_out) (void)hipEventDestroy(s->ev_out);
-  if (s->stream) (void)hipStreamDestroy(s->stream);
-  if (s->state_host) (void)hipHostFree(s->state_host);
   delete s;
 }
 
@@ -308,25 +316,48 @@ extern "C" int m2m_encode(m2m_session* s, const float* inputs_embeds_dev, int B,
 }
 
 // ----------------------------------------------------------------- decode ---
-static int ensure_graph(m2m_session* s) {
-  if (s->graph_exec && s->graph_B == s->B && s->graph_S == s->S) return M2M_OK;
-  if (s->graph_exec) { (void)hipGraphExecDestroy(s->graph_exec); s->graph_exec = nullptr; }
-  if (s->graph) { (void)hipGraphDestroy(s->graph); s->graph = nullptr; }
-  M2M_CHECK_HIP(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-  int rc = decode_launch_step(s, false, nullptr, 0, s->stream);
-  hipGraph_t gph = nullptr;
-  hipError_t e = hipStreamEndCapture(s->stream, &gph);
-  if (rc != M2M_OK) { if (gph) (void)hipGraphDestroy(gph); return rc; }
-  if (e != hipSuccess) { set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return M2M_ERR_HIP; }
-  s->graph = gph;
-  M2M_CHECK_HIP(hipGraphInstantiate(&s->graph_exec, s->graph, nullptr, nullptr, 0));
-  s->graph_B = s->B; s->graph_S = s->S;
-  return M2M_OK;
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && v[0]) ? atoi(v) : dflt;
 }
 
-static bool use_graph() {
-  const char* v = getenv("M2M_NO_GRAPH");
-  return !(v && v[0] == '1');
+static bool use_graph() { return env_int("M2M_NO_GRAPH", 0) != 1; }
+
+// Split the B encoded clips into independent chains: M2M_GROUP_ROWS clips per chain
+// (default 16: two chains at B = 32 measured best on MI355X; more chains become dispatch-bound), at most MAX_GROUPS chains.
+static int plan_groups(m2m_session* s) {
+  int rows = env_int("M2M_GROUP_ROWS", 16);
+  if (rows < 1) rows = 1;
+  int G = ceil_div(s->B, rows);
+  if (G > MAX_GROUPS) G = MAX_GROUPS;
+  const int base = s->B / G, extra = s->B % G;
+  int b0 = 0;
+  for (int i = 0; i < G; ++i) {
+    s->groups[i].view.b0 = b0;
+    s->groups[i].view.nb = base + (i < extra ? 1 : 0);
+    b0 += s->groups[i].view.nb;
+  }
+  return G;
+}
+
+// One graph = `steps` consecutive decode steps of one chain (kernels read the step index from
+// device memory, so the same graph replays for every position; steps past the end are no-ops).
+static int ensure_graph(m2m_session* s, DecGroup& gr, int steps) {
+  const int key[5] = {s->B, s->S, gr.view.b0, gr.view.nb, steps};
+  if (gr.graph_exec && memcmp(key, gr.graph_key, sizeof(key)) == 0) return M2M_OK;
+  if (gr.graph_exec) { (void)hipGraphExecDestroy(gr.graph_exec); gr.graph_exec = nullptr; }
+  if (gr.graph) { (void)hipGraphDestroy(gr.graph); gr.graph = nullptr; }
+  M2M_CHECK_HIP(hipStreamBeginCapture(gr.stream, hipStreamCaptureModeThreadLocal));
+  int rc = M2M_OK;
+  for (int i = 0; i < steps && rc == M2M_OK; ++i) rc = decode_launch_step(s, gr.view, false, nullptr, 0, gr.stream);
+  hipGraph_t gph = nullptr;
+  hipError_t e = hipStreamEndCapture(gr.stream, &gph);
+  if (rc != M2M_OK) { if (gph) (void)hipGraphDestroy(gph); return rc; }
+  if (e != hipSuccess) { set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return M2M_ERR_HIP; }
+  gr.graph = gph;
+  M2M_CHECK_HIP(hipGraphInstantiate(&gr.graph_exec, gr.graph, nullptr, nullptr, 0));
+  memcpy(gr.graph_key, key, sizeof(key));
+  return M2M_OK;
 }
 
 extern "C" int m2m_generate_greedy(m2m_session* s, int max_length, int64_t* tokens_out_dev, int* out_len_host, void* stream) {
@@ -335,37 +366,62 @@ extern "C" int m2m_generate_greedy(m2m_session* s, int max_length, int64_t* toke
   M2M_REQUIRE(max_length >= 1 && max_length <= s->max_dec, "m2m_generate_greedy: max_length %d outside [1, %d]", max_length, s->max_dec);
   hipStream_t caller = (hipStream_t)stream;
   const int steps = max_length - 1;
-  // order the session stream after whatever the caller enqueued (encode ran on the caller's stream)
-  M2M_CHECK_HIP(hipEventRecord(s->ev_in, caller));
-  M2M_CHECK_HIP(hipStreamWaitEvent(s->stream, s->ev_in, 0));
-  int rc;
-  if ((rc = decode_init(s, steps, false, s->stream))) return rc;
+  const int G = plan_groups(s);
   const bool graph = use_graph();
-  if (graph && (rc = ensure_graph(s))) return rc;
-  // Launch in chunks; after each chunk fetch the loop state so a batch whose rows have all
-  // emitted EOS stops early (the kernels themselves turn into no-ops once state.done is set).
+  const int U = env_int("M2M_GRAPH_STEPS", 8) < 1 ? 1 : env_int("M2M_GRAPH_STEPS", 8);   // decode steps per graph
+  int rc;
+  // order every chain after whatever the caller enqueued (encode ran on the caller's stream)
+  M2M_CHECK_HIP(hipEventRecord(s->ev_in, caller));
+  for (int i = 0; i < G; ++i) {
+    DecGroup& gr = s->groups[i];
+    M2M_CHECK_HIP(hipStreamWaitEvent(gr.stream, s->ev_in, 0));
+    if ((rc = decode_init(s, gr.view, steps, false, gr.stream))) return rc;
+    if (graph && (rc = ensure_graph(s, gr, U))) return rc;
+    gr.state_host->done = (steps == 0);
+  }
+  // Launch round-robin over the chains in chunks; after each chunk fetch the loop states so a
+  // batch whose rows have all emitted EOS stops early (the kernels themselves turn into
+  // no-ops once their chain's state.done is set).
   const int CHUNK = 64;
   int launched = 0;
-  bool done = steps == 0;
-  while (!done && launched < steps) {
+  bool all_done = steps == 0;
+  while (!all_done && launched < steps) {
     const int n = steps - launched < CHUNK ? steps - launched : CHUNK;
-    for (int i = 0; i < n; ++i) {
-      if (graph) M2M_CHECK_HIP(hipGraphLaunch(s->graph_exec, s->stream));
-      else if ((rc = decode_launch_step(s, false, nullptr, 0, s->stream))) return rc;
+    for (int k = 0; k < n; k += (graph ? U : 1)) {
+      for (int i = 0; i < G; ++i) {
+        DecGroup& gr = s->groups[i];
+        if (gr.state_host->done) continue;
+        if (graph) M2M_CHECK_HIP(hipGraphLaunch(gr.graph_exec, gr.stream));
+        else if ((rc = decode_launch_step(s, gr.view, false, nullptr, 0, gr.stream))) return rc;
+      }
     }
-    launched += n;
-    M2M_CHECK_HIP(hipMemcpyAsync(s->state_host, s->state, sizeof(DecState), hipMemcpyDeviceToHost, s->stream));
-    M2M_CHECK_HIP(hipStreamSynchronize(s->stream));
-    done = s->state_host->done != 0;
+    launched += ceil_div(n, graph ? U : 1) * (graph ? U : 1);
+    all_done = true;
+    for (int i = 0; i < G; ++i) {
+      DecGroup& gr = s->groups[i];
+      if (gr.state_host->done) continue;
+      M2M_CHECK_HIP(hipMemcpyAsync(gr.state_host, gr.view.state, sizeof(DecState), hipMemcpyDeviceToHost, gr.stream));
+    }
+    for (int i = 0; i < G; ++i) {
+      DecGroup& gr = s->groups[i];
+      M2M_CHECK_HIP(hipStreamSynchronize(gr.stream));
+      if (!gr.state_host->done) all_done = false;
+    }
   }
-  M2M_CHECK_HIP(hipMemcpyAsync(s->state_host, s->state, sizeof(DecState), hipMemcpyDeviceToHost, s->stream));
-  // pack [B, max_dec] -> caller's [B, max_length]
+  // valid length = the longest chain (one process decoding the whole batch stops when EVERY row has finished)
+  int out_len = 1;
+  for (int i = 0; i < G; ++i) {
+    DecGroup& gr = s->groups[i];
+    M2M_CHECK_HIP(hipMemcpyAsync(gr.state_host, gr.view.state, sizeof(DecState), hipMemcpyDeviceToHost, gr.stream));
+    M2M_CHECK_HIP(hipStreamSynchronize(gr.stream));
+    const int l = steps == 0 ? 1 : gr.state_host->out_len;
+    if (l > out_len) out_len = l;
+  }
+  // pack [B, max_dec] -> caller's [B, max_length] on the caller's stream (all chains are idle now)
   M2M_CHECK_HIP(hipMemcpy2DAsync(tokens_out_dev, (size_t)max_length * 8, s->tokens, (size_t)s->max_dec * 8,
-                                 (size_t)max_length * 8, (size_t)s->B, hipMemcpyDeviceToDevice, s->stream));
-  M2M_CHECK_HIP(hipEventRecord(s->ev_out, s->stream));
-  M2M_CHECK_HIP(hipStreamWaitEvent(caller, s->ev_out, 0));
-  M2M_CHECK_HIP(hipStreamSynchronize(s->stream));
-  *out_len_host = steps == 0 ? 1 : s->state_host->out_len;
+                                 (size_t)max_length * 8, (size_t)s->B, hipMemcpyDeviceToDevice, caller));
+  M2M_CHECK_HIP(hipStreamSynchronize(caller));
+  *out_len_host = out_len;
   return M2M_OK;
 }
 
@@ -375,10 +431,11 @@ extern "C" int m2m_decode_forced(m2m_session* s, const int64_t* dec_input_ids_de
   M2M_REQUIRE(Ld >= 1 && Ld <= s->max_dec, "m2m_decode_forced: Ld %d outside [1, %d]", Ld, s->max_dec);
   hipStream_t st = (hipStream_t)stream;
   M2M_CHECK_HIP(hipMemcpyAsync(s->forced_ids, dec_input_ids_dev, (size_t)s->B * Ld * 8, hipMemcpyDeviceToDevice, st));
+  const DecView all{0, s->B, s->states};
   int rc;
-  if ((rc = decode_init(s, Ld, true, st))) return rc;
+  if ((rc = decode_init(s, all, Ld, true, st))) return rc;
   for (int t = 0; t < Ld; ++t)
-    if ((rc = decode_launch_step(s, true, logits_out_dev, Ld, st))) return rc;
+    if ((rc = decode_launch_step(s, all, true, logits_out_dev, Ld, st))) return rc;
   return M2M_OK;
 }
 
@@ -388,54 +445,73 @@ extern "C" int m2m_bench_kernel(m2m_session* s, int which, int self_len, int ite
   M2M_REQUIRE(s && avg_us_host && bytes_host && iters >= 1, "m2m_bench_kernel: bad argument");
   if (!s->encoded) { set_error("m2m_bench_kernel: call m2m_encode first"); return M2M_ERR_STATE; }
   M2M_REQUIRE(self_len >= 1 && self_len <= s->max_dec, "m2m_bench_kernel: self_len out of range");
+  M2M_REQUIRE(which == M2M_KERNEL_DEC_CROSS_ATTN || which == M2M_KERNEL_DEC_SELF_ATTN || which == M2M_KERNEL_DEC_STEP,
+              "m2m_bench_kernel: unknown kernel id %d", which);
   const m2m_model* m = s->m;
   const int Ld = m->g.num_decoder_layers;
-  hipStream_t st = s->stream;
   hipStream_t caller = (hipStream_t)stream;
+  const int G = plan_groups(s);
   M2M_CHECK_HIP(hipEventRecord(s->ev_in, caller));
-  M2M_CHECK_HIP(hipStreamWaitEvent(st, s->ev_in, 0));
+  for (int i = 0; i < G; ++i) M2M_CHECK_HIP(hipStreamWaitEvent(s->groups[i].stream, s->ev_in, 0));
   int rc;
-  // state.t = self_len - 1, not done: the kernels see a live loop in its (self_len)-th step
+  // every chain sees a live loop in its (self_len)-th step
   DecState hs{}; hs.t = self_len - 1; hs.done = 0; hs.out_len = 1; hs.n_unfinished = s->B; hs.max_steps = s->max_dec;
-  M2M_CHECK_HIP(hipMemcpyAsync(s->state, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
-  M2M_CHECK_HIP(hipStreamSynchronize(st));
+  for (int i = 0; i < G; ++i)
+    M2M_CHECK_HIP(hipMemcpyAsync(s->groups[i].view.state, &hs, sizeof(hs), hipMemcpyHostToDevice, s->groups[i].stream));
+  for (int i = 0; i < G; ++i) M2M_CHECK_HIP(hipStreamSynchronize(s->groups[i].stream));
+  hipStream_t st = s->groups[0].stream;
   hipEvent_t e0, e1;
   M2M_CHECK_HIP(hipEventCreate(&e0));
   M2M_CHECK_HIP(hipEventCreate(&e1));
-  const int64_t qo = (int64_t)s->B * m->inner * 4 * 2;
+  const DecView all{0, s->B, s->groups[0].view.state};
   auto run = [&](int n) -> int {
     for (int i = 0; i < n; ++i) {
-      if (which == M2M_KERNEL_DEC_CROSS_ATTN) { if ((rc = decode_launch_attn(s, false, i % Ld, 0, st))) return rc; }
-      else if (which == M2M_KERNEL_DEC_SELF_ATTN) { if ((rc = decode_launch_attn(s, true, i % Ld, self_len, st))) return rc; }
-      else {
-        // whole step: re-pin t so every replay does the same amount of work
-        M2M_CHECK_HIP(hipMemcpyAsync(s->state, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
-        if (use_graph()) { if ((rc = ensure_graph(s))) return rc; M2M_CHECK_HIP(hipGraphLaunch(s->graph_exec, st)); }
-        else if ((rc = decode_launch_step(s, false, nullptr, 0, st))) return rc;
-      }
+      if (which == M2M_KERNEL_DEC_CROSS_ATTN) { if ((rc = decode_launch_attn(s, all, false, i % Ld, 0, st))) return rc; }
+      else if (which == M2M_KERNEL_DEC_SELF_ATTN) { if ((rc = decode_launch_attn(s, all, true, i % Ld, self_len, st))) return rc; }
     }
     return M2M_OK;
   };
-  if (which != M2M_KERNEL_DEC_CROSS_ATTN && which != M2M_KERNEL_DEC_SELF_ATTN && which != M2M_KERNEL_DEC_STEP) {
-    set_error("m2m_bench_kernel: unknown kernel id %d", which);
-    return M2M_ERR_INVALID;
-  }
-  if ((rc = run(Ld))) return rc;  // warm-up
-  M2M_CHECK_HIP(hipEventRecord(e0, st));
-  if ((rc = run(iters))) return rc;
-  M2M_CHECK_HIP(hipEventRecord(e1, st));
-  M2M_CHECK_HIP(hipEventSynchronize(e1));
   float ms = 0.f;
-  M2M_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+  if (which != M2M_KERNEL_DEC_STEP) {
+    // ONE launch covering all B clips (B*H workgroups), back to back on one stream, cycling
+    // through the decoder layers so the K/V working set is the real loop's
+    if ((rc = run(Ld))) return rc;  // warm-up
+    M2M_CHECK_HIP(hipEventRecord(e0, st));
+    if ((rc = run(iters))) return rc;
+    M2M_CHECK_HIP(hipEventRecord(e1, st));
+    M2M_CHECK_HIP(hipEventSynchronize(e1));
+    M2M_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+  } else {
+    // the whole decode step as the loop runs it: all chains concurrently, each replaying its graph
+    // (t advances by `iters` from self_len - 1, so self-attention lengths are the real ones)
+    M2M_REQUIRE(self_len - 1 + iters < s->max_dec, "m2m_bench_kernel: self_len + iters exceeds max_dec_len");
+    const int U = 1;
+    for (int i = 0; i < G; ++i) if (use_graph() && (rc = ensure_graph(s, s->groups[i], U))) return rc;
+    M2M_CHECK_HIP(hipEventRecord(e0, caller));
+    for (int i = 0; i < G; ++i) M2M_CHECK_HIP(hipStreamWaitEvent(s->groups[i].stream, e0, 0));
+    for (int k = 0; k < iters; ++k)
+      for (int i = 0; i < G; ++i) {
+        DecGroup& gr = s->groups[i];
+        if (use_graph()) M2M_CHECK_HIP(hipGraphLaunch(gr.graph_exec, gr.stream));
+        else if ((rc = decode_launch_step(s, gr.view, false, nullptr, 0, gr.stream))) return rc;
+      }
+    for (int i = 0; i < G; ++i) {
+      M2M_CHECK_HIP(hipEventRecord(s->groups[i].ev_done, s->groups[i].stream));
+      M2M_CHECK_HIP(hipStreamWaitEvent(caller, s->groups[i].ev_done, 0));
+    }
+    M2M_CHECK_HIP(hipEventRecord(e1, caller));
+    M2M_CHECK_HIP(hipEventSynchronize(e1));
+    M2M_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+  }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   *avg_us_host = ms * 1000.0f / (float)iters;
+  const int64_t qo = (int64_t)s->B * m->inner * (4 + (int64_t)m->esize);
   const int64_t kv_cross = (int64_t)s->B * m->inner * s->S * 2 * (int64_t)m->esize;
   const int64_t kv_self = (int64_t)s->B * m->inner * self_len * 2 * (int64_t)m->esize;
   if (which == M2M_KERNEL_DEC_CROSS_ATTN) *bytes_host = kv_cross + qo;
   else if (which == M2M_KERNEL_DEC_SELF_ATTN) *bytes_host = kv_self + qo;
-  else *bytes_host = (int64_t)Ld * (kv_cross + kv_self);  // + weights: reported by the caller
-  M2M_CHECK_HIP(hipEventRecord(s->ev_out, st));
-  M2M_CHECK_HIP(hipStreamWaitEvent(caller, s->ev_out, 0));
+  else *bytes_host = (int64_t)Ld * (kv_cross + kv_self + 2 * qo);  // + weights: added by the caller
+  for (int i = 0; i < G; ++i) M2M_CHECK_HIP(hipStreamSynchronize(s->groups[i].stream));
   return M2M_OK;
 }
