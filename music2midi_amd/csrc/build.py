@@ -21,6 +21,12 @@ BUILD = CSRC / "build"
 LIB = PKG / "lib" / "libmusic2midi_amd.so"
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+# diagnostic builds: M2M_BUILD_VARIANT=stamps adds -DM2M_STAMPS and writes lib/libmusic2midi_amd_stamps.so
+VARIANT = os.environ.get("M2M_BUILD_VARIANT", "")
+if VARIANT == "stamps":
+    FLAGS = FLAGS + ["-DM2M_STAMPS"]
+    BUILD = CSRC / "build_stamps"
+    LIB = PKG / "lib" / "libmusic2midi_amd_stamps.so"
 
 
 def _hipcc() -> str:

@@ -10,20 +10,40 @@
 // are latency-bound (12..72 workgroups each); running several chains side by side fills the
 // 256 CUs and overlaps one chain's HBM-bound attention with another chain's projections.
 //
+//   dec_attn_kernel  one (clip, head) per 1024-thread workgroup: RMSNorm + that head's projection
+//                    (self: q,k,v + cache append; cross: q) fused in front of the attention, which
+//                    streams K then V straight from HBM to registers (16 B per lane per load, no
+//                    LDS staging: each byte is used once), fp32 softmax, shuffle + LDS reduction.
 //   dec_gemm_kernel  skinny projection  out[<=32 rows, 32 cols] per workgroup, 8 waves split K,
 //                    MFMA 32x32 tiles; optional fused RMSNorm on the input rows; epilogues:
-//                    QKV (+KV-cache append), plain, residual-add, gated-GELU, logits.
-//   dec_attn_kernel  one (clip, head) per 1024-thread workgroup streams K then V straight from
-//                    HBM to registers (16 B per lane per load, no LDS staging: each byte is
-//                    used once), fp32 softmax, shuffle + LDS reduction.  HBM-bound.
+//                    residual-add (O-projections, FFN down), gated-GELU (FFN up), plain (lm_head).
 //   dec_head_kernel  argmax / EOS+pad bookkeeping / next-token embedding / step counter.
 #include "mma.h"
 #include "t5.h"
 
 namespace m2m {
 
+// ---- optional in-kernel wall-clock stamps (diagnostic builds only: -DM2M_STAMPS) ----
+// s_memrealtime runs at a constant 100 MHz and is the same clock on every CU, so stamps from
+// different kernels can be laid on one timeline.  Block 0 / thread 0 of every decode kernel logs
+// {kernel id, phase, ticks}.  Never compiled into the product library.
+#ifdef M2M_STAMPS
+__device__ unsigned long long g_stamps[1 << 18];
+__device__ unsigned int g_stamp_n;
+#define M2M_STAMP(kid, phase)                                                                   \
+  do {                                                                                          \
+    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) {                               \
+      const unsigned long long tk = __builtin_amdgcn_s_memrealtime();                           \
+      const unsigned int i_ = atomicAdd(&g_stamp_n, 1u);                                        \
+      if (i_ < (1u << 18)) g_stamps[i_] = ((unsigned long long)(kid) << 56) | ((unsigned long long)(phase) << 48) | (tk & 0xFFFFFFFFFFFFull); \
+    }                                                                                           \
+  } while (0)
+#else
+#define M2M_STAMP(kid, phase) do {} while (0)
+#endif
+
 // ===================================================== skinny projection ====
-enum { DEPI_QKV = 0, DEPI_PLAIN = 1, DEPI_RESID = 2, DEPI_GATED = 3 };
+enum { DEPI_PLAIN = 1, DEPI_RESID = 2, DEPI_GATED = 3 };
 
 struct DecGemmArgs {
   const void* x;         // [rows, K] input activations: fp32 (normed epilogues) or T (DEPI_RESID)
@@ -34,35 +54,35 @@ struct DecGemmArgs {
   int K, N, B;
   const DecState* state;
   // outputs
-  void* out;             // PLAIN: float [B, N]; RESID: float x_res [B, N] (+=); GATED: T [B, N/2]; QKV: float q [B, inner]
+  void* out;             // PLAIN: float [B, N]; RESID: float x_res [B, N] (+=); GATED: T [B, N/2]
   int ldo;
-  void* kcache;          // QKV: [B][H][Lmax][64] T for this layer
-  void* vcache;
-  int H, Lmax, inner;
 };
 
 // 512 threads = 8 waves, each owning K/8 of the reduction (<= 9 macro steps of 16).  Every global
 // load of the workgroup (weights, activations, norm weights, loop state) is issued before the
 // first use, so a launch costs about one memory round trip instead of one per k-step; the
 // RMSNorm statistics are reduced across waves through LDS while the weight loads are in flight.
-constexpr int DG_WAVES = 8;
-constexpr int DG_MAXS = 9;   // K <= 8 * 9 * 16 = 1152
+constexpr int DG_WAVES = 8;   // K = 8 waves * NS steps * 16
 
-template <typename T, int EPI>
+// NS (k-steps per wave) is a template parameter: a runtime bound would put every load of the
+// unrolled batch behind its own branch + s_waitcnt (cdna_hip_programming.md, "three .s-level
+// traps" item c) and turn one memory round trip into NS of them.
+template <typename T, int EPI, int NS>
 __global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
   constexpr bool NORM = (EPI != DEPI_RESID);
+  constexpr int DG_MAXS = NS;
+  constexpr int ns = NS;
   __shared__ float ss_s[DG_WAVES][32];
   __shared__ float red[DG_WAVES][32 * 33];
+  M2M_STAMP(1 + EPI, 0);
   const int done = a.state->done;   // consumed only before the stores
-  const int t = a.state->t;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int n0 = blockIdx.x * 32;
   const int b0 = blockIdx.y * 32;
   const int K = a.K;
   const T* W = reinterpret_cast<const T*>(a.W);
-  const int ks = K / DG_WAVES;          // multiple of 16
-  const int ns = ks / 16;               // <= DG_MAXS
+  const int ks = K / DG_WAVES;          // = 16 * NS
   const int kbeg = wave * ks + 8 * h;
   const bool row_ok = (b0 + r) < a.B;
   const T* wr = W + (int64_t)(n0 + r) * K + kbeg;
@@ -79,13 +99,8 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
 #pragma unroll
     for (int s = 0; s < DG_MAXS; ++s) {
       if (s < ns) {
-        if (row_ok) {
-          x0[s] = *reinterpret_cast<const float4*>(xr + 16 * s);
-          x1[s] = *reinterpret_cast<const float4*>(xr + 16 * s + 4);
-        } else {
-          x0[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-          x1[s] = x0[s];
-        }
+        x0[s] = *reinterpret_cast<const float4*>(xr + 16 * s);   // rows past B read row 0 and are zeroed below
+        x1[s] = *reinterpret_cast<const float4*>(xr + 16 * s + 4);
         g0[s] = *reinterpret_cast<const float4*>(a.ln_w + kbeg + 16 * s);
         g1[s] = *reinterpret_cast<const float4*>(a.ln_w + kbeg + 16 * s + 4);
       }
@@ -102,7 +117,7 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
     float tot = 0.f;
 #pragma unroll
     for (int w = 0; w < DG_WAVES; ++w) tot += ss_s[w][r];
-    const float rs = rsqrtf(tot / (float)K + a.eps);
+    const float rs = row_ok ? rsqrtf(tot / (float)K + a.eps) : 0.f;   // rs = 0 zeroes the padding rows
 #pragma unroll
     for (int s = 0; s < DG_MAXS; ++s) {
       if (s < ns) {
@@ -118,7 +133,7 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
     Frag<T> xf[DG_MAXS];
 #pragma unroll
     for (int s = 0; s < DG_MAXS; ++s)
-      if (s < ns) xf[s] = row_ok ? load_frag(xr + 16 * s) : zero_frag<T>();
+      if (s < ns) xf[s] = load_frag(xr + 16 * s);   // padding rows read row 0; their outputs are never stored
 #pragma unroll
     for (int s = 0; s < DG_MAXS; ++s)
       if (s < ns) mma16(acc, xf[s], wf[s]);
@@ -126,6 +141,7 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
   // ---- cross-wave reduction (fixed order: deterministic) ----
 #pragma unroll
   for (int i = 0; i < 16; ++i) red[wave][acc_row(i, lane) * 33 + r] = acc[i];
+  M2M_STAMP(1 + EPI, 1);
   __syncthreads();
   if (done) return;
 
@@ -156,35 +172,40 @@ __global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
       float* outf = reinterpret_cast<float*>(a.out);
       if constexpr (EPI == DEPI_PLAIN) {
         outf[(int64_t)b * a.ldo + n] = v;
-      } else if constexpr (EPI == DEPI_RESID) {
+      } else {  // DEPI_RESID
         outf[(int64_t)b * a.ldo + n] += v;
-      } else {  // DEPI_QKV
-        const int which = n / a.inner, rem = n - which * a.inner;
-        if (which == 0) {
-          outf[(int64_t)b * a.ldo + rem] = v;
-        } else {
-          const int hh = rem / DK, dd = rem - hh * DK;
-          T* cache = reinterpret_cast<T*>(which == 1 ? a.kcache : a.vcache);
-          cache[(((int64_t)b * a.H + hh) * a.Lmax + t) * DK + dd] = from_f32<T>(v);
-        }
       }
     }
   }
+  M2M_STAMP(1 + EPI, 2);
+}
+
+template <typename T, int EPI>
+static int launch_dec_gemm_e(const DecGemmArgs& a, hipStream_t st) {
+  const int npad = ceil_div(a.N, 32) * 32;
+  dim3 grid((unsigned)(npad / 32), (unsigned)ceil_div(a.B, 32));
+  switch (a.K / (DG_WAVES * 16)) {
+    case 1: hipLaunchKernelGGL((dec_gemm_kernel<T, EPI, 1>), grid, dim3(512), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((dec_gemm_kernel<T, EPI, 2>), grid, dim3(512), 0, st, a); break;
+    case 3: hipLaunchKernelGGL((dec_gemm_kernel<T, EPI, 3>), grid, dim3(512), 0, st, a); break;
+    case 4: hipLaunchKernelGGL((dec_gemm_kernel<T, EPI, 4>), grid, dim3(512), 0, st, a); break;
+    case 9: hipLaunchKernelGGL((dec_gemm_kernel<T, EPI, 9>), grid, dim3(512), 0, st, a); break;
+    default:
+      set_error("dec_gemm: K=%d not supported by the decode projections (need K/128 in {1,2,3,4,9})", a.K);
+      return M2M_ERR_INVALID;
+  }
+  M2M_CHECK_HIP(hipGetLastError());
+  return M2M_OK;
 }
 
 template <typename T>
 static int launch_dec_gemm_t(int epi, const DecGemmArgs& a, hipStream_t st) {
-  const int npad = ceil_div(a.N, 32) * 32;
-  dim3 grid((unsigned)(npad / 32), (unsigned)ceil_div(a.B, 32));
   switch (epi) {
-    case DEPI_QKV: hipLaunchKernelGGL((dec_gemm_kernel<T, DEPI_QKV>), grid, dim3(512), 0, st, a); break;
-    case DEPI_PLAIN: hipLaunchKernelGGL((dec_gemm_kernel<T, DEPI_PLAIN>), grid, dim3(512), 0, st, a); break;
-    case DEPI_RESID: hipLaunchKernelGGL((dec_gemm_kernel<T, DEPI_RESID>), grid, dim3(512), 0, st, a); break;
-    case DEPI_GATED: hipLaunchKernelGGL((dec_gemm_kernel<T, DEPI_GATED>), grid, dim3(512), 0, st, a); break;
+    case DEPI_PLAIN: return launch_dec_gemm_e<T, DEPI_PLAIN>(a, st);
+    case DEPI_RESID: return launch_dec_gemm_e<T, DEPI_RESID>(a, st);
+    case DEPI_GATED: return launch_dec_gemm_e<T, DEPI_GATED>(a, st);
     default: return M2M_ERR_INVALID;
   }
-  M2M_CHECK_HIP(hipGetLastError());
-  return M2M_OK;
 }
 
 static int launch_dec_gemm(int precision, int epi, const DecGemmArgs& a, hipStream_t st) {
@@ -192,79 +213,186 @@ static int launch_dec_gemm(int precision, int epi, const DecGemmArgs& a, hipStre
 }
 
 // ======================================================= decode attention ====
+// Fused per-(clip, head) kernel:  RMSNorm(x[b]) -> this head's projection (self: q,k,v + cache
+// append at slot t; cross: q) -> scores over the cached keys -> softmax -> P.V -> o[b, head].
+// The K rows are requested from HBM FIRST, so their latency is covered by the norm and the
+// projection; V rows are requested before the softmax reduction.  Every byte of K/V is used once,
+// so it goes HBM -> registers (16 B per lane) with no LDS staging.
 struct DecAttnArgs {
-  const float* q;        // [B, inner] fp32
-  const void* K;         // [B][H][kv_stride][64] T
-  const void* V;
+  const float* x;        // [B, d] fp32 residual stream
+  const float* ln_w;     // [d] RMSNorm weight of this sub-layer
+  float eps;
+  int d;                 // d_model
+  const void* Wp;        // self: wqkv [3*inner, d] ; cross: wcq [inner, d]        (T)
+  void* Kc;              // self: K cache [B][H][kv_stride][64] (slot t is written) ; cross: cross K (read only)
+  void* Vc;
   int kv_stride;         // keys allocated per (b,h): Lmax (self) or S (cross)
-  int n_keys;            // cross: S ; self: ignored (t+1 from state unless self_len_override > 0)
-  int self_len_override; // bench only
-  const float* bias;     // self: [H][Lmax] by n = q_pos - k_pos ; cross: nullptr
+  int n_keys;            // cross: S
+  int self_len_override; // bench only: pretend t = self_len_override - 1
+  const float* bias;     // self: [H][Lmax] by n = q_pos - k_pos
   int bias_stride;
   void* out;             // [B, inner] T (input of the output projection)
   int H, inner;
+  int sc_cap;            // floats reserved for the score buffer in dynamic LDS (multiple of 4)
   const DecState* state;
-  int is_self;
 };
 
-template <typename T>
+
+template <typename T, bool SELF>
 __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
   constexpr int E = 16 / sizeof(T);      // elements per 16-byte chunk: 8 (bf16) / 4 (fp32)
   constexpr int LPR = DK / E;            // lanes per key row: 8 / 16
   constexpr int KPW = 64 / LPR;          // keys per wave-load: 8 / 4
   constexpr int KPB = 16 * KPW;          // keys per block round: 128 / 64
+  constexpr int NOUT = SELF ? 3 * DK : DK;
+  constexpr int LPO = SELF ? 4 : 16;     // lanes per projection output
+  // K (then V) loads in flight per lane.  The self kernel also holds 12 weight chunks per lane for
+  // its 3x larger projection, so it takes half the batch to stay inside 128 VGPRs (1024 threads).
+  constexpr int DA_BATCH = SELF ? 4 : 7;   // 7 x 128 keys covers S = 864 in one batch (bf16)
+  using V16 = decltype(Vec16<T>().v);
   extern __shared__ __align__(16) float sm[];
-  float* sc = sm;                         // [n_keys] scores -> probabilities
+  float* sc = sm;                         // [n_keys (+1)] scores -> probabilities
+  float* hn = sm + a.sc_cap;              // [d] normalised input row (already rounded to T)
   __shared__ float redw[16];
   __shared__ float redo[16][DK];
   __shared__ float bcast[2];
+  __shared__ __align__(16) float qs[DK];
+  __shared__ float kn[DK], vn[DK];
+  M2M_STAMP(6 + (SELF ? 1 : 0), 0);
   if (a.state->done) return;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x / a.H, hh = blockIdx.x - b * a.H;
-  const int t = a.state->t;
-  const int n_keys = a.is_self ? (a.self_len_override > 0 ? a.self_len_override : t + 1) : a.n_keys;
-  const int qpos = a.is_self ? n_keys - 1 : 0;
+  const int t = SELF ? (a.self_len_override > 0 ? a.self_len_override - 1 : a.state->t) : 0;
+  const int n_prev = SELF ? t : a.n_keys;            // keys that are read from memory
+  const int n_all = SELF ? n_prev + 1 : n_prev;      // + the key/value this step appends
+  const int last = max(n_prev - 1, 0);
   const int sub = lane % LPR;
   const int kslot = wave * KPW + lane / LPR;
-  const T* Kb = reinterpret_cast<const T*>(a.K) + ((int64_t)b * a.H + hh) * a.kv_stride * DK + sub * E;
-  const T* Vb = reinterpret_cast<const T*>(a.V) + ((int64_t)b * a.H + hh) * a.kv_stride * DK + sub * E;
+  T* Kb = reinterpret_cast<T*>(a.Kc) + ((int64_t)b * a.H + hh) * a.kv_stride * DK;
+  T* Vb = reinterpret_cast<T*>(a.Vc) + ((int64_t)b * a.H + hh) * a.kv_stride * DK;
 
-  float qv[E];
-  {
-    const float* qp = a.q + (int64_t)b * a.inner + hh * DK + sub * E;
+  // ---- 0. request EVERYTHING up front, in the order it is consumed (loads return in issue order):
+  //         x row + norm weights, this lane's projection-weight chunks, first batch of K rows.
+  //         Clamped addresses, never predicated, so all of it is in flight at once and the K stream
+  //         runs from the first cycle while norm / projection execute.  (Requesting the V batch here
+  //         too measured SLOWER on MI355X: 363 vs 343 ms per batch; it is requested before the softmax.) ----
+  const int xc = min(tid * 4, a.d - 4);
+  const float4 xv = *reinterpret_cast<const float4*>(a.x + (int64_t)b * a.d + xc);
+  const float4 gv = *reinterpret_cast<const float4*>(a.ln_w + xc);
+
+  constexpr int WMAX = SELF ? 12 : 3;    // weight chunks per lane held in registers (d_model 384, bf16)
+  const int po = min(tid / LPO, NOUT - 1), part = tid % LPO;
+  const int which = po / DK, dd = po - which * DK;
+  const T* wrow = reinterpret_cast<const T*>(a.Wp) + ((int64_t)which * a.inner + hh * DK + dd) * a.d;
+  const int cnt = a.d / E / LPO;         // chunks per lane
+  Vec16<T> w[WMAX];
 #pragma unroll
-    for (int e = 0; e < E; ++e) qv[e] = qp[e];
+  for (int u = 0; u < WMAX; ++u) w[u].v = *reinterpret_cast<const V16*>(wrow + (min(u, cnt - 1) * LPO + part) * E);
+
+  Vec16<T> kv[DA_BATCH];
+#pragma unroll
+  for (int u = 0; u < DA_BATCH; ++u)
+    kv[u].v = *reinterpret_cast<const V16*>(Kb + (int64_t)min(kslot + u * KPB, last) * DK + sub * E);
+
+  // ---- 1. RMSNorm of x[b] -> hn (rounded to the GEMM-input type T) ----
+  {
+    const bool own = tid * 4 < a.d;
+    float ss = own ? (xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w) : 0.f;
+    ss = wave_sum(ss);
+    if (lane == 0) redw[wave] = ss;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < 16; ++wv) tot += redw[wv];
+    const float rs = rsqrtf(tot / (float)a.d + a.eps);
+    if (own) {
+      hn[xc + 0] = to_f32(from_f32<T>(gv.x * (xv.x * rs)));
+      hn[xc + 1] = to_f32(from_f32<T>(gv.y * (xv.y * rs)));
+      hn[xc + 2] = to_f32(from_f32<T>(gv.z * (xv.z * rs)));
+      hn[xc + 3] = to_f32(from_f32<T>(gv.w * (xv.w * rs)));
+    }
+    __syncthreads();
   }
 
-  // ---- phase 1: scores ----
-  for (int k0 = kslot; k0 < n_keys; k0 += 4 * KPB) {
-    Vec16<T> kv[4];
+  // ---- 2. this head's projection: NOUT outputs, LPO lanes each, 16-byte chunks strided over lanes ----
+  {
+    float acc = 0.f;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int key = k0 + u * KPB;
-      if (key < n_keys) kv[u].v = *reinterpret_cast<const decltype(kv[u].v)*>(Kb + (int64_t)key * DK);
+    for (int u = 0; u < WMAX; ++u) {
+      if (u < cnt) {
+        const float* hp = hn + (u * LPO + part) * E;
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc = fmaf(hp[e], w[u].get(e), acc);
+      }
+    }
+    for (int i = WMAX; i < cnt; i += 4) {   // d_model / dtype combinations beyond the register budget (fp32)
+      Vec16<T> w2[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) w2[u].v = *reinterpret_cast<const V16*>(wrow + (min(i + u, cnt - 1) * LPO + part) * E);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (i + u < cnt) {
+          const float* hp = hn + ((i + u) * LPO + part) * E;
+#pragma unroll
+          for (int e = 0; e < E; ++e) acc = fmaf(hp[e], w2[u].get(e), acc);
+        }
+      }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int key = k0 + u * KPB;
-      float d = 0.f;
-      if (key < n_keys) {
-#pragma unroll
-        for (int e = 0; e < E; ++e) d = fmaf(qv[e], kv[u].get(e), d);
-      }
-#pragma unroll
-      for (int o = 1; o < LPR; o <<= 1) d += __shfl_xor(d, o, 64);
-      if (sub == 0 && key < n_keys) {
-        if (a.bias) d += a.bias[(int64_t)hh * a.bias_stride + (qpos - key)];
-        sc[key] = d;
+    for (int ofs = 1; ofs < LPO; ofs <<= 1) acc += __shfl_xor(acc, ofs, 64);
+    if (part == 0 && tid < NOUT * LPO) {
+      if (which == 0) {
+        qs[dd] = acc;                                     // q stays fp32
+      } else {
+        const T r = from_f32<T>(acc);                     // k, v are stored (and used) rounded to T
+        const int64_t slot = (int64_t)t * DK + dd;
+        if (which == 1) { kn[dd] = to_f32(r); Kb[slot] = r; }
+        else            { vn[dd] = to_f32(r); Vb[slot] = r; }
       }
     }
   }
   __syncthreads();
-  // ---- phase 2: softmax statistics ----
+  M2M_STAMP(6 + (SELF ? 1 : 0), 1);
+
+  // ---- 3. scores ----
+  float qv[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) qv[e] = qs[sub * E + e];
+  for (int k0 = 0; k0 < n_prev; k0 += DA_BATCH * KPB) {
+    if (k0 > 0) {
+#pragma unroll
+      for (int u = 0; u < DA_BATCH; ++u)
+        kv[u].v = *reinterpret_cast<const V16*>(Kb + (int64_t)min(k0 + kslot + u * KPB, last) * DK + sub * E);
+    }
+#pragma unroll
+    for (int u = 0; u < DA_BATCH; ++u) {
+      const int key = k0 + kslot + u * KPB;
+      float d = 0.f;
+#pragma unroll
+      for (int e = 0; e < E; ++e) d = fmaf(qv[e], kv[u].get(e), d);
+#pragma unroll
+      for (int ofs = 1; ofs < LPR; ofs <<= 1) d += __shfl_xor(d, ofs, 64);
+      if (sub == 0 && key < n_prev) {
+        if (SELF) d += a.bias[(int64_t)hh * a.bias_stride + (t - key)];
+        sc[key] = d;
+      }
+    }
+  }
+  if (SELF && wave == 0) {   // the key appended this step (relative position 0)
+    float d = wave_sum(qs[lane] * kn[lane]);
+    if (lane == 0) sc[n_prev] = d + a.bias[(int64_t)hh * a.bias_stride];
+  }
+  // request the first batch of V rows before the softmax reduction
+  Vec16<T> vv[DA_BATCH];
+#pragma unroll
+  for (int u = 0; u < DA_BATCH; ++u)
+    vv[u].v = *reinterpret_cast<const V16*>(Vb + (int64_t)min(kslot + u * KPB, last) * DK + sub * E);
+  __syncthreads();
+
+  // ---- 4. softmax statistics ----
   float mx = -1e30f;
-  for (int k = tid; k < n_keys; k += 1024) mx = fmaxf(mx, sc[k]);
+  for (int k = tid; k < n_all; k += 1024) mx = fmaxf(mx, sc[k]);
   mx = wave_max(mx);
   if (lane == 0) redw[wave] = mx;
   __syncthreads();
@@ -277,7 +405,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
   __syncthreads();
   mx = bcast[0];
   float sum = 0.f;
-  for (int k = tid; k < n_keys; k += 1024) {
+  for (int k = tid; k < n_all; k += 1024) {
     const float p = expf(sc[k] - mx);
     sc[k] = p;
     sum += p;
@@ -292,21 +420,22 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
     for (int w = 0; w < 16; ++w) s += redw[w];
     bcast[1] = s;
   }
-  // ---- phase 3: P.V ----
+  M2M_STAMP(6 + (SELF ? 1 : 0), 2);
+
+  // ---- 5. P.V ----
   float acc[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) acc[e] = 0.f;
-  for (int k0 = kslot; k0 < n_keys; k0 += 4 * KPB) {
-    Vec16<T> vv[4];
+  for (int k0 = 0; k0 < n_prev; k0 += DA_BATCH * KPB) {
+    if (k0 > 0) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int key = k0 + u * KPB;
-      if (key < n_keys) vv[u].v = *reinterpret_cast<const decltype(vv[u].v)*>(Vb + (int64_t)key * DK);
+      for (int u = 0; u < DA_BATCH; ++u)
+        vv[u].v = *reinterpret_cast<const V16*>(Vb + (int64_t)min(k0 + kslot + u * KPB, last) * DK + sub * E);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int key = k0 + u * KPB;
-      if (key < n_keys) {
+    for (int u = 0; u < DA_BATCH; ++u) {
+      const int key = k0 + kslot + u * KPB;
+      if (key < n_prev) {   // VALU-only predicate (the loads above are unconditional)
         const float p = sc[key];
 #pragma unroll
         for (int e = 0; e < E; ++e) acc[e] = fmaf(p, vv[u].get(e), acc[e]);
@@ -316,7 +445,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
 #pragma unroll
   for (int e = 0; e < E; ++e) {
 #pragma unroll
-    for (int o = LPR; o < 64; o <<= 1) acc[e] += __shfl_xor(acc[e], o, 64);
+    for (int ofs = LPR; ofs < 64; ofs <<= 1) acc[e] += __shfl_xor(acc[e], ofs, 64);
   }
   if (lane < LPR) {
 #pragma unroll
@@ -327,17 +456,23 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
     float s = 0.f;
 #pragma unroll
     for (int w = 0; w < 16; ++w) s += redo[w][tid];
+    if (SELF) s = fmaf(sc[n_prev], vn[tid], s);
     reinterpret_cast<T*>(a.out)[(int64_t)b * a.inner + hh * DK + tid] = from_f32<T>(s / bcast[1]);
   }
+  M2M_STAMP(6 + (SELF ? 1 : 0), 3);
 }
 
-static int launch_dec_attn(int precision, const DecAttnArgs& a, int B, int max_keys, hipStream_t st) {
-  const size_t smem = (size_t)max_keys * sizeof(float);
+static int launch_dec_attn(int precision, bool self, DecAttnArgs a, int B, int max_keys, hipStream_t st) {
+  a.sc_cap = (max_keys + 1 + 3) & ~3;
+  const size_t smem = (size_t)(a.sc_cap + a.d) * sizeof(float);
   dim3 grid((unsigned)(B * a.H));
-  if (precision == M2M_PREC_BF16)
-    hipLaunchKernelGGL(dec_attn_kernel<bf16_t>, grid, dim3(1024), smem, st, a);
-  else
-    hipLaunchKernelGGL(dec_attn_kernel<float>, grid, dim3(1024), smem, st, a);
+  if (precision == M2M_PREC_BF16) {
+    if (self) hipLaunchKernelGGL((dec_attn_kernel<bf16_t, true>), grid, dim3(1024), smem, st, a);
+    else hipLaunchKernelGGL((dec_attn_kernel<bf16_t, false>), grid, dim3(1024), smem, st, a);
+  } else {
+    if (self) hipLaunchKernelGGL((dec_attn_kernel<float, true>), grid, dim3(1024), smem, st, a);
+    else hipLaunchKernelGGL((dec_attn_kernel<float, false>), grid, dim3(1024), smem, st, a);
+  }
   M2M_CHECK_HIP(hipGetLastError());
   return M2M_OK;
 }
@@ -359,25 +494,28 @@ struct DecHeadArgs {
   float* logits_out;       // [B, Ld, V]
 };
 
+// 32 lanes per clip: with B <= 32 every row is handled concurrently (one pass of independent loads,
+// then one dependent embedding fetch), so the kernel is two memory round trips long.
 __global__ __launch_bounds__(1024) void dec_head_kernel(DecHeadArgs a) {
   __shared__ int s_unfinished;
   DecState* stp = a.state;
+  M2M_STAMP(8, 0);
   if (stp->done) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, l32 = tid & 31, grp = tid >> 5;
   const int t = stp->t;
   if (tid == 0) s_unfinished = 0;
   __syncthreads();
-  for (int b = wave; b < a.B; b += 16) {
+  for (int b = grp; b < a.B; b += 32) {
     const float* lg = a.logits + (int64_t)b * a.ldl;
     const int fin = a.forced ? 0 : a.finished[b];
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int v = lane; v < a.V; v += 64) {
+    for (int v = l32; v < a.V; v += 32) {
       const float x = lg[v];
       if (x > best || (x == best && v < bi)) { best = x; bi = v; }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int o = 16; o > 0; o >>= 1) {          // stays inside the 32-lane half
       const float ob = __shfl_xor(best, o, 64);
       const int oi = __shfl_xor(bi, o, 64);
       if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
@@ -385,12 +523,12 @@ __global__ __launch_bounds__(1024) void dec_head_kernel(DecHeadArgs a) {
     int next;
     if (a.forced) {
       if (a.logits_out)
-        for (int v = lane; v < a.V; v += 64) a.logits_out[((int64_t)b * a.Ld + t) * a.V + v] = lg[v];
+        for (int v = l32; v < a.V; v += 32) a.logits_out[((int64_t)b * a.Ld + t) * a.V + v] = lg[v];
       next = (t + 1 < a.Ld) ? (int)a.forced[(int64_t)b * a.Ld + t + 1] : a.pad_id;
     } else {
       // hf generation/utils.py:2925-2937: argmax; finished rows emit pad; EOS finishes a row
       next = fin ? a.pad_id : (bi == 0x7fffffff ? 0 : bi);
-      if (lane == 0) {
+      if (l32 == 0) {
         if (t + 1 < a.max_len) a.tokens[(int64_t)b * a.max_len + t + 1] = next;
         const int nf = fin | (next == a.eos_id);
         a.finished[b] = nf;
@@ -399,7 +537,8 @@ __global__ __launch_bounds__(1024) void dec_head_kernel(DecHeadArgs a) {
     }
     if (next < 0 || next >= a.V) next = a.pad_id;
     const float* emb = a.shared + (int64_t)next * a.d;
-    for (int c = lane; c < a.d; c += 64) a.x[(int64_t)b * a.d + c] = emb[c];
+    for (int c = l32 * 4; c < a.d; c += 128)
+      *reinterpret_cast<float4*>(a.x + (int64_t)b * a.d + c) = *reinterpret_cast<const float4*>(emb + c);
   }
   __syncthreads();
   if (tid == 0) {
@@ -412,6 +551,7 @@ __global__ __launch_bounds__(1024) void dec_head_kernel(DecHeadArgs a) {
       if (s_unfinished == 0 || nt >= stp->max_steps) { stp->done = 1; stp->out_len = nt + 1; }
     }
   }
+  M2M_STAMP(8, 2);
 }
 
 __global__ void dec_init_kernel(DecHeadArgs a, int start_id, int max_steps) {
@@ -459,27 +599,31 @@ static size_t kv_layer_elems(const m2m_session* s, int len) {
 
 int decode_launch_attn(m2m_session* s, const DecView& v, bool self, int layer, int self_len, hipStream_t st) {
   const m2m_model* m = s->m;
+  const m2m_t5_geometry& g = m->g;
   const size_t es = m->esize;
-  const int H = m->g.num_heads;
+  const int H = g.num_heads;
+  const DecLayerPacked& L = m->dec[layer];
   DecAttnArgs a{};
-  a.q = s->q_dec + (int64_t)v.b0 * m->inner;
+  a.x = s->x_dec + (int64_t)v.b0 * g.d_model; a.eps = g.layer_norm_eps; a.d = g.d_model;
   a.out = (unsigned char*)s->o_dec + (size_t)v.b0 * m->inner * es;
   a.H = H; a.inner = m->inner; a.state = v.state;
   if (self) {
     const size_t off = ((size_t)layer * kv_layer_elems(s, s->max_dec) + (size_t)v.b0 * H * s->max_dec * DK) * es;
-    a.K = (const unsigned char*)s->self_k + off;
-    a.V = (const unsigned char*)s->self_v + off;
+    a.ln_w = L.ln0; a.Wp = L.wqkv;
+    a.Kc = (unsigned char*)s->self_k + off;
+    a.Vc = (unsigned char*)s->self_v + off;
     a.kv_stride = s->max_dec; a.n_keys = 0; a.self_len_override = self_len;
-    a.bias = s->dec_bias_tab; a.bias_stride = s->max_dec; a.is_self = 1;
-    return launch_dec_attn(m->precision, a, v.nb, s->max_dec, st);
+    a.bias = s->dec_bias_tab; a.bias_stride = s->max_dec;
+    return launch_dec_attn(m->precision, true, a, v.nb, s->max_dec, st);
   }
   // cross K/V: [L][2][B][H][S][64] with B, S = the encoded problem
   const size_t per = (size_t)s->B * H * s->S * DK;
   const size_t voff = (size_t)v.b0 * H * s->S * DK;
-  a.K = (const unsigned char*)s->cross_kv + (((size_t)layer * 2 + 0) * per + voff) * es;
-  a.V = (const unsigned char*)s->cross_kv + (((size_t)layer * 2 + 1) * per + voff) * es;
-  a.kv_stride = s->S; a.n_keys = s->S; a.self_len_override = 0; a.bias = nullptr; a.bias_stride = 0; a.is_self = 0;
-  return launch_dec_attn(m->precision, a, v.nb, s->S, st);
+  a.ln_w = L.ln1; a.Wp = L.wcq;
+  a.Kc = (unsigned char*)s->cross_kv + (((size_t)layer * 2 + 0) * per + voff) * es;
+  a.Vc = (unsigned char*)s->cross_kv + (((size_t)layer * 2 + 1) * per + voff) * es;
+  a.kv_stride = s->S; a.n_keys = s->S; a.self_len_override = 0; a.bias = nullptr; a.bias_stride = 0;
+  return launch_dec_attn(m->precision, false, a, v.nb, s->S, st);
 }
 
 int decode_launch_step(m2m_session* s, const DecView& v, bool forced, float* logits_out, int Ld, hipStream_t st) {
@@ -487,51 +631,38 @@ int decode_launch_step(m2m_session* s, const DecView& v, bool forced, float* log
   const m2m_t5_geometry& g = m->g;
   const int P = m->precision;
   const size_t es = m->esize;
-  const int H = g.num_heads;
   float* x = s->x_dec + (int64_t)v.b0 * g.d_model;
-  float* q = s->q_dec + (int64_t)v.b0 * m->inner;
   unsigned char* o = (unsigned char*)s->o_dec + (size_t)v.b0 * m->inner * es;
   unsigned char* gg = (unsigned char*)s->g_dec + (size_t)v.b0 * g.d_ff * es;
   int rc;
   for (int l = 0; l < g.num_decoder_layers; ++l) {
     const DecLayerPacked& L = m->dec[l];
     DecGemmArgs a{};
-    a.eps = g.layer_norm_eps; a.B = v.nb; a.state = v.state; a.H = H; a.Lmax = s->max_dec; a.inner = m->inner;
-    // 1. RMSNorm + fused QKV projection, K/V appended to the cache at slot t
-    a.x = x; a.ldx = g.d_model; a.ln_w = L.ln0; a.W = L.wqkv; a.K = g.d_model; a.N = 3 * m->inner;
-    a.out = q; a.ldo = m->inner;
-    const size_t koff = ((size_t)l * kv_layer_elems(s, s->max_dec) + (size_t)v.b0 * H * s->max_dec * DK) * es;
-    a.kcache = (unsigned char*)s->self_k + koff;
-    a.vcache = (unsigned char*)s->self_v + koff;
-    if ((rc = launch_dec_gemm(P, DEPI_QKV, a, st))) return rc;
-    // 2. causal self-attention over t+1 cached keys
+    a.eps = g.layer_norm_eps; a.B = v.nb; a.state = v.state;
+    // 1. RMSNorm + per-head QKV projection + KV-cache append + causal self-attention (one kernel)
     if ((rc = decode_launch_attn(s, v, true, l, 0, st))) return rc;
-    // 3. output projection + residual
+    // 2. output projection + residual
     a.x = o; a.ldx = m->inner; a.ln_w = nullptr; a.W = L.wo; a.K = m->inner; a.N = g.d_model;
     a.out = x; a.ldo = g.d_model;
     if ((rc = launch_dec_gemm(P, DEPI_RESID, a, st))) return rc;
-    // 4. RMSNorm + cross-attention query projection
-    a.x = x; a.ldx = g.d_model; a.ln_w = L.ln1; a.W = L.wcq; a.K = g.d_model; a.N = m->inner;
-    a.out = q; a.ldo = m->inner;
-    if ((rc = launch_dec_gemm(P, DEPI_PLAIN, a, st))) return rc;
-    // 5. cross-attention over the S encoder positions (K/V projected once in m2m_encode)
+    // 3. RMSNorm + per-head query projection + cross-attention over the S encoder positions (one kernel)
     if ((rc = decode_launch_attn(s, v, false, l, 0, st))) return rc;
-    // 6. output projection + residual
+    // 4. output projection + residual
     a.x = o; a.ldx = m->inner; a.ln_w = nullptr; a.W = L.wco; a.K = m->inner; a.N = g.d_model;
     a.out = x; a.ldo = g.d_model;
     if ((rc = launch_dec_gemm(P, DEPI_RESID, a, st))) return rc;
-    // 7. RMSNorm + gated-GELU up projection
+    // 5. RMSNorm + gated-GELU up projection
     a.x = x; a.ldx = g.d_model; a.ln_w = L.ln2; a.W = L.wi; a.K = g.d_model; a.N = 2 * g.d_ff;
     a.out = gg; a.ldo = g.d_ff;
     if ((rc = launch_dec_gemm(P, DEPI_GATED, a, st))) return rc;
-    // 8. down projection + residual
+    // 6. down projection + residual
     a.x = gg; a.ldx = g.d_ff; a.ln_w = nullptr; a.W = L.wo_ff; a.K = g.d_ff; a.N = g.d_model;
     a.out = x; a.ldo = g.d_model;
     if ((rc = launch_dec_gemm(P, DEPI_RESID, a, st))) return rc;
   }
   // final RMSNorm + lm_head (untied, no d_model**-0.5 scaling: transformers 4.34 semantics)
   DecGemmArgs a{};
-  a.eps = g.layer_norm_eps; a.B = v.nb; a.state = v.state; a.H = H; a.Lmax = s->max_dec; a.inner = m->inner;
+  a.eps = g.layer_norm_eps; a.B = v.nb; a.state = v.state;
   a.x = x; a.ldx = g.d_model; a.ln_w = m->dec_final_ln; a.W = m->lm_head; a.K = g.d_model; a.N = g.vocab_size;
   a.out = s->logits + (int64_t)v.b0 * m->vocab_pad; a.ldo = m->vocab_pad;
   if ((rc = launch_dec_gemm(P, DEPI_PLAIN, a, st))) return rc;
@@ -542,3 +673,17 @@ int decode_launch_step(m2m_session* s, const DecView& v, bool forced, float* log
 }
 
 }  // namespace m2m
+
+#ifdef M2M_STAMPS
+// diagnostic builds only: copy the stamp log to the host and reset it (not declared in the public header)
+extern "C" int m2m_debug_read_stamps(unsigned long long* out_host, int max_n) {
+  unsigned int n = 0;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(m2m::g_stamp_n), sizeof(n)) != hipSuccess) return -1;
+  if ((int)n > max_n) n = (unsigned)max_n;
+  if (n > (1u << 18)) n = 1u << 18;
+  if (n && hipMemcpyFromSymbol(out_host, HIP_SYMBOL(m2m::g_stamps), (size_t)n * 8) != hipSuccess) return -1;
+  unsigned int z = 0;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(m2m::g_stamp_n), &z, sizeof(z));
+  return (int)n;
+}
+#endif

@@ -39,7 +39,10 @@ extern "C" int m2m_model_create(const m2m_t5_geometry* geom, const m2m_t5_weight
   M2M_REQUIRE(precision == M2M_PREC_FP32 || precision == M2M_PREC_BF16, "m2m_model_create: bad precision %d", precision);
   const m2m_t5_geometry& g = *geom;
   M2M_REQUIRE(g.d_kv == DK, "m2m_model_create: d_kv=%d unsupported (attention kernels are specialised for 64)", g.d_kv);
-  M2M_REQUIRE(g.d_model >= 128 && g.d_model % 128 == 0 && g.d_model <= 1152, "m2m_model_create: d_model=%d must be a multiple of 128, <= 1152", g.d_model);
+  auto k_ok = [](int k) { return k == 128 || k == 256 || k == 384 || k == 512 || k == 1152; };
+  M2M_REQUIRE(k_ok(g.d_model) && k_ok(g.d_ff) && k_ok(g.num_heads * g.d_kv),
+              "m2m_model_create: d_model=%d, d_ff=%d, num_heads*d_kv=%d must each be one of 128/256/384/512/1152 "
+              "(the reduction lengths the decode projections are instantiated for)", g.d_model, g.d_ff, g.num_heads * g.d_kv);
   M2M_REQUIRE(g.d_ff >= 128 && g.d_ff % 128 == 0 && g.d_ff <= 1152, "m2m_model_create: d_ff=%d must be a multiple of 128, <= 1152", g.d_ff);
   M2M_REQUIRE((g.num_heads * g.d_kv) % 128 == 0 && g.num_heads * g.d_kv <= 1152, "m2m_model_create: num_heads*d_kv=%d must be a multiple of 128, <= 1152", g.num_heads * g.d_kv);
   M2M_REQUIRE(g.num_heads >= 1 && g.num_layers >= 1 && g.num_decoder_layers >= 1 && g.vocab_size >= 2,
