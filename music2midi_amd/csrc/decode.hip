@@ -30,16 +30,22 @@ namespace m2m {
 #ifdef M2M_STAMPS
 __device__ unsigned long long g_stamps[1 << 18];
 __device__ unsigned int g_stamp_n;
+// phase 0 claims 8 consecutive slots with ONE returning atomic (its round trip is paid at kernel
+// entry, before anything is timed); later phases are fire-and-forget stores into the claimed slots.
 #define M2M_STAMP(kid, phase)                                                                   \
   do {                                                                                          \
     if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) {                               \
+      static_assert((phase) < 8, "phase");                                                      \
+      if ((phase) == 0) m2m_stamp_base = atomicAdd(&g_stamp_n, 8u);                             \
       const unsigned long long tk = __builtin_amdgcn_s_memrealtime();                           \
-      const unsigned int i_ = atomicAdd(&g_stamp_n, 1u);                                        \
-      if (i_ < (1u << 18)) g_stamps[i_] = ((unsigned long long)(kid) << 56) | ((unsigned long long)(phase) << 48) | (tk & 0xFFFFFFFFFFFFull); \
+      if (m2m_stamp_base + 8 <= (1u << 18))                                                     \
+        g_stamps[m2m_stamp_base + (phase)] = ((unsigned long long)(kid) << 56) | ((unsigned long long)(phase) << 48) | (tk & 0xFFFFFFFFFFFFull); \
     }                                                                                           \
   } while (0)
+#define M2M_STAMP_DECL unsigned int m2m_stamp_base = 0; (void)m2m_stamp_base;
 #else
 #define M2M_STAMP(kid, phase) do {} while (0)
+#define M2M_STAMP_DECL
 #endif
 
 // ===================================================== skinny projection ====
@@ -70,6 +76,7 @@ constexpr int DG_WAVES = 8;   // K = 8 waves * NS steps * 16
 template <typename T, int EPI, int NS>
 __global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
   constexpr bool NORM = (EPI != DEPI_RESID);
+  M2M_STAMP_DECL
   constexpr int DG_MAXS = NS;
   constexpr int ns = NS;
   __shared__ float ss_s[DG_WAVES][32];
@@ -214,10 +221,11 @@ static int launch_dec_gemm(int precision, int epi, const DecGemmArgs& a, hipStre
 
 // ======================================================= decode attention ====
 // Fused per-(clip, head) kernel:  RMSNorm(x[b]) -> this head's projection (self: q,k,v + cache
-// append at slot t; cross: q) -> scores over the cached keys -> softmax -> P.V -> o[b, head].
-// The K rows are requested from HBM FIRST, so their latency is covered by the norm and the
-// projection; V rows are requested before the softmax reduction.  Every byte of K/V is used once,
-// so it goes HBM -> registers (16 B per lane) with no LDS staging.
+// append at slot t; cross: q) -> single-pass ("online") softmax attention over the cached keys ->
+// o[b, head].  Every byte of K/V is used once, so it goes HBM -> registers (16 B per lane) with no
+// LDS staging, and because the softmax is online there is no workgroup-wide reduction between
+// reading K and reading V: both are requested together at kernel start and stream continuously
+// while the norm and the projection run; the only reductions are at the very end.
 struct DecAttnArgs {
   const float* x;        // [B, d] fp32 residual stream
   const float* ln_w;     // [d] RMSNorm weight of this sub-layer
@@ -233,31 +241,35 @@ struct DecAttnArgs {
   int bias_stride;
   void* out;             // [B, inner] T (input of the output projection)
   int H, inner;
-  int sc_cap;            // floats reserved for the score buffer in dynamic LDS (multiple of 4)
   const DecState* state;
 };
-
 
 template <typename T, bool SELF>
 __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
   constexpr int E = 16 / sizeof(T);      // elements per 16-byte chunk: 8 (bf16) / 4 (fp32)
-  constexpr int LPR = DK / E;            // lanes per key row: 8 / 16
+  constexpr int LPR = DK / E;            // lanes per key row (a "group"): 8 / 16
   constexpr int KPW = 64 / LPR;          // keys per wave-load: 8 / 4
   constexpr int KPB = 16 * KPW;          // keys per block round: 128 / 64
   constexpr int NOUT = SELF ? 3 * DK : DK;
   constexpr int LPO = SELF ? 4 : 16;     // lanes per projection output
-  // K (then V) loads in flight per lane.  The self kernel also holds 12 weight chunks per lane for
-  // its 3x larger projection, so it takes half the batch to stay inside 128 VGPRs (1024 threads).
-  constexpr int DA_BATCH = SELF ? 4 : 7;   // 7 x 128 keys covers S = 864 in one batch (bf16)
+  // K/V rounds (one K row + one V row per lane = 32 KB per workgroup) kept in flight by the rolling
+  // prefetch.  The CU's memory pipeline holds only so many outstanding misses: requesting the whole
+  // 220 KB stream at once stalls the ISSUING waves (measured: the prologue then finishes at ~9 us);
+  // a window of a few rounds covers latency x per-CU bandwidth (~2 us x 24 GB/s = 48 KB).
+#ifndef M2M_DA_PF
+#define M2M_DA_PF 3
+#endif
+  constexpr int PF = M2M_DA_PF;
+  constexpr int WMAX = SELF ? 12 : 3;    // weight chunks per lane held in registers (d_model 384, bf16)
   using V16 = decltype(Vec16<T>().v);
-  extern __shared__ __align__(16) float sm[];
-  float* sc = sm;                         // [n_keys (+1)] scores -> probabilities
-  float* hn = sm + a.sc_cap;              // [d] normalised input row (already rounded to T)
-  __shared__ float redw[16];
+  extern __shared__ __align__(16) float hn[];   // [d] normalised input row (already rounded to T)
+  __shared__ float redw[16], redl[16];
   __shared__ float redo[16][DK];
-  __shared__ float bcast[2];
+  __shared__ float bcast;
   __shared__ __align__(16) float qs[DK];
-  __shared__ float kn[DK], vn[DK];
+  __shared__ __align__(16) float kn[DK];
+  __shared__ __align__(16) float vn[DK];
+  M2M_STAMP_DECL
   M2M_STAMP(6 + (SELF ? 1 : 0), 0);
   if (a.state->done) return;
 
@@ -265,23 +277,20 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
   const int b = blockIdx.x / a.H, hh = blockIdx.x - b * a.H;
   const int t = SELF ? (a.self_len_override > 0 ? a.self_len_override - 1 : a.state->t) : 0;
   const int n_prev = SELF ? t : a.n_keys;            // keys that are read from memory
-  const int n_all = SELF ? n_prev + 1 : n_prev;      // + the key/value this step appends
   const int last = max(n_prev - 1, 0);
   const int sub = lane % LPR;
   const int kslot = wave * KPW + lane / LPR;
   T* Kb = reinterpret_cast<T*>(a.Kc) + ((int64_t)b * a.H + hh) * a.kv_stride * DK;
   T* Vb = reinterpret_cast<T*>(a.Vc) + ((int64_t)b * a.H + hh) * a.kv_stride * DK;
 
-  // ---- 0. request EVERYTHING up front, in the order it is consumed (loads return in issue order):
-  //         x row + norm weights, this lane's projection-weight chunks, first batch of K rows.
-  //         Clamped addresses, never predicated, so all of it is in flight at once and the K stream
-  //         runs from the first cycle while norm / projection execute.  (Requesting the V batch here
-  //         too measured SLOWER on MI355X: 363 vs 343 ms per batch; it is requested before the softmax.) ----
+  // ---- 0. requests for the prologue: x row, norm weights, this lane's projection weights.
+  //         Every kernel starts with a cold L2 for data other XCDs produced, so these come from
+  //         memory; if the 220 KB K/V stream of this workgroup were requested at the same time they
+  //         would queue behind it in the fabric (measured: the norm then completes only after ~9 us).
+  //         The K/V stream is therefore requested right after x has arrived (step 1b). ----
   const int xc = min(tid * 4, a.d - 4);
   const float4 xv = *reinterpret_cast<const float4*>(a.x + (int64_t)b * a.d + xc);
   const float4 gv = *reinterpret_cast<const float4*>(a.ln_w + xc);
-
-  constexpr int WMAX = SELF ? 12 : 3;    // weight chunks per lane held in registers (d_model 384, bf16)
   const int po = min(tid / LPO, NOUT - 1), part = tid % LPO;
   const int which = po / DK, dd = po - which * DK;
   const T* wrow = reinterpret_cast<const T*>(a.Wp) + ((int64_t)which * a.inner + hh * DK + dd) * a.d;
@@ -290,18 +299,23 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
 #pragma unroll
   for (int u = 0; u < WMAX; ++u) w[u].v = *reinterpret_cast<const V16*>(wrow + (min(u, cnt - 1) * LPO + part) * E);
 
-  Vec16<T> kv[DA_BATCH];
-#pragma unroll
-  for (int u = 0; u < DA_BATCH; ++u)
-    kv[u].v = *reinterpret_cast<const V16*>(Kb + (int64_t)min(kslot + u * KPB, last) * DK + sub * E);
-
   // ---- 1. RMSNorm of x[b] -> hn (rounded to the GEMM-input type T) ----
+  Vec16<T> kv[PF], vv[PF];
   {
     const bool own = tid * 4 < a.d;
     float ss = own ? (xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w) : 0.f;
     ss = wave_sum(ss);
     if (lane == 0) redw[wave] = ss;
     __syncthreads();
+    M2M_STAMP(6 + (SELF ? 1 : 0), 4);
+    // ---- 1b. x is here for every wave: start the K/V stream (clamped addresses, never predicated):
+    //          the first PF rounds now, the rest by the rolling prefetch of step 3 ----
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int64_t off = (int64_t)min(kslot + u * KPB, last) * DK + sub * E;
+      kv[u].v = *reinterpret_cast<const V16*>(Kb + off);
+      vv[u].v = *reinterpret_cast<const V16*>(Vb + off);
+    }
     float tot = 0.f;
 #pragma unroll
     for (int wv = 0; wv < 16; ++wv) tot += redw[wv];
@@ -313,6 +327,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
       hn[xc + 3] = to_f32(from_f32<T>(gv.w * (xv.w * rs)));
     }
     __syncthreads();
+    M2M_STAMP(6 + (SELF ? 1 : 0), 5);
   }
 
   // ---- 2. this head's projection: NOUT outputs, LPO lanes each, 16-byte chunks strided over lanes ----
@@ -341,6 +356,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
     }
 #pragma unroll
     for (int ofs = 1; ofs < LPO; ofs <<= 1) acc += __shfl_xor(acc, ofs, 64);
+    M2M_STAMP(6 + (SELF ? 1 : 0), 6);
     if (part == 0 && tid < NOUT * LPO) {
       if (which == 0) {
         qs[dd] = acc;                                     // q stays fp32
@@ -355,116 +371,98 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
   __syncthreads();
   M2M_STAMP(6 + (SELF ? 1 : 0), 1);
 
-  // ---- 3. scores ----
+  // ---- 3. single-pass attention: each group of LPR lanes walks its keys with a running
+  //         (max, sum, weighted-V) triple; no workgroup-wide step until the end ----
   float qv[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) qv[e] = qs[sub * E + e];
-  for (int k0 = 0; k0 < n_prev; k0 += DA_BATCH * KPB) {
-    if (k0 > 0) {
-#pragma unroll
-      for (int u = 0; u < DA_BATCH; ++u)
-        kv[u].v = *reinterpret_cast<const V16*>(Kb + (int64_t)min(k0 + kslot + u * KPB, last) * DK + sub * E);
-    }
-#pragma unroll
-    for (int u = 0; u < DA_BATCH; ++u) {
-      const int key = k0 + kslot + u * KPB;
-      float d = 0.f;
-#pragma unroll
-      for (int e = 0; e < E; ++e) d = fmaf(qv[e], kv[u].get(e), d);
-#pragma unroll
-      for (int ofs = 1; ofs < LPR; ofs <<= 1) d += __shfl_xor(d, ofs, 64);
-      if (sub == 0 && key < n_prev) {
-        if (SELF) d += a.bias[(int64_t)hh * a.bias_stride + (t - key)];
-        sc[key] = d;
-      }
-    }
-  }
-  if (SELF && wave == 0) {   // the key appended this step (relative position 0)
-    float d = wave_sum(qs[lane] * kn[lane]);
-    if (lane == 0) sc[n_prev] = d + a.bias[(int64_t)hh * a.bias_stride];
-  }
-  // request the first batch of V rows before the softmax reduction
-  Vec16<T> vv[DA_BATCH];
-#pragma unroll
-  for (int u = 0; u < DA_BATCH; ++u)
-    vv[u].v = *reinterpret_cast<const V16*>(Vb + (int64_t)min(kslot + u * KPB, last) * DK + sub * E);
-  __syncthreads();
-
-  // ---- 4. softmax statistics ----
-  float mx = -1e30f;
-  for (int k = tid; k < n_all; k += 1024) mx = fmaxf(mx, sc[k]);
-  mx = wave_max(mx);
-  if (lane == 0) redw[wave] = mx;
-  __syncthreads();
-  if (tid == 0) {
-    float m = redw[0];
-#pragma unroll
-    for (int w = 1; w < 16; ++w) m = fmaxf(m, redw[w]);
-    bcast[0] = m;
-  }
-  __syncthreads();
-  mx = bcast[0];
-  float sum = 0.f;
-  for (int k = tid; k < n_all; k += 1024) {
-    const float p = expf(sc[k] - mx);
-    sc[k] = p;
-    sum += p;
-  }
-  sum = wave_sum(sum);
-  __syncthreads();  // everyone has read bcast[0]/redw before they are rewritten
-  if (lane == 0) redw[wave] = sum;
-  __syncthreads();
-  if (tid == 0) {
-    float s = 0.f;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) s += redw[w];
-    bcast[1] = s;
-  }
-  M2M_STAMP(6 + (SELF ? 1 : 0), 2);
-
-  // ---- 5. P.V ----
+  float m_run = -1e30f, l_run = 0.f;
   float acc[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) acc[e] = 0.f;
-  for (int k0 = 0; k0 < n_prev; k0 += DA_BATCH * KPB) {
-    if (k0 > 0) {
+  auto visit = [&](float s, const float (&vrow)[E]) {
+    const float m_new = fmaxf(m_run, s);
+    const float alpha = expf(m_run - m_new);
+    const float p = expf(s - m_new);
+    l_run = fmaf(l_run, alpha, p);
 #pragma unroll
-      for (int u = 0; u < DA_BATCH; ++u)
-        vv[u].v = *reinterpret_cast<const V16*>(Vb + (int64_t)min(k0 + kslot + u * KPB, last) * DK + sub * E);
-    }
+    for (int e = 0; e < E; ++e) acc[e] = fmaf(acc[e], alpha, p * vrow[e]);
+    m_run = m_new;
+  };
+  for (int k0 = 0; k0 < n_prev; k0 += PF * KPB) {
 #pragma unroll
-    for (int u = 0; u < DA_BATCH; ++u) {
+    for (int u = 0; u < PF; ++u) {
       const int key = k0 + kslot + u * KPB;
-      if (key < n_prev) {   // VALU-only predicate (the loads above are unconditional)
-        const float p = sc[key];
+      float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < E; ++e) acc[e] = fmaf(p, vv[u].get(e), acc[e]);
+      for (int e = 0; e < E; ++e) s = fmaf(qv[e], kv[u].get(e), s);
+#pragma unroll
+      for (int ofs = 1; ofs < LPR; ofs <<= 1) s += __shfl_xor(s, ofs, 64);   // every lane of the group gets the sum
+      float vrow[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) vrow[e] = vv[u].get(e);
+      // slot u is consumed: request the round PF further on into it (rolling window)
+      {
+        const int64_t off = (int64_t)min(key + PF * KPB, last) * DK + sub * E;
+        kv[u].v = *reinterpret_cast<const V16*>(Kb + off);
+        vv[u].v = *reinterpret_cast<const V16*>(Vb + off);
+      }
+      if (key < n_prev) {   // VALU-only predicate (the loads are unconditional)
+        if (SELF) s += a.bias[(int64_t)hh * a.bias_stride + (t - key)];
+        visit(s, vrow);
       }
     }
   }
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-#pragma unroll
-    for (int ofs = LPR; ofs < 64; ofs <<= 1) acc[e] += __shfl_xor(acc[e], ofs, 64);
-  }
-  if (lane < LPR) {
-#pragma unroll
-    for (int e = 0; e < E; ++e) redo[wave][lane * E + e] = acc[e];
-  }
-  __syncthreads();
-  if (tid < DK) {
+  if (SELF && wave == 0 && lane < LPR) {   // the key/value appended this step (relative position 0): group 0
     float s = 0.f;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) s += redo[w][tid];
-    if (SELF) s = fmaf(sc[n_prev], vn[tid], s);
-    reinterpret_cast<T*>(a.out)[(int64_t)b * a.inner + hh * DK + tid] = from_f32<T>(s / bcast[1]);
+    for (int e = 0; e < E; ++e) s = fmaf(qv[e], kn[sub * E + e], s);
+#pragma unroll
+    for (int ofs = 1; ofs < LPR; ofs <<= 1) s += __shfl_xor(s, ofs, 64);
+    s += a.bias[(int64_t)hh * a.bias_stride];
+    float vrow[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) vrow[e] = vn[sub * E + e];
+    visit(s, vrow);
+  }
+  M2M_STAMP(6 + (SELF ? 1 : 0), 2);
+
+  // ---- 4. merge the groups: global max, rescale, sum ----
+  {
+    const float mw = wave_max(m_run);
+    if (lane == 0) redw[wave] = mw;
+    __syncthreads();
+    float M = redw[0];
+#pragma unroll
+    for (int wv = 1; wv < 16; ++wv) M = fmaxf(M, redw[wv]);
+    const float scale = expf(m_run - M);          // groups that saw no key have m_run = -1e30 -> 0
+    float lsum = (sub == 0) ? l_run * scale : 0.f;   // l is replicated over a group's lanes: count it once
+    lsum = wave_sum(lsum);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      acc[e] *= scale;
+#pragma unroll
+      for (int ofs = LPR; ofs < 64; ofs <<= 1) acc[e] += __shfl_xor(acc[e], ofs, 64);
+    }
+    if (lane == 0) redl[wave] = lsum;
+    if (lane < LPR) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) redo[wave][lane * E + e] = acc[e];
+    }
+    __syncthreads();
+    if (tid < DK) {
+      float s = 0.f, L = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < 16; ++wv) { s += redo[wv][tid]; L += redl[wv]; }
+      reinterpret_cast<T*>(a.out)[(int64_t)b * a.inner + hh * DK + tid] = from_f32<T>(s / L);
+    }
   }
   M2M_STAMP(6 + (SELF ? 1 : 0), 3);
 }
 
 static int launch_dec_attn(int precision, bool self, DecAttnArgs a, int B, int max_keys, hipStream_t st) {
-  a.sc_cap = (max_keys + 1 + 3) & ~3;
-  const size_t smem = (size_t)(a.sc_cap + a.d) * sizeof(float);
+  (void)max_keys;
+  const size_t smem = (size_t)a.d * sizeof(float);
   dim3 grid((unsigned)(B * a.H));
   if (precision == M2M_PREC_BF16) {
     if (self) hipLaunchKernelGGL((dec_attn_kernel<bf16_t, true>), grid, dim3(1024), smem, st, a);
@@ -499,6 +497,7 @@ struct DecHeadArgs {
 __global__ __launch_bounds__(1024) void dec_head_kernel(DecHeadArgs a) {
   __shared__ int s_unfinished;
   DecState* stp = a.state;
+  M2M_STAMP_DECL
   M2M_STAMP(8, 0);
   if (stp->done) return;
   const int tid = threadIdx.x, l32 = tid & 31, grp = tid >> 5;
@@ -684,6 +683,8 @@ extern "C" int m2m_debug_read_stamps(unsigned long long* out_host, int max_n) {
   if (n && hipMemcpyFromSymbol(out_host, HIP_SYMBOL(m2m::g_stamps), (size_t)n * 8) != hipSuccess) return -1;
   unsigned int z = 0;
   (void)hipMemcpyToSymbol(HIP_SYMBOL(m2m::g_stamp_n), &z, sizeof(z));
+  void* p = nullptr;
+  if (hipGetSymbolAddress(&p, HIP_SYMBOL(m2m::g_stamps)) == hipSuccess) (void)hipMemset(p, 0, sizeof(unsigned long long) << 18);
   return (int)n;
 }
 #endif

@@ -33,7 +33,7 @@ model.generate_from_embeds(x, max_length=600)          # warm + reach long self-
 lib.m2m_debug_read_stamps(buf.ctypes.data, len(buf))   # reset
 model.generate_from_embeds(x, max_length=600)
 n = lib.m2m_debug_read_stamps(buf.ctypes.data, len(buf))
-ev = [(int(v >> 56), int((v >> 48) & 0xFF), int(v & 0xFFFFFFFFFFFF)) for v in buf[:n]]
+ev = [(int(v >> 56), int((v >> 48) & 0xFF), int(v & 0xFFFFFFFFFFFF)) for v in buf[:n] if v != 0]
 ev.sort(key=lambda e: e[2])
 # take one step late in the run: from a head stamp phase 2 to the next head stamp phase 2
 heads = [i for i, e in enumerate(ev) if e[0] == 8 and e[1] == 2]
@@ -66,6 +66,19 @@ for kid, s, mid, e, m2 in rows:
 for kid, v in sorted(agg.items()):
     g = np.mean([x[0] for x in v]); d = np.mean([x[1] for x in v]); m = np.mean([x[2] for x in v])
     print(f"{NAMES.get(kid, kid):12s} n={len(v):3d}  gap-before {g:6.2f} us   in-kernel(block0) {d:6.2f} us   to-mid {m:6.2f} us")
+print("attention kernels, all phases (us from kernel start): ph4=x arrived, ph5=hn ready, ph6=projection summed, ph1=q ready, ph2=stream consumed, ph3=end")
+cur = None
+shown = 0
+for kid, ph, tk in seg[1:]:
+    if kid in (6, 7):
+        if ph == 0:
+            cur = tk
+            line = [NAMES[kid]]
+        elif cur is not None:
+            line.append(f"ph{ph}={(tk - cur) * 0.01:.2f}")
+            if ph == 3:
+                print("  " + "  ".join(line)); shown += 1
+                if shown >= 6: break
 print("first 20 kernels of the step (gap, dur):")
 pe = t0
 for kid, s, mid, e, m2 in rows[:14]:
