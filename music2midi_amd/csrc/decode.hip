@@ -14,8 +14,8 @@
 //                    (self: q,k,v + cache append; cross: q) fused in front of the attention, which
 //                    streams K then V straight from HBM to registers (16 B per lane per load, no
 //                    LDS staging: each byte is used once), fp32 softmax, shuffle + LDS reduction.
-//   dec_gemm_kernel  skinny projection  out[<=32 rows, 32 cols] per workgroup, 8 waves split K,
-//                    MFMA 32x32 tiles; optional fused RMSNorm on the input rows; epilogues:
+//   dec_gemm_kernel  skinny projection  out[16 rows, 16 cols] per workgroup, 4..12 waves split K,
+//                    MFMA 16x16 tiles; optional fused RMSNorm on the input rows; epilogues:
 //                    residual-add (O-projections, FFN down), gated-GELU (FFN up), plain (lm_head).
 //   dec_head_kernel  argmax / EOS+pad bookkeeping / next-token embedding / step counter.
 #include "mma.h"
@@ -64,142 +64,164 @@ struct DecGemmArgs {
   int ldo;
 };
 
-// 512 threads = 8 waves, each owning K/8 of the reduction (<= 9 macro steps of 16).  Every global
-// load of the workgroup (weights, activations, norm weights, loop state) is issued before the
-// first use, so a launch costs about one memory round trip instead of one per k-step; the
-// RMSNorm statistics are reduced across waves through LDS while the weight loads are in flight.
-constexpr int DG_WAVES = 8;   // K = 8 waves * NS steps * 16
+// One 16-row x 16-column output tile per workgroup (MFMA 16x16x32 / 16x16x4), NW waves split K.
+// A CU fetches only ~10 B/clk (~24 GB/s) from beyond its L2 (MI355X_MICROARCH.md cycle constants)
+// and every kernel starts with a cold L2, so a skinny projection's time IS the bytes one workgroup
+// pulls: small tiles spread W (and the rows of x) over many CUs — 48..288 workgroups instead of
+// 12..72 with 32x32 tiles — and cut the per-workgroup fetch from 64..147 KB to 32..74 KB.
+// Every global load (weights, activations, norm weights, the old residual value) is issued before
+// the first use, so a launch is one memory round trip; RMSNorm statistics are reduced across waves
+// through LDS while the weight loads are in flight; the cross-wave sum has a fixed order.
+//
+// NS (32-wide k-steps per wave) is a template parameter: a runtime bound would put every load of
+// the unrolled batch behind its own branch + s_waitcnt (cdna_hip_programming.md, "three .s-level
+// traps" item c).  blockDim.x = 64 * NW with NW = K / (32 * NS) <= 12.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+constexpr int DG_MAXW = 12;
 
-// NS (k-steps per wave) is a template parameter: a runtime bound would put every load of the
-// unrolled batch behind its own branch + s_waitcnt (cdna_hip_programming.md, "three .s-level
-// traps" item c) and turn one memory round trip into NS of them.
+__device__ inline void mma32_16(f32x4_t& acc, const Frag<bf16_t>& a, const Frag<bf16_t>& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a.v), __builtin_bit_cast(bf16x8_t, b.v),
+                                                acc, 0, 0, 0);
+}
+// fp32: lane (r, g) holds k = 8g + j, j = 0..7; MFMA j sums the four lane groups -> k in {j, 8+j, 16+j, 24+j}
+__device__ inline void mma32_16(f32x4_t& acc, const Frag<float>& a, const Frag<float>& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo.x, b.lo.x, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo.y, b.lo.y, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo.z, b.lo.z, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo.w, b.lo.w, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi.x, b.hi.x, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi.y, b.hi.y, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi.z, b.hi.z, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi.w, b.hi.w, acc, 0, 0, 0);
+}
+
 template <typename T, int EPI, int NS>
-__global__ __launch_bounds__(512) void dec_gemm_kernel(DecGemmArgs a) {
+__global__ __launch_bounds__(64 * DG_MAXW) void dec_gemm_kernel(DecGemmArgs a) {
   constexpr bool NORM = (EPI != DEPI_RESID);
   M2M_STAMP_DECL
-  constexpr int DG_MAXS = NS;
-  constexpr int ns = NS;
-  __shared__ float ss_s[DG_WAVES][32];
-  __shared__ float red[DG_WAVES][32 * 33];
+  __shared__ float ss_s[DG_MAXW][16];
+  __shared__ float red[DG_MAXW][16 * 17];
   M2M_STAMP(1 + EPI, 0);
   const int done = a.state->done;   // consumed only before the stores
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, h = lane >> 5;
-  const int n0 = blockIdx.x * 32;
-  const int b0 = blockIdx.y * 32;
+  const int nw = blockDim.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  const int b0 = blockIdx.y * 16;
   const int K = a.K;
   const T* W = reinterpret_cast<const T*>(a.W);
-  const int ks = K / DG_WAVES;          // = 16 * NS
-  const int kbeg = wave * ks + 8 * h;
+  const int kbeg = wave * (32 * NS) + 8 * g;
   const bool row_ok = (b0 + r) < a.B;
+  const int arow = b0 + (row_ok ? r : 0);           // padding rows read row b0 and are never stored
   const T* wr = W + (int64_t)(n0 + r) * K + kbeg;
 
-  Frag<T> wf[DG_MAXS];
-#pragma unroll
-  for (int s = 0; s < DG_MAXS; ++s)
-    if (s < ns) wf[s] = load_frag(wr + 16 * s);
+  // epilogue coordinates of this thread (threads 0..255 own one output each) and, for the
+  // residual epilogue, the old value of that output: requested now, consumed at the very end
+  const int orow = (tid >> 4) & 15, ocol = tid & 15;
+  const int ob = b0 + orow, on = n0 + ocol;
+  float xold = 0.f;
+  if constexpr (EPI == DEPI_RESID) {
+    const int cb = min(ob, a.B - 1), cn = min(on, a.N - 1);
+    xold = reinterpret_cast<const float*>(a.out)[(int64_t)cb * a.ldo + cn];
+  }
 
-  f32x16 acc = zero_acc();
-  if constexpr (NORM) {
-    const float* xr = reinterpret_cast<const float*>(a.x) + (int64_t)(b0 + (row_ok ? r : 0)) * a.ldx + kbeg;
-    float4 x0[DG_MAXS], x1[DG_MAXS], g0[DG_MAXS], g1[DG_MAXS];
+  Frag<T> wf[NS];
 #pragma unroll
-    for (int s = 0; s < DG_MAXS; ++s) {
-      if (s < ns) {
-        x0[s] = *reinterpret_cast<const float4*>(xr + 16 * s);   // rows past B read row 0 and are zeroed below
-        x1[s] = *reinterpret_cast<const float4*>(xr + 16 * s + 4);
-        g0[s] = *reinterpret_cast<const float4*>(a.ln_w + kbeg + 16 * s);
-        g1[s] = *reinterpret_cast<const float4*>(a.ln_w + kbeg + 16 * s + 4);
-      }
+  for (int s = 0; s < NS; ++s) wf[s] = load_frag(wr + 32 * s);
+
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (NORM) {
+    const float* xr = reinterpret_cast<const float*>(a.x) + (int64_t)arow * a.ldx + kbeg;
+    float4 x0[NS], x1[NS], g0[NS], g1[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      x0[s] = *reinterpret_cast<const float4*>(xr + 32 * s);
+      x1[s] = *reinterpret_cast<const float4*>(xr + 32 * s + 4);
+      g0[s] = *reinterpret_cast<const float4*>(a.ln_w + kbeg + 32 * s);
+      g1[s] = *reinterpret_cast<const float4*>(a.ln_w + kbeg + 32 * s + 4);
     }
     float ss = 0.f;
 #pragma unroll
-    for (int s = 0; s < DG_MAXS; ++s)
-      if (s < ns)
-        ss += x0[s].x * x0[s].x + x0[s].y * x0[s].y + x0[s].z * x0[s].z + x0[s].w * x0[s].w +
-              x1[s].x * x1[s].x + x1[s].y * x1[s].y + x1[s].z * x1[s].z + x1[s].w * x1[s].w;
+    for (int s = 0; s < NS; ++s)
+      ss += x0[s].x * x0[s].x + x0[s].y * x0[s].y + x0[s].z * x0[s].z + x0[s].w * x0[s].w +
+            x1[s].x * x1[s].x + x1[s].y * x1[s].y + x1[s].z * x1[s].z + x1[s].w * x1[s].w;
+    ss += __shfl_xor(ss, 16, 64);
     ss += __shfl_xor(ss, 32, 64);
-    if (h == 0) ss_s[wave][r] = ss;
+    if (g == 0) ss_s[wave][r] = ss;
     __syncthreads();
     float tot = 0.f;
-#pragma unroll
-    for (int w = 0; w < DG_WAVES; ++w) tot += ss_s[w][r];
+    for (int w = 0; w < nw; ++w) tot += ss_s[w][r];
     const float rs = row_ok ? rsqrtf(tot / (float)K + a.eps) : 0.f;   // rs = 0 zeroes the padding rows
 #pragma unroll
-    for (int s = 0; s < DG_MAXS; ++s) {
-      if (s < ns) {
-        const float xv[8] = {g0[s].x * (x0[s].x * rs), g0[s].y * (x0[s].y * rs), g0[s].z * (x0[s].z * rs),
-                             g0[s].w * (x0[s].w * rs), g1[s].x * (x1[s].x * rs), g1[s].y * (x1[s].y * rs),
-                             g1[s].z * (x1[s].z * rs), g1[s].w * (x1[s].w * rs)};
-        const Frag<T> fa = pack_frag<T>(xv);
-        mma16(acc, fa, wf[s]);
-      }
+    for (int s = 0; s < NS; ++s) {
+      const float xv[8] = {g0[s].x * (x0[s].x * rs), g0[s].y * (x0[s].y * rs), g0[s].z * (x0[s].z * rs),
+                           g0[s].w * (x0[s].w * rs), g1[s].x * (x1[s].x * rs), g1[s].y * (x1[s].y * rs),
+                           g1[s].z * (x1[s].z * rs), g1[s].w * (x1[s].w * rs)};
+      const Frag<T> fa = pack_frag<T>(xv);
+      mma32_16(acc, fa, wf[s]);
     }
   } else {
-    const T* xr = reinterpret_cast<const T*>(a.x) + (int64_t)(b0 + (row_ok ? r : 0)) * a.ldx + kbeg;
-    Frag<T> xf[DG_MAXS];
+    const T* xr = reinterpret_cast<const T*>(a.x) + (int64_t)arow * a.ldx + kbeg;
+    Frag<T> xf[NS];
 #pragma unroll
-    for (int s = 0; s < DG_MAXS; ++s)
-      if (s < ns) xf[s] = load_frag(xr + 16 * s);   // padding rows read row 0; their outputs are never stored
+    for (int s = 0; s < NS; ++s) xf[s] = load_frag(xr + 32 * s);
 #pragma unroll
-    for (int s = 0; s < DG_MAXS; ++s)
-      if (s < ns) mma16(acc, xf[s], wf[s]);
+    for (int s = 0; s < NS; ++s) mma32_16(acc, xf[s], wf[s]);
   }
-  // ---- cross-wave reduction (fixed order: deterministic) ----
+  // ---- cross-wave reduction (fixed order: deterministic).  acc[i]: row 4g + i, column r ----
 #pragma unroll
-  for (int i = 0; i < 16; ++i) red[wave][acc_row(i, lane) * 33 + r] = acc[i];
+  for (int i = 0; i < 4; ++i) red[wave][(4 * g + i) * 17 + r] = acc[i];
   M2M_STAMP(1 + EPI, 1);
   __syncthreads();
-  if (done) return;
+  if (done || tid >= 256 || ob >= a.B) return;
 
   auto rsum = [&](int idx) {
     float v = red[0][idx];
-#pragma unroll
-    for (int w = 1; w < DG_WAVES; ++w) v += red[w][idx];
+    for (int w = 1; w < nw; ++w) v += red[w][idx];
     return v;
   };
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int e = tid + i * 512;
-    const int row = e >> 5, col = e & 31;
-    const int b = b0 + row;
-    if (b >= a.B) continue;
-    const int idx = row * 33 + col;
-    if constexpr (EPI == DEPI_GATED) {
-      // tile columns: [16 of wi_0 | the matching 16 of wi_1]
-      if (col < 16) {
-        const float v0 = rsum(idx), v1 = rsum(idx + 16);
-        const int oc = (n0 >> 1) + col;
-        if (2 * oc < a.N) reinterpret_cast<T*>(a.out)[(int64_t)b * a.ldo + oc] = from_f32<T>(gelu_new(v0) * v1);
-      }
-    } else {
-      const int n = n0 + col;
-      if (n >= a.N) continue;
-      const float v = rsum(idx);
-      float* outf = reinterpret_cast<float*>(a.out);
-      if constexpr (EPI == DEPI_PLAIN) {
-        outf[(int64_t)b * a.ldo + n] = v;
-      } else {  // DEPI_RESID
-        outf[(int64_t)b * a.ldo + n] += v;
-      }
+  const int idx = orow * 17 + ocol;
+  if constexpr (EPI == DEPI_GATED) {
+    // tile columns: [8 of wi_0 | the matching 8 of wi_1]
+    if (ocol < 8) {
+      const float v0 = rsum(idx), v1 = rsum(idx + 8);
+      const int oc = (n0 >> 1) + ocol;
+      if (2 * oc < a.N) reinterpret_cast<T*>(a.out)[(int64_t)ob * a.ldo + oc] = from_f32<T>(gelu_new(v0) * v1);
     }
+  } else if (on < a.N) {
+    const float v = rsum(idx);
+    float* outf = reinterpret_cast<float*>(a.out);
+    if constexpr (EPI == DEPI_PLAIN) outf[(int64_t)ob * a.ldo + on] = v;
+    else outf[(int64_t)ob * a.ldo + on] = xold + v;   // DEPI_RESID
   }
   M2M_STAMP(1 + EPI, 2);
 }
 
+// waves x steps decomposition of the reduction length: K = 32 * NS * NW
+static bool dec_gemm_shape(int K, int* ns, int* nw) {
+  switch (K) {
+    case 128: *ns = 1; *nw = 4; return true;
+    case 256: *ns = 2; *nw = 4; return true;
+    case 384: *ns = 2; *nw = 6; return true;
+    case 512: *ns = 2; *nw = 8; return true;
+    case 1152: *ns = 3; *nw = 12; return true;
+    default: return false;
+  }
+}
+
 template <typename T, int EPI>
 static int launch_dec_gemm_e(const DecGemmArgs& a, hipStream_t st) {
-  const int npad = ceil_div(a.N, 32) * 32;
-  dim3 grid((unsigned)(npad / 32), (unsigned)ceil_div(a.B, 32));
-  switch (a.K / (DG_WAVES * 16)) {
-    case 1: hipLaunchKernelGGL((dec_gemm_kernel<T, EPI, 1>), grid, dim3(512), 0, st, a); break;
-    case 2: hipLaunchKernelGGL((dec_gemm_kernel<T, EPI, 2>), grid, dim3(512), 0, st, a); break;
-    case 3: hipLaunchKernelGGL((dec_gemm_kernel<T, EPI, 3>), grid, dim3(512), 0, st, a); break;
-    case 4: hipLaunchKernelGGL((dec_gemm_kernel<T, EPI, 4>), grid, dim3(512), 0, st, a); break;
-    case 9: hipLaunchKernelGGL((dec_gemm_kernel<T, EPI, 9>), grid, dim3(512), 0, st, a); break;
-    default:
-      set_error("dec_gemm: K=%d not supported by the decode projections (need K/128 in {1,2,3,4,9})", a.K);
-      return M2M_ERR_INVALID;
+  int ns = 0, nw = 0;
+  if (!dec_gemm_shape(a.K, &ns, &nw)) {
+    set_error("dec_gemm: K=%d not supported by the decode projections (128/256/384/512/1152)", a.K);
+    return M2M_ERR_INVALID;
+  }
+  dim3 grid((unsigned)ceil_div(a.N, 16), (unsigned)ceil_div(a.B, 16));
+  dim3 block((unsigned)(64 * nw));
+  switch (ns) {
+    case 1: hipLaunchKernelGGL((dec_gemm_kernel<T, EPI, 1>), grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL((dec_gemm_kernel<T, EPI, 2>), grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL((dec_gemm_kernel<T, EPI, 3>), grid, block, 0, st, a); break;
   }
   M2M_CHECK_HIP(hipGetLastError());
   return M2M_OK;

@@ -27,7 +27,7 @@ struct DecLayerPacked {
   const void* wcq;    // [inner, d]
   const void* wco;    // [d, inner]
   const float* ln2;
-  const void* wi;     // [2*dff, d]        32-row chunks: 16 rows of wi_0 then the matching 16 rows of wi_1
+  const void* wi;     // [2*dff, d]        16-row chunks: 8 rows of wi_0 then the matching 8 rows of wi_1
   const void* wo_ff;  // [d, dff]
 };
 
@@ -37,7 +37,7 @@ struct m2m_model {
   m2m_t5_geometry g;
   int precision;
   int inner;            // num_heads * d_kv
-  int vocab_pad;        // vocab rounded up to 32 (lm_head rows beyond vocab are zero)
+  int vocab_pad;        // vocab rounded up to 16 (lm_head rows beyond vocab are zero)
   size_t esize;         // sizeof storage element (4 or 2)
   void* blob = nullptr; // one device allocation holding every packed tensor
   int64_t blob_bytes = 0;

@@ -55,7 +55,7 @@ extern "C" int m2m_model_create(const m2m_t5_geometry* geom, const m2m_t5_weight
   const int d = g.d_model, dff = g.d_ff, inner = g.num_heads * g.d_kv, V = g.vocab_size;
   const int Le = g.num_layers, Ld = g.num_decoder_layers;
   const size_t es = precision == M2M_PREC_BF16 ? 2 : 4;
-  const int vocab_pad = ceil_div(V, 32) * 32;
+  const int vocab_pad = ceil_div(V, 16) * 16;
 
   // ---- carve one blob ----
   int64_t off = 0;
@@ -120,7 +120,7 @@ extern "C" int m2m_model_create(const m2m_t5_geometry* geom, const m2m_t5_weight
     conv(s.cq, dof[l].wcq, (int64_t)inner * d);
     conv(s.co, dof[l].wco, (int64_t)d * inner);
     if (rc == M2M_OK && !(s.wi0 && s.wi1)) { set_error("m2m_model_create: null wi pointer"); rc = M2M_ERR_INVALID; }
-    if (rc == M2M_OK) rc = launch_interleave(precision, s.wi0, s.wi1, base + dof[l].wi, dff, d, 16, st);
+    if (rc == M2M_OK) rc = launch_interleave(precision, s.wi0, s.wi1, base + dof[l].wi, dff, d, 8, st);
     conv(s.wo, dof[l].wo_ff, (int64_t)d * dff);
     conv(s.ck, o_ckv + (int64_t)(l * 2 + 0) * inner * d * es, (int64_t)inner * d);
     conv(s.cv, o_ckv + (int64_t)(l * 2 + 1) * inner * d * es, (int64_t)inner * d);
