@@ -326,10 +326,11 @@ static int env_int(const char* name, int dflt) {
 
 static bool use_graph() { return env_int("M2M_NO_GRAPH", 0) != 1; }
 
-// Split the B encoded clips into independent chains: M2M_GROUP_ROWS clips per chain
-// (default 16: two chains at B = 32 measured best on MI355X; more chains become dispatch-bound), at most MAX_GROUPS chains.
+// Split the B encoded clips into independent chains: M2M_GROUP_ROWS clips per chain (default 32:
+// one 32-row MFMA tile of clips per chain), at most MAX_GROUPS chains.  Measured at B = 32 on
+// MI355X: 1 chain 322 ms, 2 chains 315 ms, 4 chains 666 ms (dispatch-bound) - see DESIGN.md.
 static int plan_groups(m2m_session* s) {
-  int rows = env_int("M2M_GROUP_ROWS", 16);
+  int rows = env_int("M2M_GROUP_ROWS", 32);
   if (rows < 1) rows = 1;
   int G = ceil_div(s->B, rows);
   if (G > MAX_GROUPS) G = MAX_GROUPS;
