@@ -23,6 +23,12 @@ ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 # diagnostic builds: M2M_BUILD_VARIANT=stamps adds -DM2M_STAMPS and writes lib/libmusic2midi_amd_stamps.so
 VARIANT = os.environ.get("M2M_BUILD_VARIANT", "")
+EXTRA = os.environ.get("M2M_BUILD_EXTRA", "").split()   # experiment builds: extra -D flags, lib suffix = M2M_BUILD_TAG
+TAG = os.environ.get("M2M_BUILD_TAG", "")
+if EXTRA and TAG:
+    FLAGS = FLAGS + EXTRA
+    BUILD = CSRC / f"build_{TAG}"
+    LIB = PKG / "lib" / f"libmusic2midi_amd_{TAG}.so"
 if VARIANT == "stamps":
     FLAGS = FLAGS + ["-DM2M_STAMPS"]
     BUILD = CSRC / "build_stamps"

@@ -279,7 +279,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
   // 220 KB stream at once stalls the ISSUING waves (measured: the prologue then finishes at ~9 us);
   // a window of a few rounds covers latency x per-CU bandwidth (~2 us x 24 GB/s = 48 KB).
 #ifndef M2M_DA_PF
-#define M2M_DA_PF 3
+#define M2M_DA_PF 1
 #endif
   constexpr int PF = M2M_DA_PF;
   constexpr int WMAX = SELF ? 12 : 3;    // weight chunks per lane held in registers (d_model 384, bf16)
@@ -332,12 +332,14 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
     M2M_STAMP(6 + (SELF ? 1 : 0), 4);
     // ---- 1b. x is here for every wave: start the K/V stream (clamped addresses, never predicated):
     //          the first PF rounds now, the rest by the rolling prefetch of step 3 ----
+#ifndef M2M_DA_LATE
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       const int64_t off = (int64_t)min(kslot + u * KPB, last) * DK + sub * E;
       kv[u].v = *reinterpret_cast<const V16*>(Kb + off);
       vv[u].v = *reinterpret_cast<const V16*>(Vb + off);
     }
+#endif
     float tot = 0.f;
 #pragma unroll
     for (int wv = 0; wv < 16; ++wv) tot += redw[wv];
@@ -349,6 +351,14 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
       hn[xc + 3] = to_f32(from_f32<T>(gv.w * (xv.w * rs)));
     }
     __syncthreads();
+#ifdef M2M_DA_LATE
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int64_t off = (int64_t)min(kslot + u * KPB, last) * DK + sub * E;
+      kv[u].v = *reinterpret_cast<const V16*>(Kb + off);
+      vv[u].v = *reinterpret_cast<const V16*>(Vb + off);
+    }
+#endif
     M2M_STAMP(6 + (SELF ? 1 : 0), 5);
   }
 
