@@ -48,11 +48,25 @@ __device__ unsigned int g_stamp_n;
 #define M2M_STAMP_DECL
 #endif
 
+// ---- decoder residual stream: int64 fixed point (scale 2^30) ----
+// The output projections of the attention sub-layers are accumulated per head straight from the
+// attention kernels (8 workgroups per clip add into the same row).  Float atomics would make the
+// sum depend on arrival order; integer adds are associative, so the result is bit-reproducible
+// whatever the order, and exact (2^-30 resolution, +-8.6e9 range) where fp32 would round.
+typedef long long xq_t;
+__device__ inline xq_t xq_fix(float v) { return __float2ll_rn(v * 1073741824.0f); }
+__device__ inline float xq_flt(xq_t q) { return (float)q * (1.0f / 1073741824.0f); }
+__device__ inline float4 xq_load4(const xq_t* p) {   // p 16-byte aligned
+  const longlong2 a = *reinterpret_cast<const longlong2*>(p);
+  const longlong2 b = *reinterpret_cast<const longlong2*>(p + 2);
+  return make_float4(xq_flt(a.x), xq_flt(a.y), xq_flt(b.x), xq_flt(b.y));
+}
+
 // ===================================================== skinny projection ====
 enum { DEPI_PLAIN = 1, DEPI_RESID = 2, DEPI_GATED = 3 };
 
 struct DecGemmArgs {
-  const void* x;         // [rows, K] input activations: fp32 (normed epilogues) or T (DEPI_RESID)
+  const void* x;         // [rows, K] input: the fixed-point residual stream xq_t (normed epilogues) or T (DEPI_RESID)
   int ldx;
   const float* ln_w;     // [K] RMSNorm weight (QKV / PLAIN / GATED), unused for RESID
   float eps;
@@ -60,7 +74,7 @@ struct DecGemmArgs {
   int K, N, B;
   const DecState* state;
   // outputs
-  void* out;             // PLAIN: float [B, N]; RESID: float x_res [B, N] (+=); GATED: T [B, N/2]
+  void* out;             // PLAIN: float [B, N]; RESID: xq_t residual stream [B, N] (+=); GATED: T [B, N/2]
   int ldo;
 };
 
@@ -119,10 +133,10 @@ __global__ __launch_bounds__(64 * DG_MAXW) void dec_gemm_kernel(DecGemmArgs a) {
   // residual epilogue, the old value of that output: requested now, consumed at the very end
   const int orow = (tid >> 4) & 15, ocol = tid & 15;
   const int ob = b0 + orow, on = n0 + ocol;
-  float xold = 0.f;
+  xq_t xold = 0;
   if constexpr (EPI == DEPI_RESID) {
     const int cb = min(ob, a.B - 1), cn = min(on, a.N - 1);
-    xold = reinterpret_cast<const float*>(a.out)[(int64_t)cb * a.ldo + cn];
+    xold = reinterpret_cast<const xq_t*>(a.out)[(int64_t)cb * a.ldo + cn];
   }
 
   Frag<T> wf[NS];
@@ -131,12 +145,12 @@ __global__ __launch_bounds__(64 * DG_MAXW) void dec_gemm_kernel(DecGemmArgs a) {
 
   f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
   if constexpr (NORM) {
-    const float* xr = reinterpret_cast<const float*>(a.x) + (int64_t)arow * a.ldx + kbeg;
+    const xq_t* xr = reinterpret_cast<const xq_t*>(a.x) + (int64_t)arow * a.ldx + kbeg;
     float4 x0[NS], x1[NS], g0[NS], g1[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      x0[s] = *reinterpret_cast<const float4*>(xr + 32 * s);
-      x1[s] = *reinterpret_cast<const float4*>(xr + 32 * s + 4);
+      x0[s] = xq_load4(xr + 32 * s);
+      x1[s] = xq_load4(xr + 32 * s + 4);
       g0[s] = *reinterpret_cast<const float4*>(a.ln_w + kbeg + 32 * s);
       g1[s] = *reinterpret_cast<const float4*>(a.ln_w + kbeg + 32 * s + 4);
     }
@@ -192,7 +206,7 @@ __global__ __launch_bounds__(64 * DG_MAXW) void dec_gemm_kernel(DecGemmArgs a) {
     const float v = rsum(idx);
     float* outf = reinterpret_cast<float*>(a.out);
     if constexpr (EPI == DEPI_PLAIN) outf[(int64_t)ob * a.ldo + on] = v;
-    else outf[(int64_t)ob * a.ldo + on] = xold + v;   // DEPI_RESID
+    else reinterpret_cast<xq_t*>(a.out)[(int64_t)ob * a.ldo + on] = xold + xq_fix(v);   // DEPI_RESID
   }
   M2M_STAMP(1 + EPI, 2);
 }
@@ -244,12 +258,13 @@ static int launch_dec_gemm(int precision, int epi, const DecGemmArgs& a, hipStre
 // ======================================================= decode attention ====
 // Fused per-(clip, head) kernel:  RMSNorm(x[b]) -> this head's projection (self: q,k,v + cache
 // append at slot t; cross: q) -> single-pass ("online") softmax attention over the cached keys ->
-// o[b, head].  Every byte of K/V is used once, so it goes HBM -> registers (16 B per lane) with no
+// o[b, head] -> this head's slice of the output projection, ADDED into the residual row (integer
+// adds: order-independent).  Every byte of K/V is used once, so it goes HBM -> registers (16 B per lane) with no
 // LDS staging, and because the softmax is online there is no workgroup-wide reduction between
 // reading K and reading V: both are requested together at kernel start and stream continuously
 // while the norm and the projection run; the only reductions are at the very end.
 struct DecAttnArgs {
-  const float* x;        // [B, d] fp32 residual stream
+  xq_t* x;               // [B, d] fixed-point residual stream: read by the norm, ADDED to by the output projection
   const float* ln_w;     // [d] RMSNorm weight of this sub-layer
   float eps;
   int d;                 // d_model
@@ -261,7 +276,7 @@ struct DecAttnArgs {
   int self_len_override; // bench only: pretend t = self_len_override - 1
   const float* bias;     // self: [H][Lmax] by n = q_pos - k_pos
   int bias_stride;
-  void* out;             // [B, inner] T (input of the output projection)
+  const void* Wo;        // [d, inner] T output projection of this sub-layer (this head uses columns [64h, 64h+64))
   int H, inner;
   const DecState* state;
 };
@@ -291,6 +306,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
   __shared__ __align__(16) float qs[DK];
   __shared__ __align__(16) float kn[DK];
   __shared__ __align__(16) float vn[DK];
+  __shared__ __align__(16) float oh[DK];
   M2M_STAMP_DECL
   M2M_STAMP(6 + (SELF ? 1 : 0), 0);
   if (a.state->done) return;
@@ -311,7 +327,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
   //         would queue behind it in the fabric (measured: the norm then completes only after ~9 us).
   //         The K/V stream is therefore requested right after x has arrived (step 1b). ----
   const int xc = min(tid * 4, a.d - 4);
-  const float4 xv = *reinterpret_cast<const float4*>(a.x + (int64_t)b * a.d + xc);
+  const float4 xv = xq_load4(a.x + (int64_t)b * a.d + xc);
   const float4 gv = *reinterpret_cast<const float4*>(a.ln_w + xc);
   const int po = min(tid / LPO, NOUT - 1), part = tid % LPO;
   const int which = po / DK, dd = po - which * DK;
@@ -403,6 +419,15 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
   __syncthreads();
   M2M_STAMP(6 + (SELF ? 1 : 0), 1);
 
+  // this head's slice of the output projection (2 lanes per output column, 32 inputs each):
+  // requested now so it arrives under the K/V stream
+  constexpr int OCH = 32 / E;            // 16-byte chunks per lane: 4 (bf16) / 8 (fp32)
+  const int on_ = min(tid >> 1, a.d - 1), opart = tid & 1;
+  const T* worow = reinterpret_cast<const T*>(a.Wo) + (int64_t)on_ * a.inner + hh * DK + opart * 32;
+  Vec16<T> wo[OCH];
+#pragma unroll
+  for (int u = 0; u < OCH; ++u) wo[u].v = *reinterpret_cast<const V16*>(worow + u * E);
+
   // ---- 3. single-pass attention: each group of LPR lanes walks its keys with a running
   //         (max, sum, weighted-V) triple; no workgroup-wide step until the end ----
   float qv[E];
@@ -486,8 +511,21 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
       float s = 0.f, L = 0.f;
 #pragma unroll
       for (int wv = 0; wv < 16; ++wv) { s += redo[wv][tid]; L += redl[wv]; }
-      reinterpret_cast<T*>(a.out)[(int64_t)b * a.inner + hh * DK + tid] = from_f32<T>(s / L);
+      oh[tid] = to_f32(from_f32<T>(s / L));      // the projection input is rounded to T, as every GEMM input
     }
+    __syncthreads();
+  }
+  // ---- 5. output projection of this head, accumulated into the residual row ----
+  {
+    float accp = 0.f;
+#pragma unroll
+    for (int u = 0; u < OCH; ++u) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) accp = fmaf(oh[opart * 32 + u * E + e], wo[u].get(e), accp);
+    }
+    accp += __shfl_xor(accp, 1, 64);
+    if (opart == 0 && tid < 2 * a.d)
+      atomicAdd(reinterpret_cast<unsigned long long*>(a.x + (int64_t)b * a.d + on_), (unsigned long long)xq_fix(accp));
   }
   M2M_STAMP(6 + (SELF ? 1 : 0), 3);
 }
@@ -512,7 +550,7 @@ struct DecHeadArgs {
   const float* logits;     // [B, ldl]
   int ldl, V, B, d;
   const float* shared;     // [V, d] embedding
-  float* x;                // [B, d] next-step input
+  xq_t* x;                 // [B, d] next-step input (fixed-point residual stream)
   int64_t* tokens;         // [B, max_len] generated ids (col 0 = start)
   int max_len;
   int* finished;           // [B]
@@ -568,8 +606,12 @@ __global__ __launch_bounds__(1024) void dec_head_kernel(DecHeadArgs a) {
     }
     if (next < 0 || next >= a.V) next = a.pad_id;
     const float* emb = a.shared + (int64_t)next * a.d;
-    for (int c = l32 * 4; c < a.d; c += 128)
-      *reinterpret_cast<float4*>(a.x + (int64_t)b * a.d + c) = *reinterpret_cast<const float4*>(emb + c);
+    for (int c = l32 * 4; c < a.d; c += 128) {
+      const float4 e4 = *reinterpret_cast<const float4*>(emb + c);
+      xq_t* xp = a.x + (int64_t)b * a.d + c;
+      *reinterpret_cast<longlong2*>(xp) = make_longlong2(xq_fix(e4.x), xq_fix(e4.y));
+      *reinterpret_cast<longlong2*>(xp + 2) = make_longlong2(xq_fix(e4.z), xq_fix(e4.w));
+    }
   }
   __syncthreads();
   if (tid == 0) {
@@ -599,7 +641,7 @@ __global__ void dec_init_kernel(DecHeadArgs a, int start_id, int max_steps) {
     const int b = i / a.d, c = i - b * a.d;
     int tok = a.forced ? (int)a.forced[(int64_t)b * a.Ld] : start_id;
     if (tok < 0 || tok >= a.V) tok = a.pad_id;
-    a.x[i] = a.shared[(int64_t)tok * a.d + c];
+    a.x[i] = xq_fix(a.shared[(int64_t)tok * a.d + c]);
   }
 }
 
@@ -609,7 +651,7 @@ static DecHeadArgs head_args(m2m_session* s, const DecView& v, bool forced, floa
   const m2m_model* m = s->m;
   DecHeadArgs h{};
   h.logits = s->logits + (int64_t)v.b0 * m->vocab_pad; h.ldl = m->vocab_pad; h.V = m->g.vocab_size; h.B = v.nb;
-  h.d = m->g.d_model; h.shared = m->shared; h.x = s->x_dec + (int64_t)v.b0 * m->g.d_model;
+  h.d = m->g.d_model; h.shared = m->shared; h.x = reinterpret_cast<xq_t*>(s->x_dec) + (int64_t)v.b0 * m->g.d_model;
   h.tokens = s->tokens + (int64_t)v.b0 * s->max_dec; h.max_len = s->max_dec;
   h.finished = s->finished + v.b0; h.state = v.state; h.pad_id = m->g.pad_token_id; h.eos_id = m->g.eos_token_id;
   h.forced = forced ? s->forced_ids + (int64_t)v.b0 * Ld : nullptr; h.Ld = Ld;
@@ -635,12 +677,11 @@ int decode_launch_attn(m2m_session* s, const DecView& v, bool self, int layer, i
   const int H = g.num_heads;
   const DecLayerPacked& L = m->dec[layer];
   DecAttnArgs a{};
-  a.x = s->x_dec + (int64_t)v.b0 * g.d_model; a.eps = g.layer_norm_eps; a.d = g.d_model;
-  a.out = (unsigned char*)s->o_dec + (size_t)v.b0 * m->inner * es;
+  a.x = reinterpret_cast<xq_t*>(s->x_dec) + (int64_t)v.b0 * g.d_model; a.eps = g.layer_norm_eps; a.d = g.d_model;
   a.H = H; a.inner = m->inner; a.state = v.state;
   if (self) {
     const size_t off = ((size_t)layer * kv_layer_elems(s, s->max_dec) + (size_t)v.b0 * H * s->max_dec * DK) * es;
-    a.ln_w = L.ln0; a.Wp = L.wqkv;
+    a.ln_w = L.ln0; a.Wp = L.wqkv; a.Wo = L.wo;
     a.Kc = (unsigned char*)s->self_k + off;
     a.Vc = (unsigned char*)s->self_v + off;
     a.kv_stride = s->max_dec; a.n_keys = 0; a.self_len_override = self_len;
@@ -650,7 +691,7 @@ int decode_launch_attn(m2m_session* s, const DecView& v, bool self, int layer, i
   // cross K/V: [L][2][B][H][S][64] with B, S = the encoded problem
   const size_t per = (size_t)s->B * H * s->S * DK;
   const size_t voff = (size_t)v.b0 * H * s->S * DK;
-  a.ln_w = L.ln1; a.Wp = L.wcq;
+  a.ln_w = L.ln1; a.Wp = L.wcq; a.Wo = L.wco;
   a.Kc = (unsigned char*)s->cross_kv + (((size_t)layer * 2 + 0) * per + voff) * es;
   a.Vc = (unsigned char*)s->cross_kv + (((size_t)layer * 2 + 1) * per + voff) * es;
   a.kv_stride = s->S; a.n_keys = s->S; a.self_len_override = 0; a.bias = nullptr; a.bias_stride = 0;
@@ -662,31 +703,23 @@ int decode_launch_step(m2m_session* s, const DecView& v, bool forced, float* log
   const m2m_t5_geometry& g = m->g;
   const int P = m->precision;
   const size_t es = m->esize;
-  float* x = s->x_dec + (int64_t)v.b0 * g.d_model;
-  unsigned char* o = (unsigned char*)s->o_dec + (size_t)v.b0 * m->inner * es;
+  xq_t* x = reinterpret_cast<xq_t*>(s->x_dec) + (int64_t)v.b0 * g.d_model;
   unsigned char* gg = (unsigned char*)s->g_dec + (size_t)v.b0 * g.d_ff * es;
   int rc;
   for (int l = 0; l < g.num_decoder_layers; ++l) {
     const DecLayerPacked& L = m->dec[l];
     DecGemmArgs a{};
     a.eps = g.layer_norm_eps; a.B = v.nb; a.state = v.state;
-    // 1. RMSNorm + per-head QKV projection + KV-cache append + causal self-attention (one kernel)
+    // 1. RMSNorm + per-head QKV projection + KV-cache append + causal self-attention + per-head
+    //    output projection accumulated into the residual stream (one kernel)
     if ((rc = decode_launch_attn(s, v, true, l, 0, st))) return rc;
-    // 2. output projection + residual
-    a.x = o; a.ldx = m->inner; a.ln_w = nullptr; a.W = L.wo; a.K = m->inner; a.N = g.d_model;
-    a.out = x; a.ldo = g.d_model;
-    if ((rc = launch_dec_gemm(P, DEPI_RESID, a, st))) return rc;
-    // 3. RMSNorm + per-head query projection + cross-attention over the S encoder positions (one kernel)
+    // 2. the same for cross-attention over the S encoder positions (query projection only)
     if ((rc = decode_launch_attn(s, v, false, l, 0, st))) return rc;
-    // 4. output projection + residual
-    a.x = o; a.ldx = m->inner; a.ln_w = nullptr; a.W = L.wco; a.K = m->inner; a.N = g.d_model;
-    a.out = x; a.ldo = g.d_model;
-    if ((rc = launch_dec_gemm(P, DEPI_RESID, a, st))) return rc;
-    // 5. RMSNorm + gated-GELU up projection
+    // 3. RMSNorm + gated-GELU up projection
     a.x = x; a.ldx = g.d_model; a.ln_w = L.ln2; a.W = L.wi; a.K = g.d_model; a.N = 2 * g.d_ff;
     a.out = gg; a.ldo = g.d_ff;
     if ((rc = launch_dec_gemm(P, DEPI_GATED, a, st))) return rc;
-    // 6. down projection + residual
+    // 4. down projection + residual
     a.x = gg; a.ldx = g.d_ff; a.ln_w = nullptr; a.W = L.wo_ff; a.K = g.d_ff; a.N = g.d_model;
     a.out = x; a.ldo = g.d_model;
     if ((rc = launch_dec_gemm(P, DEPI_RESID, a, st))) return rc;

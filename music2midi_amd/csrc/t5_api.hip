@@ -43,7 +43,7 @@ extern "C" int m2m_model_create(const m2m_t5_geometry* geom, const m2m_t5_weight
   M2M_REQUIRE(k_ok(g.d_model) && k_ok(g.d_ff) && k_ok(g.num_heads * g.d_kv),
               "m2m_model_create: d_model=%d, d_ff=%d, num_heads*d_kv=%d must each be one of 128/256/384/512/1152 "
               "(the reduction lengths the decode projections are instantiated for)", g.d_model, g.d_ff, g.num_heads * g.d_kv);
-  M2M_REQUIRE(g.d_ff >= 128 && g.d_ff % 128 == 0 && g.d_ff <= 1152, "m2m_model_create: d_ff=%d must be a multiple of 128, <= 1152", g.d_ff);
+  M2M_REQUIRE(g.d_model <= 512, "m2m_model_create: d_model=%d > 512 (the fused decode attention projects with 2 lanes per output column of a 1024-thread workgroup)", g.d_model);
   M2M_REQUIRE((g.num_heads * g.d_kv) % 128 == 0 && g.num_heads * g.d_kv <= 1152, "m2m_model_create: num_heads*d_kv=%d must be a multiple of 128, <= 1152", g.num_heads * g.d_kv);
   M2M_REQUIRE(g.num_heads >= 1 && g.num_layers >= 1 && g.num_decoder_layers >= 1 && g.vocab_size >= 2,
               "m2m_model_create: bad geometry");
@@ -181,7 +181,7 @@ WsLayout ws_layout(const m2m_model* m, int B, int S, int L) {
   w.cross_kv = take((int64_t)g.num_decoder_layers * 2 * M * m->inner * es);
   w.self_k = take((int64_t)g.num_decoder_layers * B * m->inner * L * es);
   w.self_v = take((int64_t)g.num_decoder_layers * B * m->inner * L * es);
-  w.x_dec = take(Bp * g.d_model * 4);
+  w.x_dec = take(Bp * g.d_model * 8);   // int64 fixed-point residual stream
   w.q_dec = take(Bp * m->inner * 4);
   w.o_dec = take(Bp * m->inner * es);
   w.g_dec = take(Bp * g.d_ff * es);
@@ -224,7 +224,7 @@ extern "C" int m2m_session_create(const m2m_model* m, int max_batch, int max_enc
   s->x_enc = (float*)(b + w.x_enc); s->h_enc = b + w.h_enc; s->qkv_enc = b + w.qkv_enc; s->attn_enc = b + w.attn_enc;
   s->mid_enc = b + w.mid_enc; s->enc_bias_tab = (float*)(b + w.enc_bias); s->dec_bias_tab = (float*)(b + w.dec_bias);
   s->cross_kv = b + w.cross_kv; s->self_k = b + w.self_k; s->self_v = b + w.self_v;
-  s->x_dec = (float*)(b + w.x_dec); s->q_dec = (float*)(b + w.q_dec); s->o_dec = b + w.o_dec;
+  s->x_dec = (b + w.x_dec); s->q_dec = (float*)(b + w.q_dec); s->o_dec = b + w.o_dec;
   s->g_dec = b + w.g_dec; s->logits = (float*)(b + w.logits); s->tokens = (int64_t*)(b + w.tokens);
   s->finished = (int*)(b + w.finished); s->states = (DecState*)(b + w.state); s->forced_ids = (int64_t*)(b + w.forced);
 
