@@ -339,6 +339,14 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
 
   // ---- 1. RMSNorm of x[b] -> hn (rounded to the GEMM-input type T) ----
   Vec16<T> kv[PF], vv[PF];
+#ifdef M2M_DA_TOP
+#pragma unroll
+  for (int u = 0; u < PF; ++u) {
+    const int64_t off = (int64_t)min(kslot + u * KPB, last) * DK + sub * E;
+    kv[u].v = *reinterpret_cast<const V16*>(Kb + off);
+    vv[u].v = *reinterpret_cast<const V16*>(Vb + off);
+  }
+#endif
   {
     const bool own = tid * 4 < a.d;
     float ss = own ? (xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w) : 0.f;
@@ -348,7 +356,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
     M2M_STAMP(6 + (SELF ? 1 : 0), 4);
     // ---- 1b. x is here for every wave: start the K/V stream (clamped addresses, never predicated):
     //          the first PF rounds now, the rest by the rolling prefetch of step 3 ----
-#ifndef M2M_DA_LATE
+#if !defined(M2M_DA_LATE) && !defined(M2M_DA_TOP)
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       const int64_t off = (int64_t)min(kslot + u * KPB, last) * DK + sub * E;
