@@ -100,3 +100,45 @@ def test_bf16_mode_tracks_bf16_oracle(cfg_name, B, S, L):
             if out[b, t] != ref[b, t]:
                 assert margins[b, t - 1] < 0.5, f"row {b} step {t}: diverged at margin {margins[b, t-1]:.3f}"
                 break
+
+
+@pytest.mark.parametrize("B,S,L,rows", [(1, 7, 20, 32), (17, 11, 24, 32), (33, 9, 16, 32), (40, 5, 12, 16), (9, 300, 20, 4)])
+def test_ragged_batches_and_decode_chains_fp32(monkeypatch, B, S, L, rows):
+    """Batch sizes that are not multiples of the 16-row MFMA tile, more clips than one chain holds,
+    several chains of unequal size (M2M_GROUP_ROWS), S beyond one key round: ids must not change."""
+    monkeypatch.setenv("M2M_GROUP_ROWS", str(rows))
+    model, orc, g = build(tiny_config(), "fp32", eos=(B % 2 == 1))
+    x = embeds(B, S, g.d_model, seed=B)
+    ref = orc.generate(x, L)
+    out = model.generate_from_embeds(x.cuda(), max_length=L).cpu()
+    assert out.shape == ref.shape and torch.equal(out, ref)
+
+
+def test_max_length_edge_cases_and_session_reuse():
+    model, orc, g = build(tiny_config(), "fp32")
+    x = embeds(3, 10, g.d_model)
+    for L in (1, 2, 3, 17):                       # max_length 1 -> only the start token
+        out = model.generate_from_embeds(x.cuda(), max_length=L).cpu()
+        assert torch.equal(out, orc.generate(x, L)), L
+    # a smaller problem after a bigger one re-uses the session; a bigger one re-creates it
+    big = embeds(6, 40, g.d_model, seed=2)
+    assert torch.equal(model.generate_from_embeds(big.cuda(), max_length=30).cpu(), orc.generate(big, 30))
+    assert torch.equal(model.generate_from_embeds(x.cuda(), max_length=9).cpu(), orc.generate(x, 9))
+
+
+def test_no_graph_mode_matches_graph_mode(monkeypatch):
+    model, orc, g = build(tiny_config(), "bf16")
+    x = embeds(4, 21, g.d_model).cuda()
+    a = model.generate_from_embeds(x, max_length=40)
+    monkeypatch.setenv("M2M_NO_GRAPH", "1")
+    b = model.generate_from_embeds(x, max_length=40)
+    assert torch.equal(a, b)
+
+
+def test_error_paths_report_instead_of_faulting():
+    from music2midi_amd import native
+    model, _, g = build(tiny_config(), "fp32")
+    with pytest.raises(native.NativeError, match="too short"):
+        model.spectrogram(torch.zeros(1, 512, device="cuda"))
+    with pytest.raises(native.NativeError):
+        model.generate_from_embeds(torch.zeros(1, 40000, g.d_model, device="cuda"), max_length=4)   # S beyond the LDS bias table
