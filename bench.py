@@ -39,29 +39,33 @@ N_SAMPLES = 220500        # 10 s @ 22.05 kHz
 MAX_LENGTH = 1024
 
 
-def cpu_baseline(cfg, state, new_tokens: int):
-    """Oracle on the host cores: 1 clip, frontend + encoder + `new_tokens` greedy steps, fp32."""
+def cpu_baseline(cfg, state, new_tokens: int, clips: int = 4, threads: int = 16):
+    """Oracle on the host cores: `clips` clips, frontend + encoder + `new_tokens` greedy steps, fp32.
+
+    16 intra-op threads: measured fastest on the GPU box's 256-core host (tools/cpu_threads_probe.py:
+    4/8/16/32/64/128 threads -> 198/205/211/99/44/18 tokens/s for one clip; the matmuls are tiny)."""
     from music2midi_amd import synth
     from music2midi_amd.config import T5Geometry
     from oracle.logmel import LogMelOracle, conditioning
     from oracle.t5 import T5Oracle
 
     geom = T5Geometry(cfg.model.t5)
-    threads = torch.get_num_threads()
+    threads = min(threads, os.cpu_count() or threads)
+    torch.set_num_threads(threads)
     fe = LogMelOracle(cfg.model.sample_rate, cfg.spectrogram.n_fft, cfg.spectrogram.hop_length,
                       cfg.spectrogram.f_min, geom.d_model)
     orc = T5Oracle(geom, state, emulate="fp32")
-    wav = torch.from_numpy(synth.waveform_batch(0, 1, N_SAMPLES))
-    idx = torch.from_numpy(synth.cond_index_batch(0, 1))
+    wav = torch.from_numpy(synth.waveform_batch(0, clips, N_SAMPLES))
+    idx = torch.from_numpy(synth.cond_index_batch(0, clips))
     emb = [torch.from_numpy(state[f"conditioning.embeds.{i}.weight"]) for i in range(2)]
     t0 = time.perf_counter()
     x = conditioning(fe(wav), idx, emb)
     ids = orc.generate(x, new_tokens + 1)
     dt = time.perf_counter() - t0
-    n = ids.shape[1] - 1
+    n = (ids.shape[1] - 1) * clips
     return {"value": n / dt, "unit": "tokens/s", "cores": threads, "kind": "port",
-            "sample": f"1 clip x {N_SAMPLES} samples: log-mel + encoder (S=864) + {n} greedy decode steps, "
-                      f"fp32 torch-CPU oracle, {dt:.1f} s wall, os.cpu_count()={os.cpu_count()}"}
+            "sample": f"{clips} clips x {N_SAMPLES} samples in one batch: log-mel + encoder (S=864) + {ids.shape[1] - 1} greedy "
+                      f"decode steps each, fp32 torch-CPU oracle, {dt:.1f} s wall, {threads} threads of os.cpu_count()={os.cpu_count()}"}
 
 
 def pmc_traffic_bytes(kernel_substr: str, batch: int):
@@ -86,7 +90,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
-    ap.add_argument("--cpu-tokens", type=int, default=192, help="greedy steps of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-tokens", type=int, default=1023, help="greedy steps per clip of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--max-length", type=int, default=MAX_LENGTH,
                     help="decoder max_length (profiling runs only; the headline number uses 1024)")
