@@ -64,16 +64,18 @@ int launch_final_norm_f32(const float* x, const float* w, float* out_f32, void* 
 }
 
 // ================================================================= GEMM ====
-// C[M,N] = A[M,K] * W[N,K]^T.  128x128 output tile per 256-thread workgroup, BK = 32,
+// C[M,N] = A[M,K] * W[N,K]^T.  128x128 output tile per 256-thread workgroup, BK = 64 (bf16) / 32 (fp32),
 // 2x2 waves each owning 64x64 (2x2 MFMA 32x32 tiles), register-prefetched LDS staging.
-constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int BM = 128, BN = 128;
 
 template <typename T> struct TileCfg;
 template <> struct TileCfg<bf16_t> {
-  static constexpr int PITCH = BK + 8;                       // elements per LDS row (80 B)
-  static constexpr int CPR = BK * 2 / 16;                    // 16-byte chunks per row = 4
+  static constexpr int BK = 64;                              // 16 MFMAs per wave between barriers
+  static constexpr int PITCH = BK + 8;                       // elements per LDS row (144 B)
+  static constexpr int CPR = BK * 2 / 16;                    // 16-byte chunks per row = 8
 };
 template <> struct TileCfg<float> {
+  static constexpr int BK = 32;
   static constexpr int PITCH = BK + 4;                       // 144 B
   static constexpr int CPR = BK * 4 / 16;                    // 8
 };
@@ -81,6 +83,7 @@ template <> struct TileCfg<float> {
 template <typename T, int EPI>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   using Cfg = TileCfg<T>;
+  constexpr int BK = Cfg::BK;
   constexpr int EPC = 16 / sizeof(T);                          // elements per 16-byte chunk
   constexpr int CHUNKS = BM * Cfg::CPR;                        // per operand tile
   constexpr int PER_THREAD = CHUNKS / 256;
@@ -94,26 +97,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   const T* W = reinterpret_cast<const T*>(g.W);
   const int K = g.K;
 
-  uint4 ra[PER_THREAD], rb[PER_THREAD];
-  auto gload = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < PER_THREAD; ++i) {
-      const int c = tid + i * 256;
-      const int row = c / Cfg::CPR, cc = c % Cfg::CPR;
-      const int ar = min(m0 + row, g.M - 1), br = min(n0 + row, g.N - 1);
-      ra[i] = *reinterpret_cast<const uint4*>(A + (int64_t)ar * K + k0 + cc * EPC);
-      rb[i] = *reinterpret_cast<const uint4*>(W + (int64_t)br * K + k0 + cc * EPC);
-    }
-  };
-  auto sstore = [&]() {
-#pragma unroll
-    for (int i = 0; i < PER_THREAD; ++i) {
-      const int c = tid + i * 256;
-      const int row = c / Cfg::CPR, cc = c % Cfg::CPR;
-      *reinterpret_cast<uint4*>(As + row * Cfg::PITCH + cc * EPC) = ra[i];
-      *reinterpret_cast<uint4*>(Bs + row * Cfg::PITCH + cc * EPC) = rb[i];
-    }
-  };
+  // register staging in NAMED scalars: arrays here (uint4 ra[PER_THREAD]) are demoted to scratch by
+  // hipcc 7.2 across the k-loop even when every index is a compile-time constant
+  static_assert(PER_THREAD == 2 || PER_THREAD == 4, "staging below is written for 2 or 4 chunks per thread");
+#define M2M_CHUNK(i)                                                                         \
+  const int c##i = tid + (i) * 256;                                                          \
+  const T* ap##i = A + (int64_t)min(m0 + c##i / Cfg::CPR, g.M - 1) * K + (c##i % Cfg::CPR) * EPC; \
+  const T* bp##i = W + (int64_t)min(n0 + c##i / Cfg::CPR, g.N - 1) * K + (c##i % Cfg::CPR) * EPC; \
+  const int so##i = (c##i / Cfg::CPR) * Cfg::PITCH + (c##i % Cfg::CPR) * EPC;                 \
+  uint4 ra##i, rb##i;
+  M2M_CHUNK(0) M2M_CHUNK(1) M2M_CHUNK(2) M2M_CHUNK(3)
+#undef M2M_CHUNK
+#define M2M_LD(i, k0) ra##i = *reinterpret_cast<const uint4*>(ap##i + (k0)); rb##i = *reinterpret_cast<const uint4*>(bp##i + (k0));
+#define M2M_ST(i) *reinterpret_cast<uint4*>(As + so##i) = ra##i; *reinterpret_cast<uint4*>(Bs + so##i) = rb##i;
+#define M2M_GLOAD(k0) { M2M_LD(0, k0) M2M_LD(1, k0) if constexpr (PER_THREAD == 4) { M2M_LD(2, k0) M2M_LD(3, k0) } }
+#define M2M_SSTORE() { M2M_ST(0) M2M_ST(1) if constexpr (PER_THREAD == 4) { M2M_ST(2) M2M_ST(3) } }
+  ra2 = rb2 = ra3 = rb3 = make_uint4(0, 0, 0, 0);
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -123,12 +122,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
   const int r = lane & 31, h = lane >> 5;
   const int nk = K / BK;
-  gload(0);
+  M2M_GLOAD(0)
   for (int kt = 0; kt < nk; ++kt) {
     __syncthreads();
-    sstore();
+    M2M_SSTORE()
     __syncthreads();
-    if (kt + 1 < nk) gload((kt + 1) * BK);
+    if (kt + 1 < nk) { M2M_GLOAD((kt + 1) * BK) }
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
       Frag<T> fa[2], fb[2];
@@ -144,6 +143,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
   }
 
+#undef M2M_GLOAD
+#undef M2M_SSTORE
+#undef M2M_LD
+#undef M2M_ST
   // ---- epilogue ----
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
@@ -196,7 +199,7 @@ static int launch_gemm_t(int epi, const GemmArgs& a, hipStream_t st) {
 }
 
 int launch_gemm(int precision, int epi, const GemmArgs& a, hipStream_t st) {
-  M2M_REQUIRE(a.K % BK == 0, "gemm: K=%d must be a multiple of %d", a.K, BK);
+  M2M_REQUIRE(a.K % 64 == 0, "gemm: K=%d must be a multiple of 64", a.K);
   M2M_REQUIRE(a.M >= 1 && a.N >= 1, "gemm: empty problem");
   if (epi == EPI_GATED) M2M_REQUIRE(a.N % 64 == 0, "gemm: gated epilogue needs N %% 64 == 0 (d_ff %% 32 == 0)");
   return precision == M2M_PREC_BF16 ? launch_gemm_t<bf16_t>(epi, a, st) : launch_gemm_t<float>(epi, a, st);
