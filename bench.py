@@ -110,7 +110,7 @@ def main():
                   f"--nproc-per-node {args.gpus}", file=sys.stderr)
         args.gpus = world
     native.require_gpu()
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
 
     cfg = default_config()
@@ -167,7 +167,7 @@ def main():
         }
 
     # ---- phase timings + roofline of the dominant kernel (rank 0 only, N = 1) ----
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and world == 1 and not args.no_roofline:
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         ev[0].record()
         x = model.encoder_inputs(inputs)

@@ -35,13 +35,16 @@ def init_process_group(backend: Optional[str] = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
+        backend = os.environ.get("M2M_DIST_BACKEND", backend)
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
         else:
+            if torch.cuda.is_available():
+                torch.cuda.set_device(local_rank % torch.cuda.device_count())
             dist.init_process_group(backend)
     elif torch.cuda.is_available():
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
     return rank, local_rank, world
 
 
