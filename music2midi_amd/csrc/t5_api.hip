@@ -162,7 +162,7 @@ extern "C" int64_t m2m_model_param_bytes(const m2m_model* m) { return m ? m->blo
 namespace {
 struct WsLayout {
   int64_t x_enc, h_enc, qkv_enc, attn_enc, mid_enc, enc_bias, dec_bias, cross_kv, self_k, self_v;
-  int64_t x_dec, q_dec, o_dec, g_dec, logits, tokens, finished, state, forced, total;
+  int64_t x_dec, g_dec, logits, tokens, finished, state, forced, total;
 };
 
 WsLayout ws_layout(const m2m_model* m, int B, int S, int L) {
@@ -182,8 +182,6 @@ WsLayout ws_layout(const m2m_model* m, int B, int S, int L) {
   w.self_k = take((int64_t)g.num_decoder_layers * B * m->inner * L * es);
   w.self_v = take((int64_t)g.num_decoder_layers * B * m->inner * L * es);
   w.x_dec = take(Bp * g.d_model * 8);   // int64 fixed-point residual stream
-  w.q_dec = take(Bp * m->inner * 4);
-  w.o_dec = take(Bp * m->inner * es);
   w.g_dec = take(Bp * g.d_ff * es);
   w.logits = take(Bp * m->vocab_pad * 4);
   w.tokens = take((int64_t)B * L * 8);
@@ -224,7 +222,7 @@ extern "C" int m2m_session_create(const m2m_model* m, int max_batch, int max_enc
   s->x_enc = (float*)(b + w.x_enc); s->h_enc = b + w.h_enc; s->qkv_enc = b + w.qkv_enc; s->attn_enc = b + w.attn_enc;
   s->mid_enc = b + w.mid_enc; s->enc_bias_tab = (float*)(b + w.enc_bias); s->dec_bias_tab = (float*)(b + w.dec_bias);
   s->cross_kv = b + w.cross_kv; s->self_k = b + w.self_k; s->self_v = b + w.self_v;
-  s->x_dec = (b + w.x_dec); s->q_dec = (float*)(b + w.q_dec); s->o_dec = b + w.o_dec;
+  s->x_dec = (b + w.x_dec);
   s->g_dec = b + w.g_dec; s->logits = (float*)(b + w.logits); s->tokens = (int64_t*)(b + w.tokens);
   s->finished = (int*)(b + w.finished); s->states = (DecState*)(b + w.state); s->forced_ids = (int64_t*)(b + w.forced);
 

@@ -64,3 +64,21 @@ def test_cond_rows_out_of_range_is_nan_not_fault():
     feat = torch.zeros(1, 3, 384, device="cuda")
     out = cond(feat, torch.tensor([[7, 1]], device="cuda"))
     assert torch.isnan(out[0, 0]).all() and not torch.isnan(out[0, 1]).any()
+
+
+def test_full_size_batch64_properties():
+    """BASELINE configs[1] geometry (64 clips x 220 500 samples): size-independent properties —
+    run-to-run determinism, a clip's rows do not depend on its batch mates, a digitally silent
+    tail gives exactly log(1e-6), every value finite."""
+    B, T = 64, 220500
+    wav = synth.waveform_batch(0, B, T)
+    wav[5, T // 2:] = 0.0                                  # silent second half
+    x = torch.from_numpy(wav).cuda()
+    fe = LogMelSpectrogram(16000, 2048, 256, 20.0, 384)
+    a, b = fe(x), fe(x)
+    assert a.shape == (B, 862, 384) and torch.equal(a, b) and torch.isfinite(a).all()
+    assert torch.equal(fe(x[17:18]), a[17:18]) and torch.equal(fe(x[5:7]), a[5:7])
+    floor = float(np.log(np.float32(1e-6)))
+    assert (a[5, 862 // 2 + 8:] == floor).all() and not (a[5, :400] == floor).any()
+    ref = _oracle(16000, 384)(torch.from_numpy(wav[40:42]))
+    assert (a[40:42].cpu() - ref).abs().max().item() <= TOL

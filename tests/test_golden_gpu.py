@@ -134,3 +134,20 @@ def test_full_size_properties_bf16():
     sub = model.generate_from_embeds(x[5:8].contiguous(), max_length=1024)
     n = min(sub.shape[1], a.shape[1])
     assert torch.equal(sub[:, :n], a[5:8, :n])                   # a clip's ids do not depend on its batch mates
+
+
+def test_forward_bf16_tracks_bf16_oracle():
+    """Teacher-forced logits in the bf16 throughput mode vs the oracle's bf16 emulation (same rounding points)."""
+    model, orc, g = build(DEFAULT_CONFIG, "bf16")
+    B, S, Ld = 3, 90, 20
+    x = embeds(B, S, g.d_model)
+    labels = torch.from_numpy((synth.uniform01(5, "labels", B * Ld) * 330).astype(np.int64).reshape(B, Ld)) + 3
+    _, ref = orc.forward(x, labels)
+    dec_in = torch.full_like(labels, g.decoder_start_token_id)
+    dec_in[:, 1:] = labels[:, :-1]
+    out = model.logits_from_embeds(x.cuda(), dec_in.cuda()).cpu()
+    err = (out - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    print(f"bf16 forced logits: max|diff| {err:.3f} on logits up to {scale:.1f}")
+    assert err < 0.03 * scale                      # bf16 has 8 significant bits; fp32-vs-bf16 differs by ~10x more
+    assert (out.argmax(-1) == ref.argmax(-1)).float().mean().item() > 0.9
