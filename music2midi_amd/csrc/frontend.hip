@@ -33,7 +33,6 @@ constexpr int FE_THREADS = 256;
 constexpr int FE_WAVES = 4;
 constexpr int T_PITCH = 68;           // float2 per k1 row of the transpose buffer
 constexpr int WAVE_C2 = 16 * T_PITCH; // float2 per wave (transpose buffer, aliased by Z)
-constexpr int P_PITCH = 1032;         // floats per wave (1025 power bins, padded)
 
 struct FrontendDev {
   const float* window;    // [2048]
@@ -103,9 +102,12 @@ constexpr int DPP_XOR2 = 0x4E;  // quad_perm [2,3,0,1]
 
 __device__ inline int zidx(int k) { return k + 4 * (k >> 8); }  // bank-spread layout of Z[0..1023]
 
-__global__ __launch_bounds__(FE_THREADS) void logmel_kernel(
+constexpr int FE_MAXJ = 8;          // mel filters per lane (n_mels <= 512)
+constexpr int FE_FBW_LDS = 4096;    // filter taps kept in LDS when the sparse filterbank has at most this many
+
+__global__ __launch_bounds__(FE_THREADS, 2) void logmel_kernel(
     const float* __restrict__ wav, int T, int F, FrontendDev fe, float* __restrict__ out,
-    int64_t out_bstride, int row_offset, int FR) {
+    int64_t out_bstride, int row_offset, int FR, int nnz) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -113,11 +115,13 @@ __global__ __launch_bounds__(FE_THREADS) void logmel_kernel(
   const int hop = fe.hop;
   const int span_max = (FR - 1) * hop + NFFT;
 
+  // LDS: samples | per-wave FFT scratch (transpose buffer, then Z, then the 1025 power bins) | filter taps
   float* samples = reinterpret_cast<float*>(smem_raw);
-  float2* cbuf = reinterpret_cast<float2*>(smem_raw + (size_t)((span_max + 3) & ~3) * sizeof(float)) + wave * WAVE_C2;
-  float* pbase = reinterpret_cast<float*>(reinterpret_cast<float2*>(smem_raw + (size_t)((span_max + 3) & ~3) * sizeof(float)) +
-                                          FE_WAVES * WAVE_C2);
-  float* pbuf = pbase + wave * P_PITCH;
+  float2* cbase = reinterpret_cast<float2*>(smem_raw + (size_t)((span_max + 3) & ~3) * sizeof(float));
+  float2* cbuf = cbase + wave * WAVE_C2;
+  float* pbuf = reinterpret_cast<float*>(cbuf);          // aliases cbuf: written only after every Z read of the wave
+  float* fbw_s = reinterpret_cast<float*>(cbase + FE_WAVES * WAVE_C2);
+  const bool fbw_in_lds = nnz <= FE_FBW_LDS;
 
   const int b = blockIdx.y;
   const int f0 = blockIdx.x * FR;
@@ -134,7 +138,10 @@ __global__ __launch_bounds__(FE_THREADS) void logmel_kernel(
       else if (j >= T) j = 2 * (T - 1) - j;
       samples[i] = w[j];
     }
+    if (fbw_in_lds)
+      for (int i = tid; i < nnz; i += FE_THREADS) fbw_s[i] = fe.fb_w[i];
   }
+  const float* fbw = fbw_in_lds ? fbw_s : fe.fb_w;
 
   // ---- per-lane constants, loaded once ----
   float2 win[16];   // window[2n], window[2n+1] for n = 64*n1 + lane
@@ -150,97 +157,110 @@ __global__ __launch_bounds__(FE_THREADS) void logmel_kernel(
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i) tw_p[i] = fe.tw2048[lane + 64 * i];
+  // this lane's mel filters: m = lane + 64 j (first tap bin, tap count, offset of the first weight)
+  const int n_mels = fe.n_mels;
+  int fb_s[FE_MAXJ], fb_c[FE_MAXJ], fb_o[FE_MAXJ];
+#pragma unroll
+  for (int j = 0; j < FE_MAXJ; ++j) {
+    const int m = min(lane + 64 * j, n_mels - 1);
+    fb_s[j] = fe.fb_start[m];
+    fb_c[j] = (lane + 64 * j < n_mels) ? fe.fb_count[m] : 0;
+    fb_o[j] = fe.fb_off[m];
+  }
 
   __syncthreads();
 
-  const int rounds = (nfr + FE_WAVES - 1) / FE_WAVES;
-  for (int r = 0; r < rounds; ++r) {
-    const int fl = r * FE_WAVES + wave;
-    if (fl < nfr) {  // wave-uniform
-      const float* fs = samples + fl * hop;
-      float2 z[16];
-      // stage 1: lane holds n = 64*n1 + lane
+  // Each WAVE now runs on its own: frame -> FFT -> power bins -> mel -> store, with wave-level
+  // barriers only, so the four waves of the workgroup drift apart and overlap each other's phases.
+  for (int fl = wave; fl < nfr; fl += FE_WAVES) {
+    const float* fs = samples + fl * hop;   // 8-byte aligned: hop is even (checked on the host)
+    float2 z[16];
+    // stage 1: lane holds n = 64*n1 + lane
 #pragma unroll
-      for (int n1 = 0; n1 < 16; ++n1) {
-        const int n = 64 * n1 + lane;
-        z[n1] = make_float2(fs[2 * n] * win[n1].x, fs[2 * n + 1] * win[n1].y);
-      }
-      fft16(z);
-#pragma unroll
-      for (int k1 = 0; k1 < 16; ++k1) {
-        float2 v = (k1 == 0) ? z[0] : cmul(z[k1], tw_a[k1]);
-        cbuf[k1 * T_PITCH + lane] = v;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      // stage 2: lane = (k1, m2) holds l = 4*m1 + m2
-#pragma unroll
-      for (int m1 = 0; m1 < 16; ++m1) z[m1] = cbuf[k1_lane * T_PITCH + 4 * m1 + m2];
-      __builtin_amdgcn_wave_barrier();
-      fft16(z);
-#pragma unroll
-      for (int q1 = 1; q1 < 16; ++q1) z[q1] = cmul(z[q1], tw_b[q1]);
-      // stage 3: radix-4 across the quad (m2 = lane&3) by two DPP exchanges.
-      //   after: lane m2 holds Y[q1 + 16*q2] with q2 = bitrev2(m2)
-#pragma unroll
-      for (int q1 = 0; q1 < 16; ++q1) {
-        float2 v = z[q1];
-        float2 p = make_float2(dpp_quad<DPP_XOR2>(v.x), dpp_quad<DPP_XOR2>(v.y));
-        v = (m2 & 2) ? csub(p, v) : cadd(v, p);
-        if (m2 == 3) v = mul_negi(v);
-        p = make_float2(dpp_quad<DPP_XOR1>(v.x), dpp_quad<DPP_XOR1>(v.y));
-        v = (m2 & 1) ? csub(p, v) : cadd(v, p);
-        z[q1] = v;
-      }
-      {
-        const int q2 = ((m2 & 1) << 1) | (m2 >> 1);
-#pragma unroll
-        for (int q1 = 0; q1 < 16; ++q1) cbuf[zidx(k1_lane + 16 * q1 + 256 * q2)] = z[q1];
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      // post-process pairs (k, 1024-k): X[k] = E + W2048^k O, X[1024-k] = conj(E - W2048^k O)
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int k = lane + 64 * i;
-        float2 zk = cbuf[zidx(k)];
-        float2 zn = cbuf[zidx((HALF - k) & (HALF - 1))];
-        zn.y = -zn.y;  // conj
-        float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y + zn.y));
-        float2 d = make_float2(0.5f * (zk.x - zn.x), 0.5f * (zk.y - zn.y));
-        float2 o = make_float2(d.y, -d.x);  // d / i
-        float2 t = cmul(tw_p[i], o);
-        float2 xp = cadd(e, t), xm = csub(e, t);
-        pbuf[k] = xp.x * xp.x + xp.y * xp.y;
-        pbuf[HALF - k] = xm.x * xm.x + xm.y * xm.y;
-      }
-      if (lane == 0) {  // k = 512: E = Re Z, O = Im Z, W2048^512 = -i
-        float2 zk = cbuf[zidx(512)];
-        pbuf[512] = zk.x * zk.x + zk.y * zk.y;
-      }
+    for (int n1 = 0; n1 < 16; ++n1) {
+      const float2 sv = *reinterpret_cast<const float2*>(fs + 2 * (64 * n1 + lane));
+      z[n1] = make_float2(sv.x * win[n1].x, sv.y * win[n1].y);
     }
-    __syncthreads();
-    // ---- mel filterbank + clamp + log for the frames of this round ----
+    fft16(z);
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) {
+      float2 v = (k1 == 0) ? z[0] : cmul(z[k1], tw_a[k1]);
+      cbuf[k1 * T_PITCH + lane] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // stage 2: lane = (k1, m2) holds l = 4*m1 + m2
+#pragma unroll
+    for (int m1 = 0; m1 < 16; ++m1) z[m1] = cbuf[k1_lane * T_PITCH + 4 * m1 + m2];
+    __builtin_amdgcn_wave_barrier();
+    fft16(z);
+#pragma unroll
+    for (int q1 = 1; q1 < 16; ++q1) z[q1] = cmul(z[q1], tw_b[q1]);
+    // stage 3: radix-4 across the quad (m2 = lane&3) by two DPP exchanges.
+    //   after: lane m2 holds Y[q1 + 16*q2] with q2 = bitrev2(m2)
+#pragma unroll
+    for (int q1 = 0; q1 < 16; ++q1) {
+      float2 v = z[q1];
+      float2 p = make_float2(dpp_quad<DPP_XOR2>(v.x), dpp_quad<DPP_XOR2>(v.y));
+      v = (m2 & 2) ? csub(p, v) : cadd(v, p);
+      if (m2 == 3) v = mul_negi(v);
+      p = make_float2(dpp_quad<DPP_XOR1>(v.x), dpp_quad<DPP_XOR1>(v.y));
+      v = (m2 & 1) ? csub(p, v) : cadd(v, p);
+      z[q1] = v;
+    }
     {
-      const int nround = min(FE_WAVES, nfr - r * FE_WAVES);
-      const int n_mels = fe.n_mels;
-      const int total = nround * n_mels;
-      for (int idx = tid; idx < total; idx += FE_THREADS) {
-        const int w = idx / n_mels;
-        const int m = idx - w * n_mels;
-        const float* p = pbase + w * P_PITCH + fe.fb_start[m];
-        const float* fw = fe.fb_w + fe.fb_off[m];
-        const int cnt = fe.fb_count[m];
-        float acc = 0.f;
-        for (int c = 0; c < cnt; ++c) acc = fmaf(p[c], fw[c], acc);
-        const int f = f0 + r * FE_WAVES + w;
-        // clamp(min=1e-6).log(): the floor is the correctly rounded fp32 ln(1e-6f), so silent
-        // (zero-padded) regions are bit-identical to the reference's constant.
-        out[(int64_t)b * out_bstride + (int64_t)(row_offset + f) * n_mels + m] =
-            (acc > 1e-6f) ? logf(acc) : -13.815510749816895f;
+      const int q2 = ((m2 & 1) << 1) | (m2 >> 1);
+#pragma unroll
+      for (int q1 = 0; q1 < 16; ++q1) cbuf[zidx(k1_lane + 16 * q1 + 256 * q2)] = z[q1];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // post-process pairs (k, 1024-k): X[k] = E + W2048^k O, X[1024-k] = conj(E - W2048^k O).
+    // All Z values are read into registers first: the power bins overwrite the Z image.
+    float2 zk[8], zn[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = lane + 64 * i;
+      zk[i] = cbuf[zidx(k)];
+      zn[i] = cbuf[zidx((HALF - k) & (HALF - 1))];
+    }
+    const float2 z512 = cbuf[zidx(512)];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = lane + 64 * i;
+      const float2 c = make_float2(zn[i].x, -zn[i].y);  // conj
+      const float2 e = make_float2(0.5f * (zk[i].x + c.x), 0.5f * (zk[i].y + c.y));
+      const float2 d = make_float2(0.5f * (zk[i].x - c.x), 0.5f * (zk[i].y - c.y));
+      const float2 o = make_float2(d.y, -d.x);  // d / i
+      const float2 t = cmul(tw_p[i], o);
+      const float2 xp = cadd(e, t), xm = csub(e, t);
+      pbuf[k] = xp.x * xp.x + xp.y * xp.y;
+      pbuf[HALF - k] = xm.x * xm.x + xm.y * xm.y;
+    }
+    if (lane == 0) pbuf[512] = z512.x * z512.x + z512.y * z512.y;  // k = 512: E = Re Z, O = Im Z, W2048^512 = -i
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- mel filterbank (sparse contiguous taps) + clamp + log, this wave's frame ----
+    {
+      float* orow = out + (int64_t)b * out_bstride + (int64_t)(row_offset + f0 + fl) * n_mels;
+#pragma unroll
+      for (int j = 0; j < FE_MAXJ; ++j) {
+        const int m = lane + 64 * j;
+        if (m < n_mels) {
+          const float* p = pbuf + fb_s[j];
+          const float* fw = fbw + fb_o[j];
+          float acc = 0.f;
+          for (int c = 0; c < fb_c[j]; ++c) acc = fmaf(p[c], fw[c], acc);
+          // clamp(min=1e-6).log(): the floor is the correctly rounded fp32 ln(1e-6f), so silent
+          // (zero-padded) regions are bit-identical to the reference's constant.
+          orow[m] = (acc > 1e-6f) ? logf(acc) : -13.815510749816895f;
+        }
       }
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();   // the next frame's transpose writes reuse this buffer
   }
 }
 
@@ -275,7 +295,9 @@ extern "C" int m2m_frontend_create(const m2m_frontend_desc* d, m2m_frontend** ou
   M2M_REQUIRE(d && out, "m2m_frontend_create: null argument");
   M2M_REQUIRE(d->n_fft == NFFT, "m2m_frontend_create: n_fft=%d unsupported (kernel is specialised for 2048, ref config.yaml:12)", d->n_fft);
   M2M_REQUIRE(d->n_freqs == NFFT / 2 + 1, "m2m_frontend_create: n_freqs must be n_fft/2+1");
-  M2M_REQUIRE(d->hop_length >= 1 && d->hop_length <= NFFT / 2, "m2m_frontend_create: hop_length out of range");
+  M2M_REQUIRE(d->hop_length >= 2 && d->hop_length <= NFFT / 2 && d->hop_length % 2 == 0,
+              "m2m_frontend_create: hop_length=%d must be even and in [2, n_fft/2] (the kernel reads sample pairs)", d->hop_length);
+  M2M_REQUIRE(d->n_mels <= 64 * 8, "m2m_frontend_create: n_mels=%d > 512 unsupported", d->n_mels);
   M2M_REQUIRE(d->n_mels >= 1 && d->window_host && d->fb_host, "m2m_frontend_create: bad n_mels / null tables");
 
   const int n_mels = d->n_mels, n_freqs = d->n_freqs;
@@ -355,10 +377,11 @@ extern "C" int m2m_frontend_num_frames(const m2m_frontend* fe, int n_samples) {
 
 extern "C" int m2m_frontend_fb_nnz(const m2m_frontend* fe) { return fe ? fe->nnz : M2M_ERR_INVALID; }
 
-static size_t frontend_smem_bytes(int FR, int hop) {
+static size_t frontend_smem_bytes(int FR, int hop, int nnz) {
   size_t span = (size_t)(FR - 1) * hop + NFFT;
   span = (span + 3) & ~(size_t)3;
-  return span * sizeof(float) + (size_t)FE_WAVES * WAVE_C2 * sizeof(float2) + (size_t)FE_WAVES * P_PITCH * sizeof(float);
+  return span * sizeof(float) + (size_t)FE_WAVES * WAVE_C2 * sizeof(float2) +
+         (nnz <= FE_FBW_LDS ? (size_t)nnz * sizeof(float) : 0);
 }
 
 extern "C" int m2m_logmel_f32(const m2m_frontend* fe, const float* wav_dev, int B, int T, float* out_dev,
@@ -372,8 +395,8 @@ extern "C" int m2m_logmel_f32(const m2m_frontend* fe, const float* wav_dev, int 
               "m2m_logmel_f32: out_batch_stride %lld smaller than (row_offset+frames)*n_mels", (long long)out_batch_stride);
   // 16 frames per workgroup: waveform re-read factor 1.44 at hop 256, two workgroups per CU.
   int FR = 16;
-  while (FR > 4 && frontend_smem_bytes(FR, fe->hop) > 78 * 1024) FR -= 4;
-  const size_t smem = frontend_smem_bytes(FR, fe->hop);
+  while (FR > 4 && frontend_smem_bytes(FR, fe->hop, fe->nnz) > 78 * 1024) FR -= 4;
+  const size_t smem = frontend_smem_bytes(FR, fe->hop, fe->nnz);
   dim3 grid((unsigned)ceil_div(F, FR), (unsigned)B);
   static bool attr_set = false;
   if (!attr_set) {
@@ -381,7 +404,7 @@ extern "C" int m2m_logmel_f32(const m2m_frontend* fe, const float* wav_dev, int 
     attr_set = true;
   }
   hipLaunchKernelGGL(logmel_kernel, grid, dim3(FE_THREADS), smem, (hipStream_t)stream, wav_dev, T, F, fe->dev,
-                     out_dev, out_batch_stride, row_offset, FR);
+                     out_dev, out_batch_stride, row_offset, FR, fe->nnz);
   M2M_CHECK_HIP(hipGetLastError());
   return M2M_OK;
 }
