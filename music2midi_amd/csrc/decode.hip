@@ -53,6 +53,12 @@ __device__ unsigned int g_stamp_n;
 // attention kernels (8 workgroups per clip add into the same row).  Float atomics would make the
 // sum depend on arrival order; integer adds are associative, so the result is bit-reproducible
 // whatever the order, and exact (2^-30 resolution, +-8.6e9 range) where fp32 would round.
+//
+// The stream lives in THREE buffers that rotate (A -> B -> C -> A): an attention kernel READS the
+// complete row from one buffer and ACCUMULATES residual + per-head projections into the next one,
+// which the kernel before it left zeroed, and zeroes the third.  A workgroup that starts late
+// (more workgroups than CUs) therefore never reads a row that a finished sibling has already
+// added to, which a single read-modify buffer would allow.
 typedef long long xq_t;
 __device__ inline xq_t xq_fix(float v) { return __float2ll_rn(v * 1073741824.0f); }
 __device__ inline float xq_flt(xq_t q) { return (float)q * (1.0f / 1073741824.0f); }
@@ -74,8 +80,10 @@ struct DecGemmArgs {
   int K, N, B;
   const DecState* state;
   // outputs
-  void* out;             // PLAIN: float [B, N]; RESID: xq_t residual stream [B, N] (+=); GATED: T [B, N/2]
+  void* out;             // PLAIN: float [B, N]; RESID: xq_t residual stream [B, N] (= res_in + v); GATED: T [B, N/2]
   int ldo;
+  const void* res_in;    // RESID: xq_t [B, N] the residual the projection is added to
+  void* res_zero;        // RESID: xq_t [B, N] buffer left zeroed for the next attention kernel to accumulate into
 };
 
 // One 16-row x 16-column output tile per workgroup (MFMA 16x16x32 / 16x16x4), NW waves split K.
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(64 * DG_MAXW) void dec_gemm_kernel(DecGemmArgs a) {
   xq_t xold = 0;
   if constexpr (EPI == DEPI_RESID) {
     const int cb = min(ob, a.B - 1), cn = min(on, a.N - 1);
-    xold = reinterpret_cast<const xq_t*>(a.out)[(int64_t)cb * a.ldo + cn];
+    xold = reinterpret_cast<const xq_t*>(a.res_in)[(int64_t)cb * a.ldo + cn];
   }
 
   Frag<T> wf[NS];
@@ -206,7 +214,10 @@ __global__ __launch_bounds__(64 * DG_MAXW) void dec_gemm_kernel(DecGemmArgs a) {
     const float v = rsum(idx);
     float* outf = reinterpret_cast<float*>(a.out);
     if constexpr (EPI == DEPI_PLAIN) outf[(int64_t)ob * a.ldo + on] = v;
-    else reinterpret_cast<xq_t*>(a.out)[(int64_t)ob * a.ldo + on] = xold + xq_fix(v);   // DEPI_RESID
+    else {                                                                               // DEPI_RESID
+      reinterpret_cast<xq_t*>(a.out)[(int64_t)ob * a.ldo + on] = xold + xq_fix(v);
+      reinterpret_cast<xq_t*>(a.res_zero)[(int64_t)ob * a.ldo + on] = 0;
+    }
   }
   M2M_STAMP(1 + EPI, 2);
 }
@@ -264,7 +275,9 @@ static int launch_dec_gemm(int precision, int epi, const DecGemmArgs& a, hipStre
 // reading K and reading V: both are requested together at kernel start and stream continuously
 // while the norm and the projection run; the only reductions are at the very end.
 struct DecAttnArgs {
-  xq_t* x;               // [B, d] fixed-point residual stream: read by the norm, ADDED to by the output projection
+  const xq_t* x;         // [B, d] fixed-point residual stream, complete: read by the norm (never written here)
+  xq_t* x_out;           // [B, d] zero on entry: residual + every head's output projection are ADDED into it
+  xq_t* x_zero;          // [B, d] third buffer of the rotation: zeroed for the kernel after next
   const float* ln_w;     // [d] RMSNorm weight of this sub-layer
   float eps;
   int d;                 // d_model
@@ -532,8 +545,12 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
       for (int e = 0; e < E; ++e) accp = fmaf(oh[opart * 32 + u * E + e], wo[u].get(e), accp);
     }
     accp += __shfl_xor(accp, 1, 64);
-    if (opart == 0 && tid < 2 * a.d)
-      atomicAdd(reinterpret_cast<unsigned long long*>(a.x + (int64_t)b * a.d + on_), (unsigned long long)xq_fix(accp));
+    if (opart == 0 && tid < 2 * a.d) {
+      xq_t add = xq_fix(accp);
+      if (hh == 0) add += a.x[(int64_t)b * a.d + on_];        // head 0 also carries the residual itself
+      atomicAdd(reinterpret_cast<unsigned long long*>(a.x_out + (int64_t)b * a.d + on_), (unsigned long long)add);
+      if (hh == a.H - 1) a.x_zero[(int64_t)b * a.d + on_] = 0;
+    }
   }
   M2M_STAMP(6 + (SELF ? 1 : 0), 3);
 }
@@ -558,7 +575,8 @@ struct DecHeadArgs {
   const float* logits;     // [B, ldl]
   int ldl, V, B, d;
   const float* shared;     // [V, d] embedding
-  xq_t* x;                 // [B, d] next-step input (fixed-point residual stream)
+  xq_t* x;                 // [B, d] next-step input (fixed-point residual stream, buffer A)
+  xq_t* x_zero;            // [B, d] buffer B: zeroed by the init kernel (later by every FFN down projection)
   int64_t* tokens;         // [B, max_len] generated ids (col 0 = start)
   int max_len;
   int* finished;           // [B]
@@ -650,16 +668,18 @@ __global__ void dec_init_kernel(DecHeadArgs a, int start_id, int max_steps) {
     int tok = a.forced ? (int)a.forced[(int64_t)b * a.Ld] : start_id;
     if (tok < 0 || tok >= a.V) tok = a.pad_id;
     a.x[i] = xq_fix(a.shared[(int64_t)tok * a.d + c]);
+    a.x_zero[i] = 0;
   }
 }
 
 // ============================================================ step driver ====
+static xq_t* xbuf(m2m_session* s, const DecView& v, int which);
 // All per-clip buffers are [B][...] with the clip index outermost, so a view is a pointer offset.
 static DecHeadArgs head_args(m2m_session* s, const DecView& v, bool forced, float* logits_out, int Ld) {
   const m2m_model* m = s->m;
   DecHeadArgs h{};
   h.logits = s->logits + (int64_t)v.b0 * m->vocab_pad; h.ldl = m->vocab_pad; h.V = m->g.vocab_size; h.B = v.nb;
-  h.d = m->g.d_model; h.shared = m->shared; h.x = reinterpret_cast<xq_t*>(s->x_dec) + (int64_t)v.b0 * m->g.d_model;
+  h.d = m->g.d_model; h.shared = m->shared; h.x = xbuf(s, v, 0); h.x_zero = xbuf(s, v, 1);
   h.tokens = s->tokens + (int64_t)v.b0 * s->max_dec; h.max_len = s->max_dec;
   h.finished = s->finished + v.b0; h.state = v.state; h.pad_id = m->g.pad_token_id; h.eos_id = m->g.eos_token_id;
   h.forced = forced ? s->forced_ids + (int64_t)v.b0 * Ld : nullptr; h.Ld = Ld;
@@ -678,6 +698,12 @@ static size_t kv_layer_elems(const m2m_session* s, int len) {
   return (size_t)s->max_batch * s->m->g.num_heads * len * DK;
 }
 
+// rotation of the residual-stream buffers inside a layer: A (x_dec[0]) holds the layer input
+static xq_t* xbuf(m2m_session* s, const DecView& v, int which) {
+  const size_t stride = (size_t)ceil_div(s->max_batch, 32) * 32 * s->m->g.d_model;
+  return reinterpret_cast<xq_t*>(s->x_dec) + (size_t)which * stride + (size_t)v.b0 * s->m->g.d_model;
+}
+
 int decode_launch_attn(m2m_session* s, const DecView& v, bool self, int layer, int self_len, hipStream_t st) {
   const m2m_model* m = s->m;
   const m2m_t5_geometry& g = m->g;
@@ -685,7 +711,9 @@ int decode_launch_attn(m2m_session* s, const DecView& v, bool self, int layer, i
   const int H = g.num_heads;
   const DecLayerPacked& L = m->dec[layer];
   DecAttnArgs a{};
-  a.x = reinterpret_cast<xq_t*>(s->x_dec) + (int64_t)v.b0 * g.d_model; a.eps = g.layer_norm_eps; a.d = g.d_model;
+  // self: A -> B (zero C); cross: B -> C (zero A)
+  a.x = xbuf(s, v, self ? 0 : 1); a.x_out = xbuf(s, v, self ? 1 : 2); a.x_zero = xbuf(s, v, self ? 2 : 0);
+  a.eps = g.layer_norm_eps; a.d = g.d_model;
   a.H = H; a.inner = m->inner; a.state = v.state;
   if (self) {
     const size_t off = ((size_t)layer * kv_layer_elems(s, s->max_dec) + (size_t)v.b0 * H * s->max_dec * DK) * es;
@@ -711,7 +739,9 @@ int decode_launch_step(m2m_session* s, const DecView& v, bool forced, float* log
   const m2m_t5_geometry& g = m->g;
   const int P = m->precision;
   const size_t es = m->esize;
-  xq_t* x = reinterpret_cast<xq_t*>(s->x_dec) + (int64_t)v.b0 * g.d_model;
+  xq_t* xA = xbuf(s, v, 0);
+  xq_t* xB = xbuf(s, v, 1);
+  xq_t* xC = xbuf(s, v, 2);
   unsigned char* gg = (unsigned char*)s->g_dec + (size_t)v.b0 * g.d_ff * es;
   int rc;
   for (int l = 0; l < g.num_decoder_layers; ++l) {
@@ -723,19 +753,19 @@ int decode_launch_step(m2m_session* s, const DecView& v, bool forced, float* log
     if ((rc = decode_launch_attn(s, v, true, l, 0, st))) return rc;
     // 2. the same for cross-attention over the S encoder positions (query projection only)
     if ((rc = decode_launch_attn(s, v, false, l, 0, st))) return rc;
-    // 3. RMSNorm + gated-GELU up projection
-    a.x = x; a.ldx = g.d_model; a.ln_w = L.ln2; a.W = L.wi; a.K = g.d_model; a.N = 2 * g.d_ff;
+    // 3. RMSNorm + gated-GELU up projection (reads C, the stream after both attention sub-layers)
+    a.x = xC; a.ldx = g.d_model; a.ln_w = L.ln2; a.W = L.wi; a.K = g.d_model; a.N = 2 * g.d_ff;
     a.out = gg; a.ldo = g.d_ff;
     if ((rc = launch_dec_gemm(P, DEPI_GATED, a, st))) return rc;
-    // 4. down projection + residual
+    // 4. down projection: A = C + g.Wo^T, and B is left zeroed for the next layer's self-attention
     a.x = gg; a.ldx = g.d_ff; a.ln_w = nullptr; a.W = L.wo_ff; a.K = g.d_ff; a.N = g.d_model;
-    a.out = x; a.ldo = g.d_model;
+    a.out = xA; a.ldo = g.d_model; a.res_in = xC; a.res_zero = xB;
     if ((rc = launch_dec_gemm(P, DEPI_RESID, a, st))) return rc;
   }
   // final RMSNorm + lm_head (untied, no d_model**-0.5 scaling: transformers 4.34 semantics)
   DecGemmArgs a{};
   a.eps = g.layer_norm_eps; a.B = v.nb; a.state = v.state;
-  a.x = x; a.ldx = g.d_model; a.ln_w = m->dec_final_ln; a.W = m->lm_head; a.K = g.d_model; a.N = g.vocab_size;
+  a.x = xA; a.ldx = g.d_model; a.ln_w = m->dec_final_ln; a.W = m->lm_head; a.K = g.d_model; a.N = g.vocab_size;
   a.out = s->logits + (int64_t)v.b0 * m->vocab_pad; a.ldo = m->vocab_pad;
   if ((rc = launch_dec_gemm(P, DEPI_PLAIN, a, st))) return rc;
   DecHeadArgs h = head_args(s, v, forced, logits_out, Ld);

@@ -181,7 +181,7 @@ WsLayout ws_layout(const m2m_model* m, int B, int S, int L) {
   w.cross_kv = take((int64_t)g.num_decoder_layers * 2 * M * m->inner * es);
   w.self_k = take((int64_t)g.num_decoder_layers * B * m->inner * L * es);
   w.self_v = take((int64_t)g.num_decoder_layers * B * m->inner * L * es);
-  w.x_dec = take(Bp * g.d_model * 8);   // int64 fixed-point residual stream
+  w.x_dec = take(3 * Bp * g.d_model * 8);   // int64 fixed-point residual stream, 3 rotating buffers
   w.g_dec = take(Bp * g.d_ff * es);
   w.logits = take(Bp * m->vocab_pad * 4);
   w.tokens = take((int64_t)B * L * 8);

@@ -102,7 +102,8 @@ def test_bf16_mode_tracks_bf16_oracle(cfg_name, B, S, L):
                 break
 
 
-@pytest.mark.parametrize("B,S,L,rows", [(1, 7, 20, 32), (17, 11, 24, 32), (33, 9, 16, 32), (40, 5, 12, 16), (9, 300, 20, 4)])
+@pytest.mark.parametrize("B,S,L,rows", [(1, 7, 20, 32), (17, 11, 24, 32), (33, 9, 16, 32), (40, 5, 12, 16), (9, 300, 20, 4),
+                                        (140, 5, 10, 140)])   # 280 attention workgroups > 256 CUs: late starters
 def test_ragged_batches_and_decode_chains_fp32(monkeypatch, B, S, L, rows):
     """Batch sizes that are not multiples of the 16-row MFMA tile, more clips than one chain holds,
     several chains of unequal size (M2M_GROUP_ROWS), S beyond one key round: ids must not change."""
