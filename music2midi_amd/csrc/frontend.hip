@@ -168,6 +168,9 @@ __global__ __launch_bounds__(FE_THREADS, 2) void logmel_kernel(
     fb_o[j] = fe.fb_off[m];
   }
 
+  const float sg2 = (m2 & 2) ? -1.f : 1.f, sg1 = (m2 & 1) ? -1.f : 1.f;
+  const float rc = (m2 == 3) ? 0.f : 1.f, rs_ = (m2 == 3) ? 1.f : 0.f;
+
   __syncthreads();
 
   // Each WAVE now runs on its own: frame -> FFT -> power bins -> mel -> store, with wave-level
@@ -197,16 +200,17 @@ __global__ __launch_bounds__(FE_THREADS, 2) void logmel_kernel(
 #pragma unroll
     for (int q1 = 1; q1 < 16; ++q1) z[q1] = cmul(z[q1], tw_b[q1]);
     // stage 3: radix-4 across the quad (m2 = lane&3) by two DPP exchanges.
-    //   after: lane m2 holds Y[q1 + 16*q2] with q2 = bitrev2(m2)
+    //   after: lane m2 holds Y[q1 + 16*q2] with q2 = bitrev2(m2).
+    //   Branch-free: v <- p + s*v with a per-lane sign (lanes 0,1: v+p; lanes 2,3: p-v), then lane 3
+    //   multiplies by -i, written as a rotation with per-lane (c, sn) = (1,0) or (0,1).
 #pragma unroll
     for (int q1 = 0; q1 < 16; ++q1) {
       float2 v = z[q1];
       float2 p = make_float2(dpp_quad<DPP_XOR2>(v.x), dpp_quad<DPP_XOR2>(v.y));
-      v = (m2 & 2) ? csub(p, v) : cadd(v, p);
-      if (m2 == 3) v = mul_negi(v);
+      v = make_float2(fmaf(sg2, v.x, p.x), fmaf(sg2, v.y, p.y));
+      v = make_float2(fmaf(rc, v.x, rs_ * v.y), fmaf(rc, v.y, -rs_ * v.x));   // lane 3: (x,y) -> (y,-x)
       p = make_float2(dpp_quad<DPP_XOR1>(v.x), dpp_quad<DPP_XOR1>(v.y));
-      v = (m2 & 1) ? csub(p, v) : cadd(v, p);
-      z[q1] = v;
+      z[q1] = make_float2(fmaf(sg1, v.x, p.x), fmaf(sg1, v.y, p.y));
     }
     {
       const int q2 = ((m2 & 1) << 1) | (m2 >> 1);
