@@ -315,7 +315,6 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
   extern __shared__ __align__(16) float hn[];   // [d] normalised input row (already rounded to T)
   __shared__ float redw[16], redl[16];
   __shared__ float redo[16][DK];
-  __shared__ float bcast;
   __shared__ __align__(16) float qs[DK];
   __shared__ __align__(16) float kn[DK];
   __shared__ __align__(16) float vn[DK];

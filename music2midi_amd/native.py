@@ -109,8 +109,6 @@ def load() -> C.CDLL:
             try:
                 fn = getattr(lib, name)
             except AttributeError as e:
-                if os.environ.get("M2M_ALLOW_PARTIAL") == "1":  # bring-up only
-                    continue
                 raise NativeError(f"{path} does not export {name} (stale build?)") from e
             fn.restype = res
             fn.argtypes = args
