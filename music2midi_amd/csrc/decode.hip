@@ -321,13 +321,14 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
   __shared__ __align__(16) float oh[DK];
   M2M_STAMP_DECL
   M2M_STAMP(6 + (SELF ? 1 : 0), 0);
-  if (a.state->done) return;
+  // loop state: requested now, first consumed AFTER the prologue loads below have been issued, so
+  // its round trip overlaps theirs instead of preceding it (every kernel of the step is latency-bound:
+  // at B = 1 a step still takes 196 us, i.e. 7.5 us per kernel with nothing to stream)
+  const int st_done = a.state->done;
+  const int st_t = a.state->t;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x / a.H, hh = blockIdx.x - b * a.H;
-  const int t = SELF ? (a.self_len_override > 0 ? a.self_len_override - 1 : a.state->t) : 0;
-  const int n_prev = SELF ? t : a.n_keys;            // keys that are read from memory
-  const int last = max(n_prev - 1, 0);
   const int sub = lane % LPR;
   const int kslot = wave * KPW + lane / LPR;
   T* Kb = reinterpret_cast<T*>(a.Kc) + ((int64_t)b * a.H + hh) * a.kv_stride * DK;
@@ -348,6 +349,11 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
   Vec16<T> w[WMAX];
 #pragma unroll
   for (int u = 0; u < WMAX; ++u) w[u].v = *reinterpret_cast<const V16*>(wrow + (min(u, cnt - 1) * LPO + part) * E);
+
+  if (st_done) return;   // uniform
+  const int t = SELF ? (a.self_len_override > 0 ? a.self_len_override - 1 : st_t) : 0;
+  const int n_prev = SELF ? t : a.n_keys;            // keys that are read from memory
+  const int last = max(n_prev - 1, 0);
 
   // ---- 1. RMSNorm of x[b] -> hn (rounded to the GEMM-input type T) ----
   Vec16<T> kv[PF], vv[PF];
@@ -594,9 +600,18 @@ __global__ __launch_bounds__(1024) void dec_head_kernel(DecHeadArgs a) {
   DecState* stp = a.state;
   M2M_STAMP_DECL
   M2M_STAMP(8, 0);
-  if (stp->done) return;
-  const int tid = threadIdx.x, l32 = tid & 31, grp = tid >> 5;
+  const int st_done = stp->done;
   const int t = stp->t;
+  const int tid = threadIdx.x, l32 = tid & 31, grp = tid >> 5;
+  // first batch of logits of this lane group's first row: requested before the loop state is consumed
+  constexpr int HK = 16;   // V <= 32 * HK columns are covered by the register batch (vocab 400 -> 13 used)
+  float lg0[HK];
+  {
+    const float* lg = a.logits + (int64_t)min(grp, a.B - 1) * a.ldl;
+#pragma unroll
+    for (int j = 0; j < HK; ++j) lg0[j] = lg[min(l32 + 32 * j, a.V - 1)];
+  }
+  if (st_done) return;
   if (tid == 0) s_unfinished = 0;
   __syncthreads();
   for (int b = grp; b < a.B; b += 32) {
@@ -604,7 +619,15 @@ __global__ __launch_bounds__(1024) void dec_head_kernel(DecHeadArgs a) {
     const int fin = a.forced ? 0 : a.finished[b];
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int v = l32; v < a.V; v += 32) {
+    if (b == grp) {
+#pragma unroll
+      for (int j = 0; j < HK; ++j) {
+        const int v = l32 + 32 * j;
+        const float x = lg0[j];
+        if (v < a.V && (x > best || (x == best && v < bi))) { best = x; bi = v; }
+      }
+    }
+    for (int v = l32 + (b == grp ? 32 * HK : 0); v < a.V; v += 32) {
       const float x = lg[v];
       if (x > best || (x == best && v < bi)) { best = x; bi = v; }
     }
