@@ -300,8 +300,13 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
   constexpr int LPR = DK / E;            // lanes per key row (a "group"): 8 / 16
   constexpr int KPW = 64 / LPR;          // keys per wave-load: 8 / 4
   constexpr int KPB = 16 * KPW;          // keys per block round: 128 / 64
-  constexpr int NOUT = SELF ? 3 * DK : DK;
-  constexpr int LPO = SELF ? 4 : 16;     // lanes per projection output
+  constexpr int NOUT = DK;               // the query projection (self and cross alike): 64 outputs
+  constexpr int LPO = 16;                // lanes per projection output
+  // self only: the k,v rows this step appends are projected LATER (their weights stream in under
+  // the K/V cache reads and they are needed only for the final key), so the prologue is as short
+  // as the cross kernel's: 128 outputs x 8 lanes
+  constexpr int LPO2 = 8;
+  constexpr int WMAX2 = 6;               // k/v weight chunks per lane held in registers (d_model 384, bf16)
   // K/V rounds (one K row + one V row per lane = 32 KB per workgroup) kept in flight by the rolling
   // prefetch.  The CU's memory pipeline holds only so many outstanding misses: requesting the whole
   // 220 KB stream at once stalls the ISSUING waves (measured: the prologue then finishes at ~9 us);
@@ -310,7 +315,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
 #define M2M_DA_PF 1
 #endif
   constexpr int PF = M2M_DA_PF;
-  constexpr int WMAX = SELF ? 12 : 3;    // weight chunks per lane held in registers (d_model 384, bf16)
+  constexpr int WMAX = 3;                // q weight chunks per lane held in registers (d_model 384, bf16)
   using V16 = decltype(Vec16<T>().v);
   extern __shared__ __align__(16) float hn[];   // [d] normalised input row (already rounded to T)
   __shared__ float redw[16], redl[16];
@@ -342,6 +347,10 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
   const int xc = min(tid * 4, a.d - 4);
   const float4 xv = xq_load4(a.x + (int64_t)b * a.d + xc);
   const float4 gv = *reinterpret_cast<const float4*>(a.ln_w + xc);
+  // head 0 also carries the residual row into x_out: its raw fixed-point value, requested now
+  const int on_ = min(tid >> 1, a.d - 1), opart = tid & 1;
+  xq_t xres = 0;
+  if (hh == 0) xres = a.x[(int64_t)b * a.d + on_];
   const int po = min(tid / LPO, NOUT - 1), part = tid % LPO;
   const int which = po / DK, dd = po - which * DK;
   const T* wrow = reinterpret_cast<const T*>(a.Wp) + ((int64_t)which * a.inner + hh * DK + dd) * a.d;
@@ -431,16 +440,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
 #pragma unroll
     for (int ofs = 1; ofs < LPO; ofs <<= 1) acc += __shfl_xor(acc, ofs, 64);
     M2M_STAMP(6 + (SELF ? 1 : 0), 6);
-    if (part == 0 && tid < NOUT * LPO) {
-      if (which == 0) {
-        qs[dd] = acc;                                     // q stays fp32
-      } else {
-        const T r = from_f32<T>(acc);                     // k, v are stored (and used) rounded to T
-        const int64_t slot = (int64_t)t * DK + dd;
-        if (which == 1) { kn[dd] = to_f32(r); Kb[slot] = r; }
-        else            { vn[dd] = to_f32(r); Vb[slot] = r; }
-      }
-    }
+    if (part == 0 && tid < NOUT * LPO) qs[dd] = acc;      // q stays fp32
   }
   __syncthreads();
   M2M_STAMP(6 + (SELF ? 1 : 0), 1);
@@ -448,11 +448,20 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
   // this head's slice of the output projection (2 lanes per output column, 32 inputs each):
   // requested now so it arrives under the K/V stream
   constexpr int OCH = 32 / E;            // 16-byte chunks per lane: 4 (bf16) / 8 (fp32)
-  const int on_ = min(tid >> 1, a.d - 1), opart = tid & 1;
   const T* worow = reinterpret_cast<const T*>(a.Wo) + (int64_t)on_ * a.inner + hh * DK + opart * 32;
   Vec16<T> wo[OCH];
 #pragma unroll
   for (int u = 0; u < OCH; ++u) wo[u].v = *reinterpret_cast<const V16*>(worow + u * E);
+  // self: weights of the k,v rows this step appends (128 outputs x 8 lanes), also under the stream
+  const int o2 = tid >> 3, part2 = tid & 7;
+  const int which2 = 1 + (o2 >> 6), dd2 = o2 & 63;
+  const T* wrow2 = reinterpret_cast<const T*>(a.Wp) + ((int64_t)which2 * a.inner + hh * DK + dd2) * a.d;
+  const int cnt2 = a.d / E / LPO2;
+  Vec16<T> wkv[SELF ? WMAX2 : 1];
+  if (SELF) {
+#pragma unroll
+    for (int u = 0; u < WMAX2; ++u) wkv[u].v = *reinterpret_cast<const V16*>(wrow2 + (min(u, cnt2 - 1) * LPO2 + part2) * E);
+  }
 
   // ---- 3. single-pass attention: each group of LPR lanes walks its keys with a running
   //         (max, sum, weighted-V) triple; no workgroup-wide step until the end ----
@@ -484,8 +493,10 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
       float vrow[E];
 #pragma unroll
       for (int e = 0; e < E; ++e) vrow[e] = vv[u].get(e);
-      // slot u is consumed: request the round PF further on into it (rolling window)
-      {
+      // slot u is consumed: request the round PF further on into it (rolling window).  The guard is
+      // workgroup-uniform (no lane is predicated): past the end nothing is requested, so the merge
+      // barrier below does not wait for a useless round trip.
+      if (k0 + (u + PF) * KPB < n_prev) {
         const int64_t off = (int64_t)min(key + PF * KPB, last) * DK + sub * E;
         kv[u].v = *reinterpret_cast<const V16*>(Kb + off);
         vv[u].v = *reinterpret_cast<const V16*>(Vb + off);
@@ -495,6 +506,40 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
         visit(s, vrow);
       }
     }
+  }
+  if (SELF) {
+    // project, round to T, append to the cache and publish through LDS the k,v rows of this step
+    float acc2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < WMAX2; ++u) {
+      if (u < cnt2) {
+        const float* hp = hn + (u * LPO2 + part2) * E;
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc2 = fmaf(hp[e], wkv[u].get(e), acc2);
+      }
+    }
+    for (int i = WMAX2; i < cnt2; i += 4) {   // d_model / dtype combinations beyond the register budget (fp32)
+      Vec16<T> w2[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) w2[u].v = *reinterpret_cast<const V16*>(wrow2 + (min(i + u, cnt2 - 1) * LPO2 + part2) * E);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (i + u < cnt2) {
+          const float* hp = hn + ((i + u) * LPO2 + part2) * E;
+#pragma unroll
+          for (int e = 0; e < E; ++e) acc2 = fmaf(hp[e], w2[u].get(e), acc2);
+        }
+      }
+    }
+#pragma unroll
+    for (int ofs = 1; ofs < LPO2; ofs <<= 1) acc2 += __shfl_xor(acc2, ofs, 64);
+    if (part2 == 0) {
+      const T r = from_f32<T>(acc2);                       // k, v are stored (and used) rounded to T
+      const int64_t slot = (int64_t)t * DK + dd2;
+      if (which2 == 1) { kn[dd2] = to_f32(r); Kb[slot] = r; }
+      else             { vn[dd2] = to_f32(r); Vb[slot] = r; }
+    }
+    __syncthreads();
   }
   if (SELF && wave == 0 && lane < LPR) {   // the key/value appended this step (relative position 0): group 0
     float s = 0.f;
@@ -540,6 +585,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
       oh[tid] = to_f32(from_f32<T>(s / L));      // the projection input is rounded to T, as every GEMM input
     }
     __syncthreads();
+    M2M_STAMP(6 + (SELF ? 1 : 0), 7);
   }
   // ---- 5. output projection of this head, accumulated into the residual row ----
   {
@@ -552,7 +598,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
     accp += __shfl_xor(accp, 1, 64);
     if (opart == 0 && tid < 2 * a.d) {
       xq_t add = xq_fix(accp);
-      if (hh == 0) add += a.x[(int64_t)b * a.d + on_];        // head 0 also carries the residual itself
+      if (hh == 0) add += xres;                               // head 0 also carries the residual itself
       atomicAdd(reinterpret_cast<unsigned long long*>(a.x_out + (int64_t)b * a.d + on_), (unsigned long long)add);
       if (hh == a.H - 1) a.x_zero[(int64_t)b * a.d + on_] = 0;
     }

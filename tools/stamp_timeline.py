@@ -24,7 +24,8 @@ geom = T5Geometry(cfg.model.t5)
 model = T5Transformer(cfg.to_dict(), precision="bf16")
 load_t5_state(model, synth.t5_state_dict(geom, 0), strict=False)
 model = model.cuda().eval()
-x = torch.from_numpy(synth.normal(1, "e", (32, 864, 384), 3.0)).cuda()
+BATCH = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+x = torch.from_numpy(synth.normal(1, "e", (BATCH, 864, 384), 3.0)).cuda()
 lib = native.load()
 lib.m2m_debug_read_stamps.restype = C.c_int
 lib.m2m_debug_read_stamps.argtypes = [C.c_void_p, C.c_int]
@@ -66,7 +67,7 @@ for kid, s, mid, e, m2 in rows:
 for kid, v in sorted(agg.items()):
     g = np.mean([x[0] for x in v]); d = np.mean([x[1] for x in v]); m = np.mean([x[2] for x in v])
     print(f"{NAMES.get(kid, kid):12s} n={len(v):3d}  gap-before {g:6.2f} us   in-kernel(block0) {d:6.2f} us   to-mid {m:6.2f} us")
-print("attention kernels, all phases (us from kernel start): ph4=x arrived, ph5=hn ready, ph6=projection summed, ph1=q ready, ph2=stream consumed, ph3=end")
+print("attention kernels, all phases (us from kernel start): ph4=x arrived, ph5=hn ready, ph6=projection summed, ph1=q ready, ph2=stream consumed, ph7=o ready, ph3=end")
 cur = None
 shown = 0
 for kid, ph, tk in seg[1:]:
