@@ -183,3 +183,34 @@ def test_chroma_accuracy_metric():
     assert evaluate_batch([numpy_to_midi(a)], [numpy_to_midi(wrong)]) == pytest.approx(0.0)
     half = np.array([[0.0, 1.0, 60, 80], [1.0, 2.0, 65, 80]])
     assert 0.4 < evaluate_batch([numpy_to_midi(a)], [numpy_to_midi(half)]) < 0.6
+
+
+def test_wav_ingest_fallback(tmp_path):
+    """Audio ingest without librosa: PCM WAV through the stdlib, resampled to the model rate."""
+    import wave
+    from music2midi_amd.model import _load_audio
+    sr_in, sr_out = 32000, 16000
+    t = np.arange(sr_in) / sr_in
+    y = (0.5 * np.sin(2 * np.pi * 440 * t)).astype(np.float32)
+    stereo = np.stack([y, y], axis=1)
+    p = tmp_path / "a.wav"
+    with wave.open(str(p), "wb") as w:
+        w.setnchannels(2); w.setsampwidth(2); w.setframerate(sr_in)
+        w.writeframes((stereo * 32767).astype("<i2").tobytes())
+    out = _load_audio(p, sr_out)
+    assert out.dtype == np.float32 and abs(len(out) - sr_out) <= 1
+    ref = 0.5 * np.sin(2 * np.pi * 440 * np.arange(len(out)) / sr_out)
+    assert np.abs(out[200:-200] - ref[200:-200]).max() < 5e-3
+
+
+def test_simple_midi_writer_roundtrip(tmp_path):
+    from music2midi_amd.utils import SimpleMIDI, numpy_to_midi
+    notes = np.array([[0.0, 0.5, 60, 80], [0.5, 1.0, 64, 80], [1.0, 1.0, 67, 80]])   # last one is invalid (zero length)
+    midi = numpy_to_midi(notes)
+    assert len(midi.instruments[0].notes) == 2 and midi.get_end_time() == pytest.approx(1.0)
+    p = tmp_path / "x.mid"
+    midi.write(str(p))
+    raw = p.read_bytes()
+    assert raw[:4] == b"MThd" and raw[14:18] == b"MTrk" and raw.count(b"\x90") >= 2
+    if isinstance(midi, SimpleMIDI):
+        assert midi.note_array().shape == (2, 4)
