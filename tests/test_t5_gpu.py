@@ -143,3 +143,29 @@ def test_error_paths_report_instead_of_faulting():
         model.spectrogram(torch.zeros(1, 512, device="cuda"))
     with pytest.raises(native.NativeError):
         model.generate_from_embeds(torch.zeros(1, 40000, g.d_model, device="cuda"), max_length=4)   # S beyond the LDS bias table
+
+
+@pytest.mark.parametrize("d_model,d_ff,heads,layers", [(256, 512, 4, 1), (512, 1152, 2, 1), (384, 256, 8, 2)])
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_other_geometries(d_model, d_ff, heads, layers, precision):
+    """Every reduction length the decode projections are instantiated for (128/256/384/512/1152) and
+    head counts other than the reference's, in both precision modes."""
+    cfg = copy.deepcopy(DEFAULT_CONFIG)
+    cfg["model"]["t5"].update(d_model=d_model, d_ff=d_ff, num_layers=layers, num_decoder_layers=layers, num_heads=heads)
+    model, orc, g = build(cfg, precision)
+    x = embeds(3, 37, g.d_model)
+    ref_enc = orc.encode(x)
+    out_enc = model.encode(x.cuda()).cpu()
+    tol = 3e-4 if precision == "fp32" else 0.1
+    assert (out_enc - ref_enc).abs().max().item() < tol
+    ref, margins = orc.generate(x, 24, return_margins=True)
+    out = model.generate_from_embeds(x.cuda(), max_length=24).cpu()
+    if precision == "fp32":
+        assert torch.equal(out, ref)
+    else:
+        n = min(out.shape[1], ref.shape[1])
+        for b in range(3):
+            for t in range(1, n):
+                if out[b, t] != ref[b, t]:
+                    assert margins[b, t - 1] < 0.5
+                    break
