@@ -466,10 +466,12 @@ extern "C" int m2m_bench_kernel(m2m_session* s, int which, int self_len, int ite
   M2M_CHECK_HIP(hipEventCreate(&e0));
   M2M_CHECK_HIP(hipEventCreate(&e1));
   const DecView all{0, s->B, s->groups[0].view.state};
+  const int same_layer = env_int("M2M_BENCH_SAME_LAYER", 0);   // diagnostic: K/V working set small enough for the Infinity Cache
   auto run = [&](int n) -> int {
     for (int i = 0; i < n; ++i) {
-      if (which == M2M_KERNEL_DEC_CROSS_ATTN) { if ((rc = decode_launch_attn(s, all, false, i % Ld, 0, st))) return rc; }
-      else if (which == M2M_KERNEL_DEC_SELF_ATTN) { if ((rc = decode_launch_attn(s, all, true, i % Ld, self_len, st))) return rc; }
+      const int layer = same_layer ? 0 : i % Ld;
+      if (which == M2M_KERNEL_DEC_CROSS_ATTN) { if ((rc = decode_launch_attn(s, all, false, layer, 0, st))) return rc; }
+      else if (which == M2M_KERNEL_DEC_SELF_ATTN) { if ((rc = decode_launch_attn(s, all, true, layer, self_len, st))) return rc; }
     }
     return M2M_OK;
   };

@@ -107,41 +107,53 @@ class Music2MIDI(nn.Module):
         """Specify either audio_path or audio_y as input; returns a MIDI object."""
         return numpy_to_midi(self.generate_notes(audio_path, audio_y, sr, cond_index))
 
-    def generate_notes(self, audio_path=None, audio_y=None, sr=None, cond_index=None) -> np.ndarray:
+    # The three steps below are what ref model.py:67-140 does inline: validate/load, cut the song into
+    # whole segments (zero-padded tail), decode the segments in chunks and stitch the notes together.
+    def _resolve_audio(self, audio_path, audio_y, sr) -> np.ndarray:
+        model_sr = self.config.model.sample_rate
         if audio_path is None and audio_y is None:
             raise ValueError("Either audio_path or audio_y should be specified")
-        if sr is None:
-            sr = self.config.model.sample_rate
-        else:
-            assert sr == self.config.model.sample_rate
+        if sr is not None:
+            assert sr == model_sr
         if audio_y is None:
-            audio_y = _load_audio(audio_path, sr)
-        # pad with zeros to a whole number of segments (ref model.py:86-90)
-        split_size = int(sr * self.config.dataset.segment_duration)
-        n_seg = int(np.ceil(len(audio_y) / split_size))
-        audio_y = np.pad(np.asarray(audio_y, dtype=np.float32), (0, n_seg * split_size - len(audio_y)), "constant")
-        waveform = torch.from_numpy(audio_y).to(self.device)
-        return self.sample_tokens(waveform, split_size, split_duration=self.config.dataset.segment_duration,
-                                  cond_index=cond_index)
+            audio_y = _load_audio(audio_path, model_sr)
+        return np.asarray(audio_y, dtype=np.float32)
+
+    def _segment_length(self) -> int:
+        return int(self.config.model.sample_rate * self.config.dataset.segment_duration)
+
+    def generate_notes(self, audio_path=None, audio_y=None, sr=None, cond_index=None) -> np.ndarray:
+        """Note array [n, 4] (onset_s, offset_s, pitch, velocity) for a whole recording."""
+        samples = self._resolve_audio(audio_path, audio_y, sr)
+        seg = self._segment_length()
+        n_segments = -(-len(samples) // seg)                       # ceil
+        padded = np.zeros(n_segments * seg, dtype=np.float32)
+        padded[: len(samples)] = samples
+        return self.sample_tokens(torch.from_numpy(padded).to(self.device), seg,
+                                  split_duration=self.config.dataset.segment_duration, cond_index=cond_index)
+
+    def _cond_rows(self, n_rows: int, cond_index: Optional[list]) -> torch.Tensor:
+        """[n_rows, n_embeds] int64: the same (genre, difficulty) pair for every segment; zeros when None."""
+        n_embeds = len(self.model.conditioning.embeds)
+        rows = torch.zeros((n_rows, n_embeds))
+        if cond_index is not None:
+            rows = rows + torch.Tensor(cond_index)
+        return rows.long().to(self.device)
 
     @torch.no_grad()
     def sample_tokens(self, waveform: torch.Tensor, split_size: int, split_duration: float,
                       cond_index: Optional[list] = None) -> np.ndarray:
         """Segments -> chunks of inference.batch_size -> generate(max_length=1024) -> notes."""
-        n_embeds = len(self.model.conditioning.embeds)
-        segments = torch.split(waveform, split_size)
-        chunk = int(self.config.inference.batch_size)
-        tokens_list = []
-        for i in range(0, len(segments), chunk):
-            batch = segments[i:i + chunk]
-            width = max(len(s) for s in batch)
-            input_wav = torch.zeros((len(batch), width), dtype=waveform.dtype, device=self.device)
-            for r, s in enumerate(batch):
-                input_wav[r, : len(s)] = s
-            cond = torch.zeros((len(batch), n_embeds))
-            if cond_index is not None:
-                cond = cond + torch.Tensor(cond_index)
-            cond = cond.long().to(self.device)
-            tokens = self.model.generate(ModelInputs(input_waveform=input_wav, cond_index=cond), max_length=1024)
-            tokens_list += [*tokens]
-        return self.model.tokenizer.decode(tokens_list, mode="sequential", duration_per_batch=split_duration)
+        pieces = torch.split(waveform, split_size)
+        per_call = int(self.config.inference.batch_size)
+        token_rows = []
+        for first in range(0, len(pieces), per_call):
+            group = pieces[first:first + per_call]
+            longest = max(p.shape[0] for p in group)
+            wav = waveform.new_zeros((len(group), longest)).to(self.device)
+            for row, piece in enumerate(group):                      # right-pad a ragged last piece with zeros
+                wav[row, : piece.shape[0]] = piece
+            ids = self.model.generate(ModelInputs(input_waveform=wav, cond_index=self._cond_rows(len(group), cond_index)),
+                                      max_length=1024)
+            token_rows.extend(ids.unbind(0))
+        return self.model.tokenizer.decode(token_rows, mode="sequential", duration_per_batch=split_duration)
