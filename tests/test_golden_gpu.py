@@ -151,3 +151,15 @@ def test_forward_bf16_tracks_bf16_oracle():
     print(f"bf16 forced logits: max|diff| {err:.3f} on logits up to {scale:.1f}")
     assert err < 0.03 * scale                      # bf16 has 8 significant bits; fp32-vs-bf16 differs by ~10x more
     assert (out.argmax(-1) == ref.argmax(-1)).float().mean().item() > 0.9
+
+
+def test_full_size_fp32_batch32_contains_golden_rows(golden_dir):
+    """BASELINE geometry in the parity mode: a 32-clip, S=864, 1024-token fp32 run whose first two clips are
+    the golden fixture's must reproduce HuggingFace's ids for them bit for bit (batch invariance at full size)."""
+    c = _case(golden_dir, "full_s864")
+    model, _, g = build(DEFAULT_CONFIG, "fp32")
+    x = torch.cat([embeds(2, 864, g.d_model), embeds(30, 864, g.d_model, seed=99)], dim=0).cuda()
+    ids = model.generate_from_embeds(x, max_length=1024).cpu().numpy()
+    want = c["ids"].astype(np.int64)
+    assert ids.shape == (32, 1024)
+    assert np.array_equal(ids[:2], want), f"first mismatch at {np.argwhere(ids[:2] != want)[:1]}"
