@@ -294,6 +294,19 @@ struct DecAttnArgs {
   const DecState* state;
 };
 
+// K/V rows are read once per step and the per-step working set (540 MB) is larger than the 256 MB
+// Infinity Cache: they are loaded NON-TEMPORAL so they do not evict what the latency-bound kernels
+// re-read every step (30 MB of weights, the residual rows).  Measured: 290 -> 273 ms per batch.
+#ifndef M2M_KV_TEMPORAL
+typedef unsigned int m2m_u32x4 __attribute__((ext_vector_type(4)));
+template <typename V> __device__ inline V kv_nt_load(const V* p) {
+  return __builtin_bit_cast(V, __builtin_nontemporal_load(reinterpret_cast<const m2m_u32x4*>(p)));
+}
+#define M2M_KV_LOAD(p) kv_nt_load(p)   // self K/V temporal, cross non-temporal measured the same (272.7 vs 271.2 ms)
+#else
+#define M2M_KV_LOAD(p) (*(p))
+#endif
+
 template <typename T, bool SELF>
 __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
   constexpr int E = 16 / sizeof(T);      // elements per 16-byte chunk: 8 (bf16) / 4 (fp32)
@@ -370,8 +383,8 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
 #pragma unroll
   for (int u = 0; u < PF; ++u) {
     const int64_t off = (int64_t)min(kslot + u * KPB, last) * DK + sub * E;
-    kv[u].v = *reinterpret_cast<const V16*>(Kb + off);
-    vv[u].v = *reinterpret_cast<const V16*>(Vb + off);
+    kv[u].v = M2M_KV_LOAD(reinterpret_cast<const V16*>(Kb + off));
+    vv[u].v = M2M_KV_LOAD(reinterpret_cast<const V16*>(Vb + off));
   }
 #endif
   {
@@ -387,8 +400,8 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       const int64_t off = (int64_t)min(kslot + u * KPB, last) * DK + sub * E;
-      kv[u].v = *reinterpret_cast<const V16*>(Kb + off);
-      vv[u].v = *reinterpret_cast<const V16*>(Vb + off);
+      kv[u].v = M2M_KV_LOAD(reinterpret_cast<const V16*>(Kb + off));
+      vv[u].v = M2M_KV_LOAD(reinterpret_cast<const V16*>(Vb + off));
     }
 #endif
     float tot = 0.f;
@@ -406,8 +419,8 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       const int64_t off = (int64_t)min(kslot + u * KPB, last) * DK + sub * E;
-      kv[u].v = *reinterpret_cast<const V16*>(Kb + off);
-      vv[u].v = *reinterpret_cast<const V16*>(Vb + off);
+      kv[u].v = M2M_KV_LOAD(reinterpret_cast<const V16*>(Kb + off));
+      vv[u].v = M2M_KV_LOAD(reinterpret_cast<const V16*>(Vb + off));
     }
 #endif
     M2M_STAMP(6 + (SELF ? 1 : 0), 5);
@@ -498,8 +511,8 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
       // barrier below does not wait for a useless round trip.
       if (k0 + (u + PF) * KPB < n_prev) {
         const int64_t off = (int64_t)min(key + PF * KPB, last) * DK + sub * E;
-        kv[u].v = *reinterpret_cast<const V16*>(Kb + off);
-        vv[u].v = *reinterpret_cast<const V16*>(Vb + off);
+        kv[u].v = M2M_KV_LOAD(reinterpret_cast<const V16*>(Kb + off));
+        vv[u].v = M2M_KV_LOAD(reinterpret_cast<const V16*>(Vb + off));
       }
       if (key < n_prev) {   // VALU-only predicate (the loads are unconditional)
         if (SELF) s += a.bias[(int64_t)hh * a.bias_stride + (t - key)];
