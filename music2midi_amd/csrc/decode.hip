@@ -294,20 +294,19 @@ struct DecAttnArgs {
   const DecState* state;
 };
 
-// K/V rows are read once per step and the per-step working set (540 MB) is larger than the 256 MB
-// Infinity Cache: they are loaded NON-TEMPORAL so they do not evict what the latency-bound kernels
-// re-read every step (30 MB of weights, the residual rows).  Measured: 290 -> 273 ms per batch.
-#ifndef M2M_KV_TEMPORAL
+// K/V rows are read once per step.  When the per-step K/V working set is larger than the 256 MB
+// Infinity Cache (540 MB at B = 32) they are loaded NON-TEMPORAL, so they do not evict what the
+// latency-bound kernels re-read every step (30 MB of weights, the residual rows): 290 -> 271 ms per
+// batch at B = 32.  When it fits (B <= 8) the default policy keeps K/V itself cache-resident across
+// steps, which is faster (B = 1: 196 vs 204 us per step) — NT is a launch-time template choice.
 typedef unsigned int m2m_u32x4 __attribute__((ext_vector_type(4)));
-template <typename V> __device__ inline V kv_nt_load(const V* p) {
-  return __builtin_bit_cast(V, __builtin_nontemporal_load(reinterpret_cast<const m2m_u32x4*>(p)));
+template <bool NT, typename V> __device__ inline V kv_load(const V* p) {
+  if constexpr (NT) return __builtin_bit_cast(V, __builtin_nontemporal_load(reinterpret_cast<const m2m_u32x4*>(p)));
+  else return *p;
 }
-#define M2M_KV_LOAD(p) kv_nt_load(p)   // self K/V temporal, cross non-temporal measured the same (272.7 vs 271.2 ms)
-#else
-#define M2M_KV_LOAD(p) (*(p))
-#endif
+#define M2M_KV_LOAD(p) kv_load<NT>(p)
 
-template <typename T, bool SELF>
+template <typename T, bool SELF, bool NT>
 __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
   constexpr int E = 16 / sizeof(T);      // elements per 16-byte chunk: 8 (bf16) / 4 (fp32)
   constexpr int LPR = DK / E;            // lanes per key row (a "group"): 8 / 16
@@ -619,17 +618,23 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
   M2M_STAMP(6 + (SELF ? 1 : 0), 3);
 }
 
-static int launch_dec_attn(int precision, bool self, DecAttnArgs a, int B, int max_keys, hipStream_t st) {
+template <typename T>
+static void launch_dec_attn_t(bool self, bool nt, const DecAttnArgs& a, dim3 grid, size_t smem, hipStream_t st) {
+  if (self) {
+    if (nt) hipLaunchKernelGGL((dec_attn_kernel<T, true, true>), grid, dim3(1024), smem, st, a);
+    else hipLaunchKernelGGL((dec_attn_kernel<T, true, false>), grid, dim3(1024), smem, st, a);
+  } else {
+    if (nt) hipLaunchKernelGGL((dec_attn_kernel<T, false, true>), grid, dim3(1024), smem, st, a);
+    else hipLaunchKernelGGL((dec_attn_kernel<T, false, false>), grid, dim3(1024), smem, st, a);
+  }
+}
+
+static int launch_dec_attn(int precision, bool self, bool nt, DecAttnArgs a, int B, int max_keys, hipStream_t st) {
   (void)max_keys;
   const size_t smem = (size_t)a.d * sizeof(float);
   dim3 grid((unsigned)(B * a.H));
-  if (precision == M2M_PREC_BF16) {
-    if (self) hipLaunchKernelGGL((dec_attn_kernel<bf16_t, true>), grid, dim3(1024), smem, st, a);
-    else hipLaunchKernelGGL((dec_attn_kernel<bf16_t, false>), grid, dim3(1024), smem, st, a);
-  } else {
-    if (self) hipLaunchKernelGGL((dec_attn_kernel<float, true>), grid, dim3(1024), smem, st, a);
-    else hipLaunchKernelGGL((dec_attn_kernel<float, false>), grid, dim3(1024), smem, st, a);
-  }
+  if (precision == M2M_PREC_BF16) launch_dec_attn_t<bf16_t>(self, nt, a, grid, smem, st);
+  else launch_dec_attn_t<float>(self, nt, a, grid, smem, st);
   M2M_CHECK_HIP(hipGetLastError());
   return M2M_OK;
 }
@@ -792,6 +797,9 @@ int decode_launch_attn(m2m_session* s, const DecView& v, bool self, int layer, i
   const int H = g.num_heads;
   const DecLayerPacked& L = m->dec[layer];
   DecAttnArgs a{};
+  // K/V working set of one decode step (all layers, cross + self at the session's maximum length)
+  const double kv_step_bytes = (double)g.num_decoder_layers * 2.0 * s->B * m->inner * ((double)s->S + s->max_dec) * (double)es;
+  const bool nt = kv_step_bytes > 200e6;   // beyond what the 256 MB Infinity Cache can keep between steps
   // self: A -> B (zero C); cross: B -> C (zero A)
   a.x = xbuf(s, v, self ? 0 : 1); a.x_out = xbuf(s, v, self ? 1 : 2); a.x_zero = xbuf(s, v, self ? 2 : 0);
   a.eps = g.layer_norm_eps; a.d = g.d_model;
@@ -803,7 +811,7 @@ int decode_launch_attn(m2m_session* s, const DecView& v, bool self, int layer, i
     a.Vc = (unsigned char*)s->self_v + off;
     a.kv_stride = s->max_dec; a.n_keys = 0; a.self_len_override = self_len;
     a.bias = s->dec_bias_tab; a.bias_stride = s->max_dec;
-    return launch_dec_attn(m->precision, true, a, v.nb, s->max_dec, st);
+    return launch_dec_attn(m->precision, true, nt, a, v.nb, s->max_dec, st);
   }
   // cross K/V: [L][2][B][H][S][64] with B, S = the encoded problem
   const size_t per = (size_t)s->B * H * s->S * DK;
@@ -812,7 +820,7 @@ int decode_launch_attn(m2m_session* s, const DecView& v, bool self, int layer, i
   a.Kc = (unsigned char*)s->cross_kv + (((size_t)layer * 2 + 0) * per + voff) * es;
   a.Vc = (unsigned char*)s->cross_kv + (((size_t)layer * 2 + 1) * per + voff) * es;
   a.kv_stride = s->S; a.n_keys = s->S; a.self_len_override = 0; a.bias = nullptr; a.bias_stride = 0;
-  return launch_dec_attn(m->precision, false, a, v.nb, s->S, st);
+  return launch_dec_attn(m->precision, false, nt, a, v.nb, s->S, st);
 }
 
 int decode_launch_step(m2m_session* s, const DecView& v, bool forced, float* logits_out, int Ld, hipStream_t st) {
