@@ -89,6 +89,24 @@ __device__ inline float wave_max(float v) {
   return v;
 }
 
+// Sum over aligned groups of 8 or 16 lanes with DPP operand modifiers (plain VALU adds: no LDS
+// crossbar round trip as __shfl_xor's ds_bpermute has).  Same pairing as an xor-butterfly 1,2,4(,8):
+// after the two quad steps the value is quad-uniform, so the half-row / row mirrors fetch exactly the
+// partner quad / half a butterfly would — results are bit-identical to it.
+template <int CTRL>
+__device__ inline float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int LANES>
+__device__ inline float group_sum(float v) {
+  static_assert(LANES == 8 || LANES == 16, "group_sum: 8 or 16 lanes");
+  v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);   // row_half_mirror
+  if constexpr (LANES == 16) v += dpp_mov<0x140>(v);   // row_mirror
+  return v;
+}
+
 // gelu_new (hf: activations.py NewGELUActivation), fp32, accurate tanhf.
 __device__ inline float gelu_new(float x) {
   const float k = 0.7978845608028654f;  // sqrt(2/pi)

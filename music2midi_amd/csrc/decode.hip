@@ -268,6 +268,175 @@ static int launch_dec_gemm(int precision, int epi, const DecGemmArgs& a, hipStre
   return precision == M2M_PREC_BF16 ? launch_dec_gemm_t<bf16_t>(epi, a, st) : launch_dec_gemm_t<float>(epi, a, st);
 }
 
+// ===================================================== fused feed-forward ====
+// One kernel per layer for  x += wo( gelu_new(wi_0 . n) * (wi_1 . n) ),  n = RMSNorm(x)
+// (hf: modeling_t5.py T5DenseGatedActDense + T5LayerFF).  A workgroup owns 32 of the d_ff hidden
+// columns for one 16-row block: it computes that slice of the gated activation (64 rows of the
+// interleaved wi), keeps it in LDS, multiplies it with the matching 32 columns of wo and ADDS the
+// [16 x d_model] partial result into the fixed-point residual stream (integer atomics: the sum does
+// not depend on arrival order, see xq_t above).  The hidden activations never reach memory and the
+// dependent kernel boundary between the up and the down projection is gone (26 -> 20 kernels/step).
+// 32 columns per workgroup is the balance point measured with tools/atomic_rate.hip: d_ff/32 = 36
+// adds per residual element cost ~2 us, 72 would cost ~5 us; wider slices put >100 KB of weights
+// behind one CU's ~24..60 GB/s fetch path.
+//
+// Waves = KS = d_model / 64: wave ks multiplies k-slice ks of the normalised rows with all four
+// n-tiles of the slice (a tile = 8 wi_0 rows + the matching 8 wi_1 rows, as repack.hip interleaves
+// them), so the rows of x — 8 bytes per element, the largest operand — are fetched once per
+// workgroup; in phase 2 wave w owns output columns [64 w, 64 w + 64).  A CU pulls only ~25-30 GB/s
+// from beyond its L2, so the kernel's time is the bytes one workgroup requests (x 49 KB + weights
+// 74 KB at d_model 384); every global load is issued before the first use.
+struct DecFfArgs {
+  const xq_t* x;         // [B, d] residual stream after the attention sub-layers (complete)
+  xq_t* x_out;           // [B, d] zero on entry: x + FF(x) is accumulated into it
+  xq_t* x_zero;          // [B, d] third buffer of the rotation, left zeroed
+  const float* ln_w;
+  float eps;
+  const void* Wi;        // [2 * d_ff, d] T, 16-row groups: 8 rows of wi_0 then the same 8 of wi_1
+  const void* Wo;        // [d, d_ff] T
+  int d, d_ff, B;
+  const DecState* state;
+};
+
+constexpr int FF_C = 32;        // hidden columns per workgroup
+constexpr int FF_HP = FF_C + 8; // LDS row pitch of the activation slice (elements; keeps 16-byte alignment)
+
+template <typename T, int KS>
+__global__ __launch_bounds__(64 * KS) void dec_ff_kernel(DecFfArgs a) {
+  M2M_STAMP_DECL
+  __shared__ float ss_s[KS][16];
+  __shared__ float red[KS][4][16 * 17];
+  __shared__ __align__(16) T hs[16 * FF_HP];
+  M2M_STAMP(4, 0);
+  const int done = a.state->done;   // consumed only after every load has been issued
+  const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int c = blockIdx.x, b0 = blockIdx.y * 16;
+  const int K = a.d;
+  const int kbeg = ks * 64 + 8 * g;
+  const bool row_ok = (b0 + r) < a.B;
+  const int arow = b0 + (row_ok ? r : 0);            // padding rows read row b0; their activations are zeroed
+  const T* Wi = reinterpret_cast<const T*>(a.Wi);
+  const T* Wo = reinterpret_cast<const T*>(a.Wo);
+
+  const xq_t* xr = a.x + (int64_t)arow * K + kbeg;
+  float4 x0[2], x1[2], g0[2], g1[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    x0[s] = xq_load4(xr + 32 * s);
+    x1[s] = xq_load4(xr + 32 * s + 4);
+    g0[s] = *reinterpret_cast<const float4*>(a.ln_w + kbeg + 32 * s);
+    g1[s] = *reinterpret_cast<const float4*>(a.ln_w + kbeg + 32 * s + 4);
+  }
+  Frag<T> wf[4][2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) wf[j][s] = load_frag(Wi + (int64_t)(2 * FF_C * c + 16 * j + r) * K + kbeg + 32 * s);
+  // phase-2 operands: this wave's four output n-tiles of wo, columns [32 c, 32 c + 32) of d_ff
+  Frag<T> wo[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wo[j] = load_frag(Wo + (int64_t)(16 * (4 * ks + j) + r) * a.d_ff + FF_C * c + 8 * g);
+  // slice 0 carries the residual itself into x_out: raw fixed-point values of this lane's outputs
+  xq_t xres[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      xres[j][i] = 0;
+      if (c == 0) xres[j][i] = a.x[(int64_t)min(b0 + 4 * g + i, a.B - 1) * K + 16 * (4 * ks + j) + r];
+    }
+
+  // ---- phase 1: RMSNorm + up projection of this slice ----
+  float ss = 0.f;
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+    ss += x0[s].x * x0[s].x + x0[s].y * x0[s].y + x0[s].z * x0[s].z + x0[s].w * x0[s].w +
+          x1[s].x * x1[s].x + x1[s].y * x1[s].y + x1[s].z * x1[s].z + x1[s].w * x1[s].w;
+  ss += __shfl_xor(ss, 16, 64);
+  ss += __shfl_xor(ss, 32, 64);
+  if (g == 0) ss_s[ks][r] = ss;
+  __syncthreads();
+  M2M_STAMP(4, 3);
+  float tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < KS; ++w) tot += ss_s[w][r];
+  const float rs = row_ok ? rsqrtf(tot / (float)K + a.eps) : 0.f;   // rs = 0 zeroes the padding rows
+  f32x4_t acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const float xv[8] = {g0[s].x * (x0[s].x * rs), g0[s].y * (x0[s].y * rs), g0[s].z * (x0[s].z * rs),
+                         g0[s].w * (x0[s].w * rs), g1[s].x * (x1[s].x * rs), g1[s].y * (x1[s].y * rs),
+                         g1[s].z * (x1[s].z * rs), g1[s].w * (x1[s].w * rs)};
+    const Frag<T> fa = pack_frag<T>(xv);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mma32_16(acc[j], fa, wf[j][s]);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[ks][j][(4 * g + i) * 17 + r] = acc[j][i];
+  M2M_STAMP(4, 1);
+  __syncthreads();
+  if (done) return;   // uniform
+  // gated activation: column cc of the slice lives in tile cc / 8 at columns (cc % 8) [wi_0] and (cc % 8) + 8 [wi_1];
+  // k-slices are summed in a fixed order
+  for (int idx = tid; idx < 16 * FF_C; idx += 64 * KS) {
+    const int row = idx / FF_C, cc = idx % FF_C;
+    const int t = cc >> 3, q = row * 17 + (cc & 7);
+    float v0 = red[0][t][q], v1 = red[0][t][q + 8];
+#pragma unroll
+    for (int w = 1; w < KS; ++w) { v0 += red[w][t][q]; v1 += red[w][t][q + 8]; }
+    hs[row * FF_HP + cc] = from_f32<T>(gelu_new(v0) * v1);
+  }
+  __syncthreads();
+  M2M_STAMP(4, 5);
+
+  // ---- phase 2: [16 x 32] activations x [32 x d_model] slice of wo, added into the residual rows ----
+  const Frag<T> fh = load_frag(hs + r * FF_HP + 8 * g);
+  const bool last = (c == (int)gridDim.x - 1);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f32x4_t o = {0.f, 0.f, 0.f, 0.f};
+    mma32_16(o, fh, wo[j]);
+    const int col = 16 * (4 * ks + j) + r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = b0 + 4 * g + i;
+      if (row < a.B) {
+        const int64_t at = (int64_t)row * K + col;
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.x_out + at), (unsigned long long)(xq_fix(o[i]) + xres[j][i]));
+        if (last) a.x_zero[at] = 0;
+      }
+    }
+  }
+  M2M_STAMP(4, 2);
+}
+
+template <typename T>
+static int launch_dec_ff_t(const DecFfArgs& a, hipStream_t st) {
+  dim3 grid((unsigned)(a.d_ff / FF_C), (unsigned)ceil_div(a.B, 16));
+  switch (a.d / 64) {
+    case 2: hipLaunchKernelGGL((dec_ff_kernel<T, 2>), grid, dim3(128), 0, st, a); break;
+    case 4: hipLaunchKernelGGL((dec_ff_kernel<T, 4>), grid, dim3(256), 0, st, a); break;
+    case 6: hipLaunchKernelGGL((dec_ff_kernel<T, 6>), grid, dim3(384), 0, st, a); break;
+    case 8: hipLaunchKernelGGL((dec_ff_kernel<T, 8>), grid, dim3(512), 0, st, a); break;
+    default: set_error("dec_ff: d_model=%d not supported (128/256/384/512)", a.d); return M2M_ERR_INVALID;
+  }
+  M2M_CHECK_HIP(hipGetLastError());
+  return M2M_OK;
+}
+
+static int launch_dec_ff(int precision, const DecFfArgs& a, hipStream_t st) {
+  if (a.d % 64 != 0 || a.d_ff % FF_C != 0) {
+    set_error("dec_ff: d_model=%d must be a multiple of 64 and d_ff=%d of %d", a.d, a.d_ff, FF_C);
+    return M2M_ERR_INVALID;
+  }
+  return precision == M2M_PREC_BF16 ? launch_dec_ff_t<bf16_t>(a, st) : launch_dec_ff_t<float>(a, st);
+}
+
 // ======================================================= decode attention ====
 // Fused per-(clip, head) kernel:  RMSNorm(x[b]) -> this head's projection (self: q,k,v + cache
 // append at slot t; cross: q) -> single-pass ("online") softmax attention over the cached keys ->
@@ -307,6 +476,15 @@ template <bool NT, typename V> __device__ inline V kv_load(const V* p) {
   else return *p;
 }
 #define M2M_KV_LOAD(p) kv_load<NT>(p)
+
+// softmax exponential of a non-positive argument.  fp32 (parity) mode: accurate expf.  bf16 mode
+// (-DM2M_FAST_EXP builds only, experiment): one v_exp_f32.
+template <typename T> __device__ inline float m2m_exp(float x) {
+#ifdef M2M_FAST_EXP
+  if constexpr (sizeof(T) == 2) return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
+#endif
+  return expf(x);
+}
 
 template <typename T, bool SELF, bool NT>
 __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
@@ -486,10 +664,13 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
   float acc[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) acc[e] = 0.f;
+  // one exponential per key: of (alpha, p) = (exp(m_run - m_new), exp(s - m_new)) one is always exp(0) = 1
   auto visit = [&](float s, const float (&vrow)[E]) {
-    const float m_new = fmaxf(m_run, s);
-    const float alpha = expf(m_run - m_new);
-    const float p = expf(s - m_new);
+    const bool up = s > m_run;
+    const float m_new = up ? s : m_run;
+    const float ex = m2m_exp<T>(up ? m_run - s : s - m_run);
+    const float alpha = up ? ex : 1.f;
+    const float p = up ? 1.f : ex;
     l_run = fmaf(l_run, alpha, p);
 #pragma unroll
     for (int e = 0; e < E; ++e) acc[e] = fmaf(acc[e], alpha, p * vrow[e]);
@@ -502,8 +683,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
       float s = 0.f;
 #pragma unroll
       for (int e = 0; e < E; ++e) s = fmaf(qv[e], kv[u].get(e), s);
-#pragma unroll
-      for (int ofs = 1; ofs < LPR; ofs <<= 1) s += __shfl_xor(s, ofs, 64);   // every lane of the group gets the sum
+      s = group_sum<LPR>(s);                                                   // every lane of the group gets the sum
       float vrow[E];
 #pragma unroll
       for (int e = 0; e < E; ++e) vrow[e] = vv[u].get(e);
@@ -559,8 +739,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
     float s = 0.f;
 #pragma unroll
     for (int e = 0; e < E; ++e) s = fmaf(qv[e], kn[sub * E + e], s);
-#pragma unroll
-    for (int ofs = 1; ofs < LPR; ofs <<= 1) s += __shfl_xor(s, ofs, 64);
+    s = group_sum<LPR>(s);
     s += a.bias[(int64_t)hh * a.bias_stride];
     float vrow[E];
 #pragma unroll
@@ -853,7 +1032,17 @@ int decode_launch_step(m2m_session* s, const DecView& v, bool forced, float* log
     if ((rc = decode_launch_attn(s, v, true, l, 0, st))) return rc;
     // 2. the same for cross-attention over the S encoder positions (query projection only)
     if ((rc = decode_launch_attn(s, v, false, l, 0, st))) return rc;
-    // 3. RMSNorm + gated-GELU up projection (reads C, the stream after both attention sub-layers)
+    // 3. feed-forward sub-layer, one kernel: reads C (the stream after both attention sub-layers),
+    //    accumulates C + FF(C) into A (zeroed by the cross-attention kernel) and leaves B zeroed for
+    //    the next layer's self-attention
+    static const bool split_ff = getenv("M2M_FF_SPLIT") != nullptr;   // diagnostic: the two-kernel form
+    if (!split_ff) {
+      DecFfArgs f{};
+      f.x = xC; f.x_out = xA; f.x_zero = xB; f.ln_w = L.ln2; f.eps = g.layer_norm_eps;
+      f.Wi = L.wi; f.Wo = L.wo_ff; f.d = g.d_model; f.d_ff = g.d_ff; f.B = v.nb; f.state = v.state;
+      if ((rc = launch_dec_ff(P, f, st))) return rc;
+      continue;
+    }
     a.x = xC; a.ldx = g.d_model; a.ln_w = L.ln2; a.W = L.wi; a.K = g.d_model; a.N = 2 * g.d_ff;
     a.out = gg; a.ldo = g.d_ff;
     if ((rc = launch_dec_gemm(P, DEPI_GATED, a, st))) return rc;

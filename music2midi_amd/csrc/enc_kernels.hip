@@ -176,7 +176,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
             const int which = col / g.inner, rem = col - which * g.inner;
             const int hh = rem / DK, dd = rem - hh * DK;
             const int b = row / g.S, s = row - b * g.S;
-            reinterpret_cast<T*>(g.out)[((((int64_t)which * g.Bsz + b) * g.H + hh) * g.S + s) * DK + dd] = from_f32<T>(v);
+            if (which == g.vt_which)
+              reinterpret_cast<T*>(g.vt_out)[(((int64_t)b * g.H + hh) * DK + dd) * g.Sp + s] = from_f32<T>(v);
+            else
+              reinterpret_cast<T*>(g.out)[((((int64_t)which * g.Bsz + b) * g.H + hh) * g.S + s) * DK + dd] = from_f32<T>(v);
           }
         }
       }
@@ -226,9 +229,9 @@ template <> struct AttnCfg<float> { static constexpr int KP = DK + 4, VP = AK + 
 __device__ inline int vt_pos(int kk) { return (kk & ~0xC) | ((kk & 4) << 1) | ((kk & 8) >> 1); }
 
 template <typename T>
-__global__ __launch_bounds__(256) void enc_attn_kernel(const T* __restrict__ qkv, const float* __restrict__ bias_tab,
-                                                       int tab_stride, int tab_center, T* __restrict__ out, int B,
-                                                       int H, int S) {
+__global__ __launch_bounds__(256) void enc_attn_kernel(const T* __restrict__ qkv, const T* __restrict__ vt, int Sp,
+                                                       const float* __restrict__ bias_tab, int tab_stride,
+                                                       int tab_center, T* __restrict__ out, int B, int H, int S) {
   using Cfg = AttnCfg<T>;
   constexpr int EPC = 16 / sizeof(T);
   extern __shared__ __align__(16) unsigned char smem[];
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const T* __restrict__ qkv
   const int64_t head_stride = (int64_t)S * DK;
   const T* Q = qkv + ((int64_t)(0 * B + b) * H + hh) * head_stride;
   const T* Kg = qkv + ((int64_t)(1 * B + b) * H + hh) * head_stride;
-  const T* Vg = qkv + ((int64_t)(2 * B + b) * H + hh) * head_stride;
+  const T* Vtg = vt + ((int64_t)b * H + hh) * DK * Sp;      // V^T of this (clip, head): [64][Sp]
 
   for (int i = tid; i < 2 * S - 1; i += 256) tb[i] = bias_tab[(int64_t)hh * tab_stride + tab_center - (S - 1) + i];
 
@@ -260,17 +263,32 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const T* __restrict__ qkv
   const int ntiles = ceil_div(S, AK);
   for (int kt = 0; kt < ntiles; ++kt) {
     __syncthreads();
-    // ---- stage K (row-major) and V (transposed + slot-permuted) ----
+    // ---- stage K (row-major) and V^T (already transposed in memory by the QKV GEMM epilogue;
+    //      key slots permuted to the accumulator k-order in whole 4-key groups, so it is 8/16-byte copies) ----
     for (int c = tid; c < AK * (DK / EPC); c += 256) {
       const int key = c / (DK / EPC), dc = c % (DK / EPC);
       const int gk = min(kt * AK + key, S - 1);
       *reinterpret_cast<uint4*>(Ks + key * Cfg::KP + dc * EPC) =
           *reinterpret_cast<const uint4*>(Kg + (int64_t)gk * DK + dc * EPC);
-      uint4 vv = *reinterpret_cast<const uint4*>(Vg + (int64_t)gk * DK + dc * EPC);
-      const T* ve = reinterpret_cast<const T*>(&vv);
-      const int slot = (key & 32) + vt_pos(key & 31);
+    }
+    for (int c = tid; c < DK * (AK / EPC); c += 256) {
+      const int d = c / (AK / EPC), kc = c % (AK / EPC);
+      const int k0 = kt * AK + kc * EPC;                       // first key of this 16-byte chunk (row pitch Sp >= tile end)
+      uint4 vv = *reinterpret_cast<const uint4*>(Vtg + (int64_t)d * Sp + k0);
+      if (k0 + EPC > S) {                                       // columns past S are uninitialised: zero them (0 * NaN would poison P.V)
+        T* ve = reinterpret_cast<T*>(&vv);
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) Vt[(dc * EPC + e) * Cfg::VP + slot] = ve[e];
+        for (int e = 0; e < EPC; ++e)
+          if (k0 + e >= S) ve[e] = from_f32<T>(0.f);
+      }
+      const int kl = kc * EPC;                                  // key index inside the 64-key tile
+      T* dst = Vt + d * Cfg::VP + (kl & 32);
+      if constexpr (EPC == 8) {                                 // bf16: two 4-key groups per chunk
+        *reinterpret_cast<uint2*>(dst + vt_pos(kl & 31)) = make_uint2(vv.x, vv.y);
+        *reinterpret_cast<uint2*>(dst + vt_pos((kl & 31) + 4)) = make_uint2(vv.z, vv.w);
+      } else {                                                  // fp32: one 4-key group per chunk
+        *reinterpret_cast<uint4*>(dst + vt_pos(kl & 31)) = vv;
+      }
     }
     __syncthreads();
 #pragma unroll
@@ -341,8 +359,8 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const T* __restrict__ qkv
 }
 
 template <typename T>
-static int launch_enc_attn_t(const void* qkv, const float* bias_tab, int tab_stride, int tab_center, void* out, int B,
-                             int H, int S, hipStream_t st) {
+static int launch_enc_attn_t(const void* qkv, const void* vt, int Sp, const float* bias_tab, int tab_stride,
+                             int tab_center, void* out, int B, int H, int S, hipStream_t st) {
   using Cfg = AttnCfg<T>;
   const size_t smem = (size_t)(AK * Cfg::KP + DK * Cfg::VP) * sizeof(T) + (size_t)(2 * S - 1) * sizeof(float);
   M2M_REQUIRE(smem <= 150 * 1024, "enc_attn: S=%d too long for the LDS bias table", S);
@@ -352,16 +370,17 @@ static int launch_enc_attn_t(const void* qkv, const float* bias_tab, int tab_str
     attr_set = true;
   }
   dim3 grid((unsigned)ceil_div(S, AQ), (unsigned)(B * H));
-  hipLaunchKernelGGL(enc_attn_kernel<T>, grid, dim3(256), smem, st, (const T*)qkv, bias_tab, tab_stride, tab_center,
-                     (T*)out, B, H, S);
+  hipLaunchKernelGGL(enc_attn_kernel<T>, grid, dim3(256), smem, st, (const T*)qkv, (const T*)vt, Sp, bias_tab, tab_stride,
+                     tab_center, (T*)out, B, H, S);
   M2M_CHECK_HIP(hipGetLastError());
   return M2M_OK;
 }
 
-int launch_enc_attn(int precision, const void* qkv, const float* bias_tab, int tab_stride, int tab_center, void* out,
-                    int B, int H, int S, hipStream_t st) {
-  return precision == M2M_PREC_BF16 ? launch_enc_attn_t<bf16_t>(qkv, bias_tab, tab_stride, tab_center, out, B, H, S, st)
-                                    : launch_enc_attn_t<float>(qkv, bias_tab, tab_stride, tab_center, out, B, H, S, st);
+int launch_enc_attn(int precision, const void* qkv, const void* vt, int Sp, const float* bias_tab, int tab_stride,
+                    int tab_center, void* out, int B, int H, int S, hipStream_t st) {
+  return precision == M2M_PREC_BF16
+             ? launch_enc_attn_t<bf16_t>(qkv, vt, Sp, bias_tab, tab_stride, tab_center, out, B, H, S, st)
+             : launch_enc_attn_t<float>(qkv, vt, Sp, bias_tab, tab_stride, tab_center, out, B, H, S, st);
 }
 
 }  // namespace m2m

@@ -94,7 +94,8 @@ struct m2m_session {
   // carved buffers
   float* x_enc;            // [B*S, d] fp32 residual stream
   void* h_enc;             // [B*S, d] T normalised activations
-  void* qkv_enc;           // [3][B][H][S][64] T
+  void* qkv_enc;           // [3][B][H][S][64] T  (the V third is unused: V is written transposed)
+  void* vt_enc;            // [B][H][64][Sp] T, Sp = S rounded up to 64
   void* attn_enc;          // [B*S, inner] T
   void* mid_enc;           // [B*S, dff] T
   float* enc_bias_tab;     // [H][2*max_enc-1]
@@ -131,12 +132,17 @@ struct GemmArgs {
   int ldo;           // leading dimension of out (STORE/RESID/GATED)
   // EPI_HEADS: out[(which*B + b)*H + h][s][64], which = n / inner
   int Bsz, S, H, inner;
+  // EPI_HEADS, optional: the projection `vt_which` (V of the encoder) is written TRANSPOSED instead,
+  // vt_out[(b*H + h)*64 + d][s] with row pitch Sp, so the attention kernel stages V^T with 16-byte copies
+  int vt_which;      // -1: none
+  void* vt_out;
+  int Sp;
 };
 
 int launch_gemm(int precision, int epi, const GemmArgs& a, hipStream_t st);
 int launch_rmsnorm(int precision, const float* x, const float* w, void* out, int M, int d, float eps, hipStream_t st);
-int launch_enc_attn(int precision, const void* qkv, const float* bias_tab, int tab_stride, int tab_center,
-                    void* out, int B, int H, int S, hipStream_t st);
+int launch_enc_attn(int precision, const void* qkv, const void* vt, int Sp, const float* bias_tab, int tab_stride,
+                    int tab_center, void* out, int B, int H, int S, hipStream_t st);
 int launch_final_norm_f32(const float* x, const float* w, float* out_f32, void* out_T, int precision, int M, int d,
                           float eps, hipStream_t st);
 

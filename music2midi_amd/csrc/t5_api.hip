@@ -161,7 +161,7 @@ extern "C" int64_t m2m_model_param_bytes(const m2m_model* m) { return m ? m->blo
 // ---------------------------------------------------------------- session ---
 namespace {
 struct WsLayout {
-  int64_t x_enc, h_enc, qkv_enc, attn_enc, mid_enc, enc_bias, dec_bias, cross_kv, self_k, self_v;
+  int64_t x_enc, h_enc, qkv_enc, vt_enc, attn_enc, mid_enc, enc_bias, dec_bias, cross_kv, self_k, self_v;
   int64_t x_dec, g_dec, logits, tokens, finished, state, forced, total;
 };
 
@@ -174,6 +174,7 @@ WsLayout ws_layout(const m2m_model* m, int B, int S, int L) {
   w.x_enc = take(M * g.d_model * 4);
   w.h_enc = take(M * g.d_model * es);
   w.qkv_enc = take(3 * M * m->inner * es);
+  w.vt_enc = take((int64_t)B * m->inner * (ceil_div(S, 64) * 64) * es);
   w.attn_enc = take(M * m->inner * es);
   w.mid_enc = take(M * g.d_ff * es);
   w.enc_bias = take((int64_t)g.num_heads * (2 * S - 1) * 4);
@@ -219,7 +220,7 @@ extern "C" int m2m_session_create(const m2m_model* m, int max_batch, int max_enc
   s->m = m; s->max_batch = max_batch; s->max_enc = max_enc_len; s->max_dec = max_dec_len;
   s->ws = (unsigned char*)workspace_dev; s->ws_bytes = workspace_bytes;
   unsigned char* b = s->ws;
-  s->x_enc = (float*)(b + w.x_enc); s->h_enc = b + w.h_enc; s->qkv_enc = b + w.qkv_enc; s->attn_enc = b + w.attn_enc;
+  s->x_enc = (float*)(b + w.x_enc); s->h_enc = b + w.h_enc; s->qkv_enc = b + w.qkv_enc; s->vt_enc = b + w.vt_enc; s->attn_enc = b + w.attn_enc;
   s->mid_enc = b + w.mid_enc; s->enc_bias_tab = (float*)(b + w.enc_bias); s->dec_bias_tab = (float*)(b + w.dec_bias);
   s->cross_kv = b + w.cross_kv; s->self_k = b + w.self_k; s->self_v = b + w.self_v;
   s->x_dec = (b + w.x_dec);
@@ -289,19 +290,21 @@ extern "C" int m2m_encode(m2m_session* s, const float* inputs_embeds_dev, int B,
     const EncLayerPacked& L = m->enc[l];
     if ((rc = launch_rmsnorm(P, s->x_enc, L.ln0, s->h_enc, M, d, g.layer_norm_eps, st))) return rc;
     GemmArgs a{};
+    const int Sp = ceil_div(S, 64) * 64;
     a.A = s->h_enc; a.W = L.wqkv; a.M = M; a.N = 3 * m->inner; a.K = d; a.out = s->qkv_enc;
     a.Bsz = B; a.S = S; a.H = g.num_heads; a.inner = m->inner;
+    a.vt_which = 2; a.vt_out = s->vt_enc; a.Sp = Sp;
     if ((rc = launch_gemm(P, EPI_HEADS, a, st))) return rc;
-    if ((rc = launch_enc_attn(P, s->qkv_enc, s->enc_bias_tab, 2 * s->max_enc - 1, s->max_enc - 1, s->attn_enc, B,
+    if ((rc = launch_enc_attn(P, s->qkv_enc, s->vt_enc, Sp, s->enc_bias_tab, 2 * s->max_enc - 1, s->max_enc - 1, s->attn_enc, B,
                               g.num_heads, S, st))) return rc;
-    a = GemmArgs{};
+    a = GemmArgs{}; a.vt_which = -1;
     a.A = s->attn_enc; a.W = L.wo; a.M = M; a.N = d; a.K = m->inner; a.out = s->x_enc; a.ldo = d;
     if ((rc = launch_gemm(P, EPI_RESID, a, st))) return rc;
     if ((rc = launch_rmsnorm(P, s->x_enc, L.ln1, s->h_enc, M, d, g.layer_norm_eps, st))) return rc;
-    a = GemmArgs{};
+    a = GemmArgs{}; a.vt_which = -1;
     a.A = s->h_enc; a.W = L.wi; a.M = M; a.N = 2 * g.d_ff; a.K = d; a.out = s->mid_enc; a.ldo = g.d_ff;
     if ((rc = launch_gemm(P, EPI_GATED, a, st))) return rc;
-    a = GemmArgs{};
+    a = GemmArgs{}; a.vt_which = -1;
     a.A = s->mid_enc; a.W = L.wo_ff; a.M = M; a.N = d; a.K = g.d_ff; a.out = s->x_enc; a.ldo = d;
     if ((rc = launch_gemm(P, EPI_RESID, a, st))) return rc;
   }
@@ -309,6 +312,7 @@ extern "C" int m2m_encode(m2m_session* s, const float* inputs_embeds_dev, int B,
   if ((rc = launch_final_norm_f32(s->x_enc, m->enc_final_ln, enc_out_dev, s->h_enc, P, M, d, g.layer_norm_eps, st))) return rc;
   // cross-attention K/V of every decoder layer in one GEMM, written in decode layout
   GemmArgs a{};
+  a.vt_which = -1;
   a.A = s->h_enc; a.W = m->wckv; a.M = M; a.N = g.num_decoder_layers * 2 * m->inner; a.K = d; a.out = s->cross_kv;
   a.Bsz = B; a.S = S; a.H = g.num_heads; a.inner = m->inner;
   if ((rc = launch_gemm(P, EPI_HEADS, a, st))) return rc;

@@ -17,7 +17,7 @@ from music2midi_amd.checkpoint import load_t5_state
 from music2midi_amd.config import T5Geometry, default_config
 from music2midi_amd.transformer import T5Transformer
 
-NAMES = {1: "gemm_qkv", 2: "gemm_plain", 3: "gemm_resid", 4: "gemm_gated", 6: "attn_cross", 7: "attn_self", 8: "head"}
+NAMES = {1: "gemm_qkv", 2: "gemm_plain", 3: "gemm_resid", 4: "ff", 6: "attn_cross", 7: "attn_self", 8: "head"}
 
 cfg = default_config()
 geom = T5Geometry(cfg.model.t5)
@@ -71,15 +71,15 @@ print("attention kernels, all phases (us from kernel start): ph4=x arrived, ph5=
 cur = None
 shown = 0
 for kid, ph, tk in seg[1:]:
-    if kid in (6, 7):
+    if kid in (4, 6, 7):
         if ph == 0:
             cur = tk
             line = [NAMES[kid]]
         elif cur is not None:
             line.append(f"ph{ph}={(tk - cur) * 0.01:.2f}")
-            if ph == 3:
+            if ph == (2 if kid == 4 else 3):
                 print("  " + "  ".join(line)); shown += 1
-                if shown >= 6: break
+                if shown >= 9: break
 print("first 20 kernels of the step (gap, dur):")
 pe = t0
 for kid, s, mid, e, m2 in rows[:14]:
