@@ -63,7 +63,9 @@ __device__ unsigned int g_stamp_n;
 // added to, which a single read-modify buffer would allow.
 typedef long long xq_t;
 __device__ inline xq_t xq_fix(float v) { return __float2ll_rn(v * 1073741824.0f); }
-__device__ inline float xq_flt(xq_t q) { return (float)q * (1.0f / 1073741824.0f); }
+// via double: int64 -> f64 is 4 instructions (two 32-bit converts + fma) against ~12 for the correctly
+// rounded int64 -> f32 sequence, and the result is the same single rounding while |q| < 2^53 (|x| < 8.4e6)
+__device__ inline float xq_flt(xq_t q) { return (float)((double)q * (1.0 / 1073741824.0)); }
 __device__ inline float4 xq_load4(const xq_t* p) {   // p 16-byte aligned
   const longlong2 a = *reinterpret_cast<const longlong2*>(p);
   const longlong2 b = *reinterpret_cast<const longlong2*>(p + 2);
@@ -152,6 +154,7 @@ __global__ __launch_bounds__(64 * DG_MAXW) void dec_gemm_kernel(DecGemmArgs a) {
   Frag<T> wf[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) wf[s] = load_frag(wr + 32 * s);
+  asm volatile("" ::"s"(done));   // materialise the flag now, under the vector loads (else it is sunk to the epilogue)
 
   f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
   if constexpr (NORM) {
@@ -283,7 +286,8 @@ static int launch_dec_gemm(int precision, int epi, const DecGemmArgs& a, hipStre
 // Waves = KS = d_model / 64: wave ks multiplies k-slice ks of the normalised rows with all four
 // n-tiles of the slice (a tile = 8 wi_0 rows + the matching 8 wi_1 rows, as repack.hip interleaves
 // them), so the rows of x — 8 bytes per element, the largest operand — are fetched once per
-// workgroup; in phase 2 wave w owns output columns [64 w, 64 w + 64).  A CU pulls only ~25-30 GB/s
+// workgroup; in phase 2 wave w owns output columns [64 w, 64 w + 64).  One extra workgroup per row
+// block adds the residual rows themselves and zeroes the third buffer of the rotation.  A CU pulls only ~25-30 GB/s
 // from beyond its L2, so the kernel's time is the bytes one workgroup requests (x 49 KB + weights
 // 74 KB at d_model 384); every global load is issued before the first use.
 struct DecFfArgs {
@@ -298,33 +302,59 @@ struct DecFfArgs {
   const DecState* state;
 };
 
+#ifndef M2M_FF_ROWS
+#define M2M_FF_ROWS 8
+#endif
+// residual rows per workgroup (<= 16, the MFMA tile height).  8 halves the fixed-point rows a workgroup
+// pulls (they were just written, so they come from HBM, not from a cache: tools/l2_persist.hip) at the
+// price of reading the weight slices twice from the Infinity Cache: 247.3 -> 244.6 ms per batch; 4 rows: 259.5
+constexpr int FF_R = M2M_FF_ROWS;
 constexpr int FF_C = 32;        // hidden columns per workgroup
 constexpr int FF_HP = FF_C + 8; // LDS row pitch of the activation slice (elements; keeps 16-byte alignment)
 
 template <typename T, int KS>
-__global__ __launch_bounds__(64 * KS) void dec_ff_kernel(DecFfArgs a) {
+__global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(1, 2))) void dec_ff_kernel(DecFfArgs a) {
   M2M_STAMP_DECL
   __shared__ float ss_s[KS][16];
   __shared__ float red[KS][4][16 * 17];
   __shared__ __align__(16) T hs[16 * FF_HP];
   M2M_STAMP(4, 0);
-  const int done = a.state->done;   // consumed only after every load has been issued
+  const int done = a.state->done;
   const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int c = blockIdx.x, b0 = blockIdx.y * 16;
+  const int c = blockIdx.x, b0 = blockIdx.y * FF_R;
   const int K = a.d;
+  if (c == (int)gridDim.x - 1) {
+    // the extra workgroup of each row block carries the residual itself into x_out and zeroes the
+    // third buffer (blockDim.x == d_model: one column per thread), so the slice workgroups issue no
+    // conditional loads (a branch around a load costs them a full s_waitcnt)
+    xq_t v[FF_R];
+#pragma unroll
+    for (int i = 0; i < FF_R; ++i) v[i] = a.x[(int64_t)min(b0 + i, a.B - 1) * K + tid];
+    if (done) return;
+#pragma unroll
+    for (int i = 0; i < FF_R; ++i) {
+      if (b0 + i < a.B) {
+        const int64_t at = (int64_t)(b0 + i) * K + tid;
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.x_out + at), (unsigned long long)v[i]);
+        a.x_zero[at] = 0;
+      }
+    }
+    return;
+  }
   const int kbeg = ks * 64 + 8 * g;
-  const bool row_ok = (b0 + r) < a.B;
+  const bool row_ok = r < FF_R && (b0 + r) < a.B;
   const int arow = b0 + (row_ok ? r : 0);            // padding rows read row b0; their activations are zeroed
   const T* Wi = reinterpret_cast<const T*>(a.Wi);
   const T* Wo = reinterpret_cast<const T*>(a.Wo);
 
   const xq_t* xr = a.x + (int64_t)arow * K + kbeg;
-  float4 x0[2], x1[2], g0[2], g1[2];
+  longlong2 xraw[2][4];   // raw fixed-point rows: converted only after every load has been issued
+  float4 g0[2], g1[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    x0[s] = xq_load4(xr + 32 * s);
-    x1[s] = xq_load4(xr + 32 * s + 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) xraw[s][q] = *reinterpret_cast<const longlong2*>(xr + 32 * s + 2 * q);
     g0[s] = *reinterpret_cast<const float4*>(a.ln_w + kbeg + 32 * s);
     g1[s] = *reinterpret_cast<const float4*>(a.ln_w + kbeg + 32 * s + 4);
   }
@@ -337,15 +367,16 @@ __global__ __launch_bounds__(64 * KS) void dec_ff_kernel(DecFfArgs a) {
   Frag<T> wo[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) wo[j] = load_frag(Wo + (int64_t)(16 * (4 * ks + j) + r) * a.d_ff + FF_C * c + 8 * g);
-  // slice 0 carries the residual itself into x_out: raw fixed-point values of this lane's outputs
-  xq_t xres[4][4];
+  // every load is in flight; the loop-state flag is forced here (two dependent scalar loads that the
+  // compiler would otherwise sink to the first use, in front of the barrier on the critical path)
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("" ::"s"(done));
+  float4 x0[2], x1[2];
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      xres[j][i] = 0;
-      if (c == 0) xres[j][i] = a.x[(int64_t)min(b0 + 4 * g + i, a.B - 1) * K + 16 * (4 * ks + j) + r];
-    }
+  for (int s = 0; s < 2; ++s) {
+    x0[s] = make_float4(xq_flt(xraw[s][0].x), xq_flt(xraw[s][0].y), xq_flt(xraw[s][1].x), xq_flt(xraw[s][1].y));
+    x1[s] = make_float4(xq_flt(xraw[s][2].x), xq_flt(xraw[s][2].y), xq_flt(xraw[s][3].x), xq_flt(xraw[s][3].y));
+  }
 
   // ---- phase 1: RMSNorm + up projection of this slice ----
   float ss = 0.f;
@@ -396,7 +427,6 @@ __global__ __launch_bounds__(64 * KS) void dec_ff_kernel(DecFfArgs a) {
 
   // ---- phase 2: [16 x 32] activations x [32 x d_model] slice of wo, added into the residual rows ----
   const Frag<T> fh = load_frag(hs + r * FF_HP + 8 * g);
-  const bool last = (c == (int)gridDim.x - 1);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     f32x4_t o = {0.f, 0.f, 0.f, 0.f};
@@ -405,10 +435,9 @@ __global__ __launch_bounds__(64 * KS) void dec_ff_kernel(DecFfArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = b0 + 4 * g + i;
-      if (row < a.B) {
+      if (4 * g + i < FF_R && row < a.B) {
         const int64_t at = (int64_t)row * K + col;
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.x_out + at), (unsigned long long)(xq_fix(o[i]) + xres[j][i]));
-        if (last) a.x_zero[at] = 0;
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.x_out + at), (unsigned long long)xq_fix(o[i]));
       }
     }
   }
@@ -417,7 +446,7 @@ __global__ __launch_bounds__(64 * KS) void dec_ff_kernel(DecFfArgs a) {
 
 template <typename T>
 static int launch_dec_ff_t(const DecFfArgs& a, hipStream_t st) {
-  dim3 grid((unsigned)(a.d_ff / FF_C), (unsigned)ceil_div(a.B, 16));
+  dim3 grid((unsigned)(a.d_ff / FF_C + 1), (unsigned)ceil_div(a.B, FF_R));   // + 1: the residual-carry workgroup
   switch (a.d / 64) {
     case 2: hipLaunchKernelGGL((dec_ff_kernel<T, 2>), grid, dim3(128), 0, st, a); break;
     case 4: hipLaunchKernelGGL((dec_ff_kernel<T, 4>), grid, dim3(256), 0, st, a); break;
@@ -500,11 +529,14 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
   constexpr int LPO2 = 8;
   constexpr int WMAX2 = 6;               // k/v weight chunks per lane held in registers (d_model 384, bf16)
   // K/V rounds (one K row + one V row per lane = 32 KB per workgroup) kept in flight by the rolling
-  // prefetch.  The CU's memory pipeline holds only so many outstanding misses: requesting the whole
-  // 220 KB stream at once stalls the ISSUING waves (measured: the prologue then finishes at ~9 us);
-  // a window of a few rounds covers latency x per-CU bandwidth (~2 us x 24 GB/s = 48 KB).
+  // prefetch.  The first PF rounds are requested at kernel entry, right behind the prologue's own
+  // loads, so the stream is already running while the norm and the query projection execute.  Two
+  // rounds is the measured optimum (B = 32: 252.3 ms per batch with one round requested after x
+  // arrived, 249.1 with two at entry, 251.1 / 262.2 with three / four): deeper windows flood the
+  // fabric queues ahead of the latency-critical x / weight loads of workgroups that start a little
+  // later, and the whole 220 KB stream at once stalls the issuing waves (prologue done at ~9 us).
 #ifndef M2M_DA_PF
-#define M2M_DA_PF 1
+#define M2M_DA_PF 2
 #endif
   constexpr int PF = M2M_DA_PF;
   constexpr int WMAX = 3;                // q weight chunks per lane held in registers (d_model 384, bf16)
@@ -535,14 +567,13 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
   //         Every kernel starts with a cold L2 for data other XCDs produced, so these come from
   //         memory; if the 220 KB K/V stream of this workgroup were requested at the same time they
   //         would queue behind it in the fabric (measured: the norm then completes only after ~9 us).
-  //         The K/V stream is therefore requested right after x has arrived (step 1b). ----
+  //         Only the first PF rounds of the stream follow them here. ----
   const int xc = min(tid * 4, a.d - 4);
   const float4 xv = xq_load4(a.x + (int64_t)b * a.d + xc);
   const float4 gv = *reinterpret_cast<const float4*>(a.ln_w + xc);
   // head 0 also carries the residual row into x_out: its raw fixed-point value, requested now
   const int on_ = min(tid >> 1, a.d - 1), opart = tid & 1;
-  xq_t xres = 0;
-  if (hh == 0) xres = a.x[(int64_t)b * a.d + on_];
+  const xq_t xres = a.x[(int64_t)b * a.d + on_];   // unconditional: a branch would split the block of loads
   const int po = min(tid / LPO, NOUT - 1), part = tid % LPO;
   const int which = po / DK, dd = po - which * DK;
   const T* wrow = reinterpret_cast<const T*>(a.Wp) + ((int64_t)which * a.inner + hh * DK + dd) * a.d;
@@ -550,22 +581,25 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
   Vec16<T> w[WMAX];
 #pragma unroll
   for (int u = 0; u < WMAX; ++u) w[u].v = *reinterpret_cast<const V16*>(wrow + (min(u, cnt - 1) * LPO + part) * E);
+  // all of the above are in flight before anything waits: without the fence the scheduler places the
+  // wait for x (and its int64 -> float conversion) ahead of the weight loads, serialising two round trips
+  __builtin_amdgcn_sched_barrier(0);
 
-  if (st_done) return;   // uniform
+  // No early exit on st_done: a branch here makes the compiler sink the weight loads above below
+  // it, behind the wait for x (one more serial round trip).  A finished chain runs at most the rest
+  // of its graph with every store suppressed.
   const int t = SELF ? (a.self_len_override > 0 ? a.self_len_override - 1 : st_t) : 0;
   const int n_prev = SELF ? t : a.n_keys;            // keys that are read from memory
   const int last = max(n_prev - 1, 0);
 
   // ---- 1. RMSNorm of x[b] -> hn (rounded to the GEMM-input type T) ----
   Vec16<T> kv[PF], vv[PF];
-#ifdef M2M_DA_TOP
 #pragma unroll
-  for (int u = 0; u < PF; ++u) {
+  for (int u = 0; u < PF; ++u) {   // clamped addresses, never predicated
     const int64_t off = (int64_t)min(kslot + u * KPB, last) * DK + sub * E;
     kv[u].v = M2M_KV_LOAD(reinterpret_cast<const V16*>(Kb + off));
     vv[u].v = M2M_KV_LOAD(reinterpret_cast<const V16*>(Vb + off));
   }
-#endif
   {
     const bool own = tid * 4 < a.d;
     float ss = own ? (xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w) : 0.f;
@@ -573,16 +607,6 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
     if (lane == 0) redw[wave] = ss;
     __syncthreads();
     M2M_STAMP(6 + (SELF ? 1 : 0), 4);
-    // ---- 1b. x is here for every wave: start the K/V stream (clamped addresses, never predicated):
-    //          the first PF rounds now, the rest by the rolling prefetch of step 3 ----
-#if !defined(M2M_DA_LATE) && !defined(M2M_DA_TOP)
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      const int64_t off = (int64_t)min(kslot + u * KPB, last) * DK + sub * E;
-      kv[u].v = M2M_KV_LOAD(reinterpret_cast<const V16*>(Kb + off));
-      vv[u].v = M2M_KV_LOAD(reinterpret_cast<const V16*>(Vb + off));
-    }
-#endif
     float tot = 0.f;
 #pragma unroll
     for (int wv = 0; wv < 16; ++wv) tot += redw[wv];
@@ -594,14 +618,6 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
       hn[xc + 3] = to_f32(from_f32<T>(gv.w * (xv.w * rs)));
     }
     __syncthreads();
-#ifdef M2M_DA_LATE
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      const int64_t off = (int64_t)min(kslot + u * KPB, last) * DK + sub * E;
-      kv[u].v = M2M_KV_LOAD(reinterpret_cast<const V16*>(Kb + off));
-      vv[u].v = M2M_KV_LOAD(reinterpret_cast<const V16*>(Vb + off));
-    }
-#endif
     M2M_STAMP(6 + (SELF ? 1 : 0), 5);
   }
 
@@ -629,8 +645,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
         }
       }
     }
-#pragma unroll
-    for (int ofs = 1; ofs < LPO; ofs <<= 1) acc += __shfl_xor(acc, ofs, 64);
+    acc = group_sum<LPO>(acc);
     M2M_STAMP(6 + (SELF ? 1 : 0), 6);
     if (part == 0 && tid < NOUT * LPO) qs[dd] = acc;      // q stays fp32
   }
@@ -725,13 +740,12 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
         }
       }
     }
-#pragma unroll
-    for (int ofs = 1; ofs < LPO2; ofs <<= 1) acc2 += __shfl_xor(acc2, ofs, 64);
+    acc2 = group_sum<LPO2>(acc2);
     if (part2 == 0) {
       const T r = from_f32<T>(acc2);                       // k, v are stored (and used) rounded to T
       const int64_t slot = (int64_t)t * DK + dd2;
-      if (which2 == 1) { kn[dd2] = to_f32(r); Kb[slot] = r; }
-      else             { vn[dd2] = to_f32(r); Vb[slot] = r; }
+      if (which2 == 1) { kn[dd2] = to_f32(r); if (!st_done) Kb[slot] = r; }
+      else             { vn[dd2] = to_f32(r); if (!st_done) Vb[slot] = r; }
     }
     __syncthreads();
   }
@@ -789,7 +803,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
       for (int e = 0; e < E; ++e) accp = fmaf(oh[opart * 32 + u * E + e], wo[u].get(e), accp);
     }
     accp += __shfl_xor(accp, 1, 64);
-    if (opart == 0 && tid < 2 * a.d) {
+    if (opart == 0 && tid < 2 * a.d && !st_done) {
       xq_t add = xq_fix(accp);
       if (hh == 0) add += xres;                               // head 0 also carries the residual itself
       atomicAdd(reinterpret_cast<unsigned long long*>(a.x_out + (int64_t)b * a.d + on_), (unsigned long long)add);
