@@ -25,8 +25,10 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-
 VARIANT = os.environ.get("M2M_BUILD_VARIANT", "")
 EXTRA = os.environ.get("M2M_BUILD_EXTRA", "").split()   # experiment builds: extra -D flags, lib suffix = M2M_BUILD_TAG
 TAG = os.environ.get("M2M_BUILD_TAG", "")
-if EXTRA and TAG:
-    FLAGS = FLAGS + EXTRA
+if EXTRA and not (TAG or VARIANT):
+    raise SystemExit("M2M_BUILD_EXTRA needs M2M_BUILD_TAG (or M2M_BUILD_VARIANT): experiment flags never go into the product library")
+FLAGS = FLAGS + EXTRA
+if TAG:
     BUILD = CSRC / f"build_{TAG}"
     LIB = PKG / "lib" / f"libmusic2midi_amd_{TAG}.so"
 if VARIANT == "stamps":

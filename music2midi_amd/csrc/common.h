@@ -78,14 +78,46 @@ template <> struct Vec16<bf16_t> {
 };
 
 // ------------------------------------------------------------- wave ops ---
+// Cross-lane exchanges without the LDS crossbar (__shfl_xor compiles to ds_bpermute_b32: an LDS-pipe
+// round trip of ~100 clocks per step, and the steps of a reduction are dependent):
+//   xor 1, 2   DPP quad_perm            xor 4   two DPP row shifts under complementary bank masks
+//   xor 8      DPP row_ror:8            xor 16 / 32   v_permlane16_swap / v_permlane32_swap (gfx950)
+// lane_xor<M>(v) returns v of lane (lane ^ M) for ANY data, so a reduction built from it pairs the same
+// operands as the __shfl_xor butterfly it replaces and is bit-identical to it.
+// (The swap instructions are issued as inline asm: __builtin_amdgcn_permlane32_swap with both operands
+// the same value is miscompiled by ROCm 7.2 - tools/permlane_test.hip.)
+template <int CTRL, int BANK_MASK = 0xF>
+__device__ inline float dpp_mov(float v, float old = 0.f) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL,
+                                                               0xF, BANK_MASK, BANK_MASK == 0xF));
+}
+template <int M>
+__device__ inline float lane_xor(float v) {
+  static_assert(M == 1 || M == 2 || M == 4 || M == 8 || M == 16 || M == 32, "lane_xor: power of two below 64");
+  if constexpr (M == 1) return dpp_mov<0xB1>(v);          // quad_perm [1,0,3,2]
+  else if constexpr (M == 2) return dpp_mov<0x4E>(v);     // quad_perm [2,3,0,1]
+  else if constexpr (M == 4) {
+    // banks (4-lane groups) 0 and 2 of every row take lane + 4 (row_shl:4), banks 1 and 3 lane - 4 (row_shr:4)
+    const float up = dpp_mov<0x104, 0x5>(v, v);
+    return dpp_mov<0x114, 0xA>(v, up);
+  } else if constexpr (M == 8) return dpp_mov<0x128>(v);  // row_ror:8
+  else {
+    float a = v, b = v;
+    if constexpr (M == 16) asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    else asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    // M == 32: a = [lo, lo], b = [hi, hi] (halves of the wave); M == 16: a = [r0, r0, r2, r2], b = [r1, r1, r3, r3]
+    const int lane = __lane_id();
+    return (lane & M) ? a : b;
+  }
+}
 __device__ inline float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  v += lane_xor<32>(v); v += lane_xor<16>(v); v += lane_xor<8>(v);
+  v += lane_xor<4>(v);  v += lane_xor<2>(v);  v += lane_xor<1>(v);
   return v;
 }
 __device__ inline float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  v = fmaxf(v, lane_xor<32>(v)); v = fmaxf(v, lane_xor<16>(v)); v = fmaxf(v, lane_xor<8>(v));
+  v = fmaxf(v, lane_xor<4>(v));  v = fmaxf(v, lane_xor<2>(v));  v = fmaxf(v, lane_xor<1>(v));
   return v;
 }
 
@@ -93,10 +125,6 @@ __device__ inline float wave_max(float v) {
 // crossbar round trip as __shfl_xor's ds_bpermute has).  Same pairing as an xor-butterfly 1,2,4(,8):
 // after the two quad steps the value is quad-uniform, so the half-row / row mirrors fetch exactly the
 // partner quad / half a butterfly would — results are bit-identical to it.
-template <int CTRL>
-__device__ inline float dpp_mov(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
 template <int LANES>
 __device__ inline float group_sum(float v) {
   static_assert(LANES == 8 || LANES == 16, "group_sum: 8 or 16 lanes");

@@ -172,8 +172,8 @@ __global__ __launch_bounds__(64 * DG_MAXW) void dec_gemm_kernel(DecGemmArgs a) {
     for (int s = 0; s < NS; ++s)
       ss += x0[s].x * x0[s].x + x0[s].y * x0[s].y + x0[s].z * x0[s].z + x0[s].w * x0[s].w +
             x1[s].x * x1[s].x + x1[s].y * x1[s].y + x1[s].z * x1[s].z + x1[s].w * x1[s].w;
-    ss += __shfl_xor(ss, 16, 64);
-    ss += __shfl_xor(ss, 32, 64);
+    ss += lane_xor<16>(ss);
+    ss += lane_xor<32>(ss);
     if (g == 0) ss_s[wave][r] = ss;
     __syncthreads();
     float tot = 0.f;
@@ -384,8 +384,8 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(1, 2)))
   for (int s = 0; s < 2; ++s)
     ss += x0[s].x * x0[s].x + x0[s].y * x0[s].y + x0[s].z * x0[s].z + x0[s].w * x0[s].w +
           x1[s].x * x1[s].x + x1[s].y * x1[s].y + x1[s].z * x1[s].z + x1[s].w * x1[s].w;
-  ss += __shfl_xor(ss, 16, 64);
-  ss += __shfl_xor(ss, 32, 64);
+  ss += lane_xor<16>(ss);
+  ss += lane_xor<32>(ss);
   if (g == 0) ss_s[ks][r] = ss;
   __syncthreads();
   M2M_STAMP(4, 3);
@@ -594,6 +594,9 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
 
   // ---- 1. RMSNorm of x[b] -> hn (rounded to the GEMM-input type T) ----
   Vec16<T> kv[PF], vv[PF];
+#ifdef M2M_DA_SLEEP
+  __builtin_amdgcn_s_sleep(M2M_DA_SLEEP);   // experiment: let the x / weight requests get ahead of the stream
+#endif
 #pragma unroll
   for (int u = 0; u < PF; ++u) {   // clamped addresses, never predicated
     const int64_t off = (int64_t)min(kslot + u * KPB, last) * DK + sub * E;
@@ -646,7 +649,9 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
       }
     }
     acc = group_sum<LPO>(acc);
+#ifndef M2M_STAMPS_MERGE
     M2M_STAMP(6 + (SELF ? 1 : 0), 6);
+#endif
     if (part == 0 && tid < NOUT * LPO) qs[dd] = acc;      // q stays fp32
   }
   __syncthreads();
@@ -767,6 +772,9 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
     const float mw = wave_max(m_run);
     if (lane == 0) redw[wave] = mw;
     __syncthreads();
+#ifdef M2M_STAMPS_MERGE
+    M2M_STAMP(6 + (SELF ? 1 : 0), 6);
+#endif
     float M = redw[0];
 #pragma unroll
     for (int wv = 1; wv < 16; ++wv) M = fmaxf(M, redw[wv]);
@@ -776,8 +784,9 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       acc[e] *= scale;
-#pragma unroll
-      for (int ofs = LPR; ofs < 64; ofs <<= 1) acc[e] += __shfl_xor(acc[e], ofs, 64);
+      if constexpr (LPR == 8) acc[e] += lane_xor<8>(acc[e]);
+      acc[e] += lane_xor<16>(acc[e]);
+      acc[e] += lane_xor<32>(acc[e]);
     }
     if (lane == 0) redl[wave] = lsum;
     if (lane < LPR) {
@@ -802,7 +811,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
 #pragma unroll
       for (int e = 0; e < E; ++e) accp = fmaf(oh[opart * 32 + u * E + e], wo[u].get(e), accp);
     }
-    accp += __shfl_xor(accp, 1, 64);
+    accp += lane_xor<1>(accp);
     if (opart == 0 && tid < 2 * a.d && !st_done) {
       xq_t add = xq_fix(accp);
       if (hh == 0) add += xres;                               // head 0 also carries the residual itself
