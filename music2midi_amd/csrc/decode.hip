@@ -532,7 +532,9 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
   // prefetch.  The first PF rounds are requested at kernel entry, right behind the prologue's own
   // loads, so the stream is already running while the norm and the query projection execute.  Two
   // rounds is the measured optimum (B = 32: 252.3 ms per batch with one round requested after x
-  // arrived, 249.1 with two at entry, 251.1 / 262.2 with three / four): deeper windows flood the
+  // arrived, 249.1 with two at entry, 251.1 / 262.2 with three / four; one at entry + one when x
+  // arrives, a short s_sleep in front of them, or two extra one-shot rounds in the cross kernel
+  // all measure the same within noise): deeper windows flood the
   // fabric queues ahead of the latency-critical x / weight loads of workgroups that start a little
   // later, and the whole 220 KB stream at once stalls the issuing waves (prologue done at ~9 us).
 #ifndef M2M_DA_PF
@@ -544,6 +546,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
   extern __shared__ __align__(16) float hn[];   // [d] normalised input row (already rounded to T)
   __shared__ float redw[16], redl[16];
   __shared__ float redo[16][DK];
+  __shared__ __align__(16) float redg[16 * (64 / LPR)][DK];   // per-group partial outputs (32 KB bf16 / 16 KB fp32)
   __shared__ __align__(16) float qs[DK];
   __shared__ __align__(16) float kn[DK];
   __shared__ __align__(16) float vn[DK];
@@ -594,9 +597,6 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
 
   // ---- 1. RMSNorm of x[b] -> hn (rounded to the GEMM-input type T) ----
   Vec16<T> kv[PF], vv[PF];
-#ifdef M2M_DA_SLEEP
-  __builtin_amdgcn_s_sleep(M2M_DA_SLEEP);   // experiment: let the x / weight requests get ahead of the stream
-#endif
 #pragma unroll
   for (int u = 0; u < PF; ++u) {   // clamped addresses, never predicated
     const int64_t off = (int64_t)min(kslot + u * KPB, last) * DK + sub * E;
@@ -767,37 +767,44 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
   }
   M2M_STAMP(6 + (SELF ? 1 : 0), 2);
 
-  // ---- 4. merge the groups: global max, rescale, sum ----
+  // ---- 4. merge the 128 key groups (16 waves x 64 / LPR groups) ----
+  // Each group's partial output goes to LDS scaled to its WAVE's maximum (one LDS write per lane
+  // instead of 3 cross-lane exchanges per accumulator register: the exchanges were the bulk of the
+  // tail's VALU time with 16 waves on 4 SIMDs); waves are then summed group by group, and the 16 wave
+  // results are brought to the global maximum by the 64 threads that finish the row.
   {
+    constexpr int GPW = 64 / LPR;                    // groups per wave: 8 (bf16) / 4 (fp32)
     const float mw = wave_max(m_run);
-    if (lane == 0) redw[wave] = mw;
+    const float scale = expf(m_run - mw);            // groups that saw no key have m_run = -1e30 -> 0 (or 1 if the whole wave saw none: l = acc = 0)
+    float lsum = (sub == 0) ? l_run * scale : 0.f;   // l is replicated over a group's lanes: count it once
+    lsum = wave_sum(lsum);
+    float* gp = &redg[wave * GPW + lane / LPR][sub * E];
+#pragma unroll
+    for (int e = 0; e < E; e += 4)
+      *reinterpret_cast<float4*>(gp + e) = make_float4(acc[e] * scale, acc[e + 1] * scale, acc[e + 2] * scale, acc[e + 3] * scale);
+    if (lane == 0) { redw[wave] = mw; redl[wave] = lsum; }
     __syncthreads();
 #ifdef M2M_STAMPS_MERGE
     M2M_STAMP(6 + (SELF ? 1 : 0), 6);
 #endif
-    float M = redw[0];
+    {
+      float sw = redg[wave * GPW][lane];             // thread (wave, lane = dim): this wave's groups, fixed order
 #pragma unroll
-    for (int wv = 1; wv < 16; ++wv) M = fmaxf(M, redw[wv]);
-    const float scale = expf(m_run - M);          // groups that saw no key have m_run = -1e30 -> 0
-    float lsum = (sub == 0) ? l_run * scale : 0.f;   // l is replicated over a group's lanes: count it once
-    lsum = wave_sum(lsum);
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      acc[e] *= scale;
-      if constexpr (LPR == 8) acc[e] += lane_xor<8>(acc[e]);
-      acc[e] += lane_xor<16>(acc[e]);
-      acc[e] += lane_xor<32>(acc[e]);
-    }
-    if (lane == 0) redl[wave] = lsum;
-    if (lane < LPR) {
-#pragma unroll
-      for (int e = 0; e < E; ++e) redo[wave][lane * E + e] = acc[e];
+      for (int j = 1; j < GPW; ++j) sw += redg[wave * GPW + j][lane];
+      redo[wave][lane] = sw;
     }
     __syncthreads();
     if (tid < DK) {
+      float M = redw[0];
+#pragma unroll
+      for (int wv = 1; wv < 16; ++wv) M = fmaxf(M, redw[wv]);
       float s = 0.f, L = 0.f;
 #pragma unroll
-      for (int wv = 0; wv < 16; ++wv) { s += redo[wv][tid]; L += redl[wv]; }
+      for (int wv = 0; wv < 16; ++wv) {
+        const float f = expf(redw[wv] - M);
+        s = fmaf(f, redo[wv][tid], s);
+        L = fmaf(f, redl[wv], L);
+      }
       oh[tid] = to_f32(from_f32<T>(s / L));      // the projection input is rounded to T, as every GEMM input
     }
     __syncthreads();
