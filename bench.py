@@ -39,7 +39,7 @@ N_SAMPLES = 220500        # 10 s @ 22.05 kHz
 MAX_LENGTH = 1024
 
 
-def cpu_baseline(cfg, state, new_tokens: int, clips: int = 4, threads: int = 16):
+def cpu_baseline(cfg, state, new_tokens: int, clips: int = 8, threads: int = 16):
     """Oracle on the host cores: `clips` clips, frontend + encoder + `new_tokens` greedy steps, fp32.
 
     16 intra-op threads: measured fastest on the GPU box's 256-core host (tools/cpu_threads_probe.py:

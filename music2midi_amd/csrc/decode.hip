@@ -906,12 +906,15 @@ __global__ __launch_bounds__(1024) void dec_head_kernel(DecHeadArgs a) {
       const float x = lg[v];
       if (x > best || (x == best && v < bi)) { best = x; bi = v; }
     }
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) {          // stays inside the 32-lane half
-      const float ob = __shfl_xor(best, o, 64);
-      const int oi = __shfl_xor(bi, o, 64);
+    auto take = [&](float ob, int oi) {
       if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-    }
+    };
+    // butterfly inside the 32-lane half (xor 16, 8, 4, 2, 1), LDS-free exchanges
+    take(lane_xor<16>(best), __builtin_bit_cast(int, lane_xor<16>(__builtin_bit_cast(float, bi))));
+    take(lane_xor<8>(best), __builtin_bit_cast(int, lane_xor<8>(__builtin_bit_cast(float, bi))));
+    take(lane_xor<4>(best), __builtin_bit_cast(int, lane_xor<4>(__builtin_bit_cast(float, bi))));
+    take(lane_xor<2>(best), __builtin_bit_cast(int, lane_xor<2>(__builtin_bit_cast(float, bi))));
+    take(lane_xor<1>(best), __builtin_bit_cast(int, lane_xor<1>(__builtin_bit_cast(float, bi))));
     int next;
     if (a.forced) {
       if (a.logits_out)
