@@ -14,9 +14,9 @@
 //                    (self: q,k,v + cache append; cross: q) fused in front of the attention, which
 //                    streams K then V straight from HBM to registers (16 B per lane per load, no
 //                    LDS staging: each byte is used once), fp32 softmax, shuffle + LDS reduction.
-//   dec_gemm_kernel  skinny projection  out[16 rows, 16 cols] per workgroup, 4..12 waves split K,
-//                    MFMA 16x16 tiles; optional fused RMSNorm on the input rows; epilogues:
-//                    residual-add (O-projections, FFN down), gated-GELU (FFN up), plain (lm_head).
+//   dec_ff_kernel    the whole gated feed-forward sub-layer: RMSNorm + MFMA up projection of a 32-column
+//                    slice + gated GELU (LDS) + MFMA down projection, added into the residual stream.
+//   dec_gemm_kernel  lm_head: RMSNorm + skinny projection, one 16x16 MFMA tile per workgroup, waves split K.
 //   dec_head_kernel  argmax / EOS+pad bookkeeping / next-token embedding / step counter.
 #include "mma.h"
 #include "t5.h"
@@ -73,31 +73,25 @@ __device__ inline float4 xq_load4(const xq_t* p) {   // p 16-byte aligned
 }
 
 // ===================================================== skinny projection ====
-enum { DEPI_PLAIN = 1, DEPI_RESID = 2, DEPI_GATED = 3 };
-
+// lm_head: logits[B, V] = RMSNorm(x) . W^T (untied, no d_model**-0.5 scaling: transformers 4.34 semantics).
 struct DecGemmArgs {
-  const void* x;         // [rows, K] input: the fixed-point residual stream xq_t (normed epilogues) or T (DEPI_RESID)
+  const xq_t* x;         // [rows, K] fixed-point residual stream
   int ldx;
-  const float* ln_w;     // [K] RMSNorm weight (QKV / PLAIN / GATED), unused for RESID
+  const float* ln_w;     // [K] RMSNorm weight
   float eps;
   const void* W;         // [Npad, K] T
   int K, N, B;
   const DecState* state;
-  // outputs
-  void* out;             // PLAIN: float [B, N]; RESID: xq_t residual stream [B, N] (= res_in + v); GATED: T [B, N/2]
+  float* out;            // [B, ldo] logits
   int ldo;
-  const void* res_in;    // RESID: xq_t [B, N] the residual the projection is added to
-  void* res_zero;        // RESID: xq_t [B, N] buffer left zeroed for the next attention kernel to accumulate into
 };
 
 // One 16-row x 16-column output tile per workgroup (MFMA 16x16x32 / 16x16x4), NW waves split K.
-// A CU fetches only ~10 B/clk (~24 GB/s) from beyond its L2 (MI355X_MICROARCH.md cycle constants)
-// and every kernel starts with a cold L2, so a skinny projection's time IS the bytes one workgroup
-// pulls: small tiles spread W (and the rows of x) over many CUs — 48..288 workgroups instead of
-// 12..72 with 32x32 tiles — and cut the per-workgroup fetch from 64..147 KB to 32..74 KB.
-// Every global load (weights, activations, norm weights, the old residual value) is issued before
-// the first use, so a launch is one memory round trip; RMSNorm statistics are reduced across waves
-// through LDS while the weight loads are in flight; the cross-wave sum has a fixed order.
+// A CU fetches only ~25 GB/s from beyond its L2 and every kernel starts cold for what the previous
+// one wrote, so a skinny projection's time IS the bytes one workgroup pulls: small tiles spread W (and
+// the rows of x) over many CUs.  Every global load (weights, activations, norm weights) is issued
+// before the first use, so a launch is one memory round trip; RMSNorm statistics are reduced across
+// waves through LDS while the weight loads are in flight; the cross-wave sum has a fixed order.
 //
 // NS (32-wide k-steps per wave) is a template parameter: a runtime bound would put every load of
 // the unrolled batch behind its own branch + s_waitcnt (cdna_hip_programming.md, "three .s-level
@@ -121,13 +115,12 @@ __device__ inline void mma32_16(f32x4_t& acc, const Frag<float>& a, const Frag<f
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi.w, b.hi.w, acc, 0, 0, 0);
 }
 
-template <typename T, int EPI, int NS>
+template <typename T, int NS>
 __global__ __launch_bounds__(64 * DG_MAXW) void dec_gemm_kernel(DecGemmArgs a) {
-  constexpr bool NORM = (EPI != DEPI_RESID);
   M2M_STAMP_DECL
   __shared__ float ss_s[DG_MAXW][16];
   __shared__ float red[DG_MAXW][16 * 17];
-  M2M_STAMP(1 + EPI, 0);
+  M2M_STAMP(2, 0);
   const int done = a.state->done;   // consumed only before the stores
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nw = blockDim.x >> 6;
@@ -140,16 +133,9 @@ __global__ __launch_bounds__(64 * DG_MAXW) void dec_gemm_kernel(DecGemmArgs a) {
   const bool row_ok = (b0 + r) < a.B;
   const int arow = b0 + (row_ok ? r : 0);           // padding rows read row b0 and are never stored
   const T* wr = W + (int64_t)(n0 + r) * K + kbeg;
-
-  // epilogue coordinates of this thread (threads 0..255 own one output each) and, for the
-  // residual epilogue, the old value of that output: requested now, consumed at the very end
+  // epilogue coordinates of this thread (threads 0..255 own one output each)
   const int orow = (tid >> 4) & 15, ocol = tid & 15;
   const int ob = b0 + orow, on = n0 + ocol;
-  xq_t xold = 0;
-  if constexpr (EPI == DEPI_RESID) {
-    const int cb = min(ob, a.B - 1), cn = min(on, a.N - 1);
-    xold = reinterpret_cast<const xq_t*>(a.res_in)[(int64_t)cb * a.ldo + cn];
-  }
 
   Frag<T> wf[NS];
 #pragma unroll
@@ -157,8 +143,8 @@ __global__ __launch_bounds__(64 * DG_MAXW) void dec_gemm_kernel(DecGemmArgs a) {
   asm volatile("" ::"s"(done));   // materialise the flag now, under the vector loads (else it is sunk to the epilogue)
 
   f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-  if constexpr (NORM) {
-    const xq_t* xr = reinterpret_cast<const xq_t*>(a.x) + (int64_t)arow * a.ldx + kbeg;
+  {
+    const xq_t* xr = a.x + (int64_t)arow * a.ldx + kbeg;
     float4 x0[NS], x1[NS], g0[NS], g1[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -187,44 +173,18 @@ __global__ __launch_bounds__(64 * DG_MAXW) void dec_gemm_kernel(DecGemmArgs a) {
       const Frag<T> fa = pack_frag<T>(xv);
       mma32_16(acc, fa, wf[s]);
     }
-  } else {
-    const T* xr = reinterpret_cast<const T*>(a.x) + (int64_t)arow * a.ldx + kbeg;
-    Frag<T> xf[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) xf[s] = load_frag(xr + 32 * s);
-#pragma unroll
-    for (int s = 0; s < NS; ++s) mma32_16(acc, xf[s], wf[s]);
   }
   // ---- cross-wave reduction (fixed order: deterministic).  acc[i]: row 4g + i, column r ----
 #pragma unroll
   for (int i = 0; i < 4; ++i) red[wave][(4 * g + i) * 17 + r] = acc[i];
-  M2M_STAMP(1 + EPI, 1);
+  M2M_STAMP(2, 1);
   __syncthreads();
-  if (done || tid >= 256 || ob >= a.B) return;
-
-  auto rsum = [&](int idx) {
-    float v = red[0][idx];
-    for (int w = 1; w < nw; ++w) v += red[w][idx];
-    return v;
-  };
+  if (done || tid >= 256 || ob >= a.B || on >= a.N) return;
   const int idx = orow * 17 + ocol;
-  if constexpr (EPI == DEPI_GATED) {
-    // tile columns: [8 of wi_0 | the matching 8 of wi_1]
-    if (ocol < 8) {
-      const float v0 = rsum(idx), v1 = rsum(idx + 8);
-      const int oc = (n0 >> 1) + ocol;
-      if (2 * oc < a.N) reinterpret_cast<T*>(a.out)[(int64_t)ob * a.ldo + oc] = from_f32<T>(gelu_new(v0) * v1);
-    }
-  } else if (on < a.N) {
-    const float v = rsum(idx);
-    float* outf = reinterpret_cast<float*>(a.out);
-    if constexpr (EPI == DEPI_PLAIN) outf[(int64_t)ob * a.ldo + on] = v;
-    else {                                                                               // DEPI_RESID
-      reinterpret_cast<xq_t*>(a.out)[(int64_t)ob * a.ldo + on] = xold + xq_fix(v);
-      reinterpret_cast<xq_t*>(a.res_zero)[(int64_t)ob * a.ldo + on] = 0;
-    }
-  }
-  M2M_STAMP(1 + EPI, 2);
+  float v = red[0][idx];
+  for (int w = 1; w < nw; ++w) v += red[w][idx];
+  a.out[(int64_t)ob * a.ldo + on] = v;
+  M2M_STAMP(2, 2);
 }
 
 // waves x steps decomposition of the reduction length: K = 32 * NS * NW
@@ -234,41 +194,27 @@ static bool dec_gemm_shape(int K, int* ns, int* nw) {
     case 256: *ns = 2; *nw = 4; return true;
     case 384: *ns = 2; *nw = 6; return true;
     case 512: *ns = 2; *nw = 8; return true;
-    case 1152: *ns = 3; *nw = 12; return true;
     default: return false;
   }
 }
 
-template <typename T, int EPI>
-static int launch_dec_gemm_e(const DecGemmArgs& a, hipStream_t st) {
+template <typename T>
+static int launch_dec_gemm_t(const DecGemmArgs& a, hipStream_t st) {
   int ns = 0, nw = 0;
   if (!dec_gemm_shape(a.K, &ns, &nw)) {
-    set_error("dec_gemm: K=%d not supported by the decode projections (128/256/384/512/1152)", a.K);
+    set_error("dec_gemm: K=%d not supported by the decode projections (128/256/384/512)", a.K);
     return M2M_ERR_INVALID;
   }
   dim3 grid((unsigned)ceil_div(a.N, 16), (unsigned)ceil_div(a.B, 16));
   dim3 block((unsigned)(64 * nw));
-  switch (ns) {
-    case 1: hipLaunchKernelGGL((dec_gemm_kernel<T, EPI, 1>), grid, block, 0, st, a); break;
-    case 2: hipLaunchKernelGGL((dec_gemm_kernel<T, EPI, 2>), grid, block, 0, st, a); break;
-    default: hipLaunchKernelGGL((dec_gemm_kernel<T, EPI, 3>), grid, block, 0, st, a); break;
-  }
+  if (ns == 1) hipLaunchKernelGGL((dec_gemm_kernel<T, 1>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((dec_gemm_kernel<T, 2>), grid, block, 0, st, a);
   M2M_CHECK_HIP(hipGetLastError());
   return M2M_OK;
 }
 
-template <typename T>
-static int launch_dec_gemm_t(int epi, const DecGemmArgs& a, hipStream_t st) {
-  switch (epi) {
-    case DEPI_PLAIN: return launch_dec_gemm_e<T, DEPI_PLAIN>(a, st);
-    case DEPI_RESID: return launch_dec_gemm_e<T, DEPI_RESID>(a, st);
-    case DEPI_GATED: return launch_dec_gemm_e<T, DEPI_GATED>(a, st);
-    default: return M2M_ERR_INVALID;
-  }
-}
-
-static int launch_dec_gemm(int precision, int epi, const DecGemmArgs& a, hipStream_t st) {
-  return precision == M2M_PREC_BF16 ? launch_dec_gemm_t<bf16_t>(epi, a, st) : launch_dec_gemm_t<float>(epi, a, st);
+static int launch_dec_gemm(int precision, const DecGemmArgs& a, hipStream_t st) {
+  return precision == M2M_PREC_BF16 ? launch_dec_gemm_t<bf16_t>(a, st) : launch_dec_gemm_t<float>(a, st);
 }
 
 // ===================================================== fused feed-forward ====
@@ -1050,16 +996,12 @@ int decode_launch_step(m2m_session* s, const DecView& v, bool forced, float* log
   const m2m_model* m = s->m;
   const m2m_t5_geometry& g = m->g;
   const int P = m->precision;
-  const size_t es = m->esize;
   xq_t* xA = xbuf(s, v, 0);
   xq_t* xB = xbuf(s, v, 1);
   xq_t* xC = xbuf(s, v, 2);
-  unsigned char* gg = (unsigned char*)s->g_dec + (size_t)v.b0 * g.d_ff * es;
   int rc;
   for (int l = 0; l < g.num_decoder_layers; ++l) {
     const DecLayerPacked& L = m->dec[l];
-    DecGemmArgs a{};
-    a.eps = g.layer_norm_eps; a.B = v.nb; a.state = v.state;
     // 1. RMSNorm + per-head QKV projection + KV-cache append + causal self-attention + per-head
     //    output projection accumulated into the residual stream (one kernel)
     if ((rc = decode_launch_attn(s, v, true, l, 0, st))) return rc;
@@ -1068,28 +1010,17 @@ int decode_launch_step(m2m_session* s, const DecView& v, bool forced, float* log
     // 3. feed-forward sub-layer, one kernel: reads C (the stream after both attention sub-layers),
     //    accumulates C + FF(C) into A (zeroed by the cross-attention kernel) and leaves B zeroed for
     //    the next layer's self-attention
-    static const bool split_ff = getenv("M2M_FF_SPLIT") != nullptr;   // diagnostic: the two-kernel form
-    if (!split_ff) {
-      DecFfArgs f{};
-      f.x = xC; f.x_out = xA; f.x_zero = xB; f.ln_w = L.ln2; f.eps = g.layer_norm_eps;
-      f.Wi = L.wi; f.Wo = L.wo_ff; f.d = g.d_model; f.d_ff = g.d_ff; f.B = v.nb; f.state = v.state;
-      if ((rc = launch_dec_ff(P, f, st))) return rc;
-      continue;
-    }
-    a.x = xC; a.ldx = g.d_model; a.ln_w = L.ln2; a.W = L.wi; a.K = g.d_model; a.N = 2 * g.d_ff;
-    a.out = gg; a.ldo = g.d_ff;
-    if ((rc = launch_dec_gemm(P, DEPI_GATED, a, st))) return rc;
-    // 4. down projection: A = C + g.Wo^T, and B is left zeroed for the next layer's self-attention
-    a.x = gg; a.ldx = g.d_ff; a.ln_w = nullptr; a.W = L.wo_ff; a.K = g.d_ff; a.N = g.d_model;
-    a.out = xA; a.ldo = g.d_model; a.res_in = xC; a.res_zero = xB;
-    if ((rc = launch_dec_gemm(P, DEPI_RESID, a, st))) return rc;
+    DecFfArgs f{};
+    f.x = xC; f.x_out = xA; f.x_zero = xB; f.ln_w = L.ln2; f.eps = g.layer_norm_eps;
+    f.Wi = L.wi; f.Wo = L.wo_ff; f.d = g.d_model; f.d_ff = g.d_ff; f.B = v.nb; f.state = v.state;
+    if ((rc = launch_dec_ff(P, f, st))) return rc;
   }
   // final RMSNorm + lm_head (untied, no d_model**-0.5 scaling: transformers 4.34 semantics)
   DecGemmArgs a{};
   a.eps = g.layer_norm_eps; a.B = v.nb; a.state = v.state;
   a.x = xA; a.ldx = g.d_model; a.ln_w = m->dec_final_ln; a.W = m->lm_head; a.K = g.d_model; a.N = g.vocab_size;
   a.out = s->logits + (int64_t)v.b0 * m->vocab_pad; a.ldo = m->vocab_pad;
-  if ((rc = launch_dec_gemm(P, DEPI_PLAIN, a, st))) return rc;
+  if ((rc = launch_dec_gemm(P, a, st))) return rc;
   DecHeadArgs h = head_args(s, v, forced, logits_out, Ld);
   hipLaunchKernelGGL(dec_head_kernel, dim3(1), dim3(1024), 0, st, h);
   M2M_CHECK_HIP(hipGetLastError());

@@ -104,7 +104,6 @@ struct m2m_session {
   void* self_k;            // [L][B][H][max_dec][64] T
   void* self_v;
   void* x_dec;             // [32-row padded B, d] int64 fixed-point residual stream of the decoder (decode.hip xq_t)
-  void* g_dec;             // [B, dff] T (gated-GELU output = input of the down projection)
   float* logits;           // [B, vocab_pad]
   int64_t* tokens;         // [B, max_dec]
   int* finished;           // [B]

@@ -39,11 +39,11 @@ extern "C" int m2m_model_create(const m2m_t5_geometry* geom, const m2m_t5_weight
   M2M_REQUIRE(precision == M2M_PREC_FP32 || precision == M2M_PREC_BF16, "m2m_model_create: bad precision %d", precision);
   const m2m_t5_geometry& g = *geom;
   M2M_REQUIRE(g.d_kv == DK, "m2m_model_create: d_kv=%d unsupported (attention kernels are specialised for 64)", g.d_kv);
-  auto k_ok = [](int k) { return k == 128 || k == 256 || k == 384 || k == 512 || k == 1152; };
-  M2M_REQUIRE(k_ok(g.d_model) && k_ok(g.d_ff) && k_ok(g.num_heads * g.d_kv),
-              "m2m_model_create: d_model=%d, d_ff=%d, num_heads*d_kv=%d must each be one of 128/256/384/512/1152 "
-              "(the reduction lengths the decode projections are instantiated for)", g.d_model, g.d_ff, g.num_heads * g.d_kv);
-  M2M_REQUIRE(g.d_model <= 512, "m2m_model_create: d_model=%d > 512 (the fused decode attention projects with 2 lanes per output column of a 1024-thread workgroup)", g.d_model);
+  M2M_REQUIRE(g.d_model == 128 || g.d_model == 256 || g.d_model == 384 || g.d_model == 512,
+              "m2m_model_create: d_model=%d must be 128, 256, 384 or 512 (the reduction lengths the decode kernels are "
+              "instantiated for; the fused decode attention projects with 2 lanes per output column of a 1024-thread workgroup)",
+              g.d_model);
+  M2M_REQUIRE(g.d_ff >= 64 && g.d_ff % 64 == 0, "m2m_model_create: d_ff=%d must be a multiple of 64", g.d_ff);
   M2M_REQUIRE((g.num_heads * g.d_kv) % 128 == 0 && g.num_heads * g.d_kv <= 1152, "m2m_model_create: num_heads*d_kv=%d must be a multiple of 128, <= 1152", g.num_heads * g.d_kv);
   M2M_REQUIRE(g.num_heads >= 1 && g.num_layers >= 1 && g.num_decoder_layers >= 1 && g.vocab_size >= 2,
               "m2m_model_create: bad geometry");
@@ -162,7 +162,7 @@ extern "C" int64_t m2m_model_param_bytes(const m2m_model* m) { return m ? m->blo
 namespace {
 struct WsLayout {
   int64_t x_enc, h_enc, qkv_enc, vt_enc, attn_enc, mid_enc, enc_bias, dec_bias, cross_kv, self_k, self_v;
-  int64_t x_dec, g_dec, logits, tokens, finished, state, forced, total;
+  int64_t x_dec, logits, tokens, finished, state, forced, total;
 };
 
 WsLayout ws_layout(const m2m_model* m, int B, int S, int L) {
@@ -183,7 +183,6 @@ WsLayout ws_layout(const m2m_model* m, int B, int S, int L) {
   w.self_k = take((int64_t)g.num_decoder_layers * B * m->inner * L * es);
   w.self_v = take((int64_t)g.num_decoder_layers * B * m->inner * L * es);
   w.x_dec = take(3 * Bp * g.d_model * 8);   // int64 fixed-point residual stream, 3 rotating buffers
-  w.g_dec = take(Bp * g.d_ff * es);
   w.logits = take(Bp * m->vocab_pad * 4);
   w.tokens = take((int64_t)B * L * 8);
   w.finished = take((int64_t)B * 4);
@@ -224,7 +223,7 @@ extern "C" int m2m_session_create(const m2m_model* m, int max_batch, int max_enc
   s->mid_enc = b + w.mid_enc; s->enc_bias_tab = (float*)(b + w.enc_bias); s->dec_bias_tab = (float*)(b + w.dec_bias);
   s->cross_kv = b + w.cross_kv; s->self_k = b + w.self_k; s->self_v = b + w.self_v;
   s->x_dec = (b + w.x_dec);
-  s->g_dec = b + w.g_dec; s->logits = (float*)(b + w.logits); s->tokens = (int64_t*)(b + w.tokens);
+  s->logits = (float*)(b + w.logits); s->tokens = (int64_t*)(b + w.tokens);
   s->finished = (int*)(b + w.finished); s->states = (DecState*)(b + w.state); s->forced_ids = (int64_t*)(b + w.forced);
 
   // relative-position bias tables (fp32), built on the host from the bucket function

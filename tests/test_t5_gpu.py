@@ -145,11 +145,11 @@ def test_error_paths_report_instead_of_faulting():
         model.generate_from_embeds(torch.zeros(1, 40000, g.d_model, device="cuda"), max_length=4)   # S beyond the LDS bias table
 
 
-@pytest.mark.parametrize("d_model,d_ff,heads,layers", [(256, 512, 4, 1), (512, 1152, 2, 1), (384, 256, 8, 2)])
+@pytest.mark.parametrize("d_model,d_ff,heads,layers", [(256, 512, 4, 1), (512, 1152, 2, 1), (384, 256, 8, 2), (128, 640, 6, 1)])
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_other_geometries(d_model, d_ff, heads, layers, precision):
-    """Every reduction length the decode projections are instantiated for (128/256/384/512/1152) and
-    head counts other than the reference's, in both precision modes."""
+    """Every d_model the decode kernels are instantiated for (128/256/384/512), feed-forward widths other than
+    the reference's (any multiple of 64) and head counts other than 8, in both precision modes."""
     cfg = copy.deepcopy(DEFAULT_CONFIG)
     cfg["model"]["t5"].update(d_model=d_model, d_ff=d_ff, num_layers=layers, num_decoder_layers=layers, num_heads=heads)
     model, orc, g = build(cfg, precision)
