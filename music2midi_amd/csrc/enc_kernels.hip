@@ -241,8 +241,15 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const T* __restrict__ qkv
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int bh = blockIdx.y, b = bh / H, hh = bh - b * H;
-  const int q0 = blockIdx.x * AQ + wave * 32;
+  // XCD-aware block order (workgroup id -> XCD is id % 8, each XCD has its own L2): all query tiles of a
+  // (clip, head) run on ONE XCD, back to back, so its K/V is fetched into that L2 once instead of once per
+  // query tile (PMC: 433 MB fetched per launch against 85 MB of Q/K/V with the row-major order).
+  const int nq = (S + AQ - 1) / AQ;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int bh = xcd + 8 * (slot / nq), qt = slot - (slot / nq) * nq;
+  if (bh >= B * H) return;          // grid is padded to a multiple of 8 (clip, head) pairs
+  const int b = bh / H, hh = bh - b * H;
+  const int q0 = qt * AQ + wave * 32;
   const int64_t head_stride = (int64_t)S * DK;
   const T* Q = qkv + ((int64_t)(0 * B + b) * H + hh) * head_stride;
   const T* Kg = qkv + ((int64_t)(1 * B + b) * H + hh) * head_stride;
@@ -369,7 +376,7 @@ static int launch_enc_attn_t(const void* qkv, const void* vt, int Sp, const floa
     M2M_CHECK_HIP(hipFuncSetAttribute((const void*)enc_attn_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  dim3 grid((unsigned)ceil_div(S, AQ), (unsigned)(B * H));
+  dim3 grid((unsigned)(ceil_div(S, AQ) * ceil_div(B * H, 8) * 8));
   hipLaunchKernelGGL(enc_attn_kernel<T>, grid, dim3(256), smem, st, (const T*)qkv, (const T*)vt, Sp, bias_tab, tab_stride,
                      tab_center, (T*)out, B, H, S);
   M2M_CHECK_HIP(hipGetLastError());

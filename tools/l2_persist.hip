@@ -33,6 +33,17 @@ __global__ void store_touch(unsigned long long* buf) {
   unsigned long long* p = buf + (size_t)blockIdx.x * LINES * 16;
   for (int i = threadIdx.x; i < LINES * 16; i += blockDim.x) p[i] = i;
 }
+// read every line first (pulls it into the Infinity Cache), then update it with atomics / stores in the same kernel
+__global__ void touch_then_atomic(unsigned long long* buf, unsigned* sink, int use_store) {
+  unsigned long long* p = buf + (size_t)blockIdx.x * LINES * 16;
+  unsigned long long acc = 0;
+  for (int l = threadIdx.x; l < LINES; l += blockDim.x) acc += p[l * 16];
+  if (acc == 0x12345) sink[0] = 1;
+  __syncthreads();
+  for (int i = threadIdx.x; i < LINES * 16; i += blockDim.x) {
+    if (use_store) p[i] = i; else atomicAdd(p + i, 1ull);
+  }
+}
 // out[3*wg + 0] = first-read time, [1] = second-read time (10 ns ticks)
 __global__ void timed_read(const unsigned* buf, unsigned* sink, unsigned* out) {
   const unsigned* p = buf + (size_t)blockIdx.x * LINES * 32;
@@ -84,6 +95,18 @@ int main() {
     hipLaunchKernelGGL(atomic_touch, dim3(G), dim3(384), 0, st, (unsigned long long*)buf);
     hipLaunchKernelGGL(timed_read, dim3(G), dim3(384), 0, st, buf, sink, out);
     report("after atomics by same XCD");
+    hipLaunchKernelGGL(flush, dim3(2048), dim3(256), 0, st, big, big_n, sink);
+    hipLaunchKernelGGL(touch_then_atomic, dim3(G), dim3(384), 0, st, (unsigned long long*)buf + LINES * 16, sink, 0);
+    hipLaunchKernelGGL(timed_read, dim3(G - 1), dim3(384), 0, st, buf, sink, out);
+    report("read+atomics by other XCD");
+    hipLaunchKernelGGL(flush, dim3(2048), dim3(256), 0, st, big, big_n, sink);
+    hipLaunchKernelGGL(touch_then_atomic, dim3(G), dim3(384), 0, st, (unsigned long long*)buf + LINES * 16, sink, 1);
+    hipLaunchKernelGGL(timed_read, dim3(G - 1), dim3(384), 0, st, buf, sink, out);
+    report("read+stores by other XCD");
+    hipLaunchKernelGGL(flush, dim3(2048), dim3(256), 0, st, big, big_n, sink);
+    hipLaunchKernelGGL(atomic_touch, dim3(G), dim3(384), 0, st, (unsigned long long*)buf + LINES * 16);
+    hipLaunchKernelGGL(timed_read, dim3(G - 1), dim3(384), 0, st, buf, sink, out);
+    report("flush, atomics, read");
     // small buffer that fits the Infinity Cache but was last used by another XCD mapping: shift the grid by one
     hipLaunchKernelGGL(touch, dim3(G), dim3(384), 0, st, buf + LINES * 32, sink);
     hipLaunchKernelGGL(timed_read, dim3(G - 1), dim3(384), 0, st, buf, sink, out);
