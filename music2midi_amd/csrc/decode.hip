@@ -530,6 +530,16 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
   Vec16<T> w[WMAX];
 #pragma unroll
   for (int u = 0; u < WMAX; ++u) w[u].v = *reinterpret_cast<const V16*>(wrow + (min(u, cnt - 1) * LPO + part) * E);
+  // self: this head's relative-position bias row goes to LDS.  Read from global memory inside the key
+  // loop it would sit behind the next round's K/V request in the wave's in-order vmcnt queue: the
+  // compiler then has to wait vmcnt(0) every round, and the stream runs at one round per memory latency.
+  float* const biasl = hn + a.d;                      // [kv_stride] (self only)
+  constexpr int BPT = 2;                               // bias entries per thread held in registers (Lmax <= 2048; more: loop below)
+  float bv[SELF ? BPT : 1];
+  if (SELF) {
+#pragma unroll
+    for (int u = 0; u < BPT; ++u) bv[u] = a.bias[(int64_t)hh * a.bias_stride + min(tid + 1024 * u, a.bias_stride - 1)];
+  }
   // all of the above are in flight before anything waits: without the fence the scheduler places the
   // wait for x (and its int64 -> float conversion) ahead of the weight loads, serialising two round trips
   __builtin_amdgcn_sched_barrier(0);
@@ -600,6 +610,12 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
 #endif
     if (part == 0 && tid < NOUT * LPO) qs[dd] = acc;      // q stays fp32
   }
+  if (SELF) {
+#pragma unroll
+    for (int u = 0; u < BPT; ++u)
+      if (tid + 1024 * u < a.bias_stride) biasl[tid + 1024 * u] = bv[u];
+    for (int n = tid + 1024 * BPT; n < a.bias_stride; n += 1024) biasl[n] = a.bias[(int64_t)hh * a.bias_stride + n];
+  }
   __syncthreads();
   M2M_STAMP(6 + (SELF ? 1 : 0), 1);
 
@@ -662,7 +678,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
         vv[u].v = M2M_KV_LOAD(reinterpret_cast<const V16*>(Vb + off));
       }
       if (key < n_prev) {   // VALU-only predicate (the loads are unconditional)
-        if (SELF) s += a.bias[(int64_t)hh * a.bias_stride + (t - key)];
+        if (SELF) s += biasl[t - key];
         visit(s, vrow);
       }
     }
@@ -705,7 +721,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
 #pragma unroll
     for (int e = 0; e < E; ++e) s = fmaf(qv[e], kn[sub * E + e], s);
     s = group_sum<LPR>(s);
-    s += a.bias[(int64_t)hh * a.bias_stride];
+    s += biasl[0];
     float vrow[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) vrow[e] = vn[sub * E + e];
@@ -788,7 +804,9 @@ static void launch_dec_attn_t(bool self, bool nt, const DecAttnArgs& a, dim3 gri
 
 static int launch_dec_attn(int precision, bool self, bool nt, DecAttnArgs a, int B, int max_keys, hipStream_t st) {
   (void)max_keys;
-  const size_t smem = (size_t)a.d * sizeof(float);
+  const size_t smem = ((size_t)a.d + (self ? (size_t)a.bias_stride : 0)) * sizeof(float);   // hn + (self) the bias row
+  M2M_REQUIRE(smem <= 24 * 1024, "decode attention: max_dec_len=%d too long for the LDS bias row (<= %d)", a.bias_stride,
+              (24 * 1024 - a.d * 4) / 4);
   dim3 grid((unsigned)(B * a.H));
   if (precision == M2M_PREC_BF16) launch_dec_attn_t<bf16_t>(self, nt, a, grid, smem, st);
   else launch_dec_attn_t<float>(self, nt, a, grid, smem, st);
