@@ -658,30 +658,41 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
     for (int e = 0; e < E; ++e) acc[e] = fmaf(acc[e], alpha, p * vrow[e]);
     m_run = m_new;
   };
-  for (int k0 = 0; k0 < n_prev; k0 += PF * KPB) {
+  // One round: consume slot u (scores, online-softmax update), optionally re-request the round PF ahead
+  // into the same slot.  REISSUE is a compile-time choice per loop: in the main loop every re-request
+  // exists, so the loads are unconditional and the compiler can count them (s_waitcnt vmcnt(N) keeps the
+  // next round in flight while this one is consumed); a runtime "is there a round PF ahead" test around
+  // the loads makes it fall back to vmcnt(0) at every round, i.e. batches instead of a rolling window.
+  auto round = [&](const int k0, const int u, Vec16<T>& ks, Vec16<T>& vs, const int reissue /*0 no, 1 yes, 2 if it exists*/) {
+    const int key = k0 + kslot + u * KPB;
+    float s = 0.f;
 #pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      const int key = k0 + kslot + u * KPB;
-      float s = 0.f;
+    for (int e = 0; e < E; ++e) s = fmaf(qv[e], ks.get(e), s);
+    s = group_sum<LPR>(s);                                                   // every lane of the group gets the sum
+    float vrow[E];
 #pragma unroll
-      for (int e = 0; e < E; ++e) s = fmaf(qv[e], kv[u].get(e), s);
-      s = group_sum<LPR>(s);                                                   // every lane of the group gets the sum
-      float vrow[E];
-#pragma unroll
-      for (int e = 0; e < E; ++e) vrow[e] = vv[u].get(e);
-      // slot u is consumed: request the round PF further on into it (rolling window).  The guard is
-      // workgroup-uniform (no lane is predicated): past the end nothing is requested, so the merge
-      // barrier below does not wait for a useless round trip.
-      if (k0 + (u + PF) * KPB < n_prev) {
-        const int64_t off = (int64_t)min(key + PF * KPB, last) * DK + sub * E;
-        kv[u].v = M2M_KV_LOAD(reinterpret_cast<const V16*>(Kb + off));
-        vv[u].v = M2M_KV_LOAD(reinterpret_cast<const V16*>(Vb + off));
-      }
-      if (key < n_prev) {   // VALU-only predicate (the loads are unconditional)
-        if (SELF) s += biasl[t - key];
-        visit(s, vrow);
-      }
+    for (int e = 0; e < E; ++e) vrow[e] = vs.get(e);
+    if (reissue == 1 || (reissue == 2 && k0 + (u + PF) * KPB < n_prev)) {   // workgroup-uniform, no lane is predicated
+      const int64_t off = (int64_t)min(key + PF * KPB, last) * DK + sub * E;
+      ks.v = M2M_KV_LOAD(reinterpret_cast<const V16*>(Kb + off));
+      vs.v = M2M_KV_LOAD(reinterpret_cast<const V16*>(Vb + off));
     }
+    if (key < n_prev) {   // VALU-only predicate
+      if (SELF) s += biasl[t - key];
+      visit(s, vrow);
+    }
+  };
+  int k0 = 0;
+  // main loop: all PF re-requests of the iteration exist (the last one targets round k0 / KPB + 2 PF - 1)
+  for (; k0 + (2 * PF - 1) * KPB < n_prev; k0 += PF * KPB) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) round(k0, u, kv[u], vv[u], 1);
+  }
+  // tail (at most two iterations): past the end nothing is requested, so the merge barrier below does
+  // not wait for a useless round trip
+  for (; k0 < n_prev; k0 += PF * KPB) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) round(k0, u, kv[u], vv[u], 2);
   }
   if (SELF) {
     // project, round to T, append to the cache and publish through LDS the k,v rows of this step
