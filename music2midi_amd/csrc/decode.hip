@@ -62,7 +62,13 @@ __device__ unsigned int g_stamp_n;
 // (more workgroups than CUs) therefore never reads a row that a finished sibling has already
 // added to, which a single read-modify buffer would allow.
 typedef long long xq_t;
-__device__ inline xq_t xq_fix(float v) { return __float2ll_rn(v * 1073741824.0f); }
+// float -> fixed point, round to nearest even: (double)v * 2^30 is exact, adding 1.5 * 2^52 leaves the rounded
+// integer in the low mantissa bits (two's complement), so the conversion is cvt + mul + add + a 64-bit subtract
+// instead of the ~14-instruction float -> int64 sequence.  Valid for |v| < 2^21.
+__device__ inline xq_t xq_fix(float v) {
+  const double m = (double)v * 1073741824.0 + 6755399441055744.0;
+  return __double_as_longlong(m) - 0x4338000000000000ll;
+}
 // via double: int64 -> f64 is 4 instructions (two 32-bit converts + fma) against ~12 for the correctly
 // rounded int64 -> f32 sequence, and the result is the same single rounding while |q| < 2^53 (|x| < 8.4e6)
 __device__ inline float xq_flt(xq_t q) { return (float)((double)q * (1.0 / 1073741824.0)); }
@@ -373,17 +379,35 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(1, 2)))
 
   // ---- phase 2: [16 x 32] activations x [32 x d_model] slice of wo, added into the residual rows ----
   const Frag<T> fh = load_frag(hs + r * FF_HP + 8 * g);
+  f32x4_t o[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    f32x4_t o = {0.f, 0.f, 0.f, 0.f};
-    mma32_16(o, fh, wo[j]);
-    const int col = 16 * (4 * ks + j) + r;
+    o[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    mma32_16(o[j], fh, wo[j]);
+  }
+  if constexpr (FF_R <= 8) {
+    // Rows 8..15 of the MFMA tile are padding, i.e. lanes g >= 2 hold nothing to store.  They take over half
+    // of their partner's rows (lane ^ 32 <-> g ^ 2) so that every lane issues 2 adds per tile instead of
+    // half the lanes issuing 4: lane (r, g) stores tile rows 4 (g & 1) + 2 (g >> 1) + {0, 1}.
+    const int rl = 4 * (g & 1) + 2 * (g >> 1);
+    xq_t* const p0 = a.x_out + (int64_t)(b0 + rl) * K + 64 * ks + r;
+    const bool ok0 = rl < FF_R && b0 + rl < a.B, ok1 = rl + 1 < FF_R && b0 + rl + 1 < a.B;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = b0 + 4 * g + i;
-      if (4 * g + i < FF_R && row < a.B) {
-        const int64_t at = (int64_t)row * K + col;
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.x_out + at), (unsigned long long)xq_fix(o[i]));
+    for (int j = 0; j < 4; ++j) {
+      const float x2 = lane_xor<32>(o[j][2]), x3 = lane_xor<32>(o[j][3]);
+      const float v0 = g < 2 ? o[j][0] : x2, v1 = g < 2 ? o[j][1] : x3;
+      if (ok0) atomicAdd(reinterpret_cast<unsigned long long*>(p0 + 16 * j), (unsigned long long)xq_fix(v0));
+      if (ok1) atomicAdd(reinterpret_cast<unsigned long long*>(p0 + 16 * j + K), (unsigned long long)xq_fix(v1));
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = 16 * (4 * ks + j) + r;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = b0 + 4 * g + i;
+        if (4 * g + i < FF_R && row < a.B)
+          atomicAdd(reinterpret_cast<unsigned long long*>(a.x_out + (int64_t)row * K + col), (unsigned long long)xq_fix(o[j][i]));
       }
     }
   }
