@@ -885,7 +885,11 @@ __global__ __launch_bounds__(1024) void dec_head_kernel(DecHeadArgs a) {
 #pragma unroll
     for (int j = 0; j < HK; ++j) lg0[j] = lg[min(l32 + 32 * j, a.V - 1)];
   }
-  if (st_done) return;
+  // no early exit on st_done (a branch here makes the compiler hoist the loop-state load in front of the logits
+  // requests: two serial round trips; the state was written by this kernel one step ago, so it comes from HBM):
+  // a finished chain runs the rest of its graph with every store below suppressed
+  __builtin_amdgcn_sched_barrier(0);
+  const bool live = !st_done;
   if (tid == 0) s_unfinished = 0;
   __syncthreads();
   for (int b = grp; b < a.B; b += 32) {
@@ -916,13 +920,13 @@ __global__ __launch_bounds__(1024) void dec_head_kernel(DecHeadArgs a) {
     take(lane_xor<1>(best), __builtin_bit_cast(int, lane_xor<1>(__builtin_bit_cast(float, bi))));
     int next;
     if (a.forced) {
-      if (a.logits_out)
+      if (a.logits_out && live)
         for (int v = l32; v < a.V; v += 32) a.logits_out[((int64_t)b * a.Ld + t) * a.V + v] = lg[v];
       next = (t + 1 < a.Ld) ? (int)a.forced[(int64_t)b * a.Ld + t + 1] : a.pad_id;
     } else {
       // hf generation/utils.py:2925-2937: argmax; finished rows emit pad; EOS finishes a row
       next = fin ? a.pad_id : (bi == 0x7fffffff ? 0 : bi);
-      if (l32 == 0) {
+      if (l32 == 0 && live) {
         if (t + 1 < a.max_len) a.tokens[(int64_t)b * a.max_len + t + 1] = next;
         const int nf = fin | (next == a.eos_id);
         a.finished[b] = nf;
@@ -934,12 +938,14 @@ __global__ __launch_bounds__(1024) void dec_head_kernel(DecHeadArgs a) {
     for (int c = l32 * 4; c < a.d; c += 128) {
       const float4 e4 = *reinterpret_cast<const float4*>(emb + c);
       xq_t* xp = a.x + (int64_t)b * a.d + c;
-      *reinterpret_cast<longlong2*>(xp) = make_longlong2(xq_fix(e4.x), xq_fix(e4.y));
-      *reinterpret_cast<longlong2*>(xp + 2) = make_longlong2(xq_fix(e4.z), xq_fix(e4.w));
+      if (live) {
+        *reinterpret_cast<longlong2*>(xp) = make_longlong2(xq_fix(e4.x), xq_fix(e4.y));
+        *reinterpret_cast<longlong2*>(xp + 2) = make_longlong2(xq_fix(e4.z), xq_fix(e4.w));
+      }
     }
   }
   __syncthreads();
-  if (tid == 0) {
+  if (tid == 0 && live) {
     const int nt = t + 1;
     stp->t = nt;
     if (a.forced) {
