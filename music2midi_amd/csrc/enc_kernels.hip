@@ -165,10 +165,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
           const int col = n0 + wn * 64 + ni * 32 + r;
-          if (col >= g.N) continue;
+          if constexpr (EPI != EPI_GATED16) {
+            if (col >= g.N) continue;       // (GATED16: N is a multiple of 16 and every lane takes part in the exchange)
+          }
           const float v = acc[mi][ni][e];
           if constexpr (EPI == EPI_STORE) {
             reinterpret_cast<T*>(g.out)[(int64_t)row * g.ldo + col] = from_f32<T>(v);
+          } else if constexpr (EPI == EPI_STORE_F32) {
+            reinterpret_cast<float*>(g.out)[(int64_t)row * g.ldo + col] = v;
+          } else if constexpr (EPI == EPI_GATED16) {
+            // decoder packing of the gated up projection: 16-row groups, 8 rows of wi_0 then the matching 8 of
+            // wi_1 (repack.hip), so the gate partner of column c sits 8 lanes away
+            const float partner = lane_xor<8>(v);
+            if ((col & 8) == 0 && col < g.N) {
+              const int oc = (col >> 4) * 8 + (col & 7);
+              reinterpret_cast<T*>(g.out)[(int64_t)row * g.ldo + oc] = from_f32<T>(gelu_new(v) * partner);
+            }
           } else if constexpr (EPI == EPI_RESID) {
             float* p = reinterpret_cast<float*>(g.out) + (int64_t)row * g.ldo + col;
             *p += v;
@@ -195,6 +207,8 @@ static int launch_gemm_t(int epi, const GemmArgs& a, hipStream_t st) {
     case EPI_RESID: hipLaunchKernelGGL((gemm_kernel<T, EPI_RESID>), grid, dim3(256), 0, st, a); break;
     case EPI_GATED: hipLaunchKernelGGL((gemm_kernel<T, EPI_GATED>), grid, dim3(256), 0, st, a); break;
     case EPI_HEADS: hipLaunchKernelGGL((gemm_kernel<T, EPI_HEADS>), grid, dim3(256), 0, st, a); break;
+    case EPI_STORE_F32: hipLaunchKernelGGL((gemm_kernel<T, EPI_STORE_F32>), grid, dim3(256), 0, st, a); break;
+    case EPI_GATED16: hipLaunchKernelGGL((gemm_kernel<T, EPI_GATED16>), grid, dim3(256), 0, st, a); break;
     default: set_error("launch_gemm: bad epilogue %d", epi); return M2M_ERR_INVALID;
   }
   M2M_CHECK_HIP(hipGetLastError());
@@ -205,6 +219,7 @@ int launch_gemm(int precision, int epi, const GemmArgs& a, hipStream_t st) {
   M2M_REQUIRE(a.K % 64 == 0, "gemm: K=%d must be a multiple of 64", a.K);
   M2M_REQUIRE(a.M >= 1 && a.N >= 1, "gemm: empty problem");
   if (epi == EPI_GATED) M2M_REQUIRE(a.N % 64 == 0, "gemm: gated epilogue needs N %% 64 == 0 (d_ff %% 32 == 0)");
+  if (epi == EPI_GATED16) M2M_REQUIRE(a.N % 16 == 0, "gemm: 16-row gated epilogue needs N %% 16 == 0");
   return precision == M2M_PREC_BF16 ? launch_gemm_t<bf16_t>(epi, a, st) : launch_gemm_t<float>(epi, a, st);
 }
 
@@ -228,37 +243,36 @@ template <> struct AttnCfg<float> { static constexpr int KP = DK + 4, VP = AK + 
 // the k-order in which accumulator registers 8s..8s+7 of S^T present P^T (see mma.h).
 __device__ inline int vt_pos(int kk) { return (kk & ~0xC) | ((kk & 4) << 1) | ((kk & 8) >> 1); }
 
-template <typename T>
-__global__ __launch_bounds__(256) void enc_attn_kernel(const T* __restrict__ qkv, const T* __restrict__ vt, int Sp,
-                                                       const float* __restrict__ bias_tab, int tab_stride,
-                                                       int tab_center, T* __restrict__ out, int B, int H, int S) {
+template <typename T, bool CAUSAL, bool BIAS>
+__global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   using Cfg = AttnCfg<T>;
   constexpr int EPC = 16 / sizeof(T);
   extern __shared__ __align__(16) unsigned char smem[];
   T* Ks = reinterpret_cast<T*>(smem);                       // [AK][KP]
   T* Vt = Ks + AK * Cfg::KP;                                // [DK][VP]  (transposed, permuted key slots)
-  float* tb = reinterpret_cast<float*>(Vt + DK * Cfg::VP);  // [2S-1] bias by (key - q) + S - 1
+  float* tb = reinterpret_cast<float*>(Vt + DK * Cfg::VP);  // [Sq+Sk-1] bias by (key - q) + Sq - 1
 
+  const int B = a.B, H = a.H, Sq = a.Sq, Sk = a.Sk, Sp = a.Sp;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   // XCD-aware block order (workgroup id -> XCD is id % 8, each XCD has its own L2): all query tiles of a
   // (clip, head) run on ONE XCD, back to back, so its K/V is fetched into that L2 once instead of once per
   // query tile (PMC: 433 MB fetched per launch against 85 MB of Q/K/V with the row-major order).
-  const int nq = (S + AQ - 1) / AQ;
+  const int nq = (Sq + AQ - 1) / AQ;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int bh = xcd + 8 * (slot / nq), qt = slot - (slot / nq) * nq;
   if (bh >= B * H) return;          // grid is padded to a multiple of 8 (clip, head) pairs
   const int b = bh / H, hh = bh - b * H;
   const int q0 = qt * AQ + wave * 32;
-  const int64_t head_stride = (int64_t)S * DK;
-  const T* Q = qkv + ((int64_t)(0 * B + b) * H + hh) * head_stride;
-  const T* Kg = qkv + ((int64_t)(1 * B + b) * H + hh) * head_stride;
-  const T* Vtg = vt + ((int64_t)b * H + hh) * DK * Sp;      // V^T of this (clip, head): [64][Sp]
+  const T* Q = reinterpret_cast<const T*>(a.Q) + (int64_t)bh * Sq * DK;
+  const T* Kg = reinterpret_cast<const T*>(a.K) + (int64_t)bh * Sk * DK;
+  const T* Vtg = reinterpret_cast<const T*>(a.Vt) + (int64_t)bh * DK * Sp;      // V^T of this (clip, head): [64][Sp]
 
-  for (int i = tid; i < 2 * S - 1; i += 256) tb[i] = bias_tab[(int64_t)hh * tab_stride + tab_center - (S - 1) + i];
+  if constexpr (BIAS)
+    for (int i = tid; i < Sq + Sk - 1; i += 256) tb[i] = a.bias_tab[(int64_t)hh * a.tab_stride + a.tab_center - (Sq - 1) + i];
 
   // Q fragments (B operand): lane (r,h) holds Q[q0 + r][16 s + 8 h + j]
-  const int qrow = min(q0 + r, S - 1);
+  const int qrow = min(q0 + r, Sq - 1);
   Frag<T> qf[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) qf[s] = load_frag(Q + (int64_t)qrow * DK + s * 16 + 8 * h);
@@ -267,14 +281,16 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const T* __restrict__ qkv
   float m_run = -1e30f, l_run = 0.f;
   const int my_q = q0 + r;
 
-  const int ntiles = ceil_div(S, AK);
+  // causal: keys beyond the last query of this workgroup's tile are never needed
+  const int kend = CAUSAL ? min(Sk, qt * AQ + AQ) : Sk;
+  const int ntiles = ceil_div(kend, AK);
   for (int kt = 0; kt < ntiles; ++kt) {
     __syncthreads();
-    // ---- stage K (row-major) and V^T (already transposed in memory by the QKV GEMM epilogue;
-    //      key slots permuted to the accumulator k-order in whole 4-key groups, so it is 8/16-byte copies) ----
+    // ---- stage K (row-major) and V^T (already transposed in memory; key slots permuted to the
+    //      accumulator k-order in whole 4-key groups, so it is 8/16-byte copies) ----
     for (int c = tid; c < AK * (DK / EPC); c += 256) {
       const int key = c / (DK / EPC), dc = c % (DK / EPC);
-      const int gk = min(kt * AK + key, S - 1);
+      const int gk = min(kt * AK + key, Sk - 1);
       *reinterpret_cast<uint4*>(Ks + key * Cfg::KP + dc * EPC) =
           *reinterpret_cast<const uint4*>(Kg + (int64_t)gk * DK + dc * EPC);
     }
@@ -282,11 +298,11 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const T* __restrict__ qkv
       const int d = c / (AK / EPC), kc = c % (AK / EPC);
       const int k0 = kt * AK + kc * EPC;                       // first key of this 16-byte chunk (row pitch Sp >= tile end)
       uint4 vv = *reinterpret_cast<const uint4*>(Vtg + (int64_t)d * Sp + k0);
-      if (k0 + EPC > S) {                                       // columns past S are uninitialised: zero them (0 * NaN would poison P.V)
+      if (k0 + EPC > Sk) {                                      // columns past Sk are uninitialised: zero them (0 * NaN would poison P.V)
         T* ve = reinterpret_cast<T*>(&vv);
 #pragma unroll
         for (int e = 0; e < EPC; ++e)
-          if (k0 + e >= S) ve[e] = from_f32<T>(0.f);
+          if (k0 + e >= Sk) ve[e] = from_f32<T>(0.f);
       }
       const int kl = kc * EPC;                                  // key index inside the 64-key tile
       T* dst = Vt + d * Cfg::VP + (kl & 32);
@@ -301,7 +317,7 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const T* __restrict__ qkv
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       const int kbase = kt * AK + sub * 32;
-      if (kbase >= S) break;  // uniform
+      if (kbase >= kend) break;  // uniform
       f32x16 st = zero_acc();
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -315,15 +331,18 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const T* __restrict__ qkv
       for (int i = 0; i < 16; ++i) {
         const int key = kbase + acc_row(i, lane);
         float sc = -1e30f;
-        if (key < S) {
-          int rel = key - my_q + (S - 1);
-          rel = min(max(rel, 0), 2 * S - 2);  // rows beyond S (clamped q) are discarded later
-          sc = st[i] + tb[rel];
+        if (key < Sk && (!CAUSAL || key <= my_q)) {
+          sc = st[i];
+          if constexpr (BIAS) {
+            int rel = key - my_q + (Sq - 1);
+            rel = min(max(rel, 0), Sq + Sk - 2);  // rows beyond Sq (clamped q) are discarded later
+            sc += tb[rel];
+          }
         }
         p[i] = sc;
         mx = fmaxf(mx, sc);
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = fmaxf(mx, lane_xor<32>(mx));
       const float m_new = fmaxf(m_run, mx);
       const float alpha = __expf(m_run - m_new);
       float psum = 0.f;
@@ -332,7 +351,7 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const T* __restrict__ qkv
         p[i] = __expf(p[i] - m_new);
         psum += p[i];
       }
-      psum += __shfl_xor(psum, 32, 64);
+      psum += lane_xor<32>(psum);
       l_run = l_run * alpha + psum;
       m_run = m_new;
 #pragma unroll
@@ -355,9 +374,9 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const T* __restrict__ qkv
     }
   }
   // ---- normalise and store: O^T element i of block db is d = db*32 + acc_row(i), query my_q ----
-  if (my_q < S) {
+  if (my_q < Sq) {
     const float inv = 1.0f / l_run;
-    T* orow = out + ((int64_t)b * S + my_q) * (H * DK) + hh * DK;
+    T* orow = reinterpret_cast<T*>(a.out) + ((int64_t)b * Sq + my_q) * (H * DK) + hh * DK;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -365,29 +384,78 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const T* __restrict__ qkv
   }
 }
 
-template <typename T>
-static int launch_enc_attn_t(const void* qkv, const void* vt, int Sp, const float* bias_tab, int tab_stride,
-                             int tab_center, void* out, int B, int H, int S, hipStream_t st) {
+template <typename T, bool CAUSAL, bool BIAS>
+static int launch_attn_tt(const AttnArgs& a, hipStream_t st) {
   using Cfg = AttnCfg<T>;
-  const size_t smem = (size_t)(AK * Cfg::KP + DK * Cfg::VP) * sizeof(T) + (size_t)(2 * S - 1) * sizeof(float);
-  M2M_REQUIRE(smem <= 150 * 1024, "enc_attn: S=%d too long for the LDS bias table", S);
+  const size_t smem = (size_t)(AK * Cfg::KP + DK * Cfg::VP) * sizeof(T) + (BIAS ? (size_t)(a.Sq + a.Sk - 1) * sizeof(float) : 0);
+  M2M_REQUIRE(smem <= 150 * 1024, "attention: Sq=%d, Sk=%d too long for the LDS bias table", a.Sq, a.Sk);
   static bool attr_set = false;
   if (!attr_set) {
-    M2M_CHECK_HIP(hipFuncSetAttribute((const void*)enc_attn_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    M2M_CHECK_HIP(hipFuncSetAttribute((const void*)attn_kernel<T, CAUSAL, BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  dim3 grid((unsigned)(ceil_div(S, AQ) * ceil_div(B * H, 8) * 8));
-  hipLaunchKernelGGL(enc_attn_kernel<T>, grid, dim3(256), smem, st, (const T*)qkv, (const T*)vt, Sp, bias_tab, tab_stride,
-                     tab_center, (T*)out, B, H, S);
+  dim3 grid((unsigned)(ceil_div(a.Sq, AQ) * ceil_div(a.B * a.H, 8) * 8));
+  hipLaunchKernelGGL((attn_kernel<T, CAUSAL, BIAS>), grid, dim3(256), smem, st, a);
   M2M_CHECK_HIP(hipGetLastError());
   return M2M_OK;
 }
 
-int launch_enc_attn(int precision, const void* qkv, const void* vt, int Sp, const float* bias_tab, int tab_stride,
-                    int tab_center, void* out, int B, int H, int S, hipStream_t st) {
-  return precision == M2M_PREC_BF16
-             ? launch_enc_attn_t<bf16_t>(qkv, vt, Sp, bias_tab, tab_stride, tab_center, out, B, H, S, st)
-             : launch_enc_attn_t<float>(qkv, vt, Sp, bias_tab, tab_stride, tab_center, out, B, H, S, st);
+template <typename T>
+static int launch_attn_t(const AttnArgs& a, bool causal, hipStream_t st) {
+  if (causal) {
+    M2M_REQUIRE(a.bias_tab != nullptr && a.Sq == a.Sk, "attention: the causal form is the decoder self-attention (bias table, Sq == Sk)");
+    return launch_attn_tt<T, true, true>(a, st);
+  }
+  return a.bias_tab ? launch_attn_tt<T, false, true>(a, st) : launch_attn_tt<T, false, false>(a, st);
+}
+
+int launch_attn(int precision, const AttnArgs& a, bool causal, hipStream_t st) {
+  M2M_REQUIRE(a.Sq >= 1 && a.Sk >= 1 && a.Sp >= a.Sk && a.Sp % 4 == 0, "attention: bad geometry Sq=%d Sk=%d Sp=%d", a.Sq, a.Sk, a.Sp);
+  return precision == M2M_PREC_BF16 ? launch_attn_t<bf16_t>(a, causal, st) : launch_attn_t<float>(a, causal, st);
+}
+
+// V [B*H][S][64] -> V^T [B*H][64][Sp] (the cross-attention values are stored row-major for the decode
+// kernels; the batched teacher-forced pass wants them as the MFMA A operand of O^T = V^T P^T)
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_v_kernel(const T* __restrict__ v, T* __restrict__ vt, int S, int Sp) {
+  __shared__ T tile[64][DK + 2];
+  const int bh = blockIdx.y, s0 = blockIdx.x * 64;
+  const T* src = v + (int64_t)bh * S * DK;
+  T* dst = vt + (int64_t)bh * DK * Sp;
+  for (int i = threadIdx.x; i < 64 * DK; i += 256) {
+    const int sl = i / DK, d = i % DK;
+    tile[sl][d] = (s0 + sl < S) ? src[(int64_t)(s0 + sl) * DK + d] : from_f32<T>(0.f);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * DK; i += 256) {
+    const int d = i / 64, sl = i % 64;
+    if (s0 + sl < Sp) dst[(int64_t)d * Sp + s0 + sl] = tile[sl][d];
+  }
+}
+
+int launch_transpose_v(int precision, const void* v, void* vt, int BH, int S, int Sp, hipStream_t st) {
+  dim3 grid((unsigned)ceil_div(Sp, 64), (unsigned)BH);
+  if (precision == M2M_PREC_BF16) hipLaunchKernelGGL(transpose_v_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)v, (bf16_t*)vt, S, Sp);
+  else hipLaunchKernelGGL(transpose_v_kernel<float>, grid, dim3(256), 0, st, (const float*)v, (float*)vt, S, Sp);
+  M2M_CHECK_HIP(hipGetLastError());
+  return M2M_OK;
+}
+
+// x[row][:] = table[ids[row]][:]  (decoder input embedding of the teacher-forced pass, fp32 residual stream)
+__global__ __launch_bounds__(256) void embed_rows_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
+                                                        float* __restrict__ x, int M, int d, int V, int pad_id) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  int tok = (int)ids[row];
+  if (tok < 0 || tok >= V) tok = pad_id;
+  for (int c = lane * 4; c < d; c += 256)
+    *reinterpret_cast<float4*>(x + (int64_t)row * d + c) = *reinterpret_cast<const float4*>(table + (int64_t)tok * d + c);
+}
+
+int launch_embed_rows(const int64_t* ids, const float* table, float* x, int M, int d, int V, int pad_id, hipStream_t st) {
+  hipLaunchKernelGGL(embed_rows_kernel, dim3((unsigned)ceil_div(M, 4)), dim3(256), 0, st, ids, table, x, M, d, V, pad_id);
+  M2M_CHECK_HIP(hipGetLastError());
+  return M2M_OK;
 }
 
 }  // namespace m2m

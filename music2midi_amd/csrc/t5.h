@@ -100,6 +100,8 @@ struct m2m_session {
   void* mid_enc;           // [B*S, dff] T
   float* enc_bias_tab;     // [H][2*max_enc-1]
   float* dec_bias_tab;     // [H][max_dec]
+  float* dec_bias_full_tab;// [H][2*max_dec-1] the same bias by (key - query) + max_dec - 1 (batched causal pass)
+  void* cross_vt;          // [B][H][64][Sp] T scratch: one layer's cross V transposed (batched pass)
   void* cross_kv;          // [L][2][B][H][S][64] T
   void* self_k;            // [L][B][H][max_dec][64] T
   void* self_v;
@@ -121,7 +123,7 @@ namespace m2m {
 
 // -------------------------------------------------------- launch helpers ---
 // encoder-side (enc_kernels.hip)
-enum { EPI_STORE = 0, EPI_RESID = 1, EPI_GATED = 2, EPI_HEADS = 3 };
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_GATED = 2, EPI_HEADS = 3, EPI_STORE_F32 = 4, EPI_GATED16 = 5 };
 
 struct GemmArgs {
   const void* A;     // [M, K] T row-major
@@ -140,8 +142,20 @@ struct GemmArgs {
 
 int launch_gemm(int precision, int epi, const GemmArgs& a, hipStream_t st);
 int launch_rmsnorm(int precision, const float* x, const float* w, void* out, int M, int d, float eps, hipStream_t st);
-int launch_enc_attn(int precision, const void* qkv, const void* vt, int Sp, const float* bias_tab, int tab_stride,
-                    int tab_center, void* out, int B, int H, int S, hipStream_t st);
+// flash attention of the encoder and of the batched (teacher-forced) decoder pass
+struct AttnArgs {
+  const void* Q;          // [B*H][Sq][64] T
+  const void* K;          // [B*H][Sk][64] T
+  const void* Vt;         // [B*H][64][Sp] T (V transposed, row pitch Sp >= Sk rounded up to the 64-key tile)
+  int Sp;
+  const float* bias_tab;  // [H][tab_stride] relative-position bias by (key - query) + tab_center, or nullptr (cross-attention)
+  int tab_stride, tab_center;
+  void* out;              // [B*Sq][H*64] T
+  int B, H, Sq, Sk;
+};
+int launch_attn(int precision, const AttnArgs& a, bool causal, hipStream_t st);
+int launch_transpose_v(int precision, const void* v, void* vt, int BH, int S, int Sp, hipStream_t st);
+int launch_embed_rows(const int64_t* ids, const float* table, float* x, int M, int d, int V, int pad_id, hipStream_t st);
 int launch_final_norm_f32(const float* x, const float* w, float* out_f32, void* out_T, int precision, int M, int d,
                           float eps, hipStream_t st);
 

@@ -161,24 +161,28 @@ extern "C" int64_t m2m_model_param_bytes(const m2m_model* m) { return m ? m->blo
 // ---------------------------------------------------------------- session ---
 namespace {
 struct WsLayout {
-  int64_t x_enc, h_enc, qkv_enc, vt_enc, attn_enc, mid_enc, enc_bias, dec_bias, cross_kv, self_k, self_v;
+  int64_t x_enc, h_enc, qkv_enc, vt_enc, attn_enc, mid_enc, enc_bias, dec_bias, dec_bias_full, cross_vt, cross_kv, self_k, self_v;
   int64_t x_dec, logits, tokens, finished, state, forced, total;
 };
 
 WsLayout ws_layout(const m2m_model* m, int B, int S, int L) {
   const m2m_t5_geometry& g = m->g;
-  const int64_t es = (int64_t)m->esize, M = (int64_t)B * S, Bp = (int64_t)ceil_div(B, 32) * 32;
+  // the activation buffers serve the encoder (S rows per clip) and the batched teacher-forced decoder pass (L rows)
+  const int64_t es = (int64_t)m->esize, M = (int64_t)B * S, Ma = (int64_t)B * (S > L ? S : L), Bp = (int64_t)ceil_div(B, 32) * 32;
+  const int64_t Spa = (int64_t)ceil_div(S > L ? S : L, 64) * 64;
   WsLayout w{};
   int64_t off = 0;
   auto take = [&](int64_t bytes) { int64_t o = off; off = align_up(off + bytes, 256); return o; };
-  w.x_enc = take(M * g.d_model * 4);
-  w.h_enc = take(M * g.d_model * es);
-  w.qkv_enc = take(3 * M * m->inner * es);
-  w.vt_enc = take((int64_t)B * m->inner * (ceil_div(S, 64) * 64) * es);
-  w.attn_enc = take(M * m->inner * es);
-  w.mid_enc = take(M * g.d_ff * es);
+  w.x_enc = take(Ma * g.d_model * 4);
+  w.h_enc = take(Ma * g.d_model * es);
+  w.qkv_enc = take(3 * Ma * m->inner * es);
+  w.vt_enc = take((int64_t)B * m->inner * Spa * es);
+  w.attn_enc = take(Ma * m->inner * es);
+  w.mid_enc = take(Ma * g.d_ff * es);
   w.enc_bias = take((int64_t)g.num_heads * (2 * S - 1) * 4);
   w.dec_bias = take((int64_t)g.num_heads * L * 4);
+  w.dec_bias_full = take((int64_t)g.num_heads * (2 * L - 1) * 4);
+  w.cross_vt = take((int64_t)B * m->inner * (ceil_div(S, 64) * 64) * es);
   w.cross_kv = take((int64_t)g.num_decoder_layers * 2 * M * m->inner * es);
   w.self_k = take((int64_t)g.num_decoder_layers * B * m->inner * L * es);
   w.self_v = take((int64_t)g.num_decoder_layers * B * m->inner * L * es);
@@ -222,6 +226,7 @@ extern "C" int m2m_session_create(const m2m_model* m, int max_batch, int max_enc
   s->x_enc = (float*)(b + w.x_enc); s->h_enc = b + w.h_enc; s->qkv_enc = b + w.qkv_enc; s->vt_enc = b + w.vt_enc; s->attn_enc = b + w.attn_enc;
   s->mid_enc = b + w.mid_enc; s->enc_bias_tab = (float*)(b + w.enc_bias); s->dec_bias_tab = (float*)(b + w.dec_bias);
   s->cross_kv = b + w.cross_kv; s->self_k = b + w.self_k; s->self_v = b + w.self_v;
+  s->dec_bias_full_tab = (float*)(b + w.dec_bias_full); s->cross_vt = b + w.cross_vt;
   s->x_dec = (b + w.x_dec);
   s->logits = (float*)(b + w.logits); s->tokens = (int64_t*)(b + w.tokens);
   s->finished = (int*)(b + w.finished); s->states = (DecState*)(b + w.state); s->forced_ids = (int64_t*)(b + w.forced);
@@ -238,8 +243,14 @@ extern "C" int m2m_session_create(const m2m_model* m, int max_batch, int max_enc
     const int bk = m2m_rel_bucket(-n, 0, g.num_buckets, g.max_distance);
     for (int h = 0; h < H; ++h) dt[(size_t)h * L + n] = m->dec_rel_bias_host[(size_t)bk * H + h];
   }
+  // the same decoder bias as a (key - query) table for the batched causal pass: entry L-1-n = bias(n), n = q - k >= 0;
+  // the upper half (future keys) is masked by the kernel and stays 0
+  std::vector<float> df((size_t)H * (2 * L - 1), 0.f);
+  for (int h = 0; h < H; ++h)
+    for (int n = 0; n < L; ++n) df[(size_t)h * (2 * L - 1) + (L - 1 - n)] = dt[(size_t)h * L + n];
   hipError_t e = hipMemcpy(s->enc_bias_tab, et.data(), et.size() * 4, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(s->dec_bias_tab, dt.data(), dt.size() * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(s->dec_bias_full_tab, df.data(), df.size() * 4, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemset(s->states, 0, sizeof(DecState) * MAX_GROUPS);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming);
   for (int i = 0; i < MAX_GROUPS && e == hipSuccess; ++i) {
@@ -294,8 +305,11 @@ extern "C" int m2m_encode(m2m_session* s, const float* inputs_embeds_dev, int B,
     a.Bsz = B; a.S = S; a.H = g.num_heads; a.inner = m->inner;
     a.vt_which = 2; a.vt_out = s->vt_enc; a.Sp = Sp;
     if ((rc = launch_gemm(P, EPI_HEADS, a, st))) return rc;
-    if ((rc = launch_enc_attn(P, s->qkv_enc, s->vt_enc, Sp, s->enc_bias_tab, 2 * s->max_enc - 1, s->max_enc - 1, s->attn_enc, B,
-                              g.num_heads, S, st))) return rc;
+    AttnArgs at{};
+    at.Q = s->qkv_enc; at.K = (const unsigned char*)s->qkv_enc + (size_t)M * m->inner * m->esize; at.Vt = s->vt_enc; at.Sp = Sp;
+    at.bias_tab = s->enc_bias_tab; at.tab_stride = 2 * s->max_enc - 1; at.tab_center = s->max_enc - 1;
+    at.out = s->attn_enc; at.B = B; at.H = g.num_heads; at.Sq = S; at.Sk = S;
+    if ((rc = launch_attn(P, at, false, st))) return rc;
     a = GemmArgs{}; a.vt_which = -1;
     a.A = s->attn_enc; a.W = L.wo; a.M = M; a.N = d; a.K = m->inner; a.out = s->x_enc; a.ldo = d;
     if ((rc = launch_gemm(P, EPI_RESID, a, st))) return rc;
@@ -430,12 +444,77 @@ extern "C" int m2m_generate_greedy(m2m_session* s, int max_length, int64_t* toke
   return M2M_OK;
 }
 
+// Teacher-forced decoder pass over all Ld positions at once (hf: modeling_t5.py:448-509 per block, :898-1066 wrapper):
+// the encoder's MFMA GEMMs and flash attention applied to the decoder weights, causal + relative-position bias in
+// the self-attention, the cached cross K/V (V transposed once per layer) in the cross-attention.  Same arithmetic as
+// Ld KV-cached decode steps (M2M_FORWARD=step runs those instead), ~1/50 of the time at Ld = 1024.
+static int forward_batched(m2m_session* s, const int64_t* ids, int Ld, float* logits_out, hipStream_t st) {
+  const m2m_model* m = s->m;
+  const m2m_t5_geometry& g = m->g;
+  const int P = m->precision, B = s->B, S = s->S, H = g.num_heads, d = g.d_model;
+  const size_t es = m->esize;
+  const int M = B * Ld, Lp = ceil_div(Ld, 64) * 64, Sp = ceil_div(S, 64) * 64;
+  int rc;
+  if ((rc = launch_embed_rows(ids, m->shared, s->x_enc, M, d, g.vocab_size, g.pad_token_id, st))) return rc;
+  unsigned char* qkv = (unsigned char*)s->qkv_enc;
+  const size_t per_enc = (size_t)s->B * H * S * DK;                       // elements of one cross K (or V) block
+  for (int l = 0; l < g.num_decoder_layers; ++l) {
+    const DecLayerPacked& L = m->dec[l];
+    // --- causal self-attention
+    if ((rc = launch_rmsnorm(P, s->x_enc, L.ln0, s->h_enc, M, d, g.layer_norm_eps, st))) return rc;
+    GemmArgs a{};
+    a.A = s->h_enc; a.W = L.wqkv; a.M = M; a.N = 3 * m->inner; a.K = d; a.out = qkv;
+    a.Bsz = B; a.S = Ld; a.H = H; a.inner = m->inner; a.vt_which = 2; a.vt_out = s->vt_enc; a.Sp = Lp;
+    if ((rc = launch_gemm(P, EPI_HEADS, a, st))) return rc;
+    AttnArgs at{};
+    at.Q = qkv; at.K = qkv + (size_t)M * m->inner * es; at.Vt = s->vt_enc; at.Sp = Lp;
+    at.bias_tab = s->dec_bias_full_tab; at.tab_stride = 2 * s->max_dec - 1; at.tab_center = s->max_dec - 1;
+    at.out = s->attn_enc; at.B = B; at.H = H; at.Sq = Ld; at.Sk = Ld;
+    if ((rc = launch_attn(P, at, true, st))) return rc;
+    a = GemmArgs{}; a.vt_which = -1;
+    a.A = s->attn_enc; a.W = L.wo; a.M = M; a.N = d; a.K = m->inner; a.out = s->x_enc; a.ldo = d;
+    if ((rc = launch_gemm(P, EPI_RESID, a, st))) return rc;
+    // --- cross-attention over the cached encoder K/V
+    if ((rc = launch_rmsnorm(P, s->x_enc, L.ln1, s->h_enc, M, d, g.layer_norm_eps, st))) return rc;
+    a = GemmArgs{};
+    a.A = s->h_enc; a.W = L.wcq; a.M = M; a.N = m->inner; a.K = d; a.out = qkv;
+    a.Bsz = B; a.S = Ld; a.H = H; a.inner = m->inner; a.vt_which = -1;
+    if ((rc = launch_gemm(P, EPI_HEADS, a, st))) return rc;
+    const unsigned char* ck = (const unsigned char*)s->cross_kv + ((size_t)l * 2 + 0) * per_enc * es;
+    const unsigned char* cv = (const unsigned char*)s->cross_kv + ((size_t)l * 2 + 1) * per_enc * es;
+    if ((rc = launch_transpose_v(P, cv, s->cross_vt, B * H, S, Sp, st))) return rc;
+    at = AttnArgs{};
+    at.Q = qkv; at.K = ck; at.Vt = s->cross_vt; at.Sp = Sp; at.bias_tab = nullptr;
+    at.out = s->attn_enc; at.B = B; at.H = H; at.Sq = Ld; at.Sk = S;
+    if ((rc = launch_attn(P, at, false, st))) return rc;
+    a = GemmArgs{}; a.vt_which = -1;
+    a.A = s->attn_enc; a.W = L.wco; a.M = M; a.N = d; a.K = m->inner; a.out = s->x_enc; a.ldo = d;
+    if ((rc = launch_gemm(P, EPI_RESID, a, st))) return rc;
+    // --- gated feed-forward (the decoder's 16-row interleave of wi)
+    if ((rc = launch_rmsnorm(P, s->x_enc, L.ln2, s->h_enc, M, d, g.layer_norm_eps, st))) return rc;
+    a = GemmArgs{}; a.vt_which = -1;
+    a.A = s->h_enc; a.W = L.wi; a.M = M; a.N = 2 * g.d_ff; a.K = d; a.out = s->mid_enc; a.ldo = g.d_ff;
+    if ((rc = launch_gemm(P, EPI_GATED16, a, st))) return rc;
+    a = GemmArgs{}; a.vt_which = -1;
+    a.A = s->mid_enc; a.W = L.wo_ff; a.M = M; a.N = d; a.K = g.d_ff; a.out = s->x_enc; a.ldo = d;
+    if ((rc = launch_gemm(P, EPI_RESID, a, st))) return rc;
+  }
+  if ((rc = launch_rmsnorm(P, s->x_enc, m->dec_final_ln, s->h_enc, M, d, g.layer_norm_eps, st))) return rc;
+  GemmArgs a{};
+  a.vt_which = -1;
+  a.A = s->h_enc; a.W = m->lm_head; a.M = M; a.N = g.vocab_size; a.K = d; a.out = logits_out; a.ldo = g.vocab_size;
+  return launch_gemm(P, EPI_STORE_F32, a, st);
+}
+
 extern "C" int m2m_decode_forced(m2m_session* s, const int64_t* dec_input_ids_dev, int Ld, float* logits_out_dev, void* stream) {
   M2M_REQUIRE(s && dec_input_ids_dev && logits_out_dev, "m2m_decode_forced: null argument");
   if (!s->encoded) { set_error("m2m_decode_forced: call m2m_encode first"); return M2M_ERR_STATE; }
   M2M_REQUIRE(Ld >= 1 && Ld <= s->max_dec, "m2m_decode_forced: Ld %d outside [1, %d]", Ld, s->max_dec);
   hipStream_t st = (hipStream_t)stream;
   M2M_CHECK_HIP(hipMemcpyAsync(s->forced_ids, dec_input_ids_dev, (size_t)s->B * Ld * 8, hipMemcpyDeviceToDevice, st));
+  const char* fwd = getenv("M2M_FORWARD");          // "step": Ld KV-cached decode steps instead (read per call: tests toggle it)
+  const bool stepwise = fwd && strcmp(fwd, "step") == 0;
+  if (!stepwise) return forward_batched(s, s->forced_ids, Ld, logits_out_dev, st);
   const DecView all{0, s->B, s->states};
   int rc;
   if ((rc = decode_init(s, all, Ld, true, st))) return rc;

@@ -49,8 +49,12 @@ def test_encoder_fp32(cfg_name, B, S):
     assert err < 2e-4
 
 
-@pytest.mark.parametrize("cfg_name,B,S,Ld", [("tiny", 3, 19, 12), ("full", 2, 190, 24), ("full", 5, 64, 40)])
-def test_forced_logits_fp32(cfg_name, B, S, Ld):
+@pytest.mark.parametrize("mode", ["batched", "step"])
+@pytest.mark.parametrize("cfg_name,B,S,Ld", [("tiny", 3, 19, 12), ("full", 2, 190, 24), ("full", 5, 64, 40), ("full", 3, 70, 200)])
+def test_forced_logits_fp32(monkeypatch, mode, cfg_name, B, S, Ld):
+    """Teacher-forced logits: the batched pass (MFMA GEMMs + causal flash attention over all positions) and the
+    KV-cached decode steps in forced mode must both reproduce the oracle."""
+    monkeypatch.setenv("M2M_FORWARD", mode)
     cfg = tiny_config() if cfg_name == "tiny" else DEFAULT_CONFIG
     model, orc, g = build(cfg, "fp32")
     x = embeds(B, S, g.d_model)
