@@ -50,7 +50,8 @@ def test_encoder_fp32(cfg_name, B, S):
 
 
 @pytest.mark.parametrize("mode", ["batched", "step"])
-@pytest.mark.parametrize("cfg_name,B,S,Ld", [("tiny", 3, 19, 12), ("full", 2, 190, 24), ("full", 5, 64, 40), ("full", 3, 70, 200)])
+@pytest.mark.parametrize("cfg_name,B,S,Ld", [("tiny", 3, 19, 12), ("full", 2, 190, 24), ("full", 5, 64, 40), ("full", 3, 70, 200),
+                                             ("tiny", 2, 9, 1), ("tiny", 9, 130, 131), ("full", 17, 21, 129)])
 def test_forced_logits_fp32(monkeypatch, mode, cfg_name, B, S, Ld):
     """Teacher-forced logits: the batched pass (MFMA GEMMs + causal flash attention over all positions) and the
     KV-cached decode steps in forced mode must both reproduce the oracle."""
