@@ -274,9 +274,15 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(1, 2)))
   const int done = a.state->done;
   const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int c = blockIdx.x, b0 = blockIdx.y * FF_R;
+  // XCD-aware order (workgroup id % 8 picks the XCD, each has its own L2): the row blocks that share a weight
+  // slice run on the same XCD, so the slice is fetched into that L2 once instead of once per row block
+  // (PMC: 14.2 MB fetched per launch for 2.75 MB of unique operands with the row-major order)
+  const int nrb = (a.B + FF_R - 1) / FF_R, nsl = a.d_ff / FF_C + 1;      // row blocks; weight slices + the carry
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int c = xcd + 8 * (slot / nrb), b0 = (slot - (slot / nrb) * nrb) * FF_R;
   const int K = a.d;
-  if (c == (int)gridDim.x - 1) {
+  if (c >= nsl) return;   // padding workgroups (uniform)
+  if (c == nsl - 1) {
     // the extra workgroup of each row block carries the residual itself into x_out and zeroes the
     // third buffer (blockDim.x == d_model: one column per thread), so the slice workgroups issue no
     // conditional loads (a branch around a load costs them a full s_waitcnt)
@@ -416,7 +422,8 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(1, 2)))
 
 template <typename T>
 static int launch_dec_ff_t(const DecFfArgs& a, hipStream_t st) {
-  dim3 grid((unsigned)(a.d_ff / FF_C + 1), (unsigned)ceil_div(a.B, FF_R));   // + 1: the residual-carry workgroup
+  const int nsl = a.d_ff / FF_C + 1;                                          // + 1: the residual-carry workgroup
+  dim3 grid((unsigned)(ceil_div(nsl, 8) * 8 * ceil_div(a.B, FF_R)));
   switch (a.d / 64) {
     case 2: hipLaunchKernelGGL((dec_ff_kernel<T, 2>), grid, dim3(128), 0, st, a); break;
     case 4: hipLaunchKernelGGL((dec_ff_kernel<T, 4>), grid, dim3(256), 0, st, a); break;
