@@ -87,8 +87,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   constexpr int EPC = 16 / sizeof(T);                          // elements per 16-byte chunk
   constexpr int CHUNKS = BM * Cfg::CPR;                        // per operand tile
   constexpr int PER_THREAD = CHUNKS / 256;
-  __shared__ __align__(16) T As[BM * Cfg::PITCH];
-  __shared__ __align__(16) T Bs[BN * Cfg::PITCH];
+  __shared__ __align__(16) T AB[(BM + BN) * Cfg::PITCH];   // one block: the head-major epilogue re-uses all of it
+  T* const As = AB;
+  T* const Bs = AB + BM * Cfg::PITCH;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -96,10 +97,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   // block run back to back on ONE XCD, so the [128 x K] activation tile is fetched into that L2 once instead
   // of once per XCD (PMC: 176-187 MB fetched per launch against 21-28 MB of activations with the row-major
   // order); the weights are small and every XCD keeps its own copy.
+  // Column tiles go in groups of g.ng (chosen on the host so that a group's weight rows are <= 2 MB): they stay
+  // in the 4 MB L2 while the XCD walks its row blocks, then the next group starts (the 48 column tiles of the
+  // cross-K/V projection would otherwise push their own weights out between two row blocks: 850 MB fetched).
   const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
+  const int mtx = (ntm + 7) / 8;                                 // row blocks per XCD (padded)
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int mt = xcd + 8 * (slot / ntn), nt = slot - (slot / ntn) * ntn;
-  if (mt >= ntm) return;   // grid is padded to a multiple of 8 row blocks (uniform)
+  const int grp = slot / (mtx * g.ng), rem_ = slot - grp * (mtx * g.ng);
+  const int mt = xcd + 8 * (rem_ / g.ng), nt = grp * g.ng + rem_ % g.ng;
+  if (mt >= ntm || nt >= ntn) return;   // padding workgroups (uniform)
   const int m0 = mt * BM, n0 = nt * BN;
   const T* A = reinterpret_cast<const T*>(g.A);
   const T* W = reinterpret_cast<const T*>(g.W);
@@ -156,6 +162,65 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #undef M2M_LD
 #undef M2M_ST
   // ---- epilogue ----
+  if constexpr (EPI == EPI_HEADS) {
+    // Head-major scatter through LDS, so that every store instruction writes whole 128-byte lines: a (row, head)
+    // pair of q / k is exactly one line, and the transposed V is contiguous along the rows.  Written straight
+    // from the accumulators the same data goes out as 64-byte halves and 2-byte scatters, and the write-allocate
+    // fetches of those partial lines were 3/4 of the kernel's HBM reads (PMC: 157 MB per launch for 21 MB of
+    // activations).  A 128-column tile never straddles q / k / v (inner % 128 == 0).
+    constexpr int CP = BN + 8;                                  // LDS pitch of the staged tile (elements)
+    static_assert(BM * CP <= (BM + BN) * Cfg::PITCH || sizeof(T) == 4, "staged tile must fit the operand buffers");
+    const int which = n0 / g.inner;
+    const bool transposed = (which == g.vt_which);
+    __syncthreads();                                            // every wave is done with As / Bs
+    if constexpr (sizeof(T) == 2) {
+      T* Cs = AB;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int rl = wm * 64 + mi * 32 + acc_row(e, lane), cl = wn * 64 + ni * 32 + r;
+            Cs[transposed ? cl * CP + rl : rl * CP + cl] = from_f32<T>(acc[mi][ni][e]);
+          }
+      __syncthreads();
+      constexpr int EPC8 = 8;                                   // bf16 elements per 16-byte store
+      for (int idx = tid; idx < BM * (BN / EPC8); idx += 256) {
+        if (!transposed) {
+          const int rl = idx / (BN / EPC8), ch = idx % (BN / EPC8);
+          const int row = m0 + rl, col = n0 + ch * EPC8;
+          if (row < g.M && col < g.N) {
+            const int rem = col - which * g.inner, hh = rem / DK, dd = rem - hh * DK;
+            const int b = row / g.S, sq = row - b * g.S;
+            *reinterpret_cast<uint4*>(reinterpret_cast<T*>(g.out) + ((((int64_t)which * g.Bsz + b) * g.H + hh) * g.S + sq) * DK + dd) =
+                *reinterpret_cast<const uint4*>(Cs + rl * CP + ch * EPC8);
+          }
+        } else {
+          const int cl = idx / (BM / EPC8), rc = idx % (BM / EPC8);
+          const int col = n0 + cl, row0 = m0 + rc * EPC8;
+          if (col < g.N && row0 < g.M) {
+            const int rem = col - which * g.inner, hh = rem / DK, dd = rem - hh * DK;
+            const int b = row0 / g.S, s0 = row0 - b * g.S;
+            T* dst = reinterpret_cast<T*>(g.vt_out) + (((int64_t)b * g.H + hh) * DK + dd) * g.Sp;
+            const T* src = Cs + cl * CP + rc * EPC8;
+            if (s0 + EPC8 <= g.S && row0 + EPC8 <= g.M && (s0 & 7) == 0) {
+              *reinterpret_cast<uint4*>(dst + s0) = *reinterpret_cast<const uint4*>(src);
+            } else {                                            // chunk straddles a clip boundary / is misaligned
+              for (int j = 0; j < EPC8; ++j) {
+                const int row = row0 + j;
+                if (row < g.M) {
+                  const int bj = row / g.S, sj = row - bj * g.S;
+                  reinterpret_cast<T*>(g.vt_out)[(((int64_t)bj * g.H + hh) * DK + dd) * g.Sp + sj] = src[j];
+                }
+              }
+            }
+          }
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -208,8 +273,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 }
 
 template <typename T>
-static int launch_gemm_t(int epi, const GemmArgs& a, hipStream_t st) {
-  dim3 grid((unsigned)(ceil_div(a.N, BN) * ceil_div(ceil_div(a.M, BM), 8) * 8));
+static int launch_gemm_t(int epi, const GemmArgs& a_in, hipStream_t st) {
+  GemmArgs a = a_in;
+  const int ntn = ceil_div(a.N, BN);
+  const int ng_max = (int)((2 << 20) / ((size_t)BN * a.K * sizeof(T)));          // column tiles whose weight rows fit 2 MB
+  const int ngroups = ceil_div(ntn, ng_max < 1 ? 1 : ng_max);
+  a.ng = ceil_div(ntn, ngroups);
+  dim3 grid((unsigned)(8 * ngroups * ceil_div(ceil_div(a.M, BM), 8) * a.ng));
   switch (epi) {
     case EPI_STORE: hipLaunchKernelGGL((gemm_kernel<T, EPI_STORE>), grid, dim3(256), 0, st, a); break;
     case EPI_RESID: hipLaunchKernelGGL((gemm_kernel<T, EPI_RESID>), grid, dim3(256), 0, st, a); break;

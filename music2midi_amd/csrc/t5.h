@@ -138,6 +138,7 @@ struct GemmArgs {
   int vt_which;      // -1: none
   void* vt_out;
   int Sp;
+  int ng;            // column tiles per group of the XCD-aware tile order (set by launch_gemm)
 };
 
 int launch_gemm(int precision, int epi, const GemmArgs& a, hipStream_t st);
