@@ -221,6 +221,39 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       return;
     }
   }
+  if constexpr ((EPI == EPI_GATED || EPI == EPI_GATED16) && sizeof(T) == 2) {
+    // gated up projection, bf16: the 128-column tile yields 64 outputs per row = one 128-byte line; staged in
+    // LDS so that 8 lanes write a whole line with 16-byte stores (straight from the accumulators it is 64-byte
+    // halves of 2-byte elements)
+    constexpr int GP = BN / 2 + 8;
+    __syncthreads();
+    T* Cs = AB;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int rl = wm * 64 + mi * 32 + acc_row(e, lane);
+        if constexpr (EPI == EPI_GATED) {       // the wave's 64 columns are [32 of wi_0 | the matching 32 of wi_1]
+          Cs[rl * GP + wn * 32 + r] = from_f32<T>(gelu_new(acc[mi][0][e]) * acc[mi][1][e]);
+        } else {                                // 16-column groups: 8 of wi_0 then the matching 8 of wi_1
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            const float v = acc[mi][ni][e], partner = lane_xor<8>(v);
+            const int cl = wn * 64 + ni * 32 + r;
+            if ((cl & 8) == 0) Cs[rl * GP + (cl >> 4) * 8 + (cl & 7)] = from_f32<T>(gelu_new(v) * partner);
+          }
+        }
+      }
+    __syncthreads();
+    for (int idx = tid; idx < BM * (BN / 16); idx += 256) {
+      const int rl = idx / (BN / 16), ch = idx % (BN / 16);
+      const int row = m0 + rl, oc = n0 / 2 + ch * 8;
+      if (row < g.M && 2 * oc < g.N)
+        *reinterpret_cast<uint4*>(reinterpret_cast<T*>(g.out) + (int64_t)row * g.ldo + oc) =
+            *reinterpret_cast<const uint4*>(Cs + rl * GP + ch * 8);
+    }
+    return;
+  }
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
