@@ -354,6 +354,18 @@ template <> struct AttnCfg<float> { static constexpr int KP = DK + 4, VP = AK + 
 // the k-order in which accumulator registers 8s..8s+7 of S^T present P^T (see mma.h).
 __device__ inline int vt_pos(int kk) { return (kk & ~0xC) | ((kk & 4) << 1) | ((kk & 8) >> 1); }
 
+// keep the first `nvalid` elements of a 16-byte chunk, zero the rest (nvalid may be <= 0 or >= the chunk size)
+template <typename T> __device__ inline uint4 zero_tail(uint4 v, int nvalid);
+template <> __device__ inline uint4 zero_tail<float>(uint4 v, int nvalid) {
+  return make_uint4(nvalid > 0 ? v.x : 0u, nvalid > 1 ? v.y : 0u, nvalid > 2 ? v.z : 0u, nvalid > 3 ? v.w : 0u);
+}
+template <> __device__ inline uint4 zero_tail<bf16_t>(uint4 v, int nvalid) {
+  auto pair = [&](uint32_t w, int first) {   // elements `first` (low half) and `first + 1` (high half)
+    return (nvalid > first ? (w & 0x0000FFFFu) : 0u) | (nvalid > first + 1 ? (w & 0xFFFF0000u) : 0u);
+  };
+  return make_uint4(pair(v.x, 0), pair(v.y, 2), pair(v.z, 4), pair(v.w, 6));
+}
+
 template <typename T, bool CAUSAL, bool BIAS>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   using Cfg = AttnCfg<T>;
@@ -395,36 +407,64 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   // causal: keys beyond the last query of this workgroup's tile are never needed
   const int kend = CAUSAL ? min(Sk, qt * AQ + AQ) : Sk;
   const int ntiles = ceil_div(kend, AK);
+  // K / V^T tiles are prefetched into registers one tile ahead (the loads of tile kt+1 are in flight while
+  // tile kt is multiplied): staged straight from global memory to LDS every tile paid a full memory round trip
+  // between its two barriers.  bf16: 2 + 2 chunks of 16 bytes per thread; fp32: 4 + 4.
+  constexpr int KCH = AK * (DK / EPC) / 256;                    // K chunks per thread
+  constexpr int VCH = DK * (AK / EPC) / 256;                    // V^T chunks per thread
+  static_assert(KCH == VCH && (KCH == 2 || KCH == 4), "tile staging below is written for 2 or 4 chunks per thread");
+  // named scalars, not arrays: hipcc 7.2 demotes register arrays that live across the loop to scratch
+  uint4 kr0, kr1, kr2, kr3, vr0, vr1, vr2, vr3;
+  kr2 = kr3 = vr2 = vr3 = make_uint4(0, 0, 0, 0);
+#define M2M_AT_LDK(i, kt)                                                                     \
+  {                                                                                           \
+    const int c = tid + (i) * 256;                                                            \
+    const int key = c / (DK / EPC), dc = c % (DK / EPC);                                      \
+    const int gk = min((kt) * AK + key, Sk - 1);                                              \
+    kr##i = *reinterpret_cast<const uint4*>(Kg + (int64_t)gk * DK + dc * EPC);                \
+  }
+#define M2M_AT_LDV(i, kt)                                                                     \
+  {                                                                                           \
+    const int c = tid + (i) * 256;                                                            \
+    const int d = c / (AK / EPC), kc = c % (AK / EPC);                                        \
+    vr##i = *reinterpret_cast<const uint4*>(Vtg + (int64_t)d * Sp + (kt) * AK + kc * EPC);    \
+  }
+#define M2M_AT_FETCH(kt)                                                                      \
+  {                                                                                           \
+    M2M_AT_LDK(0, kt) M2M_AT_LDK(1, kt) if constexpr (KCH == 4) { M2M_AT_LDK(2, kt) M2M_AT_LDK(3, kt) } \
+    M2M_AT_LDV(0, kt) M2M_AT_LDV(1, kt) if constexpr (VCH == 4) { M2M_AT_LDV(2, kt) M2M_AT_LDV(3, kt) } \
+  }
+#define M2M_AT_STK(i)                                                                         \
+  {                                                                                           \
+    const int c = tid + (i) * 256;                                                            \
+    const int key = c / (DK / EPC), dc = c % (DK / EPC);                                      \
+    *reinterpret_cast<uint4*>(Ks + key * Cfg::KP + dc * EPC) = kr##i;                         \
+  }
+  // columns past Sk of the V^T rows are uninitialised memory: zero them (0 * NaN would poison P.V)
+#define M2M_AT_STV(i, kt)                                                                     \
+  {                                                                                           \
+    const int c = tid + (i) * 256;                                                            \
+    const int d = c / (AK / EPC), kc = c % (AK / EPC);                                        \
+    const int nvalid = Sk - ((kt) * AK + kc * EPC);               /* valid elements of this chunk */ \
+    const uint4 vv = zero_tail<T>(vr##i, nvalid);                                             \
+    const int kl = kc * EPC;                                                                  \
+    T* dst = Vt + d * Cfg::VP + (kl & 32);                                                    \
+    if constexpr (EPC == 8) {                                                                 \
+      *reinterpret_cast<uint2*>(dst + vt_pos(kl & 31)) = make_uint2(vv.x, vv.y);              \
+      *reinterpret_cast<uint2*>(dst + vt_pos((kl & 31) + 4)) = make_uint2(vv.z, vv.w);        \
+    } else {                                                                                  \
+      *reinterpret_cast<uint4*>(dst + vt_pos(kl & 31)) = vv;                                  \
+    }                                                                                         \
+  }
+  if (ntiles > 0) M2M_AT_FETCH(0)
   for (int kt = 0; kt < ntiles; ++kt) {
     __syncthreads();
     // ---- stage K (row-major) and V^T (already transposed in memory; key slots permuted to the
     //      accumulator k-order in whole 4-key groups, so it is 8/16-byte copies) ----
-    for (int c = tid; c < AK * (DK / EPC); c += 256) {
-      const int key = c / (DK / EPC), dc = c % (DK / EPC);
-      const int gk = min(kt * AK + key, Sk - 1);
-      *reinterpret_cast<uint4*>(Ks + key * Cfg::KP + dc * EPC) =
-          *reinterpret_cast<const uint4*>(Kg + (int64_t)gk * DK + dc * EPC);
-    }
-    for (int c = tid; c < DK * (AK / EPC); c += 256) {
-      const int d = c / (AK / EPC), kc = c % (AK / EPC);
-      const int k0 = kt * AK + kc * EPC;                       // first key of this 16-byte chunk (row pitch Sp >= tile end)
-      uint4 vv = *reinterpret_cast<const uint4*>(Vtg + (int64_t)d * Sp + k0);
-      if (k0 + EPC > Sk) {                                      // columns past Sk are uninitialised: zero them (0 * NaN would poison P.V)
-        T* ve = reinterpret_cast<T*>(&vv);
-#pragma unroll
-        for (int e = 0; e < EPC; ++e)
-          if (k0 + e >= Sk) ve[e] = from_f32<T>(0.f);
-      }
-      const int kl = kc * EPC;                                  // key index inside the 64-key tile
-      T* dst = Vt + d * Cfg::VP + (kl & 32);
-      if constexpr (EPC == 8) {                                 // bf16: two 4-key groups per chunk
-        *reinterpret_cast<uint2*>(dst + vt_pos(kl & 31)) = make_uint2(vv.x, vv.y);
-        *reinterpret_cast<uint2*>(dst + vt_pos((kl & 31) + 4)) = make_uint2(vv.z, vv.w);
-      } else {                                                  // fp32: one 4-key group per chunk
-        *reinterpret_cast<uint4*>(dst + vt_pos(kl & 31)) = vv;
-      }
-    }
+    M2M_AT_STK(0) M2M_AT_STK(1) if constexpr (KCH == 4) { M2M_AT_STK(2) M2M_AT_STK(3) }
+    M2M_AT_STV(0, kt) M2M_AT_STV(1, kt) if constexpr (VCH == 4) { M2M_AT_STV(2, kt) M2M_AT_STV(3, kt) }
     __syncthreads();
+    if (kt + 1 < ntiles) M2M_AT_FETCH(kt + 1)
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       const int kbase = kt * AK + sub * 32;
@@ -484,6 +524,11 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
       }
     }
   }
+#undef M2M_AT_LDK
+#undef M2M_AT_LDV
+#undef M2M_AT_FETCH
+#undef M2M_AT_STK
+#undef M2M_AT_STV
   // ---- normalise and store: O^T element i of block db is d = db*32 + acc_row(i), query my_q ----
   if (my_q < Sq) {
     const float inv = 1.0f / l_run;
