@@ -344,6 +344,7 @@ int launch_gemm(int precision, int epi, const GemmArgs& a, hipStream_t st) {
 // is a per-lane scalar.  P^T then feeds O^T = V^T * P^T directly as the MFMA B operand with
 // no lane movement; V^T is staged in LDS with key slots permuted to match (vt_pos).
 constexpr int AQ = 128, AK = 64;
+constexpr int TB_PAD = AQ;        // spare bias-table entries below index 0 (query rows of the last tile past Sq)
 
 template <typename T> struct AttnCfg;
 template <> struct AttnCfg<bf16_t> { static constexpr int KP = DK + 8, VP = AK + 8; };
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   T* Ks = reinterpret_cast<T*>(smem);                       // [AK][KP]
   T* Vt = Ks + AK * Cfg::KP;                                // [DK][VP]  (transposed, permuted key slots)
-  float* tb = reinterpret_cast<float*>(Vt + DK * Cfg::VP);  // [Sq+Sk-1] bias by (key - q) + Sq - 1
+  float* tb = reinterpret_cast<float*>(Vt + DK * Cfg::VP) + TB_PAD;  // [-TB_PAD, Sq+Sk-1) bias by (key - q) + Sq - 1
 
   const int B = a.B, H = a.H, Sq = a.Sq, Sk = a.Sk, Sp = a.Sp;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -391,8 +392,10 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   const T* Kg = reinterpret_cast<const T*>(a.K) + (int64_t)bh * Sk * DK;
   const T* Vtg = reinterpret_cast<const T*>(a.Vt) + (int64_t)bh * DK * Sp;      // V^T of this (clip, head): [64][Sp]
 
-  if constexpr (BIAS)
+  if constexpr (BIAS) {
     for (int i = tid; i < Sq + Sk - 1; i += 256) tb[i] = a.bias_tab[(int64_t)hh * a.tab_stride + a.tab_center - (Sq - 1) + i];
+    if (tid < TB_PAD) tb[tid - TB_PAD] = 0.f;     // only reached by query rows past Sq, which are never stored
+  }
 
   // Q fragments (B operand): lane (r,h) holds Q[q0 + r][16 s + 8 h + j]
   const int qrow = min(q0 + r, Sq - 1);
@@ -478,20 +481,35 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
       // scores for query my_q: element i is key kbase + acc_row(i, lane)
       float p[16];
       float mx = -1e30f;
+      // interior sub-tiles (every key exists and, when causal, lies at or below every query of this wave) need
+      // neither the masks nor the index clamps: the bias is then 16 LDS reads at compile-time offsets from one
+      // per-lane base (the table has TB_PAD spare entries below index 0 for the query rows past Sq)
+      const bool interior = kbase + 32 <= Sk && (!CAUSAL || kbase + 31 <= q0);
+      if (interior) {
+        const float* tbp = tb + (kbase - my_q + (Sq - 1) + 4 * h);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int key = kbase + acc_row(i, lane);
-        float sc = -1e30f;
-        if (key < Sk && (!CAUSAL || key <= my_q)) {
-          sc = st[i];
-          if constexpr (BIAS) {
-            int rel = key - my_q + (Sq - 1);
-            rel = min(max(rel, 0), Sq + Sk - 2);  // rows beyond Sq (clamped q) are discarded later
-            sc += tb[rel];
-          }
+        for (int i = 0; i < 16; ++i) {
+          float sc = st[i];
+          if constexpr (BIAS) sc += tbp[(i & 3) + 8 * (i >> 2)];
+          p[i] = sc;
+          mx = fmaxf(mx, sc);
         }
-        p[i] = sc;
-        mx = fmaxf(mx, sc);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int key = kbase + acc_row(i, lane);
+          float sc = -1e30f;
+          if (key < Sk && (!CAUSAL || key <= my_q)) {
+            sc = st[i];
+            if constexpr (BIAS) {
+              int rel = key - my_q + (Sq - 1);
+              rel = min(max(rel, -TB_PAD), Sq + Sk - 2);  // rows beyond Sq (clamped q) are discarded later
+              sc += tb[rel];
+            }
+          }
+          p[i] = sc;
+          mx = fmaxf(mx, sc);
+        }
       }
       mx = fmaxf(mx, lane_xor<32>(mx));
       const float m_new = fmaxf(m_run, mx);
@@ -543,7 +561,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 template <typename T, bool CAUSAL, bool BIAS>
 static int launch_attn_tt(const AttnArgs& a, hipStream_t st) {
   using Cfg = AttnCfg<T>;
-  const size_t smem = (size_t)(AK * Cfg::KP + DK * Cfg::VP) * sizeof(T) + (BIAS ? (size_t)(a.Sq + a.Sk - 1) * sizeof(float) : 0);
+  const size_t smem = (size_t)(AK * Cfg::KP + DK * Cfg::VP) * sizeof(T) + (BIAS ? (size_t)(a.Sq + a.Sk - 1 + TB_PAD) * sizeof(float) : 0);
   M2M_REQUIRE(smem <= 150 * 1024, "attention: Sq=%d, Sk=%d too long for the LDS bias table", a.Sq, a.Sk);
   static bool attr_set = false;
   if (!attr_set) {
