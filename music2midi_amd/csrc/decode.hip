@@ -492,6 +492,34 @@ template <typename T> __device__ inline float m2m_exp(float x) {
   return expf(x);
 }
 
+// acc += <8 (bf16) / 4 (fp32) weights of one 16-byte chunk, the matching LDS-resident inputs>.
+// bf16: the inputs are kept PACKED in LDS (they are rounded to bf16 anyway) and each pair goes through
+// v_dot2c_f32_bf16 - 4 instructions per chunk instead of 8 converts + 8 FMAs; the per-head projections
+// are VALU-bound (16 waves on 4 SIMDs), so this is their time.  fp32 (parity mode): plain FMA chain.
+typedef __bf16 m2m_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ inline float dot2_bf16(uint32_t a, uint32_t b, float c) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(m2m_bf16x2, a), __builtin_bit_cast(m2m_bf16x2, b), c, false);
+}
+template <typename T> __device__ inline float chunk_dot(const Vec16<T>& w, const float* in_lds, int chunk, float acc);
+template <> __device__ inline float chunk_dot<bf16_t>(const Vec16<bf16_t>& w, const float* in_lds, int chunk, float acc) {
+  const uint4 x = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(in_lds) + chunk * 4);
+  acc = dot2_bf16(w.v.x, x.x, acc);
+  acc = dot2_bf16(w.v.y, x.y, acc);
+  acc = dot2_bf16(w.v.z, x.z, acc);
+  return dot2_bf16(w.v.w, x.w, acc);
+}
+template <> __device__ inline float chunk_dot<float>(const Vec16<float>& w, const float* in_lds, int chunk, float acc) {
+  const float* hp = in_lds + chunk * 4;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc = fmaf(hp[e], w.get(e), acc);
+  return acc;
+}
+// store element i of an LDS input vector in the layout chunk_dot reads (bf16: packed halves; fp32: floats)
+template <typename T> __device__ inline void put_in(float* in_lds, int i, float v) {
+  if constexpr (sizeof(T) == 2) reinterpret_cast<bf16_t*>(in_lds)[i] = from_f32<bf16_t>(v);
+  else in_lds[i] = v;
+}
+
 template <typename T, bool SELF, bool NT>
 __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
   constexpr int E = 16 / sizeof(T);      // elements per 16-byte chunk: 8 (bf16) / 4 (fp32)
@@ -602,10 +630,10 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
     for (int wv = 0; wv < 16; ++wv) tot += redw[wv];
     const float rs = rsqrtf(tot / (float)a.d + a.eps);
     if (own) {
-      hn[xc + 0] = to_f32(from_f32<T>(gv.x * (xv.x * rs)));
-      hn[xc + 1] = to_f32(from_f32<T>(gv.y * (xv.y * rs)));
-      hn[xc + 2] = to_f32(from_f32<T>(gv.z * (xv.z * rs)));
-      hn[xc + 3] = to_f32(from_f32<T>(gv.w * (xv.w * rs)));
+      put_in<T>(hn, xc + 0, gv.x * (xv.x * rs));
+      put_in<T>(hn, xc + 1, gv.y * (xv.y * rs));
+      put_in<T>(hn, xc + 2, gv.z * (xv.z * rs));
+      put_in<T>(hn, xc + 3, gv.w * (xv.w * rs));
     }
     __syncthreads();
     M2M_STAMP(6 + (SELF ? 1 : 0), 5);
@@ -617,9 +645,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
 #pragma unroll
     for (int u = 0; u < WMAX; ++u) {
       if (u < cnt) {
-        const float* hp = hn + (u * LPO + part) * E;
-#pragma unroll
-        for (int e = 0; e < E; ++e) acc = fmaf(hp[e], w[u].get(e), acc);
+        acc = chunk_dot<T>(w[u], hn, u * LPO + part, acc);
       }
     }
     for (int i = WMAX; i < cnt; i += 4) {   // d_model / dtype combinations beyond the register budget (fp32)
@@ -629,9 +655,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (i + u < cnt) {
-          const float* hp = hn + ((i + u) * LPO + part) * E;
-#pragma unroll
-          for (int e = 0; e < E; ++e) acc = fmaf(hp[e], w2[u].get(e), acc);
+          acc = chunk_dot<T>(w2[u], hn, (i + u) * LPO + part, acc);
         }
       }
     }
@@ -731,9 +755,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
 #pragma unroll
     for (int u = 0; u < WMAX2; ++u) {
       if (u < cnt2) {
-        const float* hp = hn + (u * LPO2 + part2) * E;
-#pragma unroll
-        for (int e = 0; e < E; ++e) acc2 = fmaf(hp[e], wkv[u].get(e), acc2);
+        acc2 = chunk_dot<T>(wkv[u], hn, u * LPO2 + part2, acc2);
       }
     }
     for (int i = WMAX2; i < cnt2; i += 4) {   // d_model / dtype combinations beyond the register budget (fp32)
@@ -743,9 +765,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (i + u < cnt2) {
-          const float* hp = hn + ((i + u) * LPO2 + part2) * E;
-#pragma unroll
-          for (int e = 0; e < E; ++e) acc2 = fmaf(hp[e], w2[u].get(e), acc2);
+          acc2 = chunk_dot<T>(w2[u], hn, (i + u) * LPO2 + part2, acc2);
         }
       }
     }
@@ -809,7 +829,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
         s = fmaf(f, redo[wv][tid], s);
         L = fmaf(f, redl[wv], L);
       }
-      oh[tid] = to_f32(from_f32<T>(s / L));      // the projection input is rounded to T, as every GEMM input
+      put_in<T>(oh, tid, s / L);                 // the projection input is rounded to T, as every GEMM input
     }
     __syncthreads();
     M2M_STAMP(6 + (SELF ? 1 : 0), 7);
@@ -819,8 +839,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
     float accp = 0.f;
 #pragma unroll
     for (int u = 0; u < OCH; ++u) {
-#pragma unroll
-      for (int e = 0; e < E; ++e) accp = fmaf(oh[opart * 32 + u * E + e], wo[u].get(e), accp);
+      accp = chunk_dot<T>(wo[u], oh, opart * OCH + u, accp);
     }
     accp += lane_xor<1>(accp);
     if (opart == 0 && tid < 2 * a.d && !st_done) {
