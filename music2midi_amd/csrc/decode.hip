@@ -549,7 +549,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
   constexpr int WMAX = 3;                // q weight chunks per lane held in registers (d_model 384, bf16)
   using V16 = decltype(Vec16<T>().v);
   extern __shared__ __align__(16) float hn[];   // [d] normalised input row (already rounded to T)
-  __shared__ float redw[16], redl[16];
+  __shared__ float redw[16], redl[16], redlf[16];
   __shared__ float redo[16][DK];
   __shared__ __align__(16) float redg[16 * (64 / LPR)][DK];   // per-group partial outputs (32 KB bf16 / 16 KB fp32)
   __shared__ __align__(16) float qs[DK];
@@ -812,22 +812,25 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
     M2M_STAMP(6 + (SELF ? 1 : 0), 6);
 #endif
     {
+      // every wave brings ITS partial sums to the global maximum here (one exponential per wave, in parallel),
+      // so the single wave that finishes the row below only adds: the 16 exponentials it used to evaluate were
+      // ~0.4 us of serial VALU time per launch
+      float M = redw[lane & 15];
+      M = fmaxf(M, lane_xor<8>(M)); M = fmaxf(M, lane_xor<4>(M)); M = fmaxf(M, lane_xor<2>(M)); M = fmaxf(M, lane_xor<1>(M));
+      const float fw = expf(redw[wave] - M);
       float sw = redg[wave * GPW][lane];             // thread (wave, lane = dim): this wave's groups, fixed order
 #pragma unroll
       for (int j = 1; j < GPW; ++j) sw += redg[wave * GPW + j][lane];
-      redo[wave][lane] = sw;
+      redo[wave][lane] = sw * fw;
+      if (lane == 0) redlf[wave] = redl[wave] * fw;
     }
     __syncthreads();
     if (tid < DK) {
-      float M = redw[0];
-#pragma unroll
-      for (int wv = 1; wv < 16; ++wv) M = fmaxf(M, redw[wv]);
       float s = 0.f, L = 0.f;
 #pragma unroll
       for (int wv = 0; wv < 16; ++wv) {
-        const float f = expf(redw[wv] - M);
-        s = fmaf(f, redo[wv][tid], s);
-        L = fmaf(f, redl[wv], L);
+        s += redo[wv][tid];
+        L += redlf[wv];
       }
       put_in<T>(oh, tid, s / L);                 // the projection input is rounded to T, as every GEMM input
     }
