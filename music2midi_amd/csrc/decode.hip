@@ -372,7 +372,7 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(1, 2)))
   if (done) return;   // uniform
   // gated activation: column cc of the slice lives in tile cc / 8 at columns (cc % 8) [wi_0] and (cc % 8) + 8 [wi_1];
   // k-slices are summed in a fixed order
-  for (int idx = tid; idx < 16 * FF_C; idx += 64 * KS) {
+  for (int idx = tid; idx < FF_R * FF_C; idx += 64 * KS) {   // rows FF_R..15 of the tile are padding and stay unread
     const int row = idx / FF_C, cc = idx % FF_C;
     const int t = cc >> 3, q = row * 17 + (cc & 7);
     float v0 = red[0][t][q], v1 = red[0][t][q + 8];
