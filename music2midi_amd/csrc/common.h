@@ -140,6 +140,20 @@ __device__ inline float gelu_new(float x) {
   const float k = 0.7978845608028654f;  // sqrt(2/pi)
   return 0.5f * x * (1.0f + tanhf(k * (x + 0.044715f * x * x * x)));
 }
+// The same function for results that are rounded to bf16 anyway: tanh(z) = 1 - 2 / (exp(2z) + 1) through the
+// hardware exp2 / rcp (relative error ~1e-6 against bf16's 4e-3); ~8 instructions instead of ~40 for tanhf,
+// which was half of the gated GEMM's time (32 M activations per launch).  Saturates correctly: exp2 -> inf / 0.
+__device__ inline float gelu_new_fast(float x) {
+  const float z2 = 2.0f * 0.7978845608028654f * 1.4426950408889634f * (x + 0.044715f * x * x * x);   // 2 z log2(e)
+  const float t = __builtin_amdgcn_exp2f(z2);
+  const float th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
+  return 0.5f * x * (1.0f + th);
+}
+// accurate in the fp32 (parity) mode, fast where the result is stored as bf16
+template <typename T> __device__ inline float gelu_new_t(float x) {
+  if constexpr (sizeof(T) == 2) return gelu_new_fast(x);
+  else return gelu_new(x);
+}
 
 __host__ __device__ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }

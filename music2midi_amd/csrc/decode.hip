@@ -378,7 +378,7 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(1, 2)))
     float v0 = red[0][t][q], v1 = red[0][t][q + 8];
 #pragma unroll
     for (int w = 1; w < KS; ++w) { v0 += red[w][t][q]; v1 += red[w][t][q + 8]; }
-    hs[row * FF_HP + cc] = from_f32<T>(gelu_new(v0) * v1);
+    hs[row * FF_HP + cc] = from_f32<T>(gelu_new_t<T>(v0) * v1);
   }
   __syncthreads();
   M2M_STAMP(4, 5);

@@ -234,13 +234,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       for (int e = 0; e < 16; ++e) {
         const int rl = wm * 64 + mi * 32 + acc_row(e, lane);
         if constexpr (EPI == EPI_GATED) {       // the wave's 64 columns are [32 of wi_0 | the matching 32 of wi_1]
-          Cs[rl * GP + wn * 32 + r] = from_f32<T>(gelu_new(acc[mi][0][e]) * acc[mi][1][e]);
+          Cs[rl * GP + wn * 32 + r] = from_f32<T>(gelu_new_t<T>(acc[mi][0][e]) * acc[mi][1][e]);
         } else {                                // 16-column groups: 8 of wi_0 then the matching 8 of wi_1
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni) {
             const float v = acc[mi][ni][e], partner = lane_xor<8>(v);
             const int cl = wn * 64 + ni * 32 + r;
-            if ((cl & 8) == 0) Cs[rl * GP + (cl >> 4) * 8 + (cl & 7)] = from_f32<T>(gelu_new(v) * partner);
+            if ((cl & 8) == 0) Cs[rl * GP + (cl >> 4) * 8 + (cl & 7)] = from_f32<T>(gelu_new_t<T>(v) * partner);
           }
         }
       }
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         // the wave's 64 columns are [32 of wi_0 | the matching 32 of wi_1]
         const int col = (n0 + wn * 64) / 2 + r;
         if (n0 + wn * 64 < g.N) {
-          const float v = gelu_new(acc[mi][0][e]) * acc[mi][1][e];
+          const float v = gelu_new_t<T>(acc[mi][0][e]) * acc[mi][1][e];
           reinterpret_cast<T*>(g.out)[(int64_t)row * g.ldo + col] = from_f32<T>(v);
         }
       } else {
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
             const float partner = lane_xor<8>(v);
             if ((col & 8) == 0 && col < g.N) {
               const int oc = (col >> 4) * 8 + (col & 7);
-              reinterpret_cast<T*>(g.out)[(int64_t)row * g.ldo + oc] = from_f32<T>(gelu_new(v) * partner);
+              reinterpret_cast<T*>(g.out)[(int64_t)row * g.ldo + oc] = from_f32<T>(gelu_new_t<T>(v) * partner);
             }
           } else if constexpr (EPI == EPI_RESID) {
             float* p = reinterpret_cast<float*>(g.out) + (int64_t)row * g.ldo + col;
