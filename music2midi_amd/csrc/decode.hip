@@ -535,13 +535,11 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
   constexpr int WMAX2 = 6;               // k/v weight chunks per lane held in registers (d_model 384, bf16)
   // K/V rounds (one K row + one V row per lane = 32 KB per workgroup) kept in flight by the rolling
   // prefetch.  The first PF rounds are requested at kernel entry, right behind the prologue's own
-  // loads, so the stream is already running while the norm and the query projection execute.  Two
-  // rounds is the measured optimum (B = 32: 252.3 ms per batch with one round requested after x
-  // arrived, 249.1 with two at entry, 251.1 / 262.2 with three / four; one at entry + one when x
-  // arrives, a short s_sleep in front of them, or two extra one-shot rounds in the cross kernel
-  // all measure the same within noise): deeper windows flood the
-  // fabric queues ahead of the latency-critical x / weight loads of workgroups that start a little
-  // later, and the whole 220 KB stream at once stalls the issuing waves (prologue done at ~9 us).
+  // loads (the x row first: loads retire in order), so the stream is already running while the norm
+  // and the query projection execute.  Two rounds is the measured optimum (B = 32, ms per batch:
+  // PF 1 / 2 / 3 = 219.4 / 217.4 / 229.2): deeper windows flood the fabric queues ahead of the
+  // latency-critical x / weight loads of workgroups that start a little later, and the whole 220 KB
+  // stream at once stalls the issuing waves (prologue done at ~9 us).
 #ifndef M2M_DA_PF
 #define M2M_DA_PF 2
 #endif
@@ -577,11 +575,15 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
   //         would queue behind it in the fabric (measured: the norm then completes only after ~9 us).
   //         Only the first PF rounds of the stream follow them here. ----
   const int xc = min(tid * 4, a.d - 4);
-  const float4 xv = xq_load4(a.x + (int64_t)b * a.d + xc);
+  // RAW fixed-point words: converted only after every request below has been issued (the conversion needs the
+  // data, and in program order it would put the wait for x in front of the K/V prefetch)
+  const longlong2 xr0 = *reinterpret_cast<const longlong2*>(a.x + (int64_t)b * a.d + xc);
+  const longlong2 xr1 = *reinterpret_cast<const longlong2*>(a.x + (int64_t)b * a.d + xc + 2);
   const float4 gv = *reinterpret_cast<const float4*>(a.ln_w + xc);
   // head 0 also carries the residual row into x_out: its raw fixed-point value, requested now
   const int on_ = min(tid >> 1, a.d - 1), opart = tid & 1;
   const xq_t xres = a.x[(int64_t)b * a.d + on_];   // unconditional: a branch would split the block of loads
+  __builtin_amdgcn_sched_barrier(0);               // the latency-critical row goes out FIRST (loads retire in order)
   const int po = min(tid / LPO, NOUT - 1), part = tid % LPO;
   const int which = po / DK, dd = po - which * DK;
   const T* wrow = reinterpret_cast<const T*>(a.Wp) + ((int64_t)which * a.inner + hh * DK + dd) * a.d;
@@ -599,9 +601,6 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
 #pragma unroll
     for (int u = 0; u < BPT; ++u) bv[u] = a.bias[(int64_t)hh * a.bias_stride + min(tid + 1024 * u, a.bias_stride - 1)];
   }
-  // all of the above are in flight before anything waits: without the fence the scheduler places the
-  // wait for x (and its int64 -> float conversion) ahead of the weight loads, serialising two round trips
-  __builtin_amdgcn_sched_barrier(0);
 
   // No early exit on st_done: a branch here makes the compiler sink the weight loads above below
   // it, behind the wait for x (one more serial round trip).  A finished chain runs at most the rest
@@ -618,6 +617,11 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
     kv[u].v = M2M_KV_LOAD(reinterpret_cast<const V16*>(Kb + off));
     vv[u].v = M2M_KV_LOAD(reinterpret_cast<const V16*>(Vb + off));
   }
+  // everything above is in flight before anything waits: without the fence the scheduler places the wait for x
+  // (and its int64 -> float conversion) ahead of the weight loads and of the K/V prefetch (the ISA showed the
+  // prefetch going out only after x had arrived, ~2 us into the kernel)
+  __builtin_amdgcn_sched_barrier(0);
+  const float4 xv = make_float4(xq_flt(xr0.x), xq_flt(xr0.y), xq_flt(xr1.x), xq_flt(xr1.y));
   {
     const bool own = tid * 4 < a.d;
     float ss = own ? (xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w) : 0.f;
