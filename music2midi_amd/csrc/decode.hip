@@ -563,7 +563,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
   const int st_t = a.state->t;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.x / a.H, hh = blockIdx.x - b * a.H;
+  const int hh = blockIdx.x, b = blockIdx.y;   // grid (H, B): linear id = 8 b + h as before (a head's clips on one XCD), no division
   const int sub = lane % LPR;
   const int kslot = wave * KPW + lane / LPR;
   T* Kb = reinterpret_cast<T*>(a.Kc) + ((int64_t)b * a.H + hh) * a.kv_stride * DK;
@@ -875,7 +875,7 @@ static int launch_dec_attn(int precision, bool self, bool nt, DecAttnArgs a, int
   const size_t smem = ((size_t)a.d + (self ? (size_t)a.bias_stride : 0)) * sizeof(float);   // hn + (self) the bias row
   M2M_REQUIRE(smem <= 24 * 1024, "decode attention: max_dec_len=%d too long for the LDS bias row (<= %d)", a.bias_stride,
               (24 * 1024 - a.d * 4) / 4);
-  dim3 grid((unsigned)(B * a.H));
+  dim3 grid((unsigned)a.H, (unsigned)B);
   if (precision == M2M_PREC_BF16) launch_dec_attn_t<bf16_t>(self, nt, a, grid, smem, st);
   else launch_dec_attn_t<float>(self, nt, a, grid, smem, st);
   M2M_CHECK_HIP(hipGetLastError());
