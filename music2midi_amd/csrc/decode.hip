@@ -620,19 +620,28 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
   // (and its int64 -> float conversion) ahead of the weight loads and of the K/V prefetch (the ISA showed the
   // prefetch going out only after x had arrived, ~2 us into the kernel)
   __builtin_amdgcn_sched_barrier(0);
-  const float4 xv = make_float4(xq_flt(xr0.x), xq_flt(xr0.y), xq_flt(xr1.x), xq_flt(xr1.y));
+  // Only the waves that own a piece of the row (d / 4 threads: 2 of the 16 at d_model 384) convert it and
+  // reduce; the others just post a zero, so the owners do not share their SIMD's issue slots with 3 waves of
+  // duplicate work (waves are spread round-robin over the 4 SIMDs).
+  const bool own_wave = wave * 256 < a.d;           // wave-uniform
+  float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
   {
     const bool own = tid * 4 < a.d;
-    float ss = own ? (xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w) : 0.f;
-    ss = wave_sum(ss);
-    if (lane == 0) redw[wave] = ss;
+    if (own_wave) {
+      xv = make_float4(xq_flt(xr0.x), xq_flt(xr0.y), xq_flt(xr1.x), xq_flt(xr1.y));
+      float ss = own ? (xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w) : 0.f;
+      ss = wave_sum(ss);
+      if (lane == 0) redw[wave] = ss;
+    } else if (lane == 0) {
+      redw[wave] = 0.f;
+    }
     __syncthreads();
     M2M_STAMP(6 + (SELF ? 1 : 0), 4);
-    float tot = 0.f;
-#pragma unroll
-    for (int wv = 0; wv < 16; ++wv) tot += redw[wv];
-    const float rs = rsqrtf(tot / (float)a.d + a.eps);
     if (own) {
+      float tot = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < 16; ++wv) tot += redw[wv];
+      const float rs = rsqrtf(tot / (float)a.d + a.eps);
       put_in<T>(hn, xc + 0, gv.x * (xv.x * rs));
       put_in<T>(hn, xc + 1, gv.y * (xv.y * rs));
       put_in<T>(hn, xc + 2, gv.z * (xv.z * rs));
