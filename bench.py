@@ -13,17 +13,26 @@ clips -> encoder length 864); with N > 1 every rank decodes its own 32 clips
 token matrices are all-gathered every step.  Waveforms are resident in HBM when
 the timed region starts.
 
+Launching N > 1: either under ``torch.distributed.run`` (RANK / LOCAL_RANK /
+WORLD_SIZE in the environment) or plainly as ``python bench.py --gpus N`` — in
+that case THIS process starts N fresh rank processes itself (before it has made
+any HIP call; nothing that touched the GPU is ever exec'ed or forked), forwards
+rank 0's JSON line and exits non-zero if any rank failed.
+
 Prints ONE JSON line (rank 0).  `roofline` is measured live with hipEvents on
 the stream the kernels run on (m2m_bench_kernel); `cpu_baseline` times the
 oracle (a PyTorch-CPU restatement of the reference path — the reference's own
 Python cannot run here: torchaudio/lightning/omegaconf are absent) on a bounded
-sample on the host cores.
+sample on the host cores.  ``--dry-run`` exercises the launcher and both
+collectives on CPU tensors (gloo) without any GPU work — tests/test_bench_launcher.py.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -36,14 +45,58 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured-achievable)
 N_SAMPLES = 220500        # 10 s @ 22.05 kHz
+N_FRAMES = 1 + N_SAMPLES // 256
 MAX_LENGTH = 1024
+DEC_PARAMS_PER_STEP = 15201664   # decoder weights read once per step, elements
 
 
+# ------------------------------------------------------------------ launcher
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n: int) -> int:
+    """Start n rank processes of this script (one per GPU) and wait for them.
+
+    Runs in a parent that has not touched the GPU (no torch.cuda / HIP call so far): children are
+    fresh interpreters started with subprocess, each pinned to its GPU through LOCAL_RANK.  stdout
+    of rank 0 carries the JSON line and is inherited; a failing rank ends the others (by PID) and
+    makes the exit code non-zero."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), M2M_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"[bench] rank {r} exited with {code}: stopping the other ranks", file=sys.stderr)
+                for o in pending:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return rc
+
+
+# ------------------------------------------------------------------ CPU baselines (oracle; checker code, timed only)
 def cpu_baseline(cfg, state, new_tokens: int, clips: int = 8, threads: int = 16):
-    """Oracle on the host cores: `clips` clips, frontend + encoder + `new_tokens` greedy steps, fp32.
+    """Oracle on the host cores, fp32: `clips` clips batched (frontend + encoder + `new_tokens` greedy
+    steps each) and ONE clip alone (BASELINE configs[0]).
 
     16 intra-op threads: measured fastest on the GPU box's 256-core host (tools/cpu_threads_probe.py:
-    4/8/16/32/64/128 threads -> 198/205/211/99/44/18 tokens/s for one clip; the matmuls are tiny)."""
+    4/8/16/32/64/128 threads -> 198/205/211/99/44/18 tokens/s for one clip; the matmuls are tiny, so
+    one process uses ~16 cores productively — the other cores could run further independent processes)."""
     from music2midi_amd import synth
     from music2midi_amd.config import T5Geometry
     from oracle.logmel import LogMelOracle, conditioning
@@ -55,17 +108,43 @@ def cpu_baseline(cfg, state, new_tokens: int, clips: int = 8, threads: int = 16)
     fe = LogMelOracle(cfg.model.sample_rate, cfg.spectrogram.n_fft, cfg.spectrogram.hop_length,
                       cfg.spectrogram.f_min, geom.d_model)
     orc = T5Oracle(geom, state, emulate="fp32")
-    wav = torch.from_numpy(synth.waveform_batch(0, clips, N_SAMPLES))
-    idx = torch.from_numpy(synth.cond_index_batch(0, clips))
     emb = [torch.from_numpy(state[f"conditioning.embeds.{i}.weight"]) for i in range(2)]
+
+    def run(n_clips):
+        wav = torch.from_numpy(synth.waveform_batch(0, n_clips, N_SAMPLES))
+        idx = torch.from_numpy(synth.cond_index_batch(0, n_clips))
+        t0 = time.perf_counter()
+        x = conditioning(fe(wav), idx, emb)
+        ids = orc.generate(x, new_tokens + 1)
+        dt = time.perf_counter() - t0
+        return (ids.shape[1] - 1) * n_clips / dt, dt, ids.shape[1] - 1
+
+    single, dt1, n1 = run(1)
+    batched, dtb, nb = run(clips)
+    return {"value": batched, "unit": "tokens/s", "cores": threads, "kind": "port",
+            "sample": f"{clips} clips x {N_SAMPLES} samples in one batch: log-mel + encoder (S=864) + {nb} greedy "
+                      f"decode steps each, fp32 torch-CPU oracle, {dtb:.1f} s wall, {threads} threads of "
+                      f"os.cpu_count()={os.cpu_count()}",
+            "configs0_single_clip": {"value": single, "unit": "tokens/s", "cores": threads,
+                                     "sample": f"BASELINE configs[0]: ONE 10 s clip, log-mel + encoder + {n1} greedy steps, "
+                                               f"{dt1:.1f} s wall"}}
+
+
+def cpu_frontend_baseline(cfg, clips: int = 64, threads: int = 16):
+    """BASELINE configs[1]'s CPU side: torch.stft + dense mel matmul + clamp/log (the oracle) on `clips` clips."""
+    from music2midi_amd import synth
+    from oracle.logmel import LogMelOracle
+    threads = min(threads, os.cpu_count() or threads)
+    torch.set_num_threads(threads)
+    fe = LogMelOracle(cfg.model.sample_rate, cfg.spectrogram.n_fft, cfg.spectrogram.hop_length,
+                      cfg.spectrogram.f_min, cfg.model.t5.d_model)
+    wav = torch.from_numpy(synth.waveform_batch(0, clips, N_SAMPLES))
+    fe(wav[:2])
     t0 = time.perf_counter()
-    x = conditioning(fe(wav), idx, emb)
-    ids = orc.generate(x, new_tokens + 1)
+    fe(wav)
     dt = time.perf_counter() - t0
-    n = (ids.shape[1] - 1) * clips
-    return {"value": n / dt, "unit": "tokens/s", "cores": threads, "kind": "port",
-            "sample": f"{clips} clips x {N_SAMPLES} samples in one batch: log-mel + encoder (S=864) + {ids.shape[1] - 1} greedy "
-                      f"decode steps each, fp32 torch-CPU oracle, {dt:.1f} s wall, {threads} threads of os.cpu_count()={os.cpu_count()}"}
+    return {"clips_per_s": clips / dt, "ms_per_batch": dt * 1e3, "cores": threads, "kind": "port",
+            "sample": f"torch.stft + dense [1025x384] mel matmul + clamp/log on {clips} x {N_SAMPLES} samples, fp32"}
 
 
 def pmc_traffic_bytes(kernel_substr: str, batch: int):
@@ -86,6 +165,47 @@ def pmc_traffic_bytes(kernel_substr: str, batch: int):
     return best
 
 
+def decode_bytes_per_step(B: int, S: int, t_mean: float, esize: int) -> float:
+    """Algorithmic HBM bytes of one decode step: the decoder weights once for the whole
+    batch + per clip the cross K/V (6 layers x 2 x 512 x S) and the self K/V cache up to position t."""
+    return DEC_PARAMS_PER_STEP * esize + B * 6 * 2 * 512 * (S + t_mean) * esize
+
+
+# ------------------------------------------------------------------ dry mode (launcher + collectives on CPU)
+def dry_run(args):
+    from music2midi_amd import distributed as D
+    from music2midi_amd.config import T5Geometry, default_config
+    from music2midi_amd.transformer import T5Transformer
+
+    os.environ.setdefault("M2M_DIST_BACKEND", "gloo")
+    rank, local_rank, world = D.init_process_group("gloo")
+    if os.environ.get("M2M_BENCH_FAIL_RANK") == str(rank):      # test hook: a rank that dies must fail the whole launch
+        sys.exit(3)
+    cfg = default_config()
+    geom = T5Geometry(cfg.model.t5)
+    torch.manual_seed(1234 + rank)                      # ranks start from DIFFERENT weights ...
+    model = T5Transformer(cfg.to_dict(), precision=args.precision)
+    bcast = D.broadcast_module_state(model, src=0)      # ... and must all end up with rank 0's
+    probe = float(model.transformer.lm_head.weight.double().sum())
+    B = args.batch
+    lo = rank * B
+    toks = (torch.arange(B * 4).reshape(B, 4) + 1000 * lo)
+    allt = D.all_gather_tokens(toks, args.max_length, geom.pad_token_id)
+    ok = allt.shape == (B * world, 4) and all(int(allt[r * B, 0]) == 1000 * r * B for r in range(world))
+    pmin, pmax = -D.all_reduce_max(-probe, "cpu"), D.all_reduce_max(probe, "cpu")
+    D.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "decoded MIDI tokens/sec/node on 10 s clips", "value": 0.0, "unit": "tokens/s",
+                          "n_gpus": world, "dry_run": True, "backend": torch.distributed.get_backend() if world > 1 else "none",
+                          "world": torch.distributed.get_world_size() if world > 1 else 1,
+                          "gather_ok": bool(ok), "weights_identical_on_all_ranks": pmin == pmax,
+                          "config": {"weight_broadcast_bytes": bcast, "global_batch": B * world}}), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    return 0 if ok and pmin == pmax else 1
+
+
+# ------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,9 +215,18 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
     ap.add_argument("--cpu-tokens", type=int, default=1023, help="greedy steps per clip of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the fp32 parity-mode record")
+    ap.add_argument("--no-frontend", action="store_true", help="skip the configs[1] frontend record")
+    ap.add_argument("--dry-run", action="store_true", help="launcher + collectives on CPU tensors (gloo), no GPU work")
     ap.add_argument("--max-length", type=int, default=MAX_LENGTH,
                     help="decoder max_length (profiling runs only; the headline number uses 1024)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher (no HIP call has happened in this process)
+        sys.exit(spawn_ranks(args.gpus))
+    if args.dry_run:
+        sys.exit(dry_run(args))
 
     from music2midi_amd import distributed as D
     from music2midi_amd import native, synth
@@ -106,11 +235,15 @@ def main():
     from music2midi_amd.input import ModelInputs
     from music2midi_amd.transformer import T5Transformer
 
+    rank, local_rank, world = D.env_world()
+    if world > torch.cuda.device_count() and os.environ.get("M2M_DIST_BACKEND", "nccl") == "nccl":
+        print(f"[bench] WORLD_SIZE={world} but only {torch.cuda.device_count()} GPU(s) visible: RCCL needs one GPU per rank",
+              file=sys.stderr)
+        sys.exit(2)
     rank, local_rank, world = D.init_process_group()
     if world != args.gpus:
         if rank == 0:
-            print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
-                  f"--nproc-per-node {args.gpus}", file=sys.stderr)
+            print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: reporting n_gpus={world}", file=sys.stderr)
         args.gpus = world
     native.require_gpu()
     dev = torch.device("cuda", local_rank % torch.cuda.device_count())
@@ -119,6 +252,7 @@ def main():
     cfg = default_config()
     geom = T5Geometry(cfg.model.t5)
     B = args.batch
+    S = N_FRAMES + 2
 
     # ---- weights: rank 0 owns them, everyone else receives them over RCCL ----
     model = T5Transformer(cfg.to_dict(), precision=args.precision)
@@ -159,6 +293,7 @@ def main():
     assert toks.shape[0] == B * world, toks.shape
 
     out = None
+    es = 2 if args.precision == "bf16" else 4
     if rank == 0:
         value = total_tokens / elapsed
         out = {
@@ -167,10 +302,13 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: full generate (log-mel + encoder + KV-cached greedy decode), "
-                                   f"{args.precision}, batch {B} clips/GPU x {N_SAMPLES} samples, S=864, max_length {args.max_length}"
+                                   f"{args.precision}, batch {B} clips/GPU x {N_SAMPLES} samples, S={S}, max_length {args.max_length}"
                                    + (f"; configs[3] sharding over {world} GPUs" if world > 1 else ""),
                        "global_batch": B * world, "clips_per_gpu": B, "new_tokens_per_clip": toks.shape[1] - 1,
-                       "parallelism": f"clip-sharded x{world}", "weight_broadcast_bytes": bcast_bytes},
+                       "parallelism": f"clip-sharded x{world}", "weight_broadcast_bytes": bcast_bytes,
+                       "weight_broadcast_dtype": "fp32 master weights (each rank repacks to bf16 locally)",
+                       "world": torch.distributed.get_world_size() if world > 1 else 1,
+                       "backend": torch.distributed.get_backend() if world > 1 else "none"},
         }
 
     # ---- phase timings + roofline of the dominant kernel (rank 0 only, N = 1) ----
@@ -187,7 +325,6 @@ def main():
         torch.cuda.synchronize(dev)
         t_dec = time.perf_counter() - t_dec
         fe_ms, enc_ms = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
-        es = 2 if args.precision == "bf16" else 4
         # dominant kernel: decode cross-attention (6 launches per decode step, streams the
         # per-clip cross K/V: 2 * S * inner * esize bytes per clip per launch)
         t_mid = MAX_LENGTH // 2
@@ -195,22 +332,83 @@ def main():
         self_us, self_bytes = model.bench_kernel(native.KERNEL_DEC_SELF_ATTN, t_mid, 600)
         step_us, _ = model.bench_kernel(native.KERNEL_DEC_STEP, t_mid, 200)
         achieved = cross_bytes / (cross_us * 1e-6) / 1e9
+        # whole decode loop: mean algorithmic bytes per step (t averaged over the run) / mean measured step
+        n_steps = MAX_LENGTH - 1
+        mean_step_us = (t_dec - enc_ms * 1e-3) / n_steps * 1e6
+        step_bytes = decode_bytes_per_step(B, S, (1 + n_steps) / 2.0, es)
+        step_gbs = step_bytes / (mean_step_us * 1e-6) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": "dec_attn_kernel (cross-attention, decode step)",
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS,
                            "traffic": pmc_traffic_bytes("dec_attn_kernel<m2m::bf16_t, false,", B)
                            if args.precision == "bf16" else None,
-                           "algorithmic_bytes_per_launch": cross_bytes, "avg_launch_us": cross_us}
-        params_step = 15201664  # decoder weights read once per step, elements
-        bytes_step = params_step * es + 6 * (cross_bytes + self_bytes)
+                           "algorithmic_bytes_per_launch": cross_bytes, "avg_launch_us": cross_us,
+                           # the PATH's fraction (all 20 kernels of a decode step, averaged over the 1023 steps of a run):
+                           "step_frac": step_gbs / HBM_PEAK_GBS, "step_achieved": step_gbs,
+                           "step_algorithmic_bytes": step_bytes, "step_mean_us": mean_step_us}
         out["extras"] = {
             "frontend_ms": fe_ms, "encoder_plus_crosskv_ms": enc_ms,
-            "decode_s": t_dec - (fe_ms + enc_ms) * 0.0, "generate_from_embeds_s": t_dec,
+            "encoder_TFLOPs": B * 35.17e9 / (enc_ms * 1e-3) / 1e12,
+            "generate_from_embeds_s": t_dec,
             "self_attn_us_at_t512": self_us, "self_attn_GBs": self_bytes / (self_us * 1e-6) / 1e9,
             "decode_step_us_at_t512": step_us,
-            "decode_step_algorithmic_GBs": bytes_step / (step_us * 1e-6) / 1e9,
-            "frontend_GBs": B * (4 * N_SAMPLES + 4 * 862 * 384) / (fe_ms * 1e-3) / 1e9,
+            "frontend_GBs": B * (4 * N_SAMPLES + 4 * N_FRAMES * 384) / (fe_ms * 1e-3) / 1e9,
         }
+
+    # ---- BASELINE configs[1]: the log-mel kernel alone, 64 clips, beside torch.stft on the host ----
+    if rank == 0 and world == 1 and not args.no_frontend:
+        Bf = 64
+        wav64 = torch.from_numpy(synth.waveform_batch(0, Bf, N_SAMPLES)).to(dev)
+        buf = torch.empty((Bf, N_FRAMES, geom.d_model), device=dev, dtype=torch.float32)
+        for _ in range(3):
+            model.spectrogram.forward_into(wav64, buf, 0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        iters = 50
+        e0.record()      # the frontend is launched on torch's current stream, so torch events bracket it
+        for _ in range(iters):
+            model.spectrogram.forward_into(wav64, buf, 0)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        us = e0.elapsed_time(e1) * 1e3 / iters
+        nbytes = Bf * (4 * N_SAMPLES + 4 * N_FRAMES * 384)
+        rec = {"workload": f"BASELINE configs[1]: STFT + log-mel kernel only, batch {Bf} x {N_SAMPLES} samples",
+               "us_per_launch": us, "clips_per_s": Bf / (us * 1e-6), "algorithmic_bytes": nbytes,
+               "achieved_GBs": nbytes / (us * 1e-6) / 1e9, "hbm_frac": nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+               "fp32_TFLOPs": Bf * 56.8e6 / (us * 1e-6) / 1e12, "valu_frac_of_157TF": Bf * 56.8e6 / (us * 1e-6) / 157e12}
+        if args.cpu_tokens > 0:
+            rec["cpu_torch_stft"] = cpu_frontend_baseline(cfg, Bf)
+            rec["gpu_over_cpu"] = rec["cpu_torch_stft"]["ms_per_batch"] * 1e3 / us
+        out["frontend_configs1"] = rec
+        del wav64, buf
+
+    # ---- parity mode: fp32 (bit-exact against the fp32 reference) on the same workload ----
+    if rank == 0 and world == 1 and not args.no_parity and args.precision == "bf16":
+        ids_bf16 = model.generate(inputs, max_length=MAX_LENGTH)
+        m32 = T5Transformer(cfg.to_dict(), precision="fp32")
+        load_t5_state(m32, state, strict=False)
+        m32 = m32.to(dev).eval()
+        ids_fp32 = m32.generate(inputs, max_length=MAX_LENGTH)   # warm-up + ids
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        reps = 2
+        for _ in range(reps):
+            m32.generate(inputs, max_length=MAX_LENGTH)
+        torch.cuda.synchronize(dev)
+        dt32 = (time.perf_counter() - t1) / reps
+        L = min(ids_bf16.shape[1], ids_fp32.shape[1])
+        same = (ids_bf16[:, 1:L] == ids_fp32[:, 1:L])
+        first_div = [int((~row).nonzero()[0, 0]) + 1 if not bool(row.all()) else -1 for row in same]
+        prefix = [(d - 1 if d > 0 else L - 1) for d in first_div]
+        out["parity_mode"] = {
+            "dtype": "fp32", "tokens_per_s": B * (ids_fp32.shape[1] - 1) / dt32, "ms_per_step": dt32 * 1e3,
+            "note": "fp32 mode = greedy ids bit-identical to the fp32 reference (tests/test_golden_gpu.py); same workload",
+            "bf16_vs_fp32_id_agreement": float(same.float().mean()),
+            "bf16_vs_fp32_rows_identical": int(sum(1 for d in first_div if d < 0)),
+            "bf16_vs_fp32_first_divergence_step": first_div,
+            "bf16_vs_fp32_mean_identical_prefix": float(np.mean(prefix)),
+        }
+        del m32
+
     if rank == 0 and world == 1 and args.cpu_tokens > 0:
         out["cpu_baseline"] = cpu_baseline(cfg, state, args.cpu_tokens)
     if rank == 0:
