@@ -122,7 +122,6 @@ class Conditioning(nn.Module):
     def __init__(self, n_dim: int, num_embeds: list):
         super().__init__()
         self.n_dim = int(n_dim)
-        # num_embeds: list of dict size of each embed type
         self.embeds = nn.ModuleList([nn.Embedding(num, n_dim) for num in num_embeds])
 
     def write_rows(self, indices: torch.Tensor, out: torch.Tensor) -> torch.Tensor:

@@ -15,42 +15,13 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from .audio import load_audio as _load_audio
 from .checkpoint import load_t5_state, read_checkpoint
 from .config import load_config
 from .evaluation import evaluate_batch
 from .input import ModelInputs
 from .transformer import T5Transformer
 from .utils import numpy_to_midi
-
-
-def _load_audio(path, sr: int) -> np.ndarray:
-    """Mono float32 at ``sr``.  librosa when present (what the reference uses, model.py:84);
-    otherwise PCM WAV through the stdlib with polyphase resampling."""
-    try:
-        import librosa  # type: ignore
-        y, _ = librosa.load(str(path), sr=sr)
-        return y
-    except ImportError:
-        pass
-    import wave
-    with wave.open(str(path), "rb") as w:
-        n_ch, width, rate, n = w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()
-        raw = w.readframes(n)
-    if width == 2:
-        y = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
-    elif width == 4:
-        y = np.frombuffer(raw, dtype="<i4").astype(np.float32) / 2147483648.0
-    elif width == 1:
-        y = (np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
-    else:
-        raise ValueError(f"unsupported WAV sample width {width}")
-    y = y.reshape(-1, n_ch).mean(axis=1)
-    if rate != sr:
-        from math import gcd
-        from scipy.signal import resample_poly
-        g = gcd(int(rate), int(sr))
-        y = resample_poly(y, sr // g, rate // g).astype(np.float32)
-    return y.astype(np.float32)
 
 
 class Music2MIDI(nn.Module):
@@ -87,20 +58,24 @@ class Music2MIDI(nn.Module):
         raise NotImplementedError("training is not part of the MI355X inference hot path (SURVEY.md §8f)")
 
     def validation_step(self, inputs: ModelInputs, batch_idx):
-        outputs = self.model(inputs)
-        score, _, _ = self.evaluate_batch(inputs)
-        return outputs.loss, score
+        """ref model.py:45-54: teacher-forced loss + chroma score of a greedy decode; returns the LOSS (as the
+        reference does).  Lightning's ``self.log`` does not exist here: the two values are kept in
+        ``self.logged`` under the reference's metric names."""
+        loss = self.model(inputs).loss
+        score = self.evaluate_batch(inputs)[0]
+        self.logged = {"val/loss": float(loss), "val/score": float(score), "batch_size": int(inputs.input_waveform.shape[0])}
+        return loss
 
     # -- inference -----------------------------------------------------------
     @torch.no_grad()
     def evaluate_batch(self, inputs: ModelInputs):
-        max_num_notes = max(len(notes) for notes in inputs.notes_batch)
-        generated_outputs = self.model.generate(inputs, max_length=max_num_notes * 4)
-        decoded_notes = self.model.tokenizer.decode(generated_outputs, mode="batched")
-        label_midi = [numpy_to_midi(notes) for notes in inputs.notes_batch]
-        output_midi = [numpy_to_midi(notes) for notes in decoded_notes]
-        metrics = evaluate_batch(label_midi, output_midi)
-        return metrics, output_midi, label_midi
+        """(chroma accuracy, decoded MIDI per clip, label MIDI per clip) for one labelled batch — ref
+        model.py:55-65.  The decode budget is four tokens per label note of the busiest clip."""
+        budget = 4 * max(len(n) for n in inputs.notes_batch)
+        token_ids = self.model.generate(inputs, max_length=budget)
+        predicted = [numpy_to_midi(n) for n in self.model.tokenizer.decode(token_ids, mode="batched")]
+        wanted = [numpy_to_midi(n) for n in inputs.notes_batch]
+        return evaluate_batch(wanted, predicted), predicted, wanted
 
     def generate(self, audio_path: Optional[Union[str, Path]] = None, audio_y: Optional[np.ndarray] = None,
                  sr: Optional[int] = None, cond_index: Optional[list] = None):

@@ -14,6 +14,9 @@ What it restates (arithmetic lives in third-party packages that are NOT under
   ref: music2midi/input.py:25-41 (``torch.stft`` + ``melscale_fbanks``).
 * ``t5.py``      — transformers==4.34.0 ``T5ForConditionalGeneration`` forward
   and greedy ``generate`` as called at ref: music2midi/transformer.py:28-45.
+* ``chroma.py``  — pretty_midi==0.2.10 ``get_piano_roll(fs, times)`` + mir_eval==0.6
+  ``melody.to_cent_voicing`` / ``raw_chroma_accuracy`` as called at
+  ref: music2midi/evaluation.py:21-75 (plain loops; parity unpinned: neither package is in the image).
 
 Pinning.  The reference has no tests, golden vectors or
 fixtures, so nothing of its own pins this path.  The oracle is pinned instead
