@@ -40,7 +40,9 @@ enum {
   M2M_ERR_INVALID = -1,     /* bad argument / unsupported geometry */
   M2M_ERR_HIP = -2,         /* a HIP runtime call failed */
   M2M_ERR_NOMEM = -3,       /* workspace too small / allocation failed */
-  M2M_ERR_STATE = -4        /* call order violated (e.g. generate before encode) */
+  M2M_ERR_STATE = -4,       /* call order violated (e.g. generate before encode) */
+  M2M_ERR_RANGE = -5        /* the decoder produced a value outside its fixed-point residual range (|x| >= 2^21) or a
+                               non-finite one (corrupt checkpoint, diverged fine-tune): the token ids are NOT valid */
 };
 
 enum {
@@ -174,6 +176,9 @@ int m2m_encode(m2m_session* s, const float* inputs_embeds_dev, int B, int S, flo
  * pad, stop when every row has finished or the length reaches max_length.
  * tokens_out_dev [B, max_length] int64 (columns >= *out_len_host are pad).
  * *out_len_host: number of valid columns L <= max_length.  This call synchronises `stream`.
+ * Returns M2M_ERR_RANGE (tokens are still written) when an activation left the decoder's fixed-point range or
+ * was not finite - where the fp32 reference would have produced Inf/NaN logits.  On every error return all
+ * library-owned streams have been synchronised, so the caller may free or reuse the workspace at once.
  */
 int m2m_generate_greedy(m2m_session* s, int max_length, int64_t* tokens_out_dev, int* out_len_host, void* stream);
 

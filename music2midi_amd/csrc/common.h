@@ -5,6 +5,7 @@
 #include <hip/hip_bf16.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include <string>
 
 #include "../../include/music2midi_amd.h"
@@ -154,6 +155,19 @@ template <typename T> __device__ inline float gelu_new_t(float x) {
   if constexpr (sizeof(T) == 2) return gelu_new_fast(x);
   else return gelu_new(x);
 }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: remember it per device (a process may
+// use cuda:1 after cuda:0), race-free (the threaded Flask server calls in from several threads).
+#define M2M_OPT_IN_LDS(kernel_ptr, bytes)                                                             \
+  do {                                                                                                \
+    static std::atomic<bool> m2m_lds_set[64];                                                         \
+    int m2m_dev = 0;                                                                                  \
+    M2M_CHECK_HIP(hipGetDevice(&m2m_dev));                                                            \
+    if (m2m_dev < 0 || m2m_dev >= 64 || !m2m_lds_set[m2m_dev].load(std::memory_order_acquire)) {      \
+      M2M_CHECK_HIP(hipFuncSetAttribute((const void*)(kernel_ptr), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes))); \
+      if (m2m_dev >= 0 && m2m_dev < 64) m2m_lds_set[m2m_dev].store(true, std::memory_order_release);  \
+    }                                                                                                 \
+  } while (0)
 
 __host__ __device__ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }

@@ -69,6 +69,19 @@ __device__ inline xq_t xq_fix(float v) {
   const double m = (double)v * 1073741824.0 + 6755399441055744.0;
   return __double_as_longlong(m) - 0x4338000000000000ll;
 }
+// The same conversion with the range guarded: a value the magic-number add cannot represent (|v| >= 2^21, Inf,
+// NaN - a corrupt checkpoint, a diverged fine-tune) would otherwise become an arbitrary integer and the decoder
+// would go on emitting plausible-looking ids where the reference produces NaN logits.  Such a value is clamped
+// (NaN -> 0) and a sticky flag is raised in the chain's DecState; m2m_generate_greedy / m2m_decode_forced return
+// M2M_ERR_RANGE when they find it.  One compare per conversion; the store happens only on the failure path.
+constexpr float XQ_LIMIT = 2097152.0f;   // 2^21
+__device__ inline xq_t xq_fix_guarded(float v, DecState* st) {
+  if (!(fabsf(v) < XQ_LIMIT)) {          // also true for NaN
+    st->overflow = 1;
+    v = (v != v) ? 0.f : copysignf(XQ_LIMIT - 1.0f, v);
+  }
+  return xq_fix(v);
+}
 // via double: int64 -> f64 is 4 instructions (two 32-bit converts + fma) against ~12 for the correctly
 // rounded int64 -> f32 sequence, and the result is the same single rounding while |q| < 2^53 (|x| < 8.4e6)
 __device__ inline float xq_flt(xq_t q) { return (float)((double)q * (1.0 / 1073741824.0)); }
@@ -251,7 +264,7 @@ struct DecFfArgs {
   const void* Wi;        // [2 * d_ff, d] T, 16-row groups: 8 rows of wi_0 then the same 8 of wi_1
   const void* Wo;        // [d, d_ff] T
   int d, d_ff, B;
-  const DecState* state;
+  DecState* state;
 };
 
 #ifndef M2M_FF_ROWS
@@ -402,8 +415,8 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(1, 2)))
     for (int j = 0; j < 4; ++j) {
       const float x2 = lane_xor<32>(o[j][2]), x3 = lane_xor<32>(o[j][3]);
       const float v0 = g < 2 ? o[j][0] : x2, v1 = g < 2 ? o[j][1] : x3;
-      if (ok0) atomicAdd(reinterpret_cast<unsigned long long*>(p0 + 16 * j), (unsigned long long)xq_fix(v0));
-      if (ok1) atomicAdd(reinterpret_cast<unsigned long long*>(p0 + 16 * j + K), (unsigned long long)xq_fix(v1));
+      if (ok0) atomicAdd(reinterpret_cast<unsigned long long*>(p0 + 16 * j), (unsigned long long)xq_fix_guarded(v0, a.state));
+      if (ok1) atomicAdd(reinterpret_cast<unsigned long long*>(p0 + 16 * j + K), (unsigned long long)xq_fix_guarded(v1, a.state));
     }
   } else {
 #pragma unroll
@@ -413,7 +426,7 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(1, 2)))
       for (int i = 0; i < 4; ++i) {
         const int row = b0 + 4 * g + i;
         if (4 * g + i < FF_R && row < a.B)
-          atomicAdd(reinterpret_cast<unsigned long long*>(a.x_out + (int64_t)row * K + col), (unsigned long long)xq_fix(o[j][i]));
+          atomicAdd(reinterpret_cast<unsigned long long*>(a.x_out + (int64_t)row * K + col), (unsigned long long)xq_fix_guarded(o[j][i], a.state));
       }
     }
   }
@@ -468,7 +481,7 @@ struct DecAttnArgs {
   int bias_stride;
   const void* Wo;        // [d, inner] T output projection of this sub-layer (this head uses columns [64h, 64h+64))
   int H, inner;
-  const DecState* state;
+  DecState* state;
 };
 
 // K/V rows are read once per step.  When the per-step K/V working set is larger than the 256 MB
@@ -539,10 +552,13 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
   // PF 1 / 2 / 3 = 219.4 / 217.4 / 229.2): deeper windows flood the fabric queues ahead of the
   // latency-critical x / weight loads of workgroups that start a little later, and the whole 220 KB
   // stream at once stalls the issuing waves (prologue done at ~9 us).
-#ifndef M2M_DA_PF
-#define M2M_DA_PF 2
+#ifndef M2M_DA_PF_CROSS
+#define M2M_DA_PF_CROSS 2
 #endif
-  constexpr int PF = M2M_DA_PF;
+#ifndef M2M_DA_PF_SELF
+#define M2M_DA_PF_SELF 2
+#endif
+  constexpr int PF = SELF ? M2M_DA_PF_SELF : M2M_DA_PF_CROSS;
   constexpr int WMAX = 3;                // q weight chunks per lane held in registers (d_model 384, bf16)
   using V16 = decltype(Vec16<T>().v);
   extern __shared__ __align__(16) float hn[];   // [d] normalised input row (already rounded to T)
@@ -858,7 +874,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
     }
     accp += lane_xor<1>(accp);
     if (opart == 0 && tid < 2 * a.d && !st_done) {
-      xq_t add = xq_fix(accp);
+      xq_t add = xq_fix_guarded(accp, a.state);
       if (hh == 0) add += xres;                               // head 0 also carries the residual itself
       atomicAdd(reinterpret_cast<unsigned long long*>(a.x_out + (int64_t)b * a.d + on_), (unsigned long long)add);
       if (hh == a.H - 1) a.x_zero[(int64_t)b * a.d + on_] = 0;
@@ -938,18 +954,22 @@ __global__ __launch_bounds__(1024) void dec_head_kernel(DecHeadArgs a) {
     const int fin = a.forced ? 0 : a.finished[b];
     float best = -INFINITY;
     int bi = 0x7fffffff;
+    bool bad = false;      // a non-finite logit (NaN weights ...): the reference would emit NaN logits, never a silent token
     if (b == grp) {
 #pragma unroll
       for (int j = 0; j < HK; ++j) {
         const int v = l32 + 32 * j;
         const float x = lg0[j];
+        if (v < a.V) bad |= !(fabsf(x) <= 3.0e38f);
         if (v < a.V && (x > best || (x == best && v < bi))) { best = x; bi = v; }
       }
     }
     for (int v = l32 + (b == grp ? 32 * HK : 0); v < a.V; v += 32) {
       const float x = lg[v];
+      bad |= !(fabsf(x) <= 3.0e38f);
       if (x > best || (x == best && v < bi)) { best = x; bi = v; }
     }
+    if (bad && live) stp->overflow = 1;
     auto take = [&](float ob, int oi) {
       if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
     };
@@ -980,8 +1000,8 @@ __global__ __launch_bounds__(1024) void dec_head_kernel(DecHeadArgs a) {
       const float4 e4 = *reinterpret_cast<const float4*>(emb + c);
       xq_t* xp = a.x + (int64_t)b * a.d + c;
       if (live) {
-        *reinterpret_cast<longlong2*>(xp) = make_longlong2(xq_fix(e4.x), xq_fix(e4.y));
-        *reinterpret_cast<longlong2*>(xp + 2) = make_longlong2(xq_fix(e4.z), xq_fix(e4.w));
+        *reinterpret_cast<longlong2*>(xp) = make_longlong2(xq_fix_guarded(e4.x, stp), xq_fix_guarded(e4.y, stp));
+        *reinterpret_cast<longlong2*>(xp + 2) = make_longlong2(xq_fix_guarded(e4.z, stp), xq_fix_guarded(e4.w, stp));
       }
     }
   }
@@ -1013,7 +1033,7 @@ __global__ void dec_init_kernel(DecHeadArgs a, int start_id, int max_steps) {
     const int b = i / a.d, c = i - b * a.d;
     int tok = a.forced ? (int)a.forced[(int64_t)b * a.Ld] : start_id;
     if (tok < 0 || tok >= a.V) tok = a.pad_id;
-    a.x[i] = xq_fix(a.shared[(int64_t)tok * a.d + c]);
+    a.x[i] = xq_fix_guarded(a.shared[(int64_t)tok * a.d + c], a.state);
     a.x_zero[i] = 0;
   }
 }
@@ -1035,6 +1055,8 @@ static DecHeadArgs head_args(m2m_session* s, const DecView& v, bool forced, floa
 
 int decode_init(m2m_session* s, const DecView& v, int max_steps, bool forced, hipStream_t st) {
   DecHeadArgs h = head_args(s, v, forced, nullptr, forced ? max_steps : 0);
+  // the sticky range flag is cleared here, not by the init kernel: that kernel's own embedding conversions may raise it
+  M2M_CHECK_HIP(hipMemsetAsync(v.state, 0, sizeof(DecState), st));
   hipLaunchKernelGGL(dec_init_kernel, dim3(32), dim3(256), 0, st, h, s->m->g.decoder_start_token_id, max_steps);
   M2M_CHECK_HIP(hipGetLastError());
   return M2M_OK;

@@ -563,11 +563,7 @@ static int launch_attn_tt(const AttnArgs& a, hipStream_t st) {
   using Cfg = AttnCfg<T>;
   const size_t smem = (size_t)(AK * Cfg::KP + DK * Cfg::VP) * sizeof(T) + (BIAS ? (size_t)(a.Sq + a.Sk - 1 + TB_PAD) * sizeof(float) : 0);
   M2M_REQUIRE(smem <= 150 * 1024, "attention: Sq=%d, Sk=%d too long for the LDS bias table", a.Sq, a.Sk);
-  static bool attr_set = false;
-  if (!attr_set) {
-    M2M_CHECK_HIP(hipFuncSetAttribute((const void*)attn_kernel<T, CAUSAL, BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  M2M_OPT_IN_LDS((attn_kernel<T, CAUSAL, BIAS>), 160 * 1024);
   dim3 grid((unsigned)(ceil_div(a.Sq, AQ) * ceil_div(a.B * a.H, 8) * 8));
   hipLaunchKernelGGL((attn_kernel<T, CAUSAL, BIAS>), grid, dim3(256), smem, st, a);
   M2M_CHECK_HIP(hipGetLastError());

@@ -402,11 +402,7 @@ extern "C" int m2m_logmel_f32(const m2m_frontend* fe, const float* wav_dev, int 
   while (FR > 4 && frontend_smem_bytes(FR, fe->hop, fe->nnz) > 78 * 1024) FR -= 4;
   const size_t smem = frontend_smem_bytes(FR, fe->hop, fe->nnz);
   dim3 grid((unsigned)ceil_div(F, FR), (unsigned)B);
-  static bool attr_set = false;
-  if (!attr_set) {
-    M2M_CHECK_HIP(hipFuncSetAttribute((const void*)logmel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  M2M_OPT_IN_LDS(logmel_kernel, 160 * 1024);
   hipLaunchKernelGGL(logmel_kernel, grid, dim3(FE_THREADS), smem, (hipStream_t)stream, wav_dev, T, F, fe->dev,
                      out_dev, out_batch_stride, row_offset, FR, fe->nnz);
   M2M_CHECK_HIP(hipGetLastError());

@@ -61,7 +61,8 @@ struct DecState {
   int out_len;       // valid columns of the token matrix once done
   int n_unfinished;
   int max_steps;     // steps after which the loop must stop (max_length - 1)
-  int pad[3];
+  int overflow;      // sticky: a value outside the fixed-point residual range (|v| >= 2^21, Inf, NaN) was produced
+  int pad[2];
 };
 
 }  // namespace m2m

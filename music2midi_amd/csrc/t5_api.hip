@@ -379,11 +379,27 @@ static int ensure_graph(m2m_session* s, DecGroup& gr, int steps) {
   return M2M_OK;
 }
 
+// Nothing of a failed call may still be running when it returns: the caller owns the workspace and may free or
+// regrow it at once.  Errors are rare, so the blanket synchronisation of every chain stream costs nothing.
+static void quiesce(m2m_session* s, hipStream_t caller) {
+  for (int i = 0; i < MAX_GROUPS; ++i)
+    if (s->groups[i].stream) (void)hipStreamSynchronize(s->groups[i].stream);
+  (void)hipStreamSynchronize(caller);
+  (void)hipGetLastError();
+}
+
+static int generate_greedy_impl(m2m_session* s, int max_length, int64_t* tokens_out_dev, int* out_len_host, hipStream_t caller);
+
 extern "C" int m2m_generate_greedy(m2m_session* s, int max_length, int64_t* tokens_out_dev, int* out_len_host, void* stream) {
   M2M_REQUIRE(s && tokens_out_dev && out_len_host, "m2m_generate_greedy: null argument");
   if (!s->encoded) { set_error("m2m_generate_greedy: call m2m_encode first"); return M2M_ERR_STATE; }
   M2M_REQUIRE(max_length >= 1 && max_length <= s->max_dec, "m2m_generate_greedy: max_length %d outside [1, %d]", max_length, s->max_dec);
-  hipStream_t caller = (hipStream_t)stream;
+  const int rc = generate_greedy_impl(s, max_length, tokens_out_dev, out_len_host, (hipStream_t)stream);
+  if (rc != M2M_OK) quiesce(s, (hipStream_t)stream);
+  return rc;
+}
+
+static int generate_greedy_impl(m2m_session* s, int max_length, int64_t* tokens_out_dev, int* out_len_host, hipStream_t caller) {
   const int steps = max_length - 1;
   const int G = plan_groups(s);
   const bool graph = use_graph();
@@ -429,18 +445,25 @@ extern "C" int m2m_generate_greedy(m2m_session* s, int max_length, int64_t* toke
   }
   // valid length = the longest chain (one process decoding the whole batch stops when EVERY row has finished)
   int out_len = 1;
+  bool range_error = false;
   for (int i = 0; i < G; ++i) {
     DecGroup& gr = s->groups[i];
     M2M_CHECK_HIP(hipMemcpyAsync(gr.state_host, gr.view.state, sizeof(DecState), hipMemcpyDeviceToHost, gr.stream));
     M2M_CHECK_HIP(hipStreamSynchronize(gr.stream));
     const int l = steps == 0 ? 1 : gr.state_host->out_len;
     if (l > out_len) out_len = l;
+    range_error |= gr.state_host->overflow != 0;
   }
   // pack [B, max_dec] -> caller's [B, max_length] on the caller's stream (all chains are idle now)
   M2M_CHECK_HIP(hipMemcpy2DAsync(tokens_out_dev, (size_t)max_length * 8, s->tokens, (size_t)s->max_dec * 8,
                                  (size_t)max_length * 8, (size_t)s->B, hipMemcpyDeviceToDevice, caller));
   M2M_CHECK_HIP(hipStreamSynchronize(caller));
   *out_len_host = out_len;
+  if (range_error) {
+    set_error("m2m_generate_greedy: a decoder activation left the fixed-point residual range (|x| >= 2^21) or was not finite; "
+              "the fp32 reference would produce Inf/NaN logits here - token ids are not valid (check the checkpoint)");
+    return M2M_ERR_RANGE;
+  }
   return M2M_OK;
 }
 
@@ -520,6 +543,13 @@ extern "C" int m2m_decode_forced(m2m_session* s, const int64_t* dec_input_ids_de
   if ((rc = decode_init(s, all, Ld, true, st))) return rc;
   for (int t = 0; t < Ld; ++t)
     if ((rc = decode_launch_step(s, all, true, logits_out_dev, Ld, st))) return rc;
+  DecState hs{};
+  M2M_CHECK_HIP(hipMemcpyAsync(&hs, all.state, sizeof(hs), hipMemcpyDeviceToHost, st));
+  M2M_CHECK_HIP(hipStreamSynchronize(st));
+  if (hs.overflow) {
+    set_error("m2m_decode_forced: a decoder activation left the fixed-point residual range (|x| >= 2^21) or was not finite");
+    return M2M_ERR_RANGE;
+  }
   return M2M_OK;
 }
 

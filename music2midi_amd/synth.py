@@ -70,6 +70,9 @@ def waveform(clip_index: int, n_samples: int, kind: str = "noise") -> np.ndarray
     ``noise``  : U[-1, 1) white noise, seed = clip index.
     ``tones``  : three sinusoids with a silent tail (exercises the 1e-6 clamp).
     ``zeros``  : digital silence (every log-mel value must be log(1e-6)).
+    ``music``  : piano-like material — ~4 notes per second, each six decaying harmonics of a pitch in
+                 MIDI 40..87 with random phases, peak 0.9, and a digitally silent last 15 % (the input
+                 class the model actually sees: tonal, wide in-frame dynamic range, silence).
     """
     if kind == "noise":
         return (uniform01(clip_index, "waveform", n_samples) * 2.0 - 1.0).astype(np.float32)
@@ -82,6 +85,25 @@ def waveform(clip_index: int, n_samples: int, kind: str = "noise") -> np.ndarray
         y = 0.5 * np.sin(2 * np.pi * f[0] * t / sr) + 0.3 * np.sin(2 * np.pi * f[1] * t / sr)
         y += 0.15 * np.sin(2 * np.pi * f[2] * t / sr + 0.7)
         y[(n_samples * 3) // 4:] = 0.0
+        return y.astype(np.float32)
+    if kind == "music":
+        sr = 16000.0
+        t = np.arange(n_samples, dtype=np.float64) / sr
+        n_notes = max(3, int(n_samples / sr * 4))
+        u = uniform01(clip_index, "music", n_notes * 9).reshape(n_notes, 9)
+        y = np.zeros(n_samples, dtype=np.float64)
+        for on_u, pitch_u, dur_u, *phases in u:
+            on = on_u * (n_samples / sr) * 0.8
+            f0 = 440.0 * 2.0 ** ((40 + int(pitch_u * 48) - 69) / 12.0)
+            dur = 0.2 + dur_u
+            env = np.where((t >= on) & (t < on + dur), np.exp(-(t - on) / (dur / 3.0)), 0.0)
+            for h in range(1, 7):
+                if f0 * h < sr / 2:
+                    y += (0.3 / h) * env * np.sin(2.0 * np.pi * f0 * h * (t - on) + 2.0 * np.pi * phases[h - 1])
+        y[int(n_samples * 0.85):] = 0.0
+        peak = np.abs(y).max()
+        if peak > 0.9:
+            y *= 0.9 / peak
         return y.astype(np.float32)
     raise ValueError(f"unknown waveform kind {kind!r}")
 

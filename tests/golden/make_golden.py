@@ -150,7 +150,7 @@ def make_frontend(out_path):
     orc = LogMelOracle(sr, sp["n_fft"], sp["hop_length"], sp["f_min"], n_mels)
     data = dict(fb_rows=r.astype(np.int16), fb_cols=c.astype(np.int16), fb_vals=fb[r, c].astype(np.float32),
                 fb_shape=np.asarray(fb.shape, dtype=np.int32))
-    for kind in ("noise", "tones", "zeros"):
+    for kind in ("noise", "tones", "zeros", "music"):
         wav = torch.from_numpy(synth.waveform_batch(0, 2, 4096, kind))
         data[f"logmel_{kind}"] = orc(wav).numpy().astype(np.float32)             # [2, 17, 384]
         data[f"logmel64_{kind}"] = orc(wav, dtype=torch.float64).numpy().astype(np.float32)
@@ -158,6 +158,16 @@ def make_frontend(out_path):
     full = orc(wav)
     data["logmel_noise_48000_frames"] = np.asarray([0, 1, 94, 187], dtype=np.int32)
     data["logmel_noise_48000"] = full[:, [0, 1, 94, 187]].numpy().astype(np.float32)
+    # music-like material (decaying harmonic notes + digital silence) at the reference-native and the
+    # BASELINE clip length: float32 torch.stft path AND the float64 evaluation of the same formula, on
+    # sampled frames (start, onset region, middle, the silent tail, last frame)
+    for T in (48000, 220500):
+        wav = torch.from_numpy(synth.waveform_batch(3, 1, T, "music"))
+        F = 1 + T // 256
+        frames = sorted({0, 1, F // 7, F // 3, F // 2, (2 * F) // 3, int(F * 0.85) - 4, int(F * 0.85) + 9, F - 1})
+        data[f"logmel_music_{T}_frames"] = np.asarray(frames, dtype=np.int32)
+        data[f"logmel_music_{T}"] = orc(wav)[:, frames].numpy().astype(np.float32)
+        data[f"logmel64_music_{T}"] = orc(wav, dtype=torch.float64)[:, frames].numpy()          # float64 kept: the truth
     print(f"[frontend] fb nnz {len(r)} taps/filter min {np.bincount(c).min()} max {np.bincount(c).max()}")
     np.savez_compressed(out_path, **data)
 
@@ -213,9 +223,13 @@ def make_tokenizer(out_path):
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    make_tokenizer(HERE / "tokenizer_cases.json")
-    make_frontend(HERE / "frontend.npz")
-    make_t5(HERE / "t5.npz")
+    only = set(sys.argv[1:])            # e.g. `make_golden.py frontend` regenerates one fixture
+    if not only or "tokenizer" in only:
+        make_tokenizer(HERE / "tokenizer_cases.json")
+    if not only or "frontend" in only:
+        make_frontend(HERE / "frontend.npz")
+    if not only or "t5" in only:
+        make_t5(HERE / "t5.npz")
     for p in sorted(HERE.glob("*.npz")) + sorted(HERE.glob("*.json")):
         print(p.name, p.stat().st_size, "bytes")
     # never leave bytecode in the read-only reference tree

@@ -45,13 +45,39 @@ def test_fp32_device_path_reproduces_hf_goldens(golden_dir, name):
 
 
 def test_logmel_matches_golden_slices(golden_dir):
+    """Committed torch.stft outputs (float32 path and float64 truth), every input class incl. tonal ones.
+    Bins are classed by conditioning (tests/logmel_check.py): 1e-4 on the well-conditioned ones, the fp32
+    noise model on the rest; the goldens themselves are compared at 1e-4 on the well-conditioned class."""
+    from logmel_check import TOL, classify
+    from oracle.logmel import LogMelOracle
     z = np.load(golden_dir / "frontend.npz")
     fe = LogMelSpectrogram(16000, 2048, 256, 20.0, 384)
-    for kind, tol in (("noise", 1e-4), ("zeros", 0.0)):
-        out = fe(torch.from_numpy(synth.waveform_batch(0, 2, 4096, kind)).cuda()).cpu().numpy()
-        assert np.abs(out - z[f"logmel_{kind}"]).max() <= tol
-    out = fe(torch.from_numpy(synth.waveform_batch(5, 1, 48000)).cuda()).cpu().numpy()
-    assert np.abs(out[:, z["logmel_noise_48000_frames"]] - z["logmel_noise_48000"]).max() <= 1e-4
+    orc = LogMelOracle(16000, 2048, 256, 20.0, 384)
+
+    def compare(out, wav, key32, key64, frames, label):
+        _, well, bound = classify(orc, wav)
+        if frames is not None:
+            out, well, bound = out[:, frames], well[:, frames], bound[:, frames]
+        well, bound = well.numpy(), bound.numpy()
+        e32, e64 = np.abs(out - z[key32]), np.abs(out.astype(np.float64) - z[key64])
+        print(f"[golden {label}] well {100 * well.mean():.1f} %: |dev-golden32| {e32[well].max():.2e} |dev-golden64| {e64[well].max():.2e}; "
+              f"rest: {(e64[~well] / (TOL + bound[~well])).max() if (~well).any() else 0:.2f} of the noise bound")
+        assert e32[well].max() <= TOL and e64[well].max() <= TOL + 1e-6          # logmel64_* of the 4096 cases is stored as f32
+        assert not (~well).any() or (e64[~well] <= TOL + bound[~well]).all()
+
+    for kind in ("noise", "tones", "zeros", "music"):
+        wav = torch.from_numpy(synth.waveform_batch(0, 2, 4096, kind))
+        out = fe(wav.cuda()).cpu().numpy()
+        if kind == "zeros":
+            assert np.array_equal(out, z["logmel_zeros"])
+        compare(out, wav, f"logmel_{kind}", f"logmel64_{kind}", None, f"{kind} 4096")
+    wav = torch.from_numpy(synth.waveform_batch(5, 1, 48000))
+    out = fe(wav.cuda()).cpu().numpy()
+    assert np.abs(out[:, z["logmel_noise_48000_frames"]] - z["logmel_noise_48000"]).max() <= TOL
+    for T in (48000, 220500):
+        wav = torch.from_numpy(synth.waveform_batch(3, 1, T, "music"))
+        out = fe(wav.cuda()).cpu().numpy()
+        compare(out, wav, f"logmel_music_{T}", f"logmel64_music_{T}", z[f"logmel_music_{T}_frames"].tolist(), f"music {T}")
 
 
 def test_public_api_generate_and_forward_match_oracle():
@@ -163,3 +189,22 @@ def test_full_size_fp32_batch32_contains_golden_rows(golden_dir):
     want = c["ids"].astype(np.int64)
     assert ids.shape == (32, 1024)
     assert np.array_equal(ids[:2], want), f"first mismatch at {np.argwhere(ids[:2] != want)[:1]}"
+
+
+def test_bf16_vs_fp32_ids_at_headline_geometry():
+    """S=864, 1024 tokens: how far the bf16 throughput mode follows the bit-exact fp32 mode on random-init weights
+    (top-2 logit margins go down to 0.002, so the two modes MUST part somewhere; bench.py reports the same
+    figures for the full 32-clip batch).  Asserted: identical start, every row follows fp32 for a non-trivial prefix
+    on average, and where a row diverges it stays a valid token stream."""
+    m16, _, g = build(DEFAULT_CONFIG, "bf16")
+    m32, _, _ = build(DEFAULT_CONFIG, "fp32")
+    B = 8
+    x = embeds(B, 864, g.d_model, seed=11).cuda()
+    a = m16.generate_from_embeds(x, max_length=1024).cpu()
+    b = m32.generate_from_embeds(x, max_length=1024).cpu()
+    L = min(a.shape[1], b.shape[1])
+    same = a[:, :L] == b[:, :L]
+    first = [int((~r).nonzero()[0, 0]) if not bool(r.all()) else L for r in same]
+    print(f"bf16 vs fp32 at S=864: first divergence per row {first}, token agreement {same.float().mean():.3f}")
+    assert all(f >= 1 for f in first) and sum(first) / B >= 8
+    assert a.min() >= 0 and a.max() < g.vocab_size

@@ -174,3 +174,63 @@ def test_other_geometries(d_model, d_ff, heads, layers, precision):
                 if out[b, t] != ref[b, t]:
                     assert margins[b, t - 1] < 0.5
                     break
+
+
+# ------------------------------------------------------------------ fixed-point residual range guard
+def _generate_with(sd_edit, precision="fp32"):
+    from music2midi_amd import native
+    cfg = tiny_config()
+    geom = T5Geometry(load_config(cfg).model.t5)
+    sd = synth.t5_state_dict(geom, seed=0)
+    sd_edit(sd)
+    model = T5Transformer(cfg, precision=precision)
+    load_t5_state(model, sd, strict=False)
+    model = model.cuda().eval()
+    x = embeds(3, 19, geom.d_model).cuda()
+    return model, x, native
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_out_of_range_residual_is_an_error_not_silent_garbage(precision):
+    """The decoder's residual stream is int64 fixed point, valid for |x| < 2^21.  Weights that push it past that
+    (or Inf/NaN weights) must surface as M2M_ERR_RANGE (-5) — the fp32 reference would give Inf/NaN logits —
+    and the session must stay usable afterwards."""
+    def huge_embedding(sd):
+        sd["transformer.shared.weight"] = sd["transformer.shared.weight"] * 4.0e6        # |x| ~ 4e6 > 2^21
+    model, x, native = _generate_with(huge_embedding, precision)
+    with pytest.raises(native.NativeError, match=r"status -5.*fixed-point residual range"):
+        model.generate_from_embeds(x, max_length=12)
+
+    def inf_in_a_decoder_weight(sd):
+        sd["transformer.decoder.block.1.layer.2.DenseReluDense.wo.weight"][7, 5] = np.inf
+    model, x, native = _generate_with(inf_in_a_decoder_weight, precision)
+    with pytest.raises(native.NativeError, match="status -5"):
+        model.generate_from_embeds(x, max_length=12)
+
+    def nan_in_the_head(sd):
+        sd["transformer.lm_head.weight"][11, 3] = np.nan
+    model, x, native = _generate_with(nan_in_the_head, precision)
+    with pytest.raises(native.NativeError, match="status -5"):
+        model.generate_from_embeds(x, max_length=12)
+
+    # large but legal activations (|x| ~ 1e5) are fine, and a clean run after a failed one works on the same process
+    def big_but_legal(sd):
+        sd["transformer.shared.weight"] = sd["transformer.shared.weight"] * 3.0e4
+    model, x, native = _generate_with(big_but_legal, precision)
+    ids = model.generate_from_embeds(x, max_length=12)
+    assert ids.shape == (3, 12) and torch.equal(ids, model.generate_from_embeds(x, max_length=12))
+
+
+def test_large_activation_fp32_still_matches_oracle():
+    """Residual values up to ~1e5 (2^-30 resolution, 2^21 range): ids still bit-equal to the fp32 oracle."""
+    cfg = tiny_config()
+    geom = T5Geometry(load_config(cfg).model.t5)
+    sd = synth.t5_state_dict(geom, seed=0)
+    synth.perturb_layer_norms(sd, 0)
+    sd["transformer.shared.weight"] = sd["transformer.shared.weight"] * 2.0e3
+    model = T5Transformer(cfg, precision="fp32")
+    load_t5_state(model, sd, strict=False)
+    model = model.cuda().eval()
+    from oracle.t5 import T5Oracle
+    x = embeds(3, 19, geom.d_model)
+    assert torch.equal(model.generate_from_embeds(x.cuda(), max_length=24).cpu(), T5Oracle(geom, sd).generate(x, 24))
