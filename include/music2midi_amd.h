@@ -190,6 +190,62 @@ int m2m_generate_greedy(m2m_session* s, int max_length, int64_t* tokens_out_dev,
 int m2m_decode_forced(m2m_session* s, const int64_t* dec_input_ids_dev, int Ld, float* logits_out_dev, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * Training step: what ref: music2midi/model.py:27-43 drives through Lightning —
+ * `self.model(inputs).loss` (ref: music2midi/transformer.py:28-39: HF T5 forward with labels),
+ * `loss.backward()`, and `Adafactor(self.parameters(), warmup_init=True).step()` with
+ * `AdafactorSchedule` (relative step, no external learning rate).
+ *
+ * Parameters and gradients live in two caller-owned flat fp32 device buffers of
+ * m2m_trainer_num_params() floats; m2m_trainer_tensor_info() gives every tensor's state-dict key
+ * (relative to the LightningModule's `model.` prefix), shape and offset, so the host framework can
+ * expose views of the same memory as its parameters.  q/k/v (and wi_0/wi_1, cross k/v) of a layer
+ * are adjacent so that each fused projection is one matrix.  The library owns the activations,
+ * the bf16 copy of the weights (throughput mode) and the optimizer state.
+ * ------------------------------------------------------------------------- */
+typedef struct m2m_trainer m2m_trainer;
+
+typedef struct {
+  char name[160];           /* e.g. "transformer.encoder.block.0.layer.0.SelfAttention.q.weight" */
+  int64_t offset;           /* floats into the flat buffers */
+  int rows, cols;           /* 1-D tensors: rows = length, cols = 0 */
+} m2m_tensor_info;
+
+/* n_cond / cond_rows_host: the conditioning embedding tables (ref: music2midi/input.py:45-55), trainable.
+ * max_*: largest batch, encoder length (cond rows + frames) and label length of a step. */
+int  m2m_trainer_create(const m2m_t5_geometry* geom, int n_cond, const int* cond_rows_host, int precision,
+                        int max_batch, int max_enc_len, int max_dec_len, m2m_trainer** out);
+void m2m_trainer_destroy(m2m_trainer* t);
+int64_t m2m_trainer_num_params(const m2m_trainer* t);
+int  m2m_trainer_num_tensors(const m2m_trainer* t);
+int  m2m_trainer_tensor_info(const m2m_trainer* t, int index, m2m_tensor_info* out);
+int64_t m2m_trainer_workspace_bytes(const m2m_trainer* t);   /* device bytes the trainer holds (activations etc.) */
+
+/*
+ * Teacher-forced forward + backward.
+ * enc_inputs_dev [B, S, d_model] fp32: log-mel rows at [n_cond, S) as m2m_logmel_f32 writes them; rows
+ *                [0, n_cond) are overwritten from the CURRENT conditioning tables (they are trainable).
+ * cond_idx_dev   [B, n_cond] int64.        labels_dev [B, Ld] int64, -100 = ignored
+ *                (decoder inputs = shift_right(labels), hf: modeling_t5.py:618-637).
+ * loss_out_dev   fp32[1]: mean cross entropy over the non-ignored labels.
+ * grads_dev      flat fp32, OVERWRITTEN with d loss / d params; NULL = forward only.
+ * logits_out_dev optional [B, Ld, V] fp32.
+ * Deterministic: every reduction has a fixed order, two calls give bit-identical results.
+ */
+int m2m_train_forward_backward(m2m_trainer* t, const float* params_dev, const float* enc_inputs_dev,
+                               const int64_t* cond_idx_dev, const int64_t* labels_dev, int B, int S, int Ld,
+                               float* loss_out_dev, float* grads_dev, float* logits_out_dev, void* stream);
+
+/* One transformers.optimization.Adafactor step with the reference's settings (lr=None, eps=(1e-30, 1e-3),
+ * clip_threshold=1.0, decay_rate=-0.8, beta1=None, weight_decay=0, scale_parameter, relative_step,
+ * warmup_init): params_dev is updated in place from grads_dev.  The step counter and the factored second
+ * moments are library-owned; export/import them to checkpoint a run. */
+int m2m_adafactor_step(m2m_trainer* t, float* params_dev, const float* grads_dev, void* stream);
+int m2m_adafactor_get_step(const m2m_trainer* t);
+int64_t m2m_adafactor_state_floats(const m2m_trainer* t);
+int m2m_adafactor_state_export(const m2m_trainer* t, float* state_out_dev, void* stream);
+int m2m_adafactor_state_import(m2m_trainer* t, const float* state_in_dev, int step, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Measurement hooks (bench.py): time one kernel of the decode step in isolation
  * with hipEvents on `stream`, cycling through all decoder layers so the working
  * set matches the real loop.  Requires a prior m2m_encode on the session.

@@ -1,0 +1,49 @@
+// Internal structures of the training path (train.hip); not part of the C ABI.
+#pragma once
+
+#include "common.h"
+
+namespace m2m {
+
+enum { TG_STORE_T = 0, TG_STORE_F32 = 1, TG_ACC_F32 = 2, TG_RESID_F32 = 3 };
+
+// C[z][M,N] (op)= alpha * A[z][M,K] . B[z][N,K]^T ; z = (b1, b2)
+struct BGemmArgs {
+  const void* A;
+  const void* B;
+  void* C;
+  const float* R;          // TG_RESID_F32: C = R + acc (same indexing as C)
+  int M, N, K;
+  int64_t lda, ldb, ldc;   // elements between consecutive rows AS STORED
+  int a_kmajor, b_kmajor;  // 0: element (m, k) at [m*ld + k]; 1: at [k*ld + m]
+  int nb1, nb2;
+  int64_t sA1, sA2, sB1, sB2, sC1, sC2;
+  float alpha;
+};
+int launch_bgemm(int precision, int epi, const BGemmArgs& g, hipStream_t st);
+
+// Adafactor plan (device tables built once per trainer)
+struct AfTensor {
+  int64_t offset;          // into the flat parameter / gradient buffers
+  int rows, cols;          // vectors: rows = 1
+  int row_off;             // into rowsum / rfac
+  int cfac_off;            // into cfac
+  int64_t col_off;         // into colpart (nblocks * cols floats)
+  int64_t state_off;       // into the optimizer state (matrix: R[rows] | C[cols]; vector: V[cols])
+  int block0, nblocks;
+};
+struct AfBlock {
+  int tensor, row0;
+  int64_t col_off;
+};
+struct AfPlan {
+  int n_tensors = 0, n_blocks = 0;
+  AfTensor* tensors = nullptr;
+  AfBlock* blocks = nullptr;
+  float *rowsum = nullptr, *colpart = nullptr, *blk_a = nullptr, *blk_b = nullptr, *state = nullptr, *rfac = nullptr,
+        *cfac = nullptr, *tstat = nullptr;
+  int64_t state_floats = 0;
+};
+int launch_adafactor(const AfPlan& pl, float* P, const float* G, int step, hipStream_t st);
+
+}  // namespace m2m

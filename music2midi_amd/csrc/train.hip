@@ -1,0 +1,1173 @@
+// Training-step kernels: what `loss.backward()` + `Adafactor.step()` run for
+// ref: music2midi/model.py:27-43 (training_step -> T5Transformer.forward with labels, ref transformer.py:28-39;
+// optimizer = transformers Adafactor(warmup_init=True) + AdafactorSchedule), written for gfx950.
+//
+// Layout rules of the training path (train_api.hip drives these kernels):
+//   * every activation is a plain row-major [rows, features] matrix — fp32 for the residual stream, its
+//     gradient and the logits, storage type T (bf16, or fp32 in the parity mode) for every GEMM input;
+//   * attention is done with MATERIALISED probabilities: training sequences are short (S = 190..261 encoder
+//     positions, <= ~360 labels), so P [B,H,Sq,Sk] is a few MB per layer and the backward is four batched
+//     GEMMs + one row kernel instead of a second flash kernel;
+//   * ONE strided/batched MFMA GEMM (`bgemm_kernel`) serves every product of the forward and the backward:
+//     either operand may be stored k-major ("transposed"), so dX = dY . W and dW = dY^T . X read the same
+//     buffers the forward wrote — no transposed copies of weights or activations exist;
+//   * every reduction has a fixed order (per-block partials + a second pass, never float atomics), so a
+//     training step is bit-reproducible run to run.
+#include "mma.h"
+#include "t5.h"
+#include "train.h"
+
+#include <math.h>
+#include <string.h>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace m2m {
+
+// ============================================================ strided batched GEMM ====
+// C[z][M,N] (op)= alpha * A[z][M,K] . B[z][N,K]^T,  z = (b1, b2) with independent strides per operand.
+// 64x64 output tile per 256-thread workgroup (2x2 waves, one 32x32 MFMA tile each), BK = 32.
+// Operand storage: a_kmajor == 0: element (m, k) at A[m*lda + k]; a_kmajor == 1: at A[k*lda + m]
+// (the transposed product reads the buffer as it is: the tile is transposed on its way into LDS).
+constexpr int TG_BM = 64, TG_BN = 64, TG_BK = 32;
+
+template <typename T> struct TgCfg;
+template <> struct TgCfg<bf16_t> { static constexpr int E = 8, PITCH = TG_BK + 8; };
+template <> struct TgCfg<float> { static constexpr int E = 4, PITCH = TG_BK + 4; };
+
+// one operand tile [64 rows][32 k] -> LDS (row-major, k contiguous), zero-filled outside (rows_valid, k_valid)
+template <typename T>
+__device__ inline void tg_stage(T* __restrict__ S, const T* __restrict__ G, int64_t ld, int kmajor, int row0, int k0,
+                                int rows, int K, int tid) {
+  using Cfg = TgCfg<T>;
+  constexpr int E = Cfg::E;
+  if (!kmajor) {
+    constexpr int CPR = TG_BK / E;                      // chunks per row
+    for (int c = tid; c < TG_BM * CPR; c += 256) {
+      const int rl = c / CPR, kc = (c % CPR) * E;
+      const int row = row0 + rl, k = k0 + kc;
+      T* dst = S + rl * Cfg::PITCH + kc;
+      if (row < rows && k + E <= K) {
+        *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(G + (int64_t)row * ld + k);
+      } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e) dst[e] = (row < rows && k + e < K) ? G[(int64_t)row * ld + k + e] : from_f32<T>(0.f);
+      }
+    }
+  } else {
+    constexpr int CPK = TG_BM / E;                      // chunks per k-row (along the 64 "rows" of the tile)
+    for (int c = tid; c < TG_BK * CPK; c += 256) {
+      const int kl = c / CPK, rc = (c % CPK) * E;
+      const int k = k0 + kl, row = row0 + rc;
+      if (k < K && row + E <= rows) {
+        const uint4 v = *reinterpret_cast<const uint4*>(G + (int64_t)k * ld + row);
+        const T* ve = reinterpret_cast<const T*>(&v);
+#pragma unroll
+        for (int e = 0; e < E; ++e) S[(rc + e) * Cfg::PITCH + kl] = ve[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+          S[(rc + e) * Cfg::PITCH + kl] = (k < K && row + e < rows) ? G[(int64_t)k * ld + row + e] : from_f32<T>(0.f);
+      }
+    }
+  }
+}
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void bgemm_kernel(BGemmArgs g) {
+  using Cfg = TgCfg<T>;
+  __shared__ __align__(16) T As[TG_BM * Cfg::PITCH];
+  __shared__ __align__(16) T Bs[TG_BN * Cfg::PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int z1 = blockIdx.z / g.nb2, z2 = blockIdx.z - z1 * g.nb2;
+  const T* A = reinterpret_cast<const T*>(g.A) + z1 * g.sA1 + z2 * g.sA2;
+  const T* B = reinterpret_cast<const T*>(g.B) + z1 * g.sB1 + z2 * g.sB2;
+  const int64_t coff = z1 * g.sC1 + z2 * g.sC2;
+  const int m0 = blockIdx.y * TG_BM, n0 = blockIdx.x * TG_BN;
+
+  f32x16 acc = zero_acc();
+  for (int k0 = 0; k0 < g.K; k0 += TG_BK) {
+    __syncthreads();
+    tg_stage<T>(As, A, g.lda, g.a_kmajor, m0, k0, g.M, g.K, tid);
+    tg_stage<T>(Bs, B, g.ldb, g.b_kmajor, n0, k0, g.N, g.K, tid);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < TG_BK / 16; ++s) {
+      const Frag<T> fa = load_frag(As + (wm * 32 + r) * Cfg::PITCH + s * 16 + 8 * h);
+      const Frag<T> fb = load_frag(Bs + (wn * 32 + r) * Cfg::PITCH + s * 16 + 8 * h);
+      mma16(acc, fa, fb);
+    }
+  }
+  const int col = n0 + wn * 32 + r;
+  if (col >= g.N) return;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = m0 + wm * 32 + acc_row(i, lane);
+    if (row >= g.M) continue;
+    const int64_t at = coff + (int64_t)row * g.ldc + col;
+    const float v = g.alpha * acc[i];
+    if constexpr (EPI == TG_STORE_T) reinterpret_cast<T*>(g.C)[at] = from_f32<T>(v);
+    else if constexpr (EPI == TG_STORE_F32) reinterpret_cast<float*>(g.C)[at] = v;
+    else if constexpr (EPI == TG_ACC_F32) reinterpret_cast<float*>(g.C)[at] += v;
+    else reinterpret_cast<float*>(g.C)[at] = g.R[at] + v;                        // TG_RESID_F32: C = R + acc
+  }
+}
+
+template <typename T>
+static int launch_bgemm_t(int epi, const BGemmArgs& g, hipStream_t st) {
+  dim3 grid((unsigned)ceil_div(g.N, TG_BN), (unsigned)ceil_div(g.M, TG_BM), (unsigned)(g.nb1 * g.nb2));
+  switch (epi) {
+    case TG_STORE_T: hipLaunchKernelGGL((bgemm_kernel<T, TG_STORE_T>), grid, dim3(256), 0, st, g); break;
+    case TG_STORE_F32: hipLaunchKernelGGL((bgemm_kernel<T, TG_STORE_F32>), grid, dim3(256), 0, st, g); break;
+    case TG_ACC_F32: hipLaunchKernelGGL((bgemm_kernel<T, TG_ACC_F32>), grid, dim3(256), 0, st, g); break;
+    case TG_RESID_F32: hipLaunchKernelGGL((bgemm_kernel<T, TG_RESID_F32>), grid, dim3(256), 0, st, g); break;
+    default: set_error("bgemm: bad epilogue %d", epi); return M2M_ERR_INVALID;
+  }
+  M2M_CHECK_HIP(hipGetLastError());
+  return M2M_OK;
+}
+
+int launch_bgemm(int precision, int epi, const BGemmArgs& g, hipStream_t st) {
+  const int E = precision == M2M_PREC_BF16 ? 8 : 4;
+  M2M_REQUIRE(g.M >= 1 && g.N >= 1 && g.K >= 1 && g.nb1 >= 1 && g.nb2 >= 1, "bgemm: empty problem");
+  M2M_REQUIRE(g.lda % E == 0 && g.ldb % E == 0, "bgemm: operand row strides (%lld, %lld) must be multiples of %d elements (16-byte rows)",
+              (long long)g.lda, (long long)g.ldb, E);
+  M2M_REQUIRE(g.sA1 % E == 0 && g.sA2 % E == 0 && g.sB1 % E == 0 && g.sB2 % E == 0, "bgemm: batch strides must keep 16-byte alignment");
+  M2M_REQUIRE((int64_t)g.nb1 * g.nb2 <= 65535, "bgemm: too many batch entries");
+  return precision == M2M_PREC_BF16 ? launch_bgemm_t<bf16_t>(epi, g, st) : launch_bgemm_t<float>(epi, g, st);
+}
+
+// ============================================================ element / row kernels ====
+template <typename T>
+__global__ void cvt_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) dst[i] = from_f32<T>(src[i]);
+}
+static inline int grid_1d(int64_t n, int per_block = 256) {
+  int64_t g = (n + per_block - 1) / per_block;
+  return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+int launch_cvt(int precision, const float* src, void* dst, int64_t n, hipStream_t st) {
+  if (precision == M2M_PREC_BF16) hipLaunchKernelGGL(cvt_kernel<bf16_t>, dim3(grid_1d(n)), dim3(256), 0, st, src, (bf16_t*)dst, n);
+  else hipLaunchKernelGGL(cvt_kernel<float>, dim3(grid_1d(n)), dim3(256), 0, st, src, (float*)dst, n);
+  M2M_CHECK_HIP(hipGetLastError());
+  return M2M_OK;
+}
+
+// ---- attention probabilities: P = softmax(scores + bias) row by row (hf: modeling_t5.py:159-170: no 1/sqrt(d)) ----
+// scores fp32 [BH][Sq][ldp]; bias_tab [H][tab_stride] by (key - query) + tab_center, or null; causal: keys > query masked.
+// One wave per row; P is written in T with the padding columns [Sk, ldp) zeroed (they are GEMM operand columns).
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ sc, T* __restrict__ P, int rows_total, int H,
+                                                          int Sq, int Sk, int ldp, const float* __restrict__ bias_tab,
+                                                          int tab_stride, int tab_center, int causal) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows_total) return;
+  const int q = row % Sq, bh = row / Sq, hh = bh % H;
+  const float* s = sc + (int64_t)row * ldp;
+  T* p = P + (int64_t)row * ldp;
+  const int kend = causal ? min(Sk, q + 1) : Sk;
+  const float* bt = bias_tab ? bias_tab + (int64_t)hh * tab_stride + tab_center - q : nullptr;
+  float mx = -1e30f;
+  for (int k = lane; k < kend; k += 64) mx = fmaxf(mx, s[k] + (bt ? bt[k] : 0.f));
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int k = lane; k < kend; k += 64) sum += expf(s[k] + (bt ? bt[k] : 0.f) - mx);
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+  for (int k = lane; k < ldp; k += 64)
+    p[k] = from_f32<T>(k < kend ? expf(s[k] + (bt ? bt[k] : 0.f) - mx) * inv : 0.f);
+}
+
+// dS = P o (dP - rowsum(P o dP))   (softmax backward; P in T as the forward stored it, dP fp32), dS in T, padding zeroed
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* __restrict__ P, const float* __restrict__ dP, T* __restrict__ dS,
+                                                          int rows_total, int Sk, int ldp) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows_total) return;
+  const T* p = P + (int64_t)row * ldp;
+  const float* dp = dP + (int64_t)row * ldp;
+  T* ds = dS + (int64_t)row * ldp;
+  float t = 0.f;
+  for (int k = lane; k < Sk; k += 64) t += to_f32(p[k]) * dp[k];
+  t = wave_sum(t);
+  for (int k = lane; k < ldp; k += 64) ds[k] = from_f32<T>(k < Sk ? to_f32(p[k]) * (dp[k] - t) : 0.f);
+}
+
+// relative-position-bias gradient, stage 1: drel[h][rel] = sum over clips b and the diagonal key - query = rel - (Sq-1)
+// of dS[b,h,q,k].  One thread per (h, rel): fixed summation order.
+template <typename T>
+__global__ void bias_diag_kernel(const T* __restrict__ dS, float* __restrict__ drel, int B, int H, int Sq, int Sk, int ldp) {
+  const int nrel = Sq + Sk - 1;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= H * nrel) return;
+  const int hh = idx / nrel, rel = idx - hh * nrel;
+  const int off = rel - (Sq - 1);                              // key - query
+  const int q_lo = max(0, -off), q_hi = min(Sq, Sk - off);     // q with 0 <= q + off < Sk
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const T* base = dS + ((int64_t)(b * H + hh) * Sq) * ldp;
+    for (int q = q_lo; q < q_hi; ++q) acc += to_f32(base[(int64_t)q * ldp + q + off]);
+  }
+  drel[idx] = acc;
+}
+// stage 2: dtable[bucket][h] = sum of drel[h][rel] over the rels of that bucket (bucket_of_rel precomputed on the host)
+__global__ void bias_bucket_kernel(const float* __restrict__ drel, const int* __restrict__ bucket_of_rel, float* __restrict__ dtable,
+                                   int H, int nrel, int num_buckets, int accumulate) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= num_buckets * H) return;
+  const int bk = idx / H, hh = idx - bk * H;
+  float acc = 0.f;
+  for (int rel = 0; rel < nrel; ++rel)
+    if (bucket_of_rel[rel] == bk) acc += drel[(int64_t)hh * nrel + rel];
+  dtable[idx] = accumulate ? dtable[idx] + acc : acc;
+}
+
+// ---- gated GELU (hf: modeling_t5.py T5DenseGatedActDense: gelu_new(wi_0 x) * (wi_1 x)); ab = [a | b], [M, 2*dff] ----
+template <typename T>
+__global__ void gated_fwd_kernel(const T* __restrict__ ab, T* __restrict__ mid, int64_t M, int dff) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n = M * dff, stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const int64_t row = i / dff;
+    const int c = (int)(i - row * dff);
+    const float a = to_f32(ab[row * 2 * dff + c]), b = to_f32(ab[row * 2 * dff + dff + c]);
+    mid[i] = from_f32<T>(gelu_new(a) * b);
+  }
+}
+__device__ inline float gelu_new_grad(float x) {
+  const float k = 0.7978845608028654f;
+  const float u = k * (x + 0.044715f * x * x * x);
+  const float th = tanhf(u);
+  return 0.5f * (1.0f + th) + 0.5f * x * (1.0f - th * th) * k * (1.0f + 3.0f * 0.044715f * x * x);
+}
+template <typename T>
+__global__ void gated_bwd_kernel(const T* __restrict__ ab, const T* __restrict__ dmid, T* __restrict__ dab, int64_t M, int dff) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n = M * dff, stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const int64_t row = i / dff;
+    const int c = (int)(i - row * dff);
+    const float a = to_f32(ab[row * 2 * dff + c]), b = to_f32(ab[row * 2 * dff + dff + c]);
+    const float dm = to_f32(dmid[i]);
+    dab[row * 2 * dff + c] = from_f32<T>(dm * b * gelu_new_grad(a));
+    dab[row * 2 * dff + dff + c] = from_f32<T>(dm * gelu_new(a));
+  }
+}
+
+// ---- RMSNorm backward (forward: y = w * x * r, r = rsqrt(mean(x^2) + eps), hf: modeling_t5.py:59-72) ----
+// dx_out[row] = dx_res[row] (gradient arriving over the residual connection, may be null)
+//             + r * (w o dy) - x * r^3 * mean(w o dy o x);   dw partial per block (fixed order), reduced by colsum_kernel.
+constexpr int RN_BLOCKS = 128;
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ dy, const float* __restrict__ dx_res,
+                                                          float* __restrict__ dx_out, float* __restrict__ dw_part, int M, int d, float eps) {
+  extern __shared__ float red[];          // [4][d]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float dwacc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dwacc[j] = 0.f;
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const float* xr = x + (int64_t)row * d;
+    const float* dyr = dy + (int64_t)row * d;
+    float ss = 0.f, c = 0.f;
+    for (int col = lane * 4; col < d; col += 256) {
+      const float4 xv = *reinterpret_cast<const float4*>(xr + col);
+      const float4 gv = *reinterpret_cast<const float4*>(w + col);
+      const float4 dv = *reinterpret_cast<const float4*>(dyr + col);
+      ss += xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w;
+      c += gv.x * dv.x * xv.x + gv.y * dv.y * xv.y + gv.z * dv.z * xv.z + gv.w * dv.w * xv.w;
+    }
+    ss = wave_sum(ss);
+    c = wave_sum(c);
+    const float r = rsqrtf(ss / (float)d + eps);
+    const float k2 = r * r * r * c / (float)d;
+    int j = 0;
+    for (int col = lane * 4; col < d; col += 256, ++j) {
+      const float4 xv = *reinterpret_cast<const float4*>(xr + col);
+      const float4 gv = *reinterpret_cast<const float4*>(w + col);
+      const float4 dv = *reinterpret_cast<const float4*>(dyr + col);
+      float4 o = make_float4(r * gv.x * dv.x - xv.x * k2, r * gv.y * dv.y - xv.y * k2, r * gv.z * dv.z - xv.z * k2,
+                             r * gv.w * dv.w - xv.w * k2);
+      if (dx_res) {
+        const float4 rv = *reinterpret_cast<const float4*>(dx_res + (int64_t)row * d + col);
+        o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+      }
+      *reinterpret_cast<float4*>(dx_out + (int64_t)row * d + col) = o;
+      dwacc[4 * j + 0] += dv.x * xv.x * r; dwacc[4 * j + 1] += dv.y * xv.y * r;
+      dwacc[4 * j + 2] += dv.z * xv.z * r; dwacc[4 * j + 3] += dv.w * xv.w * r;
+    }
+  }
+  int j = 0;
+  for (int col = lane * 4; col < d; col += 256, ++j) {
+    red[wave * d + col + 0] = dwacc[4 * j + 0]; red[wave * d + col + 1] = dwacc[4 * j + 1];
+    red[wave * d + col + 2] = dwacc[4 * j + 2]; red[wave * d + col + 3] = dwacc[4 * j + 3];
+  }
+  __syncthreads();
+  for (int col = threadIdx.x; col < d; col += 256)
+    dw_part[(int64_t)blockIdx.x * d + col] = red[col] + red[d + col] + red[2 * d + col] + red[3 * d + col];
+}
+// out[col] (+)= sum over `parts` rows of part[p][col]   (second pass of every column reduction)
+__global__ void colsum_kernel(const float* __restrict__ part, float* __restrict__ out, int parts, int d, int accumulate) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= d) return;
+  float acc = 0.f;
+  for (int p = 0; p < parts; ++p) acc += part[(int64_t)p * d + col];
+  out[col] = accumulate ? out[col] + acc : acc;
+}
+
+// ---- cross entropy (mean over labels != -100, hf: modeling_t5.py:1049-1054) + gradient of the logits ----
+__global__ void count_valid_kernel(const int64_t* __restrict__ labels, int n, float* __restrict__ inv_n) {
+  __shared__ int cnt[256];
+  int c = 0;
+  for (int i = threadIdx.x; i < n; i += 256) c += labels[i] != -100;
+  cnt[threadIdx.x] = c;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) cnt[threadIdx.x] += cnt[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { inv_n[0] = cnt[0] > 0 ? 1.0f / (float)cnt[0] : 0.f; inv_n[1] = (float)cnt[0]; }
+}
+// one wave per row: row_loss[row] = logsumexp - logit[label] (0 if ignored); dlogits (T) = (softmax - onehot) / n_valid
+template <typename T>
+__global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                 const float* __restrict__ inv_n, float* __restrict__ row_loss, T* __restrict__ dlogits,
+                                                 int M, int V, int ldd) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* lg = logits + (int64_t)row * V;
+  const int64_t lab = labels[row];
+  const bool valid = lab >= 0 && lab < V;          // -100 (and anything out of range) is ignored, as torch's ignore_index
+  float mx = -1e30f;
+  for (int v = lane; v < V; v += 64) mx = fmaxf(mx, lg[v]);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int v = lane; v < V; v += 64) sum += expf(lg[v] - mx);
+  sum = wave_sum(sum);
+  const float lse = mx + logf(sum), scale = inv_n[0];
+  if (lane == 0) row_loss[row] = valid ? lse - lg[lab] : 0.f;
+  T* dl = dlogits + (int64_t)row * ldd;
+  for (int v = lane; v < ldd; v += 64) {
+    float gval = 0.f;
+    if (valid && v < V) gval = (expf(lg[v] - lse) - (v == (int)lab ? 1.f : 0.f)) * scale;
+    dl[v] = from_f32<T>(gval);
+  }
+}
+// loss = inv_n * sum(row_loss)  (single block, fixed order)
+__global__ void loss_reduce_kernel(const float* __restrict__ row_loss, int M, const float* __restrict__ inv_n, float* __restrict__ loss) {
+  __shared__ float part[256];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < M; i += 256) acc += row_loss[i];
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = part[0] * inv_n[0];
+}
+
+// ---- embeddings ----
+// conditioning rows of the encoder input: x[b, i, :] = table_i[idx[b, i], :]   (ref: music2midi/input.py:57-59)
+__global__ void cond_gather_kernel(const float* __restrict__ params, const int64_t* __restrict__ tab_off, const int* __restrict__ tab_rows,
+                                   int n_tab, const int64_t* __restrict__ idx, float* __restrict__ x, int S, int d) {
+  const int b = blockIdx.x / n_tab, i = blockIdx.x - b * n_tab;
+  int64_t id = idx[(int64_t)b * n_tab + i];
+  if (id < 0 || id >= tab_rows[i]) id = 0;
+  const float* src = params + tab_off[i] + id * d;
+  float* dst = x + ((int64_t)b * S + i) * d;
+  for (int c = threadIdx.x; c < d; c += blockDim.x) dst[c] = src[c];
+}
+// gradient of an embedding table: one block per table row scans the ids (fixed order): G[v] = sum of dx[row] with id[row] == v.
+// ids[row * id_stride + id_off] is the id of activation row (row * x_row_stride + x_row_off).
+__global__ void embed_bwd_kernel(const int64_t* __restrict__ ids, int n_ids, int id_stride, int id_off, const float* __restrict__ dx,
+                                 int64_t x_row_stride, int64_t x_row_off, float* __restrict__ gtab, int d, int pad_to_zero_id, int V) {
+  const int v = blockIdx.x;
+  for (int c = threadIdx.x; c < d; c += blockDim.x) {
+    float acc = 0.f;
+    for (int i = 0; i < n_ids; ++i) {
+      int64_t id = ids[(int64_t)i * id_stride + id_off];
+      if (id < 0 || id >= V) id = pad_to_zero_id;
+      if (id == v) acc += dx[((int64_t)i * x_row_stride + x_row_off) * d + c];
+    }
+    gtab[(int64_t)v * d + c] = acc;
+  }
+}
+// decoder input ids = shift_right(labels): start token, then labels[:-1] with -100 -> pad (hf: modeling_t5.py:618-637)
+__global__ void shift_right_kernel(const int64_t* __restrict__ labels, int64_t* __restrict__ dec_in, int B, int Ld, int start_id, int pad_id) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * Ld) return;
+  const int t = i % Ld;
+  int64_t v = t == 0 ? start_id : labels[i - 1];
+  if (v == -100) v = pad_id;
+  dec_in[i] = v;
+}
+
+// fp32 c = a + b (either may be null -> treated as 0)
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ c, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) c[i] = (a ? a[i] : 0.f) + (b ? b[i] : 0.f);
+}
+
+// ============================================================ Adafactor ====
+// transformers.optimization.Adafactor as ref: music2midi/model.py:27-30 builds it:
+//   Adafactor(params, lr=None, eps=(1e-30, 1e-3), clip_threshold=1.0, decay_rate=-0.8, beta1=None, weight_decay=0.0,
+//             scale_parameter=True, relative_step=True, warmup_init=True)
+// per tensor p with gradient g at step t (1-based):
+//   rho   = min(1e-6 * t, 1/sqrt(t))                       (relative step with warm-up init)
+//   lr    = max(1e-3, rms(p)) * rho                        (scale_parameter)
+//   b2    = 1 - t^-0.8
+//   u     = g^2 + 1e-30
+//   2-D:  R <- b2 R + (1-b2) mean_cols(u);  C <- b2 C + (1-b2) mean_rows(u);  upd = g * rsqrt(R / mean(R)) [row] * rsqrt(C) [col]
+//   1-D:  V <- b2 V + (1-b2) u;             upd = g * rsqrt(V)
+//   upd  /= max(1, rms(upd) / 1.0);   p <- p - lr * upd
+// Three passes over (p, g) with the reductions between them; one launch per pass for ALL tensors (block -> (tensor,
+// row block) through a table), every reduction in a fixed order.
+constexpr int AF_ROWS = 32;      // rows of a matrix per block (vectors: one "row" of up to AF_VEC elements per block)
+
+// pass A: per block: sum p^2, per-row sum of (g^2 + eps1) -> rowsum[tensor rows], per-block column partial sums
+__global__ __launch_bounds__(256) void af_pass_a(const AfBlock* __restrict__ blocks, const AfTensor* __restrict__ tensors,
+                                                 const float* __restrict__ P, const float* __restrict__ G, float* __restrict__ rowsum,
+                                                 float* __restrict__ colpart, float* __restrict__ blk_p2) {
+  __shared__ float sred[256];
+  const AfBlock bk = blocks[blockIdx.x];
+  const AfTensor t = tensors[bk.tensor];
+  const float* p = P + t.offset;
+  const float* g = G + t.offset;
+  float p2 = 0.f;
+  const int r1 = min(bk.row0 + AF_ROWS, t.rows);
+  // thread tid owns columns tid, tid + 256, ... ; rows are walked in order -> fixed summation order per column
+  for (int c = threadIdx.x; c < t.cols; c += 256) {
+    float cs = 0.f;
+    for (int r = bk.row0; r < r1; ++r) {
+      const float gv = g[(int64_t)r * t.cols + c], pv = p[(int64_t)r * t.cols + c];
+      cs += gv * gv + 1e-30f;
+      p2 += pv * pv;
+    }
+    colpart[bk.col_off + c] = cs;
+  }
+  // row sums: one wave per row at a time
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = bk.row0 + wave; r < r1; r += 4) {
+    float rs = 0.f;
+    for (int c = lane; c < t.cols; c += 64) { const float gv = g[(int64_t)r * t.cols + c]; rs += gv * gv + 1e-30f; }
+    rs = wave_sum(rs);
+    if (lane == 0) rowsum[t.row_off + r] = rs;
+  }
+  sred[threadIdx.x] = p2;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) sred[threadIdx.x] += sred[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) blk_p2[blockIdx.x] = sred[0];
+}
+
+// pass A2: one block per tensor: finish rms(p), update the factored second moments, derive the row / column factors
+__global__ __launch_bounds__(256) void af_pass_a2(const AfTensor* __restrict__ tensors, const float* __restrict__ rowsum,
+                                                  const float* __restrict__ colpart, const float* __restrict__ blk_p2,
+                                                  float* __restrict__ state, float* __restrict__ rfac, float* __restrict__ cfac,
+                                                  float* __restrict__ tstat, float beta2t) {
+  __shared__ float sred[256];
+  const AfTensor t = tensors[blockIdx.x];
+  float acc = 0.f;
+  for (int b = threadIdx.x; b < t.nblocks; b += 256) acc += blk_p2[t.block0 + b];
+  sred[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) sred[threadIdx.x] += sred[threadIdx.x + s]; __syncthreads(); }
+  const float p_rms = sqrtf(sred[0] / (float)((int64_t)t.rows * t.cols));
+  __syncthreads();
+  float* R = state + t.state_off;               // [rows] (matrix) or [cols] full second moment (vector: rows == 1)
+  float* C = R + t.rows;                        // [cols] (matrix only)
+  if (t.rows > 1) {
+    // rows
+    float racc = 0.f;
+    for (int r = threadIdx.x; r < t.rows; r += 256) {
+      const float v = beta2t * R[r] + (1.f - beta2t) * (rowsum[t.row_off + r] / (float)t.cols);
+      R[r] = v;
+      racc += v;
+    }
+    sred[threadIdx.x] = racc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) sred[threadIdx.x] += sred[threadIdx.x + s]; __syncthreads(); }
+    const float rmean = sred[0] / (float)t.rows;
+    __syncthreads();
+    for (int r = threadIdx.x; r < t.rows; r += 256) rfac[t.row_off + r] = rsqrtf(R[r] / rmean);
+    for (int c = threadIdx.x; c < t.cols; c += 256) {
+      float cs = 0.f;
+      for (int b = 0; b < t.nblocks; ++b) cs += colpart[t.col_off + (int64_t)b * t.cols + c];
+      const float v = beta2t * C[c] + (1.f - beta2t) * (cs / (float)t.rows);
+      C[c] = v;
+      cfac[t.cfac_off + c] = rsqrtf(v);
+    }
+  } else {
+    for (int c = threadIdx.x; c < t.cols; c += 256) {
+      const float v = beta2t * R[c] + (1.f - beta2t) * colpart[t.col_off + c];     // one block, one row: colpart = g^2 + eps
+      R[c] = v;
+      cfac[t.cfac_off + c] = rsqrtf(v);
+    }
+    if (threadIdx.x == 0) rfac[t.row_off] = 1.0f;
+  }
+  if (threadIdx.x == 0) tstat[2 * blockIdx.x] = p_rms;
+}
+
+// pass B: per block sum of upd^2, upd = g * rfac[row] * cfac[col]
+__global__ __launch_bounds__(256) void af_pass_b(const AfBlock* __restrict__ blocks, const AfTensor* __restrict__ tensors,
+                                                 const float* __restrict__ G, const float* __restrict__ rfac, const float* __restrict__ cfac,
+                                                 float* __restrict__ blk_u2) {
+  __shared__ float sred[256];
+  const AfBlock bk = blocks[blockIdx.x];
+  const AfTensor t = tensors[bk.tensor];
+  const float* g = G + t.offset;
+  const int r1 = min(bk.row0 + AF_ROWS, t.rows);
+  float u2 = 0.f;
+  for (int c = threadIdx.x; c < t.cols; c += 256) {
+    const float cf = cfac[t.cfac_off + c];
+    for (int r = bk.row0; r < r1; ++r) {
+      const float u = g[(int64_t)r * t.cols + c] * rfac[t.row_off + r] * cf;
+      u2 += u * u;
+    }
+  }
+  sred[threadIdx.x] = u2;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) sred[threadIdx.x] += sred[threadIdx.x + s]; __syncthreads(); }
+  if (threadIdx.x == 0) blk_u2[blockIdx.x] = sred[0];
+}
+// pass B2: per tensor: step size = lr / max(1, rms(upd))
+__global__ __launch_bounds__(256) void af_pass_b2(const AfTensor* __restrict__ tensors, const float* __restrict__ blk_u2,
+                                                  float* __restrict__ tstat, float rho) {
+  __shared__ float sred[256];
+  const AfTensor t = tensors[blockIdx.x];
+  float acc = 0.f;
+  for (int b = threadIdx.x; b < t.nblocks; b += 256) acc += blk_u2[t.block0 + b];
+  sred[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) sred[threadIdx.x] += sred[threadIdx.x + s]; __syncthreads(); }
+  if (threadIdx.x == 0) {
+    const float u_rms = sqrtf(sred[0] / (float)((int64_t)t.rows * t.cols));
+    const float lr = fmaxf(1e-3f, tstat[2 * blockIdx.x]) * rho;
+    tstat[2 * blockIdx.x + 1] = lr / fmaxf(1.0f, u_rms);
+  }
+}
+// pass C: p -= step * g * rfac[row] * cfac[col]
+__global__ __launch_bounds__(256) void af_pass_c(const AfBlock* __restrict__ blocks, const AfTensor* __restrict__ tensors,
+                                                 float* __restrict__ P, const float* __restrict__ G, const float* __restrict__ rfac,
+                                                 const float* __restrict__ cfac, const float* __restrict__ tstat) {
+  const AfBlock bk = blocks[blockIdx.x];
+  const AfTensor t = tensors[bk.tensor];
+  float* p = P + t.offset;
+  const float* g = G + t.offset;
+  const float step = tstat[2 * bk.tensor + 1];
+  const int r1 = min(bk.row0 + AF_ROWS, t.rows);
+  for (int r = bk.row0; r < r1; ++r) {
+    const float rf = rfac[t.row_off + r] * step;
+    for (int c = threadIdx.x; c < t.cols; c += 256) {
+      const int64_t at = (int64_t)r * t.cols + c;
+      p[at] -= g[at] * rf * cfac[t.cfac_off + c];
+    }
+  }
+}
+
+int launch_adafactor(const AfPlan& pl, float* P, const float* G, int step, hipStream_t st) {
+  const double t = (double)step;
+  const float beta2t = (float)(1.0 - pow(t, -0.8));
+  const double rho_d = fmin(1e-6 * t, 1.0 / sqrt(t));
+  const float rho = (float)rho_d;
+  hipLaunchKernelGGL(af_pass_a, dim3(pl.n_blocks), dim3(256), 0, st, pl.blocks, pl.tensors, P, G, pl.rowsum, pl.colpart, pl.blk_a);
+  hipLaunchKernelGGL(af_pass_a2, dim3(pl.n_tensors), dim3(256), 0, st, pl.tensors, pl.rowsum, pl.colpart, pl.blk_a, pl.state, pl.rfac,
+                     pl.cfac, pl.tstat, beta2t);
+  hipLaunchKernelGGL(af_pass_b, dim3(pl.n_blocks), dim3(256), 0, st, pl.blocks, pl.tensors, G, pl.rfac, pl.cfac, pl.blk_b);
+  hipLaunchKernelGGL(af_pass_b2, dim3(pl.n_tensors), dim3(256), 0, st, pl.tensors, pl.blk_b, pl.tstat, rho);
+  hipLaunchKernelGGL(af_pass_c, dim3(pl.n_blocks), dim3(256), 0, st, pl.blocks, pl.tensors, P, G, pl.rfac, pl.cfac, pl.tstat);
+  M2M_CHECK_HIP(hipGetLastError());
+  return M2M_OK;
+}
+
+
+// declared in enc_kernels.hip (the forward RMSNorm is the inference kernel)
+int launch_rmsnorm(int precision, const float* x, const float* w, void* out, int M, int d, float eps, hipStream_t st);
+int launch_embed_rows(const int64_t* ids, const float* table, float* x, int M, int d, int V, int pad_id, hipStream_t st);
+
+}  // namespace m2m
+
+// ============================================================ trainer ====
+using namespace m2m;
+
+namespace {
+
+struct TensorDesc {
+  std::string name;        // state-dict key under `model.` of the reference's LightningModule
+  int64_t off;             // floats into the flat buffers
+  int rows, cols;          // 1-D tensors: rows = length, cols = 0
+};
+
+struct EncOff { int64_t ln0, qkv, o, ln1, wi, wo; };
+struct DecOff { int64_t ln0, qkv, o, ln1, cq, ckv, co, ln2, wi, wo; };
+
+// build the relative-position tables for one (Sq, Sk) geometry: bucket of every (key - query) offset
+std::vector<int> bucket_table(const m2m_t5_geometry& g, int Sq, int Sk, bool bidirectional) {
+  std::vector<int> t((size_t)Sq + Sk - 1);
+  for (int i = 0; i < Sq + Sk - 1; ++i) t[i] = m2m_rel_bucket(i - (Sq - 1), bidirectional ? 1 : 0, g.num_buckets, g.max_distance);
+  return t;
+}
+
+}  // namespace
+
+struct m2m_trainer {
+  m2m_t5_geometry g;
+  int precision, inner, n_cond;
+  size_t es;
+  int max_batch, max_enc, max_dec;
+  std::vector<int> cond_rows;
+  std::vector<TensorDesc> tensors;
+  int64_t n_floats = 0;
+  // offsets
+  int64_t o_shared, o_lm, o_erb, o_drb, o_eln, o_dln;
+  std::vector<EncOff> enc;
+  std::vector<DecOff> dec;
+  std::vector<int64_t> o_cond;
+  // device memory owned by the trainer
+  unsigned char* arena = nullptr;
+  int64_t arena_bytes = 0;
+  void* Wc = nullptr;                    // T copy of the parameters (bf16 mode; fp32 mode reads the master buffer)
+  // activations (pointers into the arena)
+  std::vector<float*> xe, xd;            // residual streams: 2*Le + 1 and 3*Ld + 1 buffers
+  std::vector<void*> h0e, h1e, qkve, Pe, aoe, abe, mide;
+  std::vector<void*> h0d, h1d, h2d, qkvd, Pd, aod, cqd, ckvd, Pcd, aocd, abd, midd;
+  void *hE = nullptr, *hD = nullptr;
+  float *logits = nullptr, *sc = nullptr, *dxa = nullptr, *dxb = nullptr, *dh = nullptr, *dhE = nullptr, *dw_part = nullptr,
+        *row_loss = nullptr, *inv_n = nullptr, *drel = nullptr, *etab = nullptr, *dtab = nullptr;
+  void *dlog = nullptr, *dxT = nullptr, *dmid = nullptr, *dab = nullptr, *dO = nullptr, *dqkv = nullptr, *dS = nullptr, *dcq = nullptr,
+       *dckv = nullptr;
+  int64_t* dec_in = nullptr;
+  int *ebucket = nullptr, *dbucket = nullptr;
+  int64_t* cond_off_dev = nullptr;
+  int* cond_rows_dev = nullptr;
+  int tab_S = -1, tab_L = -1;            // geometry the bucket tables on the device were built for
+  // optimizer
+  AfPlan af;
+  unsigned char* af_mem = nullptr;
+  int step = 0;
+};
+
+namespace {
+
+int64_t add_tensor(m2m_trainer* t, const std::string& name, int rows, int cols, int64_t& off) {
+  const int64_t o = off;
+  t->tensors.push_back({name, o, rows, cols});
+  off = align_up(off + (int64_t)rows * (cols ? cols : 1), 64);
+  return o;
+}
+
+void build_layout(m2m_trainer* t) {
+  const m2m_t5_geometry& g = t->g;
+  const int d = g.d_model, dff = g.d_ff, inner = t->inner, V = g.vocab_size, H = g.num_heads;
+  int64_t off = 0;
+  const std::string T5 = "transformer.";
+  t->o_shared = add_tensor(t, T5 + "shared.weight", V, d, off);
+  t->o_lm = add_tensor(t, T5 + "lm_head.weight", V, d, off);
+  t->o_erb = add_tensor(t, T5 + "encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight", g.num_buckets, H, off);
+  t->o_drb = add_tensor(t, T5 + "decoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight", g.num_buckets, H, off);
+  t->o_eln = add_tensor(t, T5 + "encoder.final_layer_norm.weight", d, 0, off);
+  t->o_dln = add_tensor(t, T5 + "decoder.final_layer_norm.weight", d, 0, off);
+  auto attn3 = [&](const std::string& p, int64_t& first) {   // q, k, v back to back WITHOUT padding: one fused [3*inner, d] matrix
+    first = off;
+    for (const char* n : {"q", "k", "v"}) {
+      t->tensors.push_back({p + "." + n + ".weight", off, inner, d});
+      off += (int64_t)inner * d;
+    }
+    off = align_up(off, 64);
+  };
+  t->enc.resize(g.num_layers);
+  for (int l = 0; l < g.num_layers; ++l) {
+    const std::string p = T5 + "encoder.block." + std::to_string(l) + ".layer.";
+    EncOff& e = t->enc[l];
+    e.ln0 = add_tensor(t, p + "0.layer_norm.weight", d, 0, off);
+    attn3(p + "0.SelfAttention", e.qkv);
+    e.o = add_tensor(t, p + "0.SelfAttention.o.weight", d, inner, off);
+    e.ln1 = add_tensor(t, p + "1.layer_norm.weight", d, 0, off);
+    e.wi = off;
+    t->tensors.push_back({p + "1.DenseReluDense.wi_0.weight", off, dff, d}); off += (int64_t)dff * d;
+    t->tensors.push_back({p + "1.DenseReluDense.wi_1.weight", off, dff, d}); off = align_up(off + (int64_t)dff * d, 64);
+    e.wo = add_tensor(t, p + "1.DenseReluDense.wo.weight", d, dff, off);
+  }
+  t->dec.resize(g.num_decoder_layers);
+  for (int l = 0; l < g.num_decoder_layers; ++l) {
+    const std::string p = T5 + "decoder.block." + std::to_string(l) + ".layer.";
+    DecOff& e = t->dec[l];
+    e.ln0 = add_tensor(t, p + "0.layer_norm.weight", d, 0, off);
+    attn3(p + "0.SelfAttention", e.qkv);
+    e.o = add_tensor(t, p + "0.SelfAttention.o.weight", d, inner, off);
+    e.ln1 = add_tensor(t, p + "1.layer_norm.weight", d, 0, off);
+    e.cq = add_tensor(t, p + "1.EncDecAttention.q.weight", inner, d, off);
+    e.ckv = off;
+    t->tensors.push_back({p + "1.EncDecAttention.k.weight", off, inner, d}); off += (int64_t)inner * d;
+    t->tensors.push_back({p + "1.EncDecAttention.v.weight", off, inner, d}); off = align_up(off + (int64_t)inner * d, 64);
+    e.co = add_tensor(t, p + "1.EncDecAttention.o.weight", d, inner, off);
+    e.ln2 = add_tensor(t, p + "2.layer_norm.weight", d, 0, off);
+    e.wi = off;
+    t->tensors.push_back({p + "2.DenseReluDense.wi_0.weight", off, dff, d}); off += (int64_t)dff * d;
+    t->tensors.push_back({p + "2.DenseReluDense.wi_1.weight", off, dff, d}); off = align_up(off + (int64_t)dff * d, 64);
+    e.wo = add_tensor(t, p + "2.DenseReluDense.wo.weight", d, dff, off);
+  }
+  t->o_cond.resize(t->n_cond);
+  for (int i = 0; i < t->n_cond; ++i)
+    t->o_cond[i] = add_tensor(t, "conditioning.embeds." + std::to_string(i) + ".weight", t->cond_rows[i], d, off);
+  t->n_floats = off;
+}
+
+// -------------------------------------------------------------- arena
+struct Carver {
+  int64_t off = 0;
+  int64_t take(int64_t bytes) { const int64_t o = off; off = align_up(off + bytes, 256); return o; }
+};
+
+int build_optimizer(m2m_trainer* t) {
+  std::vector<AfTensor> at;
+  std::vector<AfBlock> ab;
+  int row_off = 0, cfac_off = 0;
+  int64_t col_off = 0, state_off = 0;
+  for (const TensorDesc& td : t->tensors) {
+    AfTensor a{};
+    a.offset = td.off;
+    a.rows = td.cols ? td.rows : 1;
+    a.cols = td.cols ? td.cols : td.rows;
+    a.row_off = row_off; a.cfac_off = cfac_off; a.col_off = col_off; a.state_off = state_off;
+    a.block0 = (int)ab.size();
+    a.nblocks = ceil_div(a.rows, 32);
+    for (int b = 0; b < a.nblocks; ++b) ab.push_back({(int)at.size(), b * 32, col_off + (int64_t)b * a.cols});
+    row_off += a.rows; cfac_off += a.cols; col_off += (int64_t)a.nblocks * a.cols;
+    state_off += (a.rows > 1 ? a.rows : 0) + a.cols;
+    at.push_back(a);
+  }
+  AfPlan& p = t->af;
+  p.n_tensors = (int)at.size(); p.n_blocks = (int)ab.size(); p.state_floats = state_off;
+  Carver c;
+  const int64_t o_t = c.take((int64_t)at.size() * sizeof(AfTensor)), o_b = c.take((int64_t)ab.size() * sizeof(AfBlock));
+  const int64_t o_rs = c.take((int64_t)row_off * 4), o_cp = c.take(col_off * 4), o_ba = c.take((int64_t)ab.size() * 4),
+                o_bb = c.take((int64_t)ab.size() * 4), o_st = c.take(state_off * 4), o_rf = c.take((int64_t)row_off * 4),
+                o_cf = c.take((int64_t)cfac_off * 4), o_ts = c.take((int64_t)at.size() * 2 * 4);
+  M2M_CHECK_HIP(hipMalloc((void**)&t->af_mem, (size_t)c.off));
+  M2M_CHECK_HIP(hipMemset(t->af_mem, 0, (size_t)c.off));
+  unsigned char* b = t->af_mem;
+  p.tensors = (AfTensor*)(b + o_t); p.blocks = (AfBlock*)(b + o_b); p.rowsum = (float*)(b + o_rs); p.colpart = (float*)(b + o_cp);
+  p.blk_a = (float*)(b + o_ba); p.blk_b = (float*)(b + o_bb); p.state = (float*)(b + o_st); p.rfac = (float*)(b + o_rf);
+  p.cfac = (float*)(b + o_cf); p.tstat = (float*)(b + o_ts);
+  M2M_CHECK_HIP(hipMemcpy(p.tensors, at.data(), at.size() * sizeof(AfTensor), hipMemcpyHostToDevice));
+  M2M_CHECK_HIP(hipMemcpy(p.blocks, ab.data(), ab.size() * sizeof(AfBlock), hipMemcpyHostToDevice));
+  return M2M_OK;
+}
+
+int build_arena(m2m_trainer* t) {
+  const m2m_t5_geometry& g = t->g;
+  const int64_t es = (int64_t)t->es, d = g.d_model, dff = g.d_ff, inner = t->inner, V = g.vocab_size, H = g.num_heads;
+  const int64_t B = t->max_batch, S = t->max_enc, L = t->max_dec;
+  const int64_t Me = B * S, Md = B * L, Mx = Me > Md ? Me : Md;
+  const int64_t lps = align_up(S, 8), lpl = align_up(L, 8), lpm = lps > lpl ? lps : lpl, Sm = S > L ? S : L;
+  const int Le = g.num_layers, Ld = g.num_decoder_layers;
+  Carver c;
+  std::vector<int64_t> o;
+  auto T = [&](int64_t elems) { return c.take(elems * es); };
+  auto F = [&](int64_t elems) { return c.take(elems * 4); };
+  // order of `o` must match the assignment below
+  for (int i = 0; i < 2 * Le + 1; ++i) o.push_back(F(Me * d));
+  for (int i = 0; i < 3 * Ld + 1; ++i) o.push_back(F(Md * d));
+  for (int l = 0; l < Le; ++l) { o.push_back(T(Me * d)); o.push_back(T(Me * d)); o.push_back(T(Me * 3 * inner)); o.push_back(T(B * H * S * lps));
+                                  o.push_back(T(Me * inner)); o.push_back(T(Me * 2 * dff)); o.push_back(T(Me * dff)); }
+  for (int l = 0; l < Ld; ++l) { o.push_back(T(Md * d)); o.push_back(T(Md * d)); o.push_back(T(Md * d)); o.push_back(T(Md * 3 * inner));
+                                  o.push_back(T(B * H * L * lpl)); o.push_back(T(Md * inner)); o.push_back(T(Md * inner)); o.push_back(T(Me * 2 * inner));
+                                  o.push_back(T(B * H * L * lps)); o.push_back(T(Md * inner)); o.push_back(T(Md * 2 * dff)); o.push_back(T(Md * dff)); }
+  const int64_t o_hE = T(Me * d), o_hD = T(Md * d), o_logits = F(Md * V), o_sc = F(B * H * Sm * lpm), o_dxa = F(Mx * d), o_dxb = F(Mx * d),
+                o_dh = F(Mx * d), o_dhE = F(Me * d), o_dwp = F((int64_t)RN_BLOCKS * d), o_rl = F(Md), o_inv = F(64), o_drel = F(H * (2 * Sm)),
+                o_etab = F(H * (2 * S)), o_dtab = F(H * (2 * L)), o_dlog = T(Md * align_up(V, 8)), o_dxT = T(Mx * d), o_dmid = T(Mx * dff),
+                o_dab = T(Mx * 2 * dff), o_dO = T(Mx * inner), o_dqkv = T(Mx * 3 * inner), o_dS = T(B * H * Sm * lpm), o_dcq = T(Md * inner),
+                o_dckv = T(Me * 2 * inner), o_decin = c.take(Md * 8), o_eb = c.take(2 * S * 4), o_db = c.take(2 * L * 4),
+                o_co = c.take(64 * 8), o_cr = c.take(64 * 4), o_wc = (t->precision == M2M_PREC_BF16) ? T(t->n_floats) : 0;
+  t->arena_bytes = c.off;
+  hipError_t e = hipMalloc((void**)&t->arena, (size_t)c.off);
+  if (e != hipSuccess) { set_error("m2m_trainer_create: hipMalloc(%lld) failed: %s", (long long)c.off, hipGetErrorString(e)); return M2M_ERR_NOMEM; }
+  M2M_CHECK_HIP(hipMemset(t->arena, 0, (size_t)c.off));
+  unsigned char* b = t->arena;
+  size_t k = 0;
+  auto nextF = [&]() { return (float*)(b + o[k++]); };
+  auto nextT = [&]() { return (void*)(b + o[k++]); };
+  for (int i = 0; i < 2 * Le + 1; ++i) t->xe.push_back(nextF());
+  for (int i = 0; i < 3 * Ld + 1; ++i) t->xd.push_back(nextF());
+  for (int l = 0; l < Le; ++l) { t->h0e.push_back(nextT()); t->h1e.push_back(nextT()); t->qkve.push_back(nextT()); t->Pe.push_back(nextT());
+                                  t->aoe.push_back(nextT()); t->abe.push_back(nextT()); t->mide.push_back(nextT()); }
+  for (int l = 0; l < Ld; ++l) { t->h0d.push_back(nextT()); t->h1d.push_back(nextT()); t->h2d.push_back(nextT()); t->qkvd.push_back(nextT());
+                                  t->Pd.push_back(nextT()); t->aod.push_back(nextT()); t->cqd.push_back(nextT()); t->ckvd.push_back(nextT());
+                                  t->Pcd.push_back(nextT()); t->aocd.push_back(nextT()); t->abd.push_back(nextT()); t->midd.push_back(nextT()); }
+  t->hE = b + o_hE; t->hD = b + o_hD; t->logits = (float*)(b + o_logits); t->sc = (float*)(b + o_sc); t->dxa = (float*)(b + o_dxa);
+  t->dxb = (float*)(b + o_dxb); t->dh = (float*)(b + o_dh); t->dhE = (float*)(b + o_dhE); t->dw_part = (float*)(b + o_dwp);
+  t->row_loss = (float*)(b + o_rl); t->inv_n = (float*)(b + o_inv); t->drel = (float*)(b + o_drel); t->etab = (float*)(b + o_etab);
+  t->dtab = (float*)(b + o_dtab); t->dlog = b + o_dlog; t->dxT = b + o_dxT; t->dmid = b + o_dmid; t->dab = b + o_dab; t->dO = b + o_dO;
+  t->dqkv = b + o_dqkv; t->dS = b + o_dS; t->dcq = b + o_dcq; t->dckv = b + o_dckv; t->dec_in = (int64_t*)(b + o_decin);
+  t->ebucket = (int*)(b + o_eb); t->dbucket = (int*)(b + o_db); t->cond_off_dev = (int64_t*)(b + o_co); t->cond_rows_dev = (int*)(b + o_cr);
+  t->Wc = (t->precision == M2M_PREC_BF16) ? (void*)(b + o_wc) : nullptr;
+  M2M_CHECK_HIP(hipMemcpy(t->cond_off_dev, t->o_cond.data(), t->o_cond.size() * 8, hipMemcpyHostToDevice));
+  M2M_CHECK_HIP(hipMemcpy(t->cond_rows_dev, t->cond_rows.data(), t->cond_rows.size() * 4, hipMemcpyHostToDevice));
+  return M2M_OK;
+}
+
+// bias table on the device from the CURRENT (trainable) bucket weights: tab[h][i] = weight[bucket_of_rel[i]][h]
+__global__ void bias_table_kernel(const float* __restrict__ weight, const int* __restrict__ bucket_of_rel, float* __restrict__ tab, int H, int nrel) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= H * nrel) return;
+  const int hh = idx / nrel, i = idx - hh * nrel;
+  tab[idx] = weight[(int64_t)bucket_of_rel[i] * H + hh];
+}
+
+// ------------------------------------------------------------ typed helpers
+template <typename T>
+struct Ops {
+  m2m_trainer* t;
+  hipStream_t st;
+  const float* P;      // master parameters (fp32)
+  const T* W(int64_t off) const { return (t->precision == M2M_PREC_BF16 ? reinterpret_cast<const T*>(t->Wc) : reinterpret_cast<const T*>(P)) + off; }
+
+  int mm(int epi, const void* A, int64_t lda, int akm, const void* B, int64_t ldb, int bkm, void* C, int64_t ldc, int M, int N, int K,
+         const float* R = nullptr) const {
+    BGemmArgs g{};
+    g.A = A; g.B = B; g.C = C; g.R = R; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.a_kmajor = akm; g.b_kmajor = bkm;
+    g.nb1 = 1; g.nb2 = 1; g.alpha = 1.0f;
+    return launch_bgemm(t->precision, epi, g, st);
+  }
+  // batched over (clip b, head h): operand X of clip b / head h starts at X + b*s1 + h*s2 (elements of its own type)
+  int mmbh(int epi, const T* A, int64_t lda, int akm, int64_t sA1, int64_t sA2, const T* B, int64_t ldb, int bkm, int64_t sB1, int64_t sB2,
+           void* C, int64_t ldc, int64_t sC1, int64_t sC2, int nB, int M, int N, int K) const {
+    BGemmArgs g{};
+    g.A = A; g.B = B; g.C = C; g.R = nullptr; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.a_kmajor = akm; g.b_kmajor = bkm;
+    g.nb1 = nB; g.nb2 = t->g.num_heads; g.sA1 = sA1; g.sA2 = sA2; g.sB1 = sB1; g.sB2 = sB2; g.sC1 = sC1; g.sC2 = sC2; g.alpha = 1.0f;
+    return launch_bgemm(t->precision, epi, g, st);
+  }
+  int cvt(const float* src, void* dst, int64_t n) const { return launch_cvt(t->precision, src, dst, n, st); }
+  int norm(const float* x, int64_t w_off, void* out, int M) const { return launch_rmsnorm(t->precision, x, P + w_off, out, M, t->g.d_model, t->g.layer_norm_eps, st); }
+  int norm_bwd(const float* x, int64_t w_off, const float* dy, const float* dx_res, float* dx_out, float* G, int M) const {
+    const int d = t->g.d_model;
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(RN_BLOCKS), dim3(256), (size_t)4 * d * sizeof(float), st, x, P + w_off, dy, dx_res, dx_out,
+                       t->dw_part, M, d, t->g.layer_norm_eps);
+    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(d, 128)), dim3(128), 0, st, t->dw_part, G + w_off, RN_BLOCKS, d, 0);
+    M2M_CHECK_HIP(hipGetLastError());
+    return M2M_OK;
+  }
+  int softmax(const float* sc, void* Pm, int nB, int Sq, int Sk, int ldp, const float* tab, int causal) const {
+    const int H = t->g.num_heads, rows = nB * H * Sq;
+    hipLaunchKernelGGL(softmax_fwd_kernel<T>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, sc, (T*)Pm, rows, H, Sq, Sk, ldp, tab, Sq + Sk - 1,
+                       Sq - 1, causal);
+    M2M_CHECK_HIP(hipGetLastError());
+    return M2M_OK;
+  }
+  int softmax_bwd(const void* Pm, const float* dP, void* dS, int rows, int Sk, int ldp) const {
+    hipLaunchKernelGGL(softmax_bwd_kernel<T>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, (const T*)Pm, dP, (T*)dS, rows, Sk, ldp);
+    M2M_CHECK_HIP(hipGetLastError());
+    return M2M_OK;
+  }
+  int gated(const void* ab, void* mid, int64_t M) const {
+    hipLaunchKernelGGL(gated_fwd_kernel<T>, dim3(grid_1d(M * t->g.d_ff)), dim3(256), 0, st, (const T*)ab, (T*)mid, M, t->g.d_ff);
+    M2M_CHECK_HIP(hipGetLastError());
+    return M2M_OK;
+  }
+  int gated_bwd(const void* ab, const void* dmid, void* dab, int64_t M) const {
+    hipLaunchKernelGGL(gated_bwd_kernel<T>, dim3(grid_1d(M * t->g.d_ff)), dim3(256), 0, st, (const T*)ab, (const T*)dmid, (T*)dab, M, t->g.d_ff);
+    M2M_CHECK_HIP(hipGetLastError());
+    return M2M_OK;
+  }
+  int bias_grad(const void* dS, const int* buckets, float* Gtab, int nB, int Sq, int Sk, int ldp, int accumulate) const {
+    const int H = t->g.num_heads, nrel = Sq + Sk - 1;
+    hipLaunchKernelGGL(bias_diag_kernel<T>, dim3(ceil_div(H * nrel, 128)), dim3(128), 0, st, (const T*)dS, t->drel, nB, H, Sq, Sk, ldp);
+    hipLaunchKernelGGL(bias_bucket_kernel, dim3(ceil_div(t->g.num_buckets * H, 64)), dim3(64), 0, st, t->drel, buckets, Gtab, H, nrel,
+                       t->g.num_buckets, accumulate);
+    M2M_CHECK_HIP(hipGetLastError());
+    return M2M_OK;
+  }
+};
+
+#define RC(expr) do { if ((rc = (expr)) != M2M_OK) return rc; } while (0)
+
+// self-attention block, forward: x_in -> x_out = x_in + Attn(norm(x_in)).  Buffers of this layer are passed in.
+template <typename T>
+int attn_self_fwd(const Ops<T>& o, const float* x_in, float* x_out, int64_t ln, int64_t wqkv, int64_t wo, void* h, void* qkv, void* Pm, void* ao,
+                  int nB, int S, const float* tab, int causal) {
+  m2m_trainer* t = o.t;
+  const int d = t->g.d_model, inner = t->inner, M = nB * S, ldp = (int)align_up(S, 8), H = t->g.num_heads;
+  int rc;
+  RC(o.norm(x_in, ln, h, M));
+  RC(o.mm(TG_STORE_T, h, d, 0, o.W(wqkv), d, 0, qkv, 3 * inner, M, 3 * inner, d));
+  const T* q = (const T*)qkv;
+  RC(o.mmbh(TG_STORE_F32, q, 3 * inner, 0, (int64_t)S * 3 * inner, DK, q + inner, 3 * inner, 0, (int64_t)S * 3 * inner, DK, t->sc, ldp,
+            (int64_t)H * S * ldp, (int64_t)S * ldp, nB, S, S, DK));
+  RC(o.softmax(t->sc, Pm, nB, S, S, ldp, tab, causal));
+  RC(o.mmbh(TG_STORE_T, (const T*)Pm, ldp, 0, (int64_t)H * S * ldp, (int64_t)S * ldp, q + 2 * inner, 3 * inner, 1, (int64_t)S * 3 * inner, DK, ao,
+            inner, (int64_t)S * inner, DK, nB, S, DK, S));
+  RC(o.mm(TG_RESID_F32, ao, inner, 0, o.W(wo), inner, 0, x_out, d, M, d, inner, x_in));
+  return M2M_OK;
+}
+
+// ... and backward: dx_out (fp32, gradient wrt x_out) -> dx_in; weight gradients into G
+template <typename T>
+int attn_self_bwd(const Ops<T>& o, const float* x_in, const float* dx_out, float* dx_in, float* G, int64_t ln, int64_t wqkv, int64_t wo,
+                  const void* h, const void* qkv, const void* Pm, const void* ao, int nB, int S, const int* buckets, int64_t bias_off,
+                  int bias_accumulate) {
+  m2m_trainer* t = o.t;
+  const int d = t->g.d_model, inner = t->inner, M = nB * S, ldp = (int)align_up(S, 8), H = t->g.num_heads;
+  int rc;
+  RC(o.cvt(dx_out, t->dxT, (int64_t)M * d));
+  RC(o.mm(TG_STORE_F32, t->dxT, d, 1, ao, inner, 1, G + wo, inner, d, inner, M));                 // dWo = dx^T . ao
+  RC(o.mm(TG_STORE_T, t->dxT, d, 0, o.W(wo), inner, 1, t->dO, inner, M, inner, d));               // dO = dx . Wo
+  const T* q = (const T*)qkv;
+  const T* dO = (const T*)t->dO;
+  T* dq = (T*)t->dqkv;
+  const int64_t sP1 = (int64_t)H * S * ldp, sP2 = (int64_t)S * ldp, sQ1 = (int64_t)S * 3 * inner, sO1 = (int64_t)S * inner;
+  RC(o.mmbh(TG_STORE_T, (const T*)Pm, ldp, 1, sP1, sP2, dO, inner, 1, sO1, DK, dq + 2 * inner, 3 * inner, sQ1, DK, nB, S, DK, S));   // dV = P^T dO
+  RC(o.mmbh(TG_STORE_F32, dO, inner, 0, sO1, DK, q + 2 * inner, 3 * inner, 0, sQ1, DK, t->sc, ldp, sP1, sP2, nB, S, S, DK));        // dP = dO V^T
+  RC(o.softmax_bwd(Pm, t->sc, t->dS, nB * H * S, S, ldp));
+  if (buckets) RC(o.bias_grad(t->dS, buckets, G + bias_off, nB, S, S, ldp, bias_accumulate));
+  const T* dS = (const T*)t->dS;
+  RC(o.mmbh(TG_STORE_T, dS, ldp, 0, sP1, sP2, q + inner, 3 * inner, 1, sQ1, DK, dq, 3 * inner, sQ1, DK, nB, S, DK, S));              // dQ = dS K
+  RC(o.mmbh(TG_STORE_T, dS, ldp, 1, sP1, sP2, q, 3 * inner, 1, sQ1, DK, dq + inner, 3 * inner, sQ1, DK, nB, S, DK, S));              // dK = dS^T Q
+  RC(o.mm(TG_STORE_F32, dq, 3 * inner, 1, h, d, 1, G + wqkv, d, 3 * inner, d, M));               // dWqkv = dqkv^T . h
+  RC(o.mm(TG_STORE_F32, dq, 3 * inner, 0, o.W(wqkv), d, 1, t->dh, d, M, d, 3 * inner));           // dh = dqkv . Wqkv
+  RC(o.norm_bwd(x_in, ln, t->dh, dx_out, dx_in, G, M));
+  return M2M_OK;
+}
+
+template <typename T>
+int ff_fwd(const Ops<T>& o, const float* x_in, float* x_out, int64_t ln, int64_t wi, int64_t wo, void* h, void* ab, void* mid, int M) {
+  m2m_trainer* t = o.t;
+  const int d = t->g.d_model, dff = t->g.d_ff;
+  int rc;
+  RC(o.norm(x_in, ln, h, M));
+  RC(o.mm(TG_STORE_T, h, d, 0, o.W(wi), d, 0, ab, 2 * dff, M, 2 * dff, d));
+  RC(o.gated(ab, mid, M));
+  RC(o.mm(TG_RESID_F32, mid, dff, 0, o.W(wo), dff, 0, x_out, d, M, d, dff, x_in));
+  return M2M_OK;
+}
+template <typename T>
+int ff_bwd(const Ops<T>& o, const float* x_in, const float* dx_out, float* dx_in, float* G, int64_t ln, int64_t wi, int64_t wo, const void* h,
+           const void* ab, const void* mid, int M) {
+  m2m_trainer* t = o.t;
+  const int d = t->g.d_model, dff = t->g.d_ff;
+  int rc;
+  RC(o.cvt(dx_out, t->dxT, (int64_t)M * d));
+  RC(o.mm(TG_STORE_F32, t->dxT, d, 1, mid, dff, 1, G + wo, dff, d, dff, M));                      // dWo = dx^T . mid
+  RC(o.mm(TG_STORE_T, t->dxT, d, 0, o.W(wo), dff, 1, t->dmid, dff, M, dff, d));                   // dmid = dx . Wo
+  RC(o.gated_bwd(ab, t->dmid, t->dab, M));
+  RC(o.mm(TG_STORE_F32, t->dab, 2 * dff, 1, h, d, 1, G + wi, d, 2 * dff, d, M));                  // dWi = dab^T . h
+  RC(o.mm(TG_STORE_F32, t->dab, 2 * dff, 0, o.W(wi), d, 1, t->dh, d, M, d, 2 * dff));             // dh = dab . Wi
+  RC(o.norm_bwd(x_in, ln, t->dh, dx_out, dx_in, G, M));
+  return M2M_OK;
+}
+
+template <typename T>
+int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, const int64_t* cond_idx, const int64_t* labels, int B, int S,
+                       int L, float* loss_out, float* G, float* logits_out, hipStream_t st) {
+  const m2m_t5_geometry& g = t->g;
+  const int d = g.d_model, inner = t->inner, V = g.vocab_size, H = g.num_heads, Le = g.num_layers, Ld = g.num_decoder_layers;
+  const int Me = B * S, Md = B * L, lps = (int)align_up(S, 8), ldv = (int)align_up(V, 8);
+  Ops<T> o{t, st, P};
+  int rc;
+  // ---- tables that depend on the geometry (host) and on the current bucket weights (device) ----
+  if (t->tab_S != S) {
+    const std::vector<int> eb = bucket_table(g, S, S, true);
+    M2M_CHECK_HIP(hipMemcpyAsync(t->ebucket, eb.data(), eb.size() * 4, hipMemcpyHostToDevice, st));
+    M2M_CHECK_HIP(hipStreamSynchronize(st));   // eb is a stack object
+    t->tab_S = S;
+  }
+  if (t->tab_L != L) {
+    const std::vector<int> db = bucket_table(g, L, L, false);
+    M2M_CHECK_HIP(hipMemcpyAsync(t->dbucket, db.data(), db.size() * 4, hipMemcpyHostToDevice, st));
+    M2M_CHECK_HIP(hipStreamSynchronize(st));
+    t->tab_L = L;
+  }
+  hipLaunchKernelGGL(bias_table_kernel, dim3(ceil_div(H * (2 * S - 1), 128)), dim3(128), 0, st, P + t->o_erb, t->ebucket, t->etab, H, 2 * S - 1);
+  hipLaunchKernelGGL(bias_table_kernel, dim3(ceil_div(H * (2 * L - 1), 128)), dim3(128), 0, st, P + t->o_drb, t->dbucket, t->dtab, H, 2 * L - 1);
+  M2M_CHECK_HIP(hipGetLastError());
+  if (t->precision == M2M_PREC_BF16) RC(o.cvt(P, t->Wc, t->n_floats));
+  M2M_CHECK_HIP(hipMemsetAsync(G, 0, (size_t)t->n_floats * 4, st));
+
+  // ================= forward =================
+  M2M_CHECK_HIP(hipMemcpyAsync(t->xe[0], enc_inputs, (size_t)Me * d * 4, hipMemcpyDeviceToDevice, st));
+  if (t->n_cond > 0)
+    hipLaunchKernelGGL(cond_gather_kernel, dim3(B * t->n_cond), dim3(128), 0, st, P, t->cond_off_dev, t->cond_rows_dev, t->n_cond, cond_idx,
+                       t->xe[0], S, d);
+  for (int l = 0; l < Le; ++l) {
+    const EncOff& e = t->enc[l];
+    RC(attn_self_fwd<T>(o, t->xe[2 * l], t->xe[2 * l + 1], e.ln0, e.qkv, e.o, t->h0e[l], t->qkve[l], t->Pe[l], t->aoe[l], B, S, t->etab, 0));
+    RC(ff_fwd<T>(o, t->xe[2 * l + 1], t->xe[2 * l + 2], e.ln1, e.wi, e.wo, t->h1e[l], t->abe[l], t->mide[l], Me));
+  }
+  RC(o.norm(t->xe[2 * Le], t->o_eln, t->hE, Me));
+  // decoder
+  hipLaunchKernelGGL(shift_right_kernel, dim3(ceil_div(Md, 256)), dim3(256), 0, st, labels, t->dec_in, B, L, g.decoder_start_token_id, g.pad_token_id);
+  RC(launch_embed_rows(t->dec_in, P + t->o_shared, t->xd[0], Md, d, V, g.pad_token_id, st));
+  const int64_t sPc1 = (int64_t)H * L * lps, sPc2 = (int64_t)L * lps;
+  for (int l = 0; l < Ld; ++l) {
+    const DecOff& e = t->dec[l];
+    RC(attn_self_fwd<T>(o, t->xd[3 * l], t->xd[3 * l + 1], e.ln0, e.qkv, e.o, t->h0d[l], t->qkvd[l], t->Pd[l], t->aod[l], B, L, t->dtab, 1));
+    // cross-attention (hf: modeling_t5.py:319-342: K/V from the encoder output, zero bias, no mask)
+    RC(o.norm(t->xd[3 * l + 1], e.ln1, t->h1d[l], Md));
+    RC(o.mm(TG_STORE_T, t->h1d[l], d, 0, o.W(e.cq), d, 0, t->cqd[l], inner, Md, inner, d));
+    RC(o.mm(TG_STORE_T, t->hE, d, 0, o.W(e.ckv), d, 0, t->ckvd[l], 2 * inner, Me, 2 * inner, d));
+    const T* cq = (const T*)t->cqd[l];
+    const T* ckv = (const T*)t->ckvd[l];
+    RC(o.mmbh(TG_STORE_F32, cq, inner, 0, (int64_t)L * inner, DK, ckv, 2 * inner, 0, (int64_t)S * 2 * inner, DK, t->sc, lps, sPc1, sPc2, B, L, S, DK));
+    RC(o.softmax(t->sc, t->Pcd[l], B, L, S, lps, nullptr, 0));
+    RC(o.mmbh(TG_STORE_T, (const T*)t->Pcd[l], lps, 0, sPc1, sPc2, ckv + inner, 2 * inner, 1, (int64_t)S * 2 * inner, DK, t->aocd[l], inner,
+              (int64_t)L * inner, DK, B, L, DK, S));
+    RC(o.mm(TG_RESID_F32, t->aocd[l], inner, 0, o.W(e.co), inner, 0, t->xd[3 * l + 2], d, Md, d, inner, t->xd[3 * l + 1]));
+    RC(ff_fwd<T>(o, t->xd[3 * l + 2], t->xd[3 * l + 3], e.ln2, e.wi, e.wo, t->h2d[l], t->abd[l], t->midd[l], Md));
+  }
+  RC(o.norm(t->xd[3 * Ld], t->o_dln, t->hD, Md));
+  RC(o.mm(TG_STORE_F32, t->hD, d, 0, o.W(t->o_lm), d, 0, t->logits, V, Md, V, d));
+  if (logits_out) M2M_CHECK_HIP(hipMemcpyAsync(logits_out, t->logits, (size_t)Md * V * 4, hipMemcpyDeviceToDevice, st));
+  // loss + gradient of the logits
+  hipLaunchKernelGGL(count_valid_kernel, dim3(1), dim3(256), 0, st, labels, Md, t->inv_n);
+  hipLaunchKernelGGL(ce_kernel<T>, dim3(ceil_div(Md, 4)), dim3(256), 0, st, t->logits, labels, t->inv_n, t->row_loss, (T*)t->dlog, Md, V, ldv);
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, t->row_loss, Md, t->inv_n, loss_out);
+  M2M_CHECK_HIP(hipGetLastError());
+  if (!G) return M2M_OK;
+
+  // ================= backward =================
+  RC(o.mm(TG_STORE_F32, t->dlog, ldv, 1, t->hD, d, 1, G + t->o_lm, d, V, d, Md));                 // dW_lm = dlogits^T . hD
+  RC(o.mm(TG_STORE_F32, t->dlog, ldv, 0, o.W(t->o_lm), d, 1, t->dh, d, Md, d, V));                // dhD = dlogits . W_lm
+  float* dcur = t->dxa;
+  float* dnext = t->dxb;
+  RC(o.norm_bwd(t->xd[3 * Ld], t->o_dln, t->dh, nullptr, dcur, G, Md));
+  for (int l = Ld - 1; l >= 0; --l) {
+    const DecOff& e = t->dec[l];
+    RC(ff_bwd<T>(o, t->xd[3 * l + 2], dcur, dnext, G, e.ln2, e.wi, e.wo, t->h2d[l], t->abd[l], t->midd[l], Md));
+    std::swap(dcur, dnext);
+    // ---- cross-attention backward: dcur = d x[3l+2] ----
+    RC(o.cvt(dcur, t->dxT, (int64_t)Md * d));
+    RC(o.mm(TG_STORE_F32, t->dxT, d, 1, t->aocd[l], inner, 1, G + e.co, inner, d, inner, Md));
+    RC(o.mm(TG_STORE_T, t->dxT, d, 0, o.W(e.co), inner, 1, t->dO, inner, Md, inner, d));
+    const T* cq = (const T*)t->cqd[l];
+    const T* ckv = (const T*)t->ckvd[l];
+    const T* dO = (const T*)t->dO;
+    T* dckv = (T*)t->dckv;
+    T* dcq = (T*)t->dcq;
+    const int64_t sK1 = (int64_t)S * 2 * inner, sQ1 = (int64_t)L * inner;
+    RC(o.mmbh(TG_STORE_T, (const T*)t->Pcd[l], lps, 1, sPc1, sPc2, dO, inner, 1, sQ1, DK, dckv + inner, 2 * inner, sK1, DK, B, S, DK, L));   // dV = P^T dO
+    RC(o.mmbh(TG_STORE_F32, dO, inner, 0, sQ1, DK, ckv + inner, 2 * inner, 0, sK1, DK, t->sc, lps, sPc1, sPc2, B, L, S, DK));               // dP = dO V^T
+    RC(o.softmax_bwd(t->Pcd[l], t->sc, t->dS, B * H * L, S, lps));
+    const T* dS = (const T*)t->dS;
+    RC(o.mmbh(TG_STORE_T, dS, lps, 0, sPc1, sPc2, ckv, 2 * inner, 1, sK1, DK, dcq, inner, sQ1, DK, B, L, DK, S));                            // dQ = dS K
+    RC(o.mmbh(TG_STORE_T, dS, lps, 1, sPc1, sPc2, cq, inner, 1, sQ1, DK, dckv, 2 * inner, sK1, DK, B, S, DK, L));                            // dK = dS^T Q
+    RC(o.mm(TG_STORE_F32, dcq, inner, 1, t->h1d[l], d, 1, G + e.cq, d, inner, d, Md));
+    RC(o.mm(TG_STORE_F32, dcq, inner, 0, o.W(e.cq), d, 1, t->dh, d, Md, d, inner));
+    RC(o.norm_bwd(t->xd[3 * l + 1], e.ln1, t->dh, dcur, dnext, G, Md));
+    std::swap(dcur, dnext);
+    RC(o.mm(TG_STORE_F32, dckv, 2 * inner, 1, t->hE, d, 1, G + e.ckv, d, 2 * inner, d, Me));       // dWckv = dckv^T . hE
+    RC(o.mm(l == Ld - 1 ? TG_STORE_F32 : TG_ACC_F32, dckv, 2 * inner, 0, o.W(e.ckv), d, 1, t->dhE, d, Me, d, 2 * inner));   // dhE (+)= dckv . Wckv
+    // ---- causal self-attention backward ----
+    RC(attn_self_bwd<T>(o, t->xd[3 * l], dcur, dnext, G, e.ln0, e.qkv, e.o, t->h0d[l], t->qkvd[l], t->Pd[l], t->aod[l], B, L, t->dbucket, t->o_drb,
+                        l == Ld - 1 ? 0 : 1));
+    std::swap(dcur, dnext);
+  }
+  // token embedding (decoder inputs; the encoder is fed inputs_embeds) — hf: modeling_t5.py embed_tokens = shared
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(V), dim3(128), 0, st, t->dec_in, Md, 1, 0, dcur, (int64_t)1, (int64_t)0, G + t->o_shared, d,
+                     g.pad_token_id, V);
+  // encoder
+  RC(o.norm_bwd(t->xe[2 * Le], t->o_eln, t->dhE, nullptr, dcur, G, Me));
+  for (int l = Le - 1; l >= 0; --l) {
+    const EncOff& e = t->enc[l];
+    RC(ff_bwd<T>(o, t->xe[2 * l + 1], dcur, dnext, G, e.ln1, e.wi, e.wo, t->h1e[l], t->abe[l], t->mide[l], Me));
+    std::swap(dcur, dnext);
+    RC(attn_self_bwd<T>(o, t->xe[2 * l], dcur, dnext, G, e.ln0, e.qkv, e.o, t->h0e[l], t->qkve[l], t->Pe[l], t->aoe[l], B, S, t->ebucket, t->o_erb,
+                        l == Le - 1 ? 0 : 1));
+    std::swap(dcur, dnext);
+  }
+  // conditioning embeddings: rows 0 .. n_cond-1 of every clip's encoder input (ref: music2midi/input.py:57-59)
+  for (int i = 0; i < t->n_cond; ++i)
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(t->cond_rows[i]), dim3(128), 0, st, cond_idx, B, t->n_cond, i, dcur, (int64_t)S, (int64_t)i,
+                       G + t->o_cond[i], d, 0, t->cond_rows[i]);
+  M2M_CHECK_HIP(hipGetLastError());
+  return M2M_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ C ABI ---
+extern "C" int m2m_trainer_create(const m2m_t5_geometry* geom, int n_cond, const int* cond_rows, int precision, int max_batch,
+                                  int max_enc_len, int max_dec_len, m2m_trainer** out) {
+  M2M_REQUIRE(geom && out && (n_cond == 0 || cond_rows), "m2m_trainer_create: null argument");
+  M2M_REQUIRE(precision == M2M_PREC_FP32 || precision == M2M_PREC_BF16, "m2m_trainer_create: bad precision %d", precision);
+  M2M_REQUIRE(geom->d_kv == DK, "m2m_trainer_create: d_kv=%d unsupported (64 only)", geom->d_kv);
+  M2M_REQUIRE(geom->d_model % 64 == 0 && geom->d_model <= 512 && geom->d_ff % 8 == 0, "m2m_trainer_create: d_model must be a multiple of 64 (<= 512), d_ff of 8");
+  M2M_REQUIRE(n_cond >= 0 && n_cond <= 8 && max_batch >= 1 && max_enc_len > n_cond && max_dec_len >= 1, "m2m_trainer_create: bad sizes");
+  m2m_trainer* t = new m2m_trainer();
+  t->g = *geom; t->precision = precision; t->inner = geom->num_heads * geom->d_kv; t->n_cond = n_cond;
+  t->es = precision == M2M_PREC_BF16 ? 2 : 4;
+  t->max_batch = max_batch; t->max_enc = max_enc_len; t->max_dec = max_dec_len;
+  t->cond_rows.assign(cond_rows, cond_rows + n_cond);
+  build_layout(t);
+  int rc = build_arena(t);
+  if (rc == M2M_OK) rc = build_optimizer(t);
+  if (rc != M2M_OK) { m2m_trainer_destroy(t); return rc; }
+  *out = t;
+  return M2M_OK;
+}
+
+extern "C" void m2m_trainer_destroy(m2m_trainer* t) {
+  if (!t) return;
+  if (t->arena) (void)hipFree(t->arena);
+  if (t->af_mem) (void)hipFree(t->af_mem);
+  delete t;
+}
+
+extern "C" int64_t m2m_trainer_num_params(const m2m_trainer* t) { return t ? t->n_floats : (int64_t)M2M_ERR_INVALID; }
+extern "C" int m2m_trainer_num_tensors(const m2m_trainer* t) { return t ? (int)t->tensors.size() : M2M_ERR_INVALID; }
+extern "C" int64_t m2m_trainer_workspace_bytes(const m2m_trainer* t) { return t ? t->arena_bytes : (int64_t)M2M_ERR_INVALID; }
+
+extern "C" int m2m_trainer_tensor_info(const m2m_trainer* t, int index, m2m_tensor_info* out) {
+  M2M_REQUIRE(t && out, "m2m_trainer_tensor_info: null argument");
+  M2M_REQUIRE(index >= 0 && index < (int)t->tensors.size(), "m2m_trainer_tensor_info: index %d out of range", index);
+  const TensorDesc& d = t->tensors[index];
+  memset(out, 0, sizeof(*out));
+  strncpy(out->name, d.name.c_str(), sizeof(out->name) - 1);
+  out->offset = d.off; out->rows = d.rows; out->cols = d.cols;
+  return M2M_OK;
+}
+
+extern "C" int m2m_train_forward_backward(m2m_trainer* t, const float* params_dev, const float* enc_inputs_dev, const int64_t* cond_idx_dev,
+                                          const int64_t* labels_dev, int B, int S, int Ld, float* loss_out_dev, float* grads_dev,
+                                          float* logits_out_dev, void* stream) {
+  M2M_REQUIRE(t && params_dev && enc_inputs_dev && labels_dev && loss_out_dev, "m2m_train_forward_backward: null argument");
+  M2M_REQUIRE(t->n_cond == 0 || cond_idx_dev, "m2m_train_forward_backward: cond_idx_dev is null");
+  M2M_REQUIRE(B >= 1 && B <= t->max_batch && S > t->n_cond && S <= t->max_enc && Ld >= 1 && Ld <= t->max_dec,
+              "m2m_train_forward_backward: (B=%d, S=%d, Ld=%d) outside the trainer's (%d, %d, %d)", B, S, Ld, t->max_batch, t->max_enc, t->max_dec);
+  hipStream_t st = (hipStream_t)stream;
+  return t->precision == M2M_PREC_BF16
+             ? forward_backward_t<bf16_t>(t, params_dev, enc_inputs_dev, cond_idx_dev, labels_dev, B, S, Ld, loss_out_dev, grads_dev, logits_out_dev, st)
+             : forward_backward_t<float>(t, params_dev, enc_inputs_dev, cond_idx_dev, labels_dev, B, S, Ld, loss_out_dev, grads_dev, logits_out_dev, st);
+}
+
+extern "C" int m2m_adafactor_step(m2m_trainer* t, float* params_dev, const float* grads_dev, void* stream) {
+  M2M_REQUIRE(t && params_dev && grads_dev, "m2m_adafactor_step: null argument");
+  t->step += 1;
+  return launch_adafactor(t->af, params_dev, grads_dev, t->step, (hipStream_t)stream);
+}
+
+extern "C" int m2m_adafactor_get_step(const m2m_trainer* t) { return t ? t->step : M2M_ERR_INVALID; }
+extern "C" int64_t m2m_adafactor_state_floats(const m2m_trainer* t) { return t ? t->af.state_floats : (int64_t)M2M_ERR_INVALID; }
+
+extern "C" int m2m_adafactor_state_export(const m2m_trainer* t, float* state_out_dev, void* stream) {
+  M2M_REQUIRE(t && state_out_dev, "m2m_adafactor_state_export: null argument");
+  M2M_CHECK_HIP(hipMemcpyAsync(state_out_dev, t->af.state, (size_t)t->af.state_floats * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return M2M_OK;
+}
+extern "C" int m2m_adafactor_state_import(m2m_trainer* t, const float* state_in_dev, int step, void* stream) {
+  M2M_REQUIRE(t && state_in_dev && step >= 0, "m2m_adafactor_state_import: bad argument");
+  M2M_CHECK_HIP(hipMemcpyAsync(t->af.state, state_in_dev, (size_t)t->af.state_floats * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  t->step = step;
+  return M2M_OK;
+}

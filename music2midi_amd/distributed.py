@@ -111,6 +111,17 @@ def all_gather_tokens(tokens: torch.Tensor, max_length: int, pad_id: int = 0) ->
     return out[:, :L_global].contiguous()
 
 
+def all_reduce_gradients(flat_grads: torch.Tensor) -> int:
+    """Data-parallel gradient averaging (what Lightning's DDP does for ref train.py:40-41): ONE all-reduce of the
+    flat fp32 gradient buffer (121.6 MB for the reference model; a ring all-reduce is a reduce-scatter + all-gather
+    over xGMI), then 1/world.  Every rank then applies the identical Adafactor step to its replica.  Returns bytes reduced."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0
+    dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
+    flat_grads.div_(dist.get_world_size())
+    return flat_grads.numel() * 4
+
+
 def barrier() -> None:
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

@@ -4,7 +4,8 @@ without pytorch-lightning: same constructor, ``load_from_checkpoint``,
 ``evaluate_batch``; segmentation, zero padding, chunking by
 ``inference.batch_size``, conditioning broadcast, ``max_length=1024`` and the
 sequential token decode follow the reference line by line in behaviour.
-Training hooks are out of scope for the inference hot path and raise.
+``training_step`` / ``configure_optimizers`` run the native forward+backward and Adafactor
+(csrc/train.hip) instead of autograd + Lightning.
 """
 from __future__ import annotations
 
@@ -50,12 +51,59 @@ class Music2MIDI(nn.Module):
     def device(self) -> torch.device:
         return self.model.transformer.device
 
-    # -- training surface (out of scope: SURVEY.md §8f rank 1) ----------------
-    def configure_optimizers(self):
-        raise NotImplementedError("training is not part of the MI355X inference hot path (SURVEY.md §8f)")
+    # -- training surface (ref model.py:27-43) -----------------
+    _trainer = None
+    global_step = 0
 
-    def training_step(self, inputs, batch_idx):
-        raise NotImplementedError("training is not part of the MI355X inference hot path (SURVEY.md §8f)")
+    def _native_trainer(self, B: int = 0, S: int = 0, L: int = 0):
+        """The native trainer, (re)built when a batch exceeds the sizes it was created for."""
+        from .training import NativeTrainer
+        tr = self._trainer
+        if tr is None or not tr.fits(B, S, L):
+            old = tr.limits if tr is not None else (0, 0, 0)
+            state = tr.optimizer_state() if tr is not None and tr.step_count > 0 else None
+            if tr is not None:
+                tr.close()
+            limits = (max(B, old[0], int(self.config.dataloader.batch_size)), max(S, old[1]), max(L, old[2], 64))
+            self._trainer = NativeTrainer(self.model, *limits, precision=getattr(self, "train_precision", None))
+            if state is not None:
+                self._trainer.load_optimizer_state(state)
+        return self._trainer
+
+    def configure_optimizers(self):
+        """ref model.py:27-30: Adafactor(self.parameters(), warmup_init=True) + AdafactorSchedule."""
+        from .training import Adafactor, AdafactorSchedule
+        optimizer = Adafactor(self)
+        return [optimizer], [AdafactorSchedule(optimizer)]
+
+    def training_step(self, inputs: ModelInputs, batch_idx):
+        """ref model.py:32-43.  Lightning calls backward() on the returned loss; here forward AND backward have
+        already run when this returns: every parameter's ``.grad`` holds d loss / d parameter (views of one flat
+        buffer), ready for ``distributed.all_reduce_gradients`` and ``optimizer.step()``."""
+        t5 = self.model
+        labels = t5.tokenizer(inputs.notes_batch)
+        labels[labels == t5.geometry.pad_token_id] = -100
+        x = t5.encoder_inputs(inputs)
+        tr = self._native_trainer(x.shape[0], x.shape[1], labels.shape[1])
+        loss, _ = tr.forward_backward(x, inputs.cond_index, labels)
+        self.logged = {"train/loss": float(loss), "batch_size": int(x.shape[0])}
+        if (self.global_step + 1) % int(self.config.trainer.log_every_n_steps) == 0:
+            self.logged["train/score"] = float(self.evaluate_batch(inputs)[0])
+        return loss[0]
+
+    def fit_batches(self, batches, optimizer=None, world_size: int = 1):
+        """Minimal stand-in for ``pl.Trainer.fit`` (ref train.py:40-41): step over an iterable of ModelInputs."""
+        from . import distributed as D
+        if optimizer is None:
+            optimizer = self.configure_optimizers()[0][0]
+        losses = []
+        for i, batch in enumerate(batches):
+            loss = self.training_step(batch, i)
+            D.all_reduce_gradients(self._trainer.grads)
+            optimizer.step()
+            self.global_step += 1
+            losses.append(float(loss))
+        return losses
 
     def validation_step(self, inputs: ModelInputs, batch_idx):
         """ref model.py:45-54: teacher-forced loss + chroma score of a greedy decode; returns the LOSS (as the

@@ -53,6 +53,10 @@ class T5Weights(C.Structure):
                 ("enc", C.POINTER(EncLayerWeights)), ("dec", C.POINTER(DecLayerWeights))]
 
 
+class TensorInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 160), ("offset", C.c_int64), ("rows", C.c_int), ("cols", C.c_int)]
+
+
 # name -> (restype, argtypes); every symbol include/music2midi_amd.h declares.
 _SIGNATURES = {
     "m2m_abi_version": (C.c_int, []),
@@ -79,6 +83,20 @@ _SIGNATURES = {
     "m2m_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "m2m_generate_greedy": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]),
     "m2m_decode_forced": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "m2m_trainer_create": (C.c_int, [C.POINTER(T5GeometryC), C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.POINTER(C.c_void_p)]),
+    "m2m_trainer_destroy": (None, [C.c_void_p]),
+    "m2m_trainer_num_params": (C.c_int64, [C.c_void_p]),
+    "m2m_trainer_num_tensors": (C.c_int, [C.c_void_p]),
+    "m2m_trainer_tensor_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(TensorInfo)]),
+    "m2m_trainer_workspace_bytes": (C.c_int64, [C.c_void_p]),
+    "m2m_train_forward_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                             C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "m2m_adafactor_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "m2m_adafactor_get_step": (C.c_int, [C.c_void_p]),
+    "m2m_adafactor_state_floats": (C.c_int64, [C.c_void_p]),
+    "m2m_adafactor_state_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "m2m_adafactor_state_import": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "m2m_bench_kernel": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
                                    C.POINTER(C.c_int64), C.c_void_p]),
 }

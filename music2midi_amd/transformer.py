@@ -195,7 +195,8 @@ class T5Transformer(nn.Module):
 
     def _param_key(self):
         ps = list(self.transformer.parameters())
-        return (self.precision, str(ps[0].device)) + tuple((p.data_ptr(), p._version) for p in ps)
+        # _weights_epoch: bumped by the native trainer, whose in-place kernel updates torch's version counters cannot see
+        return (self.precision, str(ps[0].device), getattr(self, "_weights_epoch", 0)) + tuple((p.data_ptr(), p._version) for p in ps)
 
     def _get_model(self):
         """Repack the current parameters into the library (once per weight version)."""

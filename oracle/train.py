@@ -1,0 +1,154 @@
+"""Oracle: training step (test infrastructure, see oracle/__init__.py).
+
+Follows ref: music2midi/model.py:27-43 — ``loss = T5Transformer.forward(inputs).loss`` (ref
+transformer.py:28-39: HF ``T5ForConditionalGeneration`` forward with labels, transformers 4.34.0),
+``loss.backward()`` and ``transformers.optimization.Adafactor(params, warmup_init=True)`` +
+``AdafactorSchedule``.
+
+* ``T5TrainOracle`` is a differentiable torch-CPU restatement of the teacher-forced forward (batched over
+  positions, explicit softmax attention) on leaf tensors keyed like the reference's state dict under
+  ``model.``; gradients come from torch autograd.
+* ``AdafactorOracle`` restates ``transformers/optimization.py`` ``Adafactor.step`` for the reference's
+  arguments (lr=None, eps=(1e-30, 1e-3), clip_threshold=1.0, decay_rate=-0.8, beta1=None, weight_decay=0,
+  scale_parameter=True, relative_step=True, warmup_init=True).
+
+Pinned in the build container against HuggingFace itself — ``T5ForConditionalGeneration`` (eager, untied
+head) loss + autograd gradients and ``transformers.optimization.Adafactor`` — by
+tests/golden/make_golden.py (``train`` case); tests/test_oracle_golden.py re-checks the fixture.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import numpy as np
+import torch
+
+from .t5 import gelu_new, relative_position_bucket
+
+
+def leaf_params(sd: Dict[str, np.ndarray]) -> Dict[str, torch.Tensor]:
+    """state dict (numpy, keys ``transformer.*`` / ``conditioning.*``) -> fp32 leaf tensors with requires_grad."""
+    return {k: torch.from_numpy(np.asarray(v, dtype=np.float32)).clone().requires_grad_(True)
+            for k, v in sd.items() if k.startswith(("transformer.", "conditioning."))
+            and not k.endswith(("encoder.embed_tokens.weight", "decoder.embed_tokens.weight"))}
+
+
+class T5TrainOracle:
+    def __init__(self, geom, params: Dict[str, torch.Tensor]):
+        self.g = geom
+        self.p = params
+
+    def w(self, name: str) -> torch.Tensor:
+        return self.p["transformer." + name]
+
+    def _norm(self, x, w):
+        return w * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + self.g.eps))
+
+    def _heads(self, x):
+        B, L, _ = x.shape
+        return x.view(B, L, self.g.num_heads, self.g.d_kv).transpose(1, 2)
+
+    def _bias(self, table, q_len, k_len, bidirectional):
+        rel = torch.arange(k_len)[None, :] - torch.arange(q_len)[:, None]
+        b = relative_position_bucket(rel, bidirectional, self.g.num_buckets, self.g.max_distance)
+        return table[b].permute(2, 0, 1).unsqueeze(0)
+
+    def _attn(self, hq, hkv, prefix, bias):
+        B, Lq, _ = hq.shape
+        q = self._heads(hq @ self.w(prefix + ".q.weight").T)
+        k = self._heads(hkv @ self.w(prefix + ".k.weight").T)
+        v = self._heads(hkv @ self.w(prefix + ".v.weight").T)
+        s = q @ k.transpose(2, 3)                      # no 1/sqrt(d_kv) (hf: modeling_t5.py:197)
+        if bias is not None:
+            s = s + bias
+        o = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B, Lq, self.g.inner_dim)
+        return o @ self.w(prefix + ".o.weight").T
+
+    def _ffn(self, h, prefix):
+        return (gelu_new(h @ self.w(prefix + ".wi_0.weight").T) * (h @ self.w(prefix + ".wi_1.weight").T)) @ self.w(prefix + ".wo.weight").T
+
+    def encoder_inputs(self, feats: torch.Tensor, cond_idx: torch.Tensor) -> torch.Tensor:
+        """ref: music2midi/input.py:57-59 — conditioning rows first, then the (constant) log-mel rows."""
+        rows = [self.p[f"conditioning.embeds.{i}.weight"][cond_idx[:, i]] for i in range(cond_idx.shape[1])]
+        return torch.cat([torch.stack(rows, dim=1), feats], dim=1)
+
+    def forward(self, feats: torch.Tensor, cond_idx: torch.Tensor, labels: torch.Tensor):
+        """-> (mean CE over labels != -100, logits [B, Ld, V])."""
+        g = self.g
+        x = self.encoder_inputs(feats, cond_idx)
+        S = x.shape[1]
+        ebias = self._bias(self.w("encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"), S, S, True)
+        for i in range(g.num_layers):
+            p = f"encoder.block.{i}.layer"
+            h = self._norm(x, self.w(f"{p}.0.layer_norm.weight"))
+            x = x + self._attn(h, h, f"{p}.0.SelfAttention", ebias)
+            x = x + self._ffn(self._norm(x, self.w(f"{p}.1.layer_norm.weight")), f"{p}.1.DenseReluDense")
+        enc = self._norm(x, self.w("encoder.final_layer_norm.weight"))
+        B, Ld = labels.shape
+        dec_in = torch.full((B, Ld), g.decoder_start_token_id, dtype=torch.long)
+        dec_in[:, 1:] = labels[:, :-1]
+        dec_in[dec_in == -100] = g.pad_token_id
+        y = self.w("shared.weight")[dec_in]
+        dbias = self._bias(self.w("decoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"), Ld, Ld, False)
+        causal = torch.full((Ld, Ld), float("-inf")).triu(1)
+        for i in range(g.num_decoder_layers):
+            p = f"decoder.block.{i}.layer"
+            h = self._norm(y, self.w(f"{p}.0.layer_norm.weight"))
+            y = y + self._attn(h, h, f"{p}.0.SelfAttention", dbias + causal)
+            h = self._norm(y, self.w(f"{p}.1.layer_norm.weight"))
+            y = y + self._attn(h, enc, f"{p}.1.EncDecAttention", None)
+            y = y + self._ffn(self._norm(y, self.w(f"{p}.2.layer_norm.weight")), f"{p}.2.DenseReluDense")
+        logits = self._norm(y, self.w("decoder.final_layer_norm.weight")) @ self.w("lm_head.weight").T
+        loss = torch.nn.functional.cross_entropy(logits.reshape(-1, g.vocab_size), labels.reshape(-1), ignore_index=-100)
+        return loss, logits
+
+    def loss_and_grads(self, feats, cond_idx, labels):
+        for t in self.p.values():
+            t.grad = None
+        loss, logits = self.forward(feats, cond_idx, labels)
+        loss.backward()
+        return loss.detach(), logits.detach(), {k: (v.grad.clone() if v.grad is not None else torch.zeros_like(v)) for k, v in self.p.items()}
+
+
+class AdafactorOracle:
+    """transformers.optimization.Adafactor.step restated (see the module docstring for the arguments)."""
+
+    def __init__(self, params: Dict[str, torch.Tensor]):
+        self.params = params
+        self.state = {k: {"step": 0} for k in params}
+
+    @staticmethod
+    def _rms(t):
+        return t.norm(2) / (t.numel() ** 0.5)
+
+    @torch.no_grad()
+    def step(self, grads: Dict[str, torch.Tensor]):
+        eps1, eps2, clip, decay = 1e-30, 1e-3, 1.0, -0.8
+        for k, p in self.params.items():
+            g = grads[k].float()
+            st = self.state[k]
+            factored = g.dim() >= 2
+            if st["step"] == 0:
+                if factored:
+                    st["row"] = torch.zeros(g.shape[:-1])
+                    st["col"] = torch.zeros(g.shape[:-2] + g.shape[-1:])
+                else:
+                    st["v"] = torch.zeros_like(g)
+            st["step"] += 1
+            t = st["step"]
+            rho = min(1e-6 * t, 1.0 / math.sqrt(t))                    # relative_step with warmup_init
+            lr = max(eps2, float(self._rms(p))) * rho                  # scale_parameter
+            beta2t = 1.0 - math.pow(t, decay)
+            upd = g ** 2 + eps1
+            if factored:
+                st["row"].mul_(beta2t).add_(upd.mean(dim=-1), alpha=1.0 - beta2t)
+                st["col"].mul_(beta2t).add_(upd.mean(dim=-2), alpha=1.0 - beta2t)
+                r = (st["row"] / st["row"].mean(dim=-1, keepdim=True)).rsqrt_().unsqueeze(-1)
+                c = st["col"].unsqueeze(-2).rsqrt()
+                upd = r * c * g
+            else:
+                st["v"].mul_(beta2t).add_(upd, alpha=1.0 - beta2t)
+                upd = st["v"].rsqrt() * g
+            upd = upd / (self._rms(upd) / clip).clamp(min=1.0)
+            p.add_(upd * lr, alpha=-1.0)

@@ -220,6 +220,69 @@ def make_tokenizer(out_path):
     out_path.write_text(json.dumps(cases))
     print(f"[tokenizer] {len(cases)} cases")
 
+# ------------------------------------------------------------------ training goldens
+def make_train(out_path):
+    """HF T5ForConditionalGeneration (eager, untied head) loss + autograd gradients, and three steps of HF's own
+    transformers.optimization.Adafactor(warmup_init=True), on the tiny config: the pin of oracle/train.py."""
+    from transformers.optimization import Adafactor
+    from oracle.train import AdafactorOracle, T5TrainOracle, leaf_params
+    cfg = ref_config()
+    t5cfg = tiny_t5(cfg)
+    geom = T5Geometry(t5cfg)
+    sd = synth.t5_state_dict(geom, seed=0)
+    synth.perturb_layer_norms(sd, 0)
+    B, F, Ld = 3, 21, 14
+    feats = torch.from_numpy(synth.normal(5, "feats", (B, F, geom.d_model), 2.0))
+    cond = torch.from_numpy(synth.cond_index_batch(2, B))
+    labels = torch.from_numpy((synth.uniform01(4, "labels", B * Ld) * 330).astype(np.int64).reshape(B, Ld)) + 3
+    labels[1, Ld - 4:] = -100
+    labels[2, Ld - 1:] = -100
+    hf = build_hf(t5cfg, sd)          # eval(): dropout off - the deterministic part of the step is what can be pinned
+    emb = [torch.nn.Parameter(torch.from_numpy(sd[f"conditioning.embeds.{i}.weight"]).clone()) for i in range(2)]
+    hf_params = list(hf.parameters()) + emb
+    opt = Adafactor(hf_params, warmup_init=True)
+
+    def hf_loss():
+        x = torch.cat([torch.stack([emb[i][cond[:, i]] for i in range(2)], dim=1), feats], dim=1)
+        return hf(inputs_embeds=x, labels=labels)
+
+    orc_params = leaf_params(sd)
+    orc = T5TrainOracle(geom, orc_params)
+    oopt = AdafactorOracle(orc_params)
+    names = {"transformer." + k: v for k, v in hf.named_parameters()}
+    names.update({f"conditioning.embeds.{i}.weight": emb[i] for i in range(2)})
+    assert set(names) == set(orc_params), sorted(set(names) ^ set(orc_params))[:5]
+    data = dict(meta=np.asarray([B, F, Ld], dtype=np.int32), labels=labels.numpy().astype(np.int16))
+    keys = sorted(orc_params)
+    data["keys"] = np.asarray(keys)
+    for step in range(3):
+        opt.zero_grad()
+        out = hf_loss()
+        out.loss.backward()
+        loss_o, logits_o, grads_o = orc.loss_and_grads(feats, cond, labels)
+        assert abs(out.loss.item() - loss_o.item()) < 2e-5, (out.loss.item(), loss_o.item())
+        worst = 0.0
+        for k in keys:
+            gh, go = names[k].grad, grads_o[k]
+            worst = max(worst, float((gh - go).abs().max() / (gh.abs().max() + 1e-12)))
+        assert worst < 2e-4, worst
+        if step == 0:
+            assert (out.logits - logits_o).abs().max() < 2e-3
+            data["logits_sample"] = out.logits[:, ::4].detach().numpy().astype(np.float32)
+            data["grad_abs_sum"] = np.asarray([names[k].grad.double().abs().sum().item() for k in keys])
+            data["grad_l2"] = np.asarray([names[k].grad.double().norm().item() for k in keys])
+            data["grad_head"] = np.stack([np.resize(names[k].grad.reshape(-1)[:8].numpy(), 8) for k in keys]).astype(np.float32)
+        data.setdefault("losses", []).append(out.loss.item())
+        opt.step()
+        oopt.step(grads_o)
+        drift = max(float((names[k].detach() - orc_params[k].detach()).abs().max()) for k in keys)
+        assert drift < 2e-6, (step, drift)
+        print(f"[train] step {step}: loss {out.loss.item():.6f} | oracle grad rel diff {worst:.2e} | param drift vs HF Adafactor {drift:.2e}")
+    data["losses"] = np.asarray(data["losses"], dtype=np.float64)
+    data["param_abs_sum_after3"] = np.asarray([names[k].detach().double().abs().sum().item() for k in keys])
+    data["param_head_after3"] = np.stack([np.resize(names[k].detach().reshape(-1)[:8].numpy(), 8) for k in keys]).astype(np.float32)
+    np.savez_compressed(out_path, **data)
+
 
 if __name__ == "__main__":
     torch.manual_seed(0)
@@ -230,6 +293,8 @@ if __name__ == "__main__":
         make_frontend(HERE / "frontend.npz")
     if not only or "t5" in only:
         make_t5(HERE / "t5.npz")
+    if not only or "train" in only:
+        make_train(HERE / "train.npz")
     for p in sorted(HERE.glob("*.npz")) + sorted(HERE.glob("*.json")):
         print(p.name, p.stat().st_size, "bytes")
     # never leave bytecode in the read-only reference tree

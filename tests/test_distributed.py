@@ -70,3 +70,28 @@ def test_single_process_paths_are_noops():
     assert D.all_gather_tokens(t, 8) is t
     assert D.broadcast_module_state(torch.nn.Linear(2, 2)) == 0
     assert D.all_reduce_max(3.0, "cpu") == 3.0
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    D.init_process_group("gloo")
+    flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)          # rank r holds (r+1) * g
+    nbytes = D.all_reduce_gradients(flat)
+    assert nbytes == 4000 and torch.equal(flat, torch.arange(1000, dtype=torch.float32) * 1.5)   # mean over the 2 ranks
+    dist.destroy_process_group()
+    q.put(rank)
+
+
+def test_gloo_world2_gradient_all_reduce_averages_the_flat_buffer():
+    """Data-parallel training (BASELINE configs[4]): one collective per step on the flat gradient buffer."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]
+    assert D.all_reduce_gradients(torch.ones(4)) == 0          # single process: no-op

@@ -84,3 +84,35 @@ def test_bf16_emulation_rounds_weights_and_caches():
     x = embeds(2, 9, geom.d_model)
     d = (o16.encode(x) - o32.encode(x)).abs().max().item()
     assert 1e-4 < d < 0.2
+
+
+def test_training_oracle_reproduces_huggingface_golden(golden_dir):
+    """oracle/train.py (differentiable forward + restated Adafactor) vs the fixture made by HF T5 autograd and
+    transformers.optimization.Adafactor(warmup_init=True): losses of 3 steps, gradients of step 0, parameters after step 3."""
+    from music2midi_amd import synth
+    from music2midi_amd.config import DEFAULT_CONFIG, T5Geometry
+    from oracle.train import AdafactorOracle, T5TrainOracle, leaf_params
+    import copy
+    z = np.load(golden_dir / "train.npz")
+    B, F, Ld = [int(v) for v in z["meta"]]
+    t5 = copy.deepcopy(DEFAULT_CONFIG["model"]["t5"])
+    t5.update(d_model=128, d_ff=256, num_layers=2, num_decoder_layers=2, num_heads=2)
+    geom = T5Geometry(t5)
+    sd = synth.t5_state_dict(geom, seed=0)
+    synth.perturb_layer_norms(sd, 0)
+    params = leaf_params(sd)
+    orc, opt = T5TrainOracle(geom, params), AdafactorOracle(params)
+    feats = torch.from_numpy(synth.normal(5, "feats", (B, F, geom.d_model), 2.0))
+    cond = torch.from_numpy(synth.cond_index_batch(2, B))
+    labels = torch.from_numpy(z["labels"].astype(np.int64))
+    keys = [str(k) for k in z["keys"]]
+    for step in range(3):
+        loss, logits, grads = orc.loss_and_grads(feats, cond, labels)
+        assert abs(loss.item() - z["losses"][step]) < 2e-5
+        if step == 0:
+            assert np.abs(logits.numpy()[:, ::4] - z["logits_sample"]).max() < 2e-3
+            for i, k in enumerate(keys):
+                assert abs(grads[k].double().norm().item() - z["grad_l2"][i]) <= 1e-4 * z["grad_l2"][i] + 1e-10, k
+        opt.step(grads)
+    for i, k in enumerate(keys):
+        assert abs(params[k].detach().double().abs().sum().item() - z["param_abs_sum_after3"][i]) <= 1e-6 * z["param_abs_sum_after3"][i], k

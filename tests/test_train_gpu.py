@@ -1,0 +1,178 @@
+"""GPU parity of the training step: native forward + backward + Adafactor vs the oracle
+(torch autograd over oracle/train.py, itself pinned to HuggingFace T5 + transformers' Adafactor by the
+`train` golden) — ref: music2midi/model.py:27-43, transformer.py:28-39."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from music2midi_amd import synth
+from music2midi_amd.checkpoint import load_t5_state
+from music2midi_amd.config import DEFAULT_CONFIG, T5Geometry, load_config
+from music2midi_amd.input import ModelInputs
+from music2midi_amd.transformer import T5Transformer
+
+from test_t5_gpu import tiny_config
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(cfg, precision, B, F, Ld, seed=0, max_sizes=None):
+    from music2midi_amd.training import NativeTrainer
+    from oracle.train import T5TrainOracle, leaf_params
+    geom = T5Geometry(load_config(cfg).model.t5)
+    sd = synth.t5_state_dict(geom, seed=seed)
+    synth.perturb_layer_norms(sd, seed)
+    model = T5Transformer(cfg, precision="fp32")
+    load_t5_state(model, sd, strict=False)
+    model = model.cuda()
+    tr = NativeTrainer(model, *(max_sizes or (B, F + 2, Ld)), precision=precision)
+    feats = torch.from_numpy(synth.normal(5, "feats", (B, F, geom.d_model), 2.0))
+    cond = torch.from_numpy(synth.cond_index_batch(2, B))
+    labels = torch.from_numpy((synth.uniform01(4, "labels", B * Ld) * 330).astype(np.int64).reshape(B, Ld)) + 3
+    if Ld > 6:
+        labels[1 % B, Ld - 4:] = -100
+        labels[(2 % B), Ld - 1:] = -100
+    x = torch.zeros((B, F + 2, geom.d_model))
+    x[:, 2:] = feats
+    params = leaf_params(sd)
+    return model, tr, T5TrainOracle(geom, params), params, geom, x, feats, cond, labels
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-20))
+
+
+@pytest.mark.parametrize("cfg_name,B,F,Ld", [("tiny", 3, 21, 14), ("tiny", 2, 70, 33), ("tiny", 1, 9, 1), ("full", 2, 40, 20)])
+def test_fp32_loss_logits_and_every_gradient_match_autograd(cfg_name, B, F, Ld):
+    cfg = tiny_config() if cfg_name == "tiny" else copy.deepcopy(DEFAULT_CONFIG)
+    model, tr, orc, params, geom, x, feats, cond, labels = _setup(cfg, "fp32", B, F, Ld)
+    loss, logits = tr.forward_backward(x.cuda(), cond.cuda(), labels.cuda(), want_logits=True)
+    loss_o, logits_o, grads_o = orc.loss_and_grads(feats, cond, labels)
+    assert abs(loss.item() - loss_o.item()) < 1e-4 * max(1.0, abs(loss_o.item()))
+    assert (logits.cpu() - logits_o).abs().max() < 2e-3
+    worst = {}
+    for name, (off, shape) in tr.layout.items():
+        g_dev = tr.grads[off:off + int(np.prod(shape))].view(shape).cpu()
+        worst[name] = _rel(g_dev, grads_o[name])
+    bad = {k: v for k, v in worst.items() if v > 1e-4}
+    print(f"{cfg_name} B={B} F={F} Ld={Ld}: loss {loss.item():.6f} (oracle {loss_o.item():.6f}); worst gradient rel err "
+          f"{max(worst.values()):.2e} over {len(worst)} tensors")
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:5]
+    # .grad of the module's parameters ARE the flat buffer
+    p = dict(model.named_parameters())["transformer.decoder.block.1.layer.1.EncDecAttention.k.weight"]
+    assert p.grad is not None and _rel(p.grad.cpu(), grads_o["transformer.decoder.block.1.layer.1.EncDecAttention.k.weight"]) < 1e-4
+    # deterministic: a second call gives the same bits
+    g1 = tr.grads.clone()
+    loss2, _ = tr.forward_backward(x.cuda(), cond.cuda(), labels.cuda())
+    assert torch.equal(g1, tr.grads)
+
+
+def test_three_steps_reproduce_the_huggingface_golden(golden_dir):
+    """Losses of three consecutive steps and the parameters after them vs the fixture produced by HF T5 +
+    transformers.optimization.Adafactor(warmup_init=True) (tests/golden/make_golden.py train)."""
+    z = np.load(golden_dir / "train.npz")
+    B, F, Ld = [int(v) for v in z["meta"]]
+    model, tr, _, _, geom, x, feats, cond, labels = _setup(tiny_config(), "fp32", B, F, Ld)
+    assert np.array_equal(labels.numpy(), z["labels"].astype(np.int64))
+    keys = [str(k) for k in z["keys"]]
+    losses = []
+    for step in range(3):
+        loss, logits = tr.forward_backward(x.cuda(), cond.cuda(), labels.cuda(), want_logits=(step == 0))
+        losses.append(loss.item())
+        if step == 0:
+            assert np.abs(logits.cpu().numpy()[:, ::4] - z["logits_sample"]).max() < 2e-3
+            for i, k in enumerate(keys):
+                off, shape = tr.layout[k]
+                g = tr.grads[off:off + int(np.prod(shape))].cpu().double()
+                assert abs(g.norm().item() - z["grad_l2"][i]) <= 2e-4 * z["grad_l2"][i] + 1e-9, k
+                assert np.abs(np.resize(g.numpy()[:8], 8) - z["grad_head"][i]).max() <= 1e-4 * np.abs(z["grad_head"][i]).max() + 1e-7, k
+        tr.optimizer_step()
+    assert np.abs(np.asarray(losses) - z["losses"]).max() < 2e-4, (losses, z["losses"])
+    assert tr.step_count == 3
+    for i, k in enumerate(keys):
+        off, shape = tr.layout[k]
+        p = tr.params[off:off + int(np.prod(shape))].cpu()
+        assert abs(p.double().abs().sum().item() - z["param_abs_sum_after3"][i]) <= 1e-5 * z["param_abs_sum_after3"][i], k
+        assert np.abs(np.resize(p.numpy()[:8], 8) - z["param_head_after3"][i]).max() < 2e-6, k
+
+
+def test_adafactor_kernels_match_the_oracle_over_many_steps():
+    """The optimizer alone on synthetic gradients (all tensor shapes of the model: matrices, vectors, the 32x8 bias
+    tables), 12 steps — relative-step warm-up, factored second moments, update clipping."""
+    from oracle.train import AdafactorOracle
+    model, tr, _, params, geom, *_ = _setup(tiny_config(), "fp32", 2, 9, 4)
+    p_ref = {k: v.detach().clone() for k, v in params.items()}
+    opt = AdafactorOracle(p_ref)
+    for step in range(12):
+        grads = {}
+        for k, (off, shape) in tr.layout.items():
+            scale = 10.0 ** (step % 4 - 2)                              # 1e-2 .. 10: exercises the clipping both ways
+            g = torch.from_numpy(synth.normal(step, k, shape, scale))
+            grads[k] = g
+            tr.grads[off:off + g.numel()].copy_(g.reshape(-1))
+        tr.optimizer_step()
+        opt.step(grads)
+    worst = max(_rel(tr.params[off:off + int(np.prod(shape))].view(shape).cpu(), p_ref[k]) for k, (off, shape) in tr.layout.items())
+    print(f"adafactor 12 steps: worst parameter rel err {worst:.2e}")
+    assert worst < 2e-5
+    # state export / import round trip continues identically
+    state = tr.optimizer_state()
+    before = tr.params.clone()
+    tr.optimizer_step()
+    after = tr.params.clone()
+    tr.params.copy_(before)
+    tr.load_optimizer_state(state)
+    tr.optimizer_step()
+    assert torch.equal(tr.params, after) and tr.step_count == 13
+
+
+def test_bf16_gradients_track_the_fp32_oracle_at_the_reference_geometry():
+    """Throughput mode (bf16 GEMM inputs, fp32 accumulate / residual / norms / softmax / loss), full model, a batch
+    shaped like ref config.yaml (3 s segments -> S = 190): per-tensor direction and size of the gradient."""
+    B, F, Ld = 4, 188, 48
+    model, tr, orc, params, geom, x, feats, cond, labels = _setup(copy.deepcopy(DEFAULT_CONFIG), "bf16", B, F, Ld)
+    loss, _ = tr.forward_backward(x.cuda(), cond.cuda(), labels.cuda())
+    loss_o, _, grads_o = orc.loss_and_grads(feats, cond, labels)
+    assert abs(loss.item() - loss_o.item()) < 2e-2 * abs(loss_o.item())
+    cos_min, worst = 1.0, 0.0
+    for name, (off, shape) in tr.layout.items():
+        g = tr.grads[off:off + int(np.prod(shape))].cpu().double()
+        r = grads_o[name].reshape(-1).double()
+        if r.norm() < 1e-12:
+            continue
+        cos = float(torch.dot(g, r) / (g.norm() * r.norm() + 1e-30))
+        cos_min = min(cos_min, cos)
+        worst = max(worst, float((g - r).norm() / r.norm()))
+    print(f"bf16 full model: loss {loss.item():.4f} vs fp32 oracle {loss_o.item():.4f}; min cosine {cos_min:.5f}, worst rel l2 {worst:.3e}")
+    assert cos_min > 0.995 and worst < 0.1
+
+
+def test_music2midi_training_surface_learns_and_serves_the_new_weights():
+    """Music2MIDI.configure_optimizers / training_step / fit_batches (ref model.py:27-43, train.py:40-41) on waveforms +
+    notes: the loss of a fixed batch goes down, and generate() afterwards runs on the UPDATED weights."""
+    from music2midi_amd.model import Music2MIDI
+    cfg = copy.deepcopy(DEFAULT_CONFIG)
+    cfg["dataloader"]["batch_size"] = 3
+    m = Music2MIDI(cfg).cuda()
+    m.train_precision = "fp32"
+    notes = (np.array([[0.10, 0.40, 60, 80], [0.50, 1.00, 64, 80], [1.20, 1.90, 67, 80]]),
+             np.array([[0.05, 0.30, 50, 80], [0.70, 1.10, 55, 80]]),
+             np.array([[0.00, 2.90, 40, 80], [0.30, 0.80, 76, 80], [1.00, 1.40, 77, 80], [1.50, 1.70, 79, 80]]))
+    wav = torch.from_numpy(synth.waveform_batch(40, 3, 48000, "music")).cuda()
+    idx = torch.from_numpy(synth.cond_index_batch(40, 3)).cuda()
+    batch = ModelInputs(input_waveform=wav, notes_batch=notes, cond_index=idx)
+    before = m.model.generate(batch, max_length=12).clone()
+    w0 = m.model.transformer.lm_head.weight.detach().clone()
+    (opt,), (sched,) = m.configure_optimizers()
+    losses = m.fit_batches([batch] * 200, optimizer=opt)
+    assert losses[-1] < losses[0] - 0.05, (losses[0], losses[-1])
+    assert m.global_step == 200 and m._trainer.step_count == 200 and 0 < sched.get_last_lr()[0] <= 2e-4
+    assert not torch.equal(w0, m.model.transformer.lm_head.weight.detach())       # the module's parameters ARE the trained buffer
+    loss_eval = m.model(batch).loss                                                # inference-path forward on the new weights
+    assert abs(loss_eval.item() - m.training_step(batch, 0).item()) < 1e-3 * max(1.0, loss_eval.item())
+    after = m.model.generate(batch, max_length=12)
+    assert after.shape[0] == 3 and (after[:, 0] == 1).all()
+    sd = m.state_dict()
+    assert torch.equal(sd["model.transformer.lm_head.weight"], m.model.transformer.lm_head.weight.detach())
