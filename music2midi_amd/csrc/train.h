@@ -19,6 +19,10 @@ struct BGemmArgs {
   int nb1, nb2;
   int64_t sA1, sA2, sB1, sB2, sC1, sC2;
   float alpha;
+  // split-K (nb1 == nb2 == 1 only): blockIdx.z takes k in [z*kchunk, (z+1)*kchunk); partial tiles go to Cpart[z][M][N]
+  // (fp32) and splitk_reduce sums them into C in a fixed order.  ksplit <= 1: off.
+  int ksplit, kchunk;
+  float* Cpart;
 };
 int launch_bgemm(int precision, int epi, const BGemmArgs& g, hipStream_t st);
 

@@ -19,6 +19,7 @@
 
 #include <math.h>
 #include <string.h>
+#include <algorithm>
 #include <string>
 #include <utility>
 #include <vector>
@@ -82,17 +83,19 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BGemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
-  const int z1 = blockIdx.z / g.nb2, z2 = blockIdx.z - z1 * g.nb2;
+  const bool split = g.ksplit > 1;
+  const int z1 = split ? 0 : blockIdx.z / g.nb2, z2 = split ? 0 : blockIdx.z - z1 * g.nb2;
   const T* A = reinterpret_cast<const T*>(g.A) + z1 * g.sA1 + z2 * g.sA2;
   const T* B = reinterpret_cast<const T*>(g.B) + z1 * g.sB1 + z2 * g.sB2;
   const int64_t coff = z1 * g.sC1 + z2 * g.sC2;
   const int m0 = blockIdx.y * TG_BM, n0 = blockIdx.x * TG_BN;
+  const int kbeg = split ? blockIdx.z * g.kchunk : 0, kend = split ? min(g.K, kbeg + g.kchunk) : g.K;
 
   f32x16 acc = zero_acc();
-  for (int k0 = 0; k0 < g.K; k0 += TG_BK) {
+  for (int k0 = kbeg; k0 < kend; k0 += TG_BK) {
     __syncthreads();
-    tg_stage<T>(As, A, g.lda, g.a_kmajor, m0, k0, g.M, g.K, tid);
-    tg_stage<T>(Bs, B, g.ldb, g.b_kmajor, n0, k0, g.N, g.K, tid);
+    tg_stage<T>(As, A, g.lda, g.a_kmajor, m0, k0, g.M, kend, tid);
+    tg_stage<T>(Bs, B, g.ldb, g.b_kmajor, n0, k0, g.N, kend, tid);
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < TG_BK / 16; ++s) {
@@ -107,6 +110,10 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BGemmArgs g) {
   for (int i = 0; i < 16; ++i) {
     const int row = m0 + wm * 32 + acc_row(i, lane);
     if (row >= g.M) continue;
+    if (split) {                                   // partial tile of this k-slice
+      g.Cpart[((int64_t)blockIdx.z * g.M + row) * g.N + col] = acc[i];
+      continue;
+    }
     const int64_t at = coff + (int64_t)row * g.ldc + col;
     const float v = g.alpha * acc[i];
     if constexpr (EPI == TG_STORE_T) reinterpret_cast<T*>(g.C)[at] = from_f32<T>(v);
@@ -118,7 +125,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BGemmArgs g) {
 
 template <typename T>
 static int launch_bgemm_t(int epi, const BGemmArgs& g, hipStream_t st) {
-  dim3 grid((unsigned)ceil_div(g.N, TG_BN), (unsigned)ceil_div(g.M, TG_BM), (unsigned)(g.nb1 * g.nb2));
+  dim3 grid((unsigned)ceil_div(g.N, TG_BN), (unsigned)ceil_div(g.M, TG_BM), (unsigned)(g.ksplit > 1 ? g.ksplit : g.nb1 * g.nb2));
   switch (epi) {
     case TG_STORE_T: hipLaunchKernelGGL((bgemm_kernel<T, TG_STORE_T>), grid, dim3(256), 0, st, g); break;
     case TG_STORE_F32: hipLaunchKernelGGL((bgemm_kernel<T, TG_STORE_F32>), grid, dim3(256), 0, st, g); break;
@@ -130,6 +137,55 @@ static int launch_bgemm_t(int epi, const BGemmArgs& g, hipStream_t st) {
   return M2M_OK;
 }
 
+// C[row][col] = alpha * sum_z part[z][row][col]   (z ascending: fixed order)
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ C, int M, int N, int64_t ldc, int ksplit, float alpha) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n = (int64_t)M * N, stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    float acc = 0.f;
+    for (int z = 0; z < ksplit; ++z) acc += part[(int64_t)z * n + i];
+    const int64_t row = i / N;
+    C[row * ldc + (i - row * N)] = alpha * acc;
+  }
+}
+
+// dst[c][r] = src[r][c]: src [R][C] (row stride ld_s) -> dst [C][ld_d]; the columns [R, Rpad) of dst are zeroed
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void transpose_kernel(const TS* __restrict__ src, int64_t ld_s, TD* __restrict__ dst, int64_t ld_d, int R, int C,
+                                                        int Rpad) {
+  __shared__ float tile[64][65];
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int rl = i >> 6, cl = i & 63;
+    tile[rl][cl] = (r0 + rl < R && c0 + cl < C) ? to_f32(src[(int64_t)(r0 + rl) * ld_s + c0 + cl]) : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int cl = i >> 6, rl = i & 63;
+    if (c0 + cl < C && r0 + rl < Rpad) dst[(int64_t)(c0 + cl) * ld_d + r0 + rl] = from_f32<TD>(tile[rl][cl]);
+  }
+}
+
+// all weight matrices of the model in one launch: WT[off .. ] = W[off ..]^T in the storage type (block -> (matrix, tile) table)
+struct WtBlock { int64_t off; int N, K, tn, tk; };
+template <typename TD>
+__global__ __launch_bounds__(256) void weights_transpose_kernel(const WtBlock* __restrict__ blocks, const float* __restrict__ P, TD* __restrict__ WT) {
+  __shared__ float tile[64][65];
+  const WtBlock b = blocks[blockIdx.x];
+  const int n0 = b.tn * 64, k0 = b.tk * 64;
+  const float* src = P + b.off;
+  TD* dst = WT + b.off;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int nl = i >> 6, kl = i & 63;
+    tile[nl][kl] = (n0 + nl < b.N && k0 + kl < b.K) ? src[(int64_t)(n0 + nl) * b.K + k0 + kl] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int kl = i >> 6, nl = i & 63;
+    if (k0 + kl < b.K && n0 + nl < b.N) dst[(int64_t)(k0 + kl) * b.N + n0 + nl] = from_f32<TD>(tile[nl][kl]);
+  }
+}
+
 int launch_bgemm(int precision, int epi, const BGemmArgs& g, hipStream_t st) {
   const int E = precision == M2M_PREC_BF16 ? 8 : 4;
   M2M_REQUIRE(g.M >= 1 && g.N >= 1 && g.K >= 1 && g.nb1 >= 1 && g.nb2 >= 1, "bgemm: empty problem");
@@ -137,6 +193,16 @@ int launch_bgemm(int precision, int epi, const BGemmArgs& g, hipStream_t st) {
               (long long)g.lda, (long long)g.ldb, E);
   M2M_REQUIRE(g.sA1 % E == 0 && g.sA2 % E == 0 && g.sB1 % E == 0 && g.sB2 % E == 0, "bgemm: batch strides must keep 16-byte alignment");
   M2M_REQUIRE((int64_t)g.nb1 * g.nb2 <= 65535, "bgemm: too many batch entries");
+  if (g.ksplit > 1) {
+    M2M_REQUIRE(g.nb1 == 1 && g.nb2 == 1 && epi == TG_STORE_F32 && g.Cpart && g.kchunk % TG_BK == 0, "bgemm: split-K is for plain fp32-store products");
+    int rc = precision == M2M_PREC_BF16 ? launch_bgemm_t<bf16_t>(epi, g, st) : launch_bgemm_t<float>(epi, g, st);
+    if (rc != M2M_OK) return rc;
+    const int64_t n = (int64_t)g.M * g.N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, st, g.Cpart,
+                       reinterpret_cast<float*>(g.C), g.M, g.N, g.ldc, g.ksplit, g.alpha);
+    M2M_CHECK_HIP(hipGetLastError());
+    return M2M_OK;
+  }
   return precision == M2M_PREC_BF16 ? launch_bgemm_t<bf16_t>(epi, g, st) : launch_bgemm_t<float>(epi, g, st);
 }
 
@@ -200,33 +266,35 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* __restrict__ 
   for (int k = lane; k < ldp; k += 64) ds[k] = from_f32<T>(k < Sk ? to_f32(p[k]) * (dp[k] - t) : 0.f);
 }
 
-// relative-position-bias gradient, stage 1: drel[h][rel] = sum over clips b and the diagonal key - query = rel - (Sq-1)
-// of dS[b,h,q,k].  One thread per (h, rel): fixed summation order.
+// relative-position-bias gradient.  Stage 1: one block per (clip, head): part[b][h][rel] = sum over the diagonal
+// key - query = rel - (Sq-1) of dS[b,h,q,k]; consecutive threads take consecutive diagonals, so every pass over q reads
+// consecutive addresses.  Stage 2 sums the clips and the diagonals of each bucket.  Fixed order throughout.
 template <typename T>
-__global__ void bias_diag_kernel(const T* __restrict__ dS, float* __restrict__ drel, int B, int H, int Sq, int Sk, int ldp) {
+__global__ __launch_bounds__(256) void bias_diag_kernel(const T* __restrict__ dS, float* __restrict__ part, int H, int Sq, int Sk, int ldp) {
   const int nrel = Sq + Sk - 1;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= H * nrel) return;
-  const int hh = idx / nrel, rel = idx - hh * nrel;
-  const int off = rel - (Sq - 1);                              // key - query
-  const int q_lo = max(0, -off), q_hi = min(Sq, Sk - off);     // q with 0 <= q + off < Sk
-  float acc = 0.f;
-  for (int b = 0; b < B; ++b) {
-    const T* base = dS + ((int64_t)(b * H + hh) * Sq) * ldp;
+  const int bh = blockIdx.x;
+  const T* base = dS + (int64_t)bh * Sq * ldp;
+  for (int rel = threadIdx.x; rel < nrel; rel += 256) {
+    const int off = rel - (Sq - 1);                              // key - query
+    const int q_lo = max(0, -off), q_hi = min(Sq, Sk - off);     // q with 0 <= q + off < Sk
+    float acc = 0.f;
     for (int q = q_lo; q < q_hi; ++q) acc += to_f32(base[(int64_t)q * ldp + q + off]);
+    part[(int64_t)bh * nrel + rel] = acc;
   }
-  drel[idx] = acc;
 }
-// stage 2: dtable[bucket][h] = sum of drel[h][rel] over the rels of that bucket (bucket_of_rel precomputed on the host)
-__global__ void bias_bucket_kernel(const float* __restrict__ drel, const int* __restrict__ bucket_of_rel, float* __restrict__ dtable,
-                                   int H, int nrel, int num_buckets, int accumulate) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= num_buckets * H) return;
-  const int bk = idx / H, hh = idx - bk * H;
+// stage 2: one block per (bucket, head): dtable[bucket][h] (+)= sum over clips b and the rels of that bucket of part[b][h][rel]
+__global__ __launch_bounds__(256) void bias_bucket_kernel(const float* __restrict__ part, const int* __restrict__ bucket_of_rel,
+                                                          float* __restrict__ dtable, int B, int H, int nrel, int accumulate) {
+  __shared__ float sred[256];
+  const int bk = blockIdx.x / H, hh = blockIdx.x - bk * H;
   float acc = 0.f;
-  for (int rel = 0; rel < nrel; ++rel)
-    if (bucket_of_rel[rel] == bk) acc += drel[(int64_t)hh * nrel + rel];
-  dtable[idx] = accumulate ? dtable[idx] + acc : acc;
+  for (int rel = threadIdx.x; rel < nrel; rel += 256)
+    if (bucket_of_rel[rel] == bk)
+      for (int b = 0; b < B; ++b) acc += part[((int64_t)b * H + hh) * nrel + rel];
+  sred[threadIdx.x] = acc;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) sred[threadIdx.x] += sred[threadIdx.x + st]; __syncthreads(); }
+  if (threadIdx.x == 0) dtable[blockIdx.x] = accumulate ? dtable[blockIdx.x] + sred[0] : sred[0];
 }
 
 // ---- gated GELU (hf: modeling_t5.py T5DenseGatedActDense: gelu_new(wi_0 x) * (wi_1 x)); ab = [a | b], [M, 2*dff] ----
@@ -264,7 +332,7 @@ __global__ void gated_bwd_kernel(const T* __restrict__ ab, const T* __restrict__
 // ---- RMSNorm backward (forward: y = w * x * r, r = rsqrt(mean(x^2) + eps), hf: modeling_t5.py:59-72) ----
 // dx_out[row] = dx_res[row] (gradient arriving over the residual connection, may be null)
 //             + r * (w o dy) - x * r^3 * mean(w o dy o x);   dw partial per block (fixed order), reduced by colsum_kernel.
-constexpr int RN_BLOCKS = 128;
+constexpr int RN_BLOCKS = 256;
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ dy, const float* __restrict__ dx_res,
                                                           float* __restrict__ dx_out, float* __restrict__ dw_part, int M, int d, float eps) {
@@ -313,13 +381,21 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
   for (int col = threadIdx.x; col < d; col += 256)
     dw_part[(int64_t)blockIdx.x * d + col] = red[col] + red[d + col] + red[2 * d + col] + red[3 * d + col];
 }
-// out[col] (+)= sum over `parts` rows of part[p][col]   (second pass of every column reduction)
-__global__ void colsum_kernel(const float* __restrict__ part, float* __restrict__ out, int parts, int d, int accumulate) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= d) return;
+// out[col] (+)= sum over `parts` rows of part[p][col]   (second pass of every column reduction): 64 columns per block,
+// 4 row groups per column summed through LDS in a fixed order
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, float* __restrict__ out, int parts, int d, int accumulate) {
+  __shared__ float sred[4][64];
+  const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cx;
   float acc = 0.f;
-  for (int p = 0; p < parts; ++p) acc += part[(int64_t)p * d + col];
-  out[col] = accumulate ? out[col] + acc : acc;
+  if (col < d)
+    for (int p = py; p < parts; p += 4) acc += part[(int64_t)p * d + col];
+  sred[py][cx] = acc;
+  __syncthreads();
+  if (py == 0 && col < d) {
+    const float v = (sred[0][cx] + sred[1][cx]) + (sred[2][cx] + sred[3][cx]);
+    out[col] = accumulate ? out[col] + v : v;
+  }
 }
 
 // ---- cross entropy (mean over labels != -100, hf: modeling_t5.py:1049-1054) + gradient of the logits ----
@@ -386,20 +462,41 @@ __global__ void cond_gather_kernel(const float* __restrict__ params, const int64
   float* dst = x + ((int64_t)b * S + i) * d;
   for (int c = threadIdx.x; c < d; c += blockDim.x) dst[c] = src[c];
 }
-// gradient of an embedding table: one block per table row scans the ids (fixed order): G[v] = sum of dx[row] with id[row] == v.
-// ids[row * id_stride + id_off] is the id of activation row (row * x_row_stride + x_row_off).
-__global__ void embed_bwd_kernel(const int64_t* __restrict__ ids, int n_ids, int id_stride, int id_off, const float* __restrict__ dx,
-                                 int64_t x_row_stride, int64_t x_row_off, float* __restrict__ gtab, int d, int pad_to_zero_id, int V) {
-  const int v = blockIdx.x;
-  for (int c = threadIdx.x; c < d; c += blockDim.x) {
-    float acc = 0.f;
-    for (int i = 0; i < n_ids; ++i) {
+// gradient of an embedding table: one block per table row v.  The ids are scanned 256 at a time; a wave ballot marks the
+// activation rows whose id is v and every thread (= column) adds those rows in order: G[v] = sum of dx[row] with id[row] == v,
+// fixed order.  ids[i * id_stride + id_off] is the id of activation row (i * x_row_stride + x_row_off).
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, int n_ids, int id_stride, int id_off,
+                                                        const float* __restrict__ dx, int64_t x_row_stride, int64_t x_row_off,
+                                                        float* __restrict__ gtab, int d, int pad_to_zero_id, int V) {
+  __shared__ unsigned long long masks[4];
+  const int v = blockIdx.x, wave = threadIdx.x >> 6;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};          // columns tid, tid + 256, ... (d <= 1024)
+  for (int i0 = 0; i0 < n_ids; i0 += 256) {
+    const int i = i0 + threadIdx.x;
+    bool match = false;
+    if (i < n_ids) {
       int64_t id = ids[(int64_t)i * id_stride + id_off];
       if (id < 0 || id >= V) id = pad_to_zero_id;
-      if (id == v) acc += dx[((int64_t)i * x_row_stride + x_row_off) * d + c];
+      match = id == v;
     }
-    gtab[(int64_t)v * d + c] = acc;
+    const unsigned long long m = __ballot(match);
+    if ((threadIdx.x & 63) == 0) masks[wave] = m;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      unsigned long long mm = masks[w];
+      while (mm) {                                    // uniform: every thread walks the same set bits in the same order
+        const int j = __ffsll((long long)mm) - 1;
+        mm &= mm - 1;
+        const float* row = dx + ((int64_t)(i0 + 64 * w + j) * x_row_stride + x_row_off) * d;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int c = threadIdx.x + 256 * u; if (c < d) acc[u] += row[c]; }
+      }
+    }
+    __syncthreads();
   }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { const int c = threadIdx.x + 256 * u; if (c < d) gtab[(int64_t)v * d + c] = acc[u]; }
 }
 // decoder input ids = shift_right(labels): start token, then labels[:-1] with -100 -> pad (hf: modeling_t5.py:618-637)
 __global__ void shift_right_kernel(const int64_t* __restrict__ labels, int64_t* __restrict__ dec_in, int B, int Ld, int start_id, int pad_id) {
@@ -639,6 +736,12 @@ struct m2m_trainer {
   unsigned char* arena = nullptr;
   int64_t arena_bytes = 0;
   void* Wc = nullptr;                    // T copy of the parameters (bf16 mode; fp32 mode reads the master buffer)
+  void* WT = nullptr;                    // every weight matrix TRANSPOSED, in T, at the same offsets (dX = dY . W as an NT product)
+  void *tA = nullptr, *tB = nullptr;     // transposed activations of the current dW product: [features][Mp]
+  float* kpart = nullptr;                // split-K partial tiles
+  int64_t kpart_floats = 0;
+  void* wt_blocks = nullptr;             // WtBlock table on the device
+  int n_wt_blocks = 0;
   // activations (pointers into the arena)
   std::vector<float*> xe, xd;            // residual streams: 2*Le + 1 and 3*Ld + 1 buffers
   std::vector<void*> h0e, h1e, qkve, Pe, aoe, abe, mide;
@@ -787,11 +890,29 @@ int build_arena(m2m_trainer* t) {
                                   o.push_back(T(B * H * L * lpl)); o.push_back(T(Md * inner)); o.push_back(T(Md * inner)); o.push_back(T(Me * 2 * inner));
                                   o.push_back(T(B * H * L * lps)); o.push_back(T(Md * inner)); o.push_back(T(Md * 2 * dff)); o.push_back(T(Md * dff)); }
   const int64_t o_hE = T(Me * d), o_hD = T(Md * d), o_logits = F(Md * V), o_sc = F(B * H * Sm * lpm), o_dxa = F(Mx * d), o_dxb = F(Mx * d),
-                o_dh = F(Mx * d), o_dhE = F(Me * d), o_dwp = F((int64_t)RN_BLOCKS * d), o_rl = F(Md), o_inv = F(64), o_drel = F(H * (2 * Sm)),
+                o_dh = F(Mx * d), o_dhE = F(Me * d), o_dwp = F((int64_t)RN_BLOCKS * d), o_rl = F(Md), o_inv = F(64), o_drel = F(B * H * (2 * Sm)),
                 o_etab = F(H * (2 * S)), o_dtab = F(H * (2 * L)), o_dlog = T(Md * align_up(V, 8)), o_dxT = T(Mx * d), o_dmid = T(Mx * dff),
                 o_dab = T(Mx * 2 * dff), o_dO = T(Mx * inner), o_dqkv = T(Mx * 3 * inner), o_dS = T(B * H * Sm * lpm), o_dcq = T(Md * inner),
                 o_dckv = T(Me * 2 * inner), o_decin = c.take(Md * 8), o_eb = c.take(2 * S * 4), o_db = c.take(2 * L * 4),
-                o_co = c.take(64 * 8), o_cr = c.take(64 * 4), o_wc = (t->precision == M2M_PREC_BF16) ? T(t->n_floats) : 0;
+                o_co = c.take(64 * 8), o_cr = c.take(64 * 4), o_wc = (t->precision == M2M_PREC_BF16) ? T(t->n_floats) : 0,
+                o_wt = T(t->n_floats);
+  const int64_t Mxp = align_up(Mx, 8), fmax = std::max<int64_t>(std::max<int64_t>(3 * inner, 2 * dff), align_up(V, 8));
+  const int64_t o_tA = T(fmax * Mxp), o_tB = T(std::max<int64_t>(std::max<int64_t>(dff, inner), d) * Mxp);
+  t->kpart_floats = std::max<int64_t>((int64_t)8 << 20, fmax * std::max<int64_t>(dff, d) + 64);
+  const int64_t o_kp = F(t->kpart_floats);
+  // weight-transpose table: every 2-D weight group as one matrix [N][K] (q|k|v, wi_0|wi_1, cross k|v are fused groups)
+  std::vector<WtBlock> wtb;
+  {
+    auto add = [&](int64_t off, int N, int K) {
+      for (int tn = 0; tn < ceil_div(N, 64); ++tn)
+        for (int tk = 0; tk < ceil_div(K, 64); ++tk) wtb.push_back({off, N, K, tn, tk});
+    };
+    add(t->o_lm, (int)V, (int)d);
+    for (const EncOff& e : t->enc) { add(e.qkv, 3 * (int)inner, (int)d); add(e.o, (int)d, (int)inner); add(e.wi, 2 * (int)dff, (int)d); add(e.wo, (int)d, (int)dff); }
+    for (const DecOff& e : t->dec) { add(e.qkv, 3 * (int)inner, (int)d); add(e.o, (int)d, (int)inner); add(e.cq, (int)inner, (int)d);
+                                     add(e.ckv, 2 * (int)inner, (int)d); add(e.co, (int)d, (int)inner); add(e.wi, 2 * (int)dff, (int)d); add(e.wo, (int)d, (int)dff); }
+  }
+  const int64_t o_wtb = c.take((int64_t)wtb.size() * sizeof(WtBlock));
   t->arena_bytes = c.off;
   hipError_t e = hipMalloc((void**)&t->arena, (size_t)c.off);
   if (e != hipSuccess) { set_error("m2m_trainer_create: hipMalloc(%lld) failed: %s", (long long)c.off, hipGetErrorString(e)); return M2M_ERR_NOMEM; }
@@ -814,6 +935,8 @@ int build_arena(m2m_trainer* t) {
   t->dqkv = b + o_dqkv; t->dS = b + o_dS; t->dcq = b + o_dcq; t->dckv = b + o_dckv; t->dec_in = (int64_t*)(b + o_decin);
   t->ebucket = (int*)(b + o_eb); t->dbucket = (int*)(b + o_db); t->cond_off_dev = (int64_t*)(b + o_co); t->cond_rows_dev = (int*)(b + o_cr);
   t->Wc = (t->precision == M2M_PREC_BF16) ? (void*)(b + o_wc) : nullptr;
+  t->WT = b + o_wt; t->tA = b + o_tA; t->tB = b + o_tB; t->kpart = (float*)(b + o_kp); t->wt_blocks = b + o_wtb; t->n_wt_blocks = (int)wtb.size();
+  M2M_CHECK_HIP(hipMemcpy(t->wt_blocks, wtb.data(), wtb.size() * sizeof(WtBlock), hipMemcpyHostToDevice));
   M2M_CHECK_HIP(hipMemcpy(t->cond_off_dev, t->o_cond.data(), t->o_cond.size() * 8, hipMemcpyHostToDevice));
   M2M_CHECK_HIP(hipMemcpy(t->cond_rows_dev, t->cond_rows.data(), t->cond_rows.size() * 4, hipMemcpyHostToDevice));
   return M2M_OK;
@@ -850,13 +973,34 @@ struct Ops {
     g.nb1 = nB; g.nb2 = t->g.num_heads; g.sA1 = sA1; g.sA2 = sA2; g.sB1 = sB1; g.sB2 = sB2; g.sC1 = sC1; g.sC2 = sC2; g.alpha = 1.0f;
     return launch_bgemm(t->precision, epi, g, st);
   }
+  // dX[M, Kw] (epi) = dY[M, Nw] . W   for a weight stored [Nw][Kw]: an NT product against the transposed copy WT [Kw][Nw]
+  int dX(int epi, const void* dY, int64_t ldy, int64_t w_off, int Nw, int Kw, void* C, int64_t ldc, int M) const {
+    return mm(epi, dY, ldy, 0, reinterpret_cast<const T*>(t->WT) + w_off, Nw, 0, C, ldc, M, Kw, Nw);
+  }
+  // G[Ny, Kx] = dY[M, Ny]^T . X[M, Kx]: both operands are transposed once (coalesced, through LDS) into [features][Mp]
+  // scratch, then it is a plain NT product with the M rows as the reduction, split over k so that the few output tiles
+  // of a weight gradient still fill the chip; the k-slices are summed in a fixed order.
+  int dW(const void* dY, int64_t ldy, int Ny, const void* X, int64_t ldx, int Kx, float* Gout, int M) const {
+    const int Mp = (int)align_up(M, 8);
+    hipLaunchKernelGGL((transpose_kernel<T, T>), dim3(ceil_div(Ny, 64), ceil_div(Mp, 64)), dim3(256), 0, st, (const T*)dY, ldy, (T*)t->tA, (int64_t)Mp, M, Ny, Mp);
+    hipLaunchKernelGGL((transpose_kernel<T, T>), dim3(ceil_div(Kx, 64), ceil_div(Mp, 64)), dim3(256), 0, st, (const T*)X, ldx, (T*)t->tB, (int64_t)Mp, M, Kx, Mp);
+    M2M_CHECK_HIP(hipGetLastError());
+    BGemmArgs g{};
+    g.A = t->tA; g.B = t->tB; g.C = Gout; g.M = Ny; g.N = Kx; g.K = M; g.lda = Mp; g.ldb = Mp; g.ldc = Kx; g.nb1 = 1; g.nb2 = 1; g.alpha = 1.0f;
+    const int tiles = ceil_div(Ny, TG_BM) * ceil_div(Kx, TG_BN);
+    int ks = 1024 / tiles;
+    if (ks > 32) ks = 32;
+    while (ks > 1 && ((int64_t)ks * Ny * Kx > t->kpart_floats || ceil_div(M, ks) < 64)) --ks;
+    if (ks > 1) { g.ksplit = ks; g.kchunk = (int)align_up(ceil_div(M, ks), TG_BK); g.ksplit = ceil_div(M, g.kchunk); g.Cpart = t->kpart; }
+    return launch_bgemm(t->precision, TG_STORE_F32, g, st);
+  }
   int cvt(const float* src, void* dst, int64_t n) const { return launch_cvt(t->precision, src, dst, n, st); }
   int norm(const float* x, int64_t w_off, void* out, int M) const { return launch_rmsnorm(t->precision, x, P + w_off, out, M, t->g.d_model, t->g.layer_norm_eps, st); }
   int norm_bwd(const float* x, int64_t w_off, const float* dy, const float* dx_res, float* dx_out, float* G, int M) const {
     const int d = t->g.d_model;
     hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(RN_BLOCKS), dim3(256), (size_t)4 * d * sizeof(float), st, x, P + w_off, dy, dx_res, dx_out,
                        t->dw_part, M, d, t->g.layer_norm_eps);
-    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(d, 128)), dim3(128), 0, st, t->dw_part, G + w_off, RN_BLOCKS, d, 0);
+    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(d, 64)), dim3(256), 0, st, t->dw_part, G + w_off, RN_BLOCKS, d, 0);
     M2M_CHECK_HIP(hipGetLastError());
     return M2M_OK;
   }
@@ -884,9 +1028,8 @@ struct Ops {
   }
   int bias_grad(const void* dS, const int* buckets, float* Gtab, int nB, int Sq, int Sk, int ldp, int accumulate) const {
     const int H = t->g.num_heads, nrel = Sq + Sk - 1;
-    hipLaunchKernelGGL(bias_diag_kernel<T>, dim3(ceil_div(H * nrel, 128)), dim3(128), 0, st, (const T*)dS, t->drel, nB, H, Sq, Sk, ldp);
-    hipLaunchKernelGGL(bias_bucket_kernel, dim3(ceil_div(t->g.num_buckets * H, 64)), dim3(64), 0, st, t->drel, buckets, Gtab, H, nrel,
-                       t->g.num_buckets, accumulate);
+    hipLaunchKernelGGL(bias_diag_kernel<T>, dim3(nB * H), dim3(256), 0, st, (const T*)dS, t->drel, H, Sq, Sk, ldp);
+    hipLaunchKernelGGL(bias_bucket_kernel, dim3(t->g.num_buckets * H), dim3(256), 0, st, t->drel, buckets, Gtab, nB, H, nrel, accumulate);
     M2M_CHECK_HIP(hipGetLastError());
     return M2M_OK;
   }
@@ -922,8 +1065,8 @@ int attn_self_bwd(const Ops<T>& o, const float* x_in, const float* dx_out, float
   const int d = t->g.d_model, inner = t->inner, M = nB * S, ldp = (int)align_up(S, 8), H = t->g.num_heads;
   int rc;
   RC(o.cvt(dx_out, t->dxT, (int64_t)M * d));
-  RC(o.mm(TG_STORE_F32, t->dxT, d, 1, ao, inner, 1, G + wo, inner, d, inner, M));                 // dWo = dx^T . ao
-  RC(o.mm(TG_STORE_T, t->dxT, d, 0, o.W(wo), inner, 1, t->dO, inner, M, inner, d));               // dO = dx . Wo
+  RC(o.dW(t->dxT, d, d, ao, inner, inner, G + wo, M));                                            // dWo = dx^T . ao
+  RC(o.dX(TG_STORE_T, t->dxT, d, wo, d, inner, t->dO, inner, M));                                 // dO = dx . Wo
   const T* q = (const T*)qkv;
   const T* dO = (const T*)t->dO;
   T* dq = (T*)t->dqkv;
@@ -935,8 +1078,8 @@ int attn_self_bwd(const Ops<T>& o, const float* x_in, const float* dx_out, float
   const T* dS = (const T*)t->dS;
   RC(o.mmbh(TG_STORE_T, dS, ldp, 0, sP1, sP2, q + inner, 3 * inner, 1, sQ1, DK, dq, 3 * inner, sQ1, DK, nB, S, DK, S));              // dQ = dS K
   RC(o.mmbh(TG_STORE_T, dS, ldp, 1, sP1, sP2, q, 3 * inner, 1, sQ1, DK, dq + inner, 3 * inner, sQ1, DK, nB, S, DK, S));              // dK = dS^T Q
-  RC(o.mm(TG_STORE_F32, dq, 3 * inner, 1, h, d, 1, G + wqkv, d, 3 * inner, d, M));               // dWqkv = dqkv^T . h
-  RC(o.mm(TG_STORE_F32, dq, 3 * inner, 0, o.W(wqkv), d, 1, t->dh, d, M, d, 3 * inner));           // dh = dqkv . Wqkv
+  RC(o.dW(dq, 3 * inner, 3 * inner, h, d, d, G + wqkv, M));                                       // dWqkv = dqkv^T . h
+  RC(o.dX(TG_STORE_F32, dq, 3 * inner, wqkv, 3 * inner, d, t->dh, d, M));                         // dh = dqkv . Wqkv
   RC(o.norm_bwd(x_in, ln, t->dh, dx_out, dx_in, G, M));
   return M2M_OK;
 }
@@ -959,11 +1102,11 @@ int ff_bwd(const Ops<T>& o, const float* x_in, const float* dx_out, float* dx_in
   const int d = t->g.d_model, dff = t->g.d_ff;
   int rc;
   RC(o.cvt(dx_out, t->dxT, (int64_t)M * d));
-  RC(o.mm(TG_STORE_F32, t->dxT, d, 1, mid, dff, 1, G + wo, dff, d, dff, M));                      // dWo = dx^T . mid
-  RC(o.mm(TG_STORE_T, t->dxT, d, 0, o.W(wo), dff, 1, t->dmid, dff, M, dff, d));                   // dmid = dx . Wo
+  RC(o.dW(t->dxT, d, d, mid, dff, dff, G + wo, M));                                               // dWo = dx^T . mid
+  RC(o.dX(TG_STORE_T, t->dxT, d, wo, d, dff, t->dmid, dff, M));                                   // dmid = dx . Wo
   RC(o.gated_bwd(ab, t->dmid, t->dab, M));
-  RC(o.mm(TG_STORE_F32, t->dab, 2 * dff, 1, h, d, 1, G + wi, d, 2 * dff, d, M));                  // dWi = dab^T . h
-  RC(o.mm(TG_STORE_F32, t->dab, 2 * dff, 0, o.W(wi), d, 1, t->dh, d, M, d, 2 * dff));             // dh = dab . Wi
+  RC(o.dW(t->dab, 2 * dff, 2 * dff, h, d, d, G + wi, M));                                         // dWi = dab^T . h
+  RC(o.dX(TG_STORE_F32, t->dab, 2 * dff, wi, 2 * dff, d, t->dh, d, M));                           // dh = dab . Wi
   RC(o.norm_bwd(x_in, ln, t->dh, dx_out, dx_in, G, M));
   return M2M_OK;
 }
@@ -993,7 +1136,11 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
   hipLaunchKernelGGL(bias_table_kernel, dim3(ceil_div(H * (2 * L - 1), 128)), dim3(128), 0, st, P + t->o_drb, t->dbucket, t->dtab, H, 2 * L - 1);
   M2M_CHECK_HIP(hipGetLastError());
   if (t->precision == M2M_PREC_BF16) RC(o.cvt(P, t->Wc, t->n_floats));
-  M2M_CHECK_HIP(hipMemsetAsync(G, 0, (size_t)t->n_floats * 4, st));
+  if (G) {
+    hipLaunchKernelGGL(weights_transpose_kernel<T>, dim3(t->n_wt_blocks), dim3(256), 0, st, (const WtBlock*)t->wt_blocks, P, (T*)t->WT);
+    M2M_CHECK_HIP(hipGetLastError());
+  }
+  if (G) M2M_CHECK_HIP(hipMemsetAsync(G, 0, (size_t)t->n_floats * 4, st));
 
   // ================= forward =================
   M2M_CHECK_HIP(hipMemcpyAsync(t->xe[0], enc_inputs, (size_t)Me * d * 4, hipMemcpyDeviceToDevice, st));
@@ -1037,8 +1184,8 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
   if (!G) return M2M_OK;
 
   // ================= backward =================
-  RC(o.mm(TG_STORE_F32, t->dlog, ldv, 1, t->hD, d, 1, G + t->o_lm, d, V, d, Md));                 // dW_lm = dlogits^T . hD
-  RC(o.mm(TG_STORE_F32, t->dlog, ldv, 0, o.W(t->o_lm), d, 1, t->dh, d, Md, d, V));                // dhD = dlogits . W_lm
+  RC(o.dW(t->dlog, ldv, V, t->hD, d, d, G + t->o_lm, Md));                                        // dW_lm = dlogits^T . hD
+  RC(o.dX(TG_STORE_F32, t->dlog, ldv, t->o_lm, V, d, t->dh, d, Md));                              // dhD = dlogits . W_lm
   float* dcur = t->dxa;
   float* dnext = t->dxb;
   RC(o.norm_bwd(t->xd[3 * Ld], t->o_dln, t->dh, nullptr, dcur, G, Md));
@@ -1048,8 +1195,8 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
     std::swap(dcur, dnext);
     // ---- cross-attention backward: dcur = d x[3l+2] ----
     RC(o.cvt(dcur, t->dxT, (int64_t)Md * d));
-    RC(o.mm(TG_STORE_F32, t->dxT, d, 1, t->aocd[l], inner, 1, G + e.co, inner, d, inner, Md));
-    RC(o.mm(TG_STORE_T, t->dxT, d, 0, o.W(e.co), inner, 1, t->dO, inner, Md, inner, d));
+    RC(o.dW(t->dxT, d, d, t->aocd[l], inner, inner, G + e.co, Md));
+    RC(o.dX(TG_STORE_T, t->dxT, d, e.co, d, inner, t->dO, inner, Md));
     const T* cq = (const T*)t->cqd[l];
     const T* ckv = (const T*)t->ckvd[l];
     const T* dO = (const T*)t->dO;
@@ -1062,19 +1209,19 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
     const T* dS = (const T*)t->dS;
     RC(o.mmbh(TG_STORE_T, dS, lps, 0, sPc1, sPc2, ckv, 2 * inner, 1, sK1, DK, dcq, inner, sQ1, DK, B, L, DK, S));                            // dQ = dS K
     RC(o.mmbh(TG_STORE_T, dS, lps, 1, sPc1, sPc2, cq, inner, 1, sQ1, DK, dckv, 2 * inner, sK1, DK, B, S, DK, L));                            // dK = dS^T Q
-    RC(o.mm(TG_STORE_F32, dcq, inner, 1, t->h1d[l], d, 1, G + e.cq, d, inner, d, Md));
-    RC(o.mm(TG_STORE_F32, dcq, inner, 0, o.W(e.cq), d, 1, t->dh, d, Md, d, inner));
+    RC(o.dW(dcq, inner, inner, t->h1d[l], d, d, G + e.cq, Md));
+    RC(o.dX(TG_STORE_F32, dcq, inner, e.cq, inner, d, t->dh, d, Md));
     RC(o.norm_bwd(t->xd[3 * l + 1], e.ln1, t->dh, dcur, dnext, G, Md));
     std::swap(dcur, dnext);
-    RC(o.mm(TG_STORE_F32, dckv, 2 * inner, 1, t->hE, d, 1, G + e.ckv, d, 2 * inner, d, Me));       // dWckv = dckv^T . hE
-    RC(o.mm(l == Ld - 1 ? TG_STORE_F32 : TG_ACC_F32, dckv, 2 * inner, 0, o.W(e.ckv), d, 1, t->dhE, d, Me, d, 2 * inner));   // dhE (+)= dckv . Wckv
+    RC(o.dW(dckv, 2 * inner, 2 * inner, t->hE, d, d, G + e.ckv, Me));                               // dWckv = dckv^T . hE
+    RC(o.dX(l == Ld - 1 ? TG_STORE_F32 : TG_ACC_F32, dckv, 2 * inner, e.ckv, 2 * inner, d, t->dhE, d, Me));                  // dhE (+)= dckv . Wckv
     // ---- causal self-attention backward ----
     RC(attn_self_bwd<T>(o, t->xd[3 * l], dcur, dnext, G, e.ln0, e.qkv, e.o, t->h0d[l], t->qkvd[l], t->Pd[l], t->aod[l], B, L, t->dbucket, t->o_drb,
                         l == Ld - 1 ? 0 : 1));
     std::swap(dcur, dnext);
   }
   // token embedding (decoder inputs; the encoder is fed inputs_embeds) — hf: modeling_t5.py embed_tokens = shared
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(V), dim3(128), 0, st, t->dec_in, Md, 1, 0, dcur, (int64_t)1, (int64_t)0, G + t->o_shared, d,
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(V), dim3(256), 0, st, t->dec_in, Md, 1, 0, dcur, (int64_t)1, (int64_t)0, G + t->o_shared, d,
                      g.pad_token_id, V);
   // encoder
   RC(o.norm_bwd(t->xe[2 * Le], t->o_eln, t->dhE, nullptr, dcur, G, Me));
@@ -1088,7 +1235,7 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
   }
   // conditioning embeddings: rows 0 .. n_cond-1 of every clip's encoder input (ref: music2midi/input.py:57-59)
   for (int i = 0; i < t->n_cond; ++i)
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(t->cond_rows[i]), dim3(128), 0, st, cond_idx, B, t->n_cond, i, dcur, (int64_t)S, (int64_t)i,
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(t->cond_rows[i]), dim3(256), 0, st, cond_idx, B, t->n_cond, i, dcur, (int64_t)S, (int64_t)i,
                        G + t->o_cond[i], d, 0, t->cond_rows[i]);
   M2M_CHECK_HIP(hipGetLastError());
   return M2M_OK;
