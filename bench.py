@@ -205,6 +205,54 @@ def dry_run(args):
     return 0 if ok and pmin == pmax else 1
 
 
+# ------------------------------------------------------------------ BASELINE configs[4]: training step
+TRAIN_SAMPLES = 66150      # ref config.yaml: 3 s segments at dataset.sample_rate 22 050 Hz -> 259 frames, S = 261
+TRAIN_LABELS = 256         # label tokens per clip (synthetic, none ignored)
+
+
+def train_step_record(model_module, cfg, geom, dev, B: int, precision: str, steps: int, warmup: int, world: int = 1):
+    """forward + backward + (gradient all-reduce) + Adafactor on B clips per GPU; returns a dict for the JSON line."""
+    from music2midi_amd import distributed as D
+    from music2midi_amd import synth
+    from music2midi_amd.input import ModelInputs
+    from music2midi_amd.training import NativeTrainer
+    rank = D.env_world()[0]
+    F = 1 + TRAIN_SAMPLES // 256
+    wav = torch.from_numpy(synth.waveform_batch(rank * B, B, TRAIN_SAMPLES)).to(dev)
+    cond = torch.from_numpy(synth.cond_index_batch(rank * B, B)).to(dev)
+    labels = (torch.from_numpy((synth.uniform01(rank, "train_labels", B * TRAIN_LABELS) * 330).astype(np.int64)
+                               .reshape(B, TRAIN_LABELS)) + 3).to(dev)
+    tr = NativeTrainer(model_module, B, F + 2, TRAIN_LABELS, precision=precision)
+
+    def step():
+        x = model_module.encoder_inputs(ModelInputs(input_waveform=wav, cond_index=cond))     # frontend kernel, every step
+        loss, _ = tr.forward_backward(x, cond, labels)
+        nbytes = D.all_reduce_gradients(tr.grads)
+        tr.optimizer_step()
+        return loss, nbytes
+
+    for _ in range(max(1, warmup)):
+        loss, nbytes = step()
+    D.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, nbytes = step()
+    torch.cuda.synchronize(dev)
+    D.barrier()
+    dt = D.all_reduce_max(time.perf_counter() - t0, dev) / steps
+    S = F + 2
+    enc = 6 * (4227072 * S + 2048 * S * S) + 4718592 * S
+    dec = TRAIN_LABELS * (6 * (2 * 384 * 512 * 6 + 3 * 2 * 384 * 1152) + 2 * 384 * 400) + 6 * (4 * TRAIN_LABELS * TRAIN_LABELS * 512 + 4 * TRAIN_LABELS * S * 512)
+    rec = {"workload": f"BASELINE configs[4]: train step (log-mel + forward + backward + Adafactor), {precision} GEMM inputs, "
+                       f"{B} clips/GPU x {TRAIN_SAMPLES} samples (S={S}), {TRAIN_LABELS} labels/clip, dropout off",
+           "ms_per_step": dt * 1e3, "clips_per_s": B * world / dt, "label_tokens_per_s": B * world * TRAIN_LABELS / dt,
+           "model_TFLOPs_per_gpu": 3 * B * (enc + dec) / dt / 1e12, "loss": float(loss), "grad_allreduce_bytes": nbytes,
+           "optimizer": "Adafactor(warmup_init=True), native", "world": world}
+    tr.close()
+    return rec
+
+
 # ------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -217,6 +265,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the fp32 parity-mode record")
     ap.add_argument("--no-frontend", action="store_true", help="skip the configs[1] frontend record")
+    ap.add_argument("--mode", default="generate", choices=["generate", "train"],
+                    help="train: BASELINE configs[4] (forward+backward+Adafactor, 16 clips/GPU, gradient all-reduce over RCCL)")
+    ap.add_argument("--no-train", action="store_true", help="skip the configs[4] training-step record of the default line")
     ap.add_argument("--dry-run", action="store_true", help="launcher + collectives on CPU tensors (gloo), no GPU work")
     ap.add_argument("--max-length", type=int, default=MAX_LENGTH,
                     help="decoder max_length (profiling runs only; the headline number uses 1024)")
@@ -262,6 +313,19 @@ def main():
         load_t5_state(model, state, strict=False)
     model = model.to(dev).eval()
     bcast_bytes = D.broadcast_module_state(model, src=0)
+
+    if args.mode == "train":
+        Bt = 16 if args.batch == 32 else args.batch
+        rec = train_step_record(model, cfg, geom, dev, Bt, args.precision, args.steps, args.warmup, world)
+        if rank == 0:
+            print(json.dumps({"metric": "training clips/sec/node (forward+backward+Adafactor step)", "value": rec["clips_per_s"], "unit": "clips/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"],
+                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+                              "config": {"workload": rec["workload"], "global_batch": Bt * world, "parallelism": f"data-parallel x{world}",
+                                         "grad_allreduce_bytes": rec["grad_allreduce_bytes"]}, "extras": rec}), flush=True)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
 
     # ---- synthetic clips of this rank, resident in HBM ----
     first = rank * B
@@ -337,7 +401,9 @@ def main():
         mean_step_us = (t_dec - enc_ms * 1e-3) / n_steps * 1e6
         step_bytes = decode_bytes_per_step(B, S, (1 + n_steps) / 2.0, es)
         step_gbs = step_bytes / (mean_step_us * 1e-6) / 1e9
+        n_chains = 2 if B >= 24 and not os.environ.get("M2M_GROUP_ROWS") else max(1, -(-B // int(os.environ.get("M2M_GROUP_ROWS") or B)))
         out["roofline"] = {"bound": "hbm", "kernel": "dec_attn_kernel (cross-attention, decode step)",
+                           "launch": f"{n_chains} co-scheduled chain launches of {B // n_chains} clips each (as the decode loop issues them) = {B} clips",
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS,
                            "traffic": pmc_traffic_bytes("dec_attn_kernel<m2m::bf16_t, false,", B)
@@ -408,6 +474,13 @@ def main():
             "bf16_vs_fp32_mean_identical_prefix": float(np.mean(prefix)),
         }
         del m32
+
+    # ---- BASELINE configs[4] (per-GPU share: 128 clips / 8 GPUs): one training step, timed on this GPU ----
+    if rank == 0 and world == 1 and not args.no_train:
+        mt = T5Transformer(cfg.to_dict(), precision="fp32")
+        load_t5_state(mt, state, strict=False)
+        out["train_configs4"] = train_step_record(mt.to(dev), cfg, geom, dev, 16, "bf16", 10, 2)
+        del mt
 
     if rank == 0 and world == 1 and args.cpu_tokens > 0:
         out["cpu_baseline"] = cpu_baseline(cfg, state, args.cpu_tokens)

@@ -21,7 +21,9 @@
 // (~26 flop/B, at the fp32-vector ridge) — see DESIGN.md.
 #include "common.h"
 
+#include <algorithm>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -39,9 +41,9 @@ struct FrontendDev {
   const float2* tw1024;   // [1024]  exp(-2 pi i k / 1024)
   const float2* tw2048;   // [1024]  exp(-2 pi i k / 2048)
   const int* fb_start;    // [n_mels] first frequency bin with a tap
-  const int* fb_count;    // [n_mels] number of contiguous taps
-  const int* fb_off;      // [n_mels] offset of the first tap weight in fb_w
-  const float* fb_w;      // [nnz]
+  const float* fb_wpad;   // [sum_j gmax[j]][64]: tap c of filter 64 j + lane at ((goff[j] + c) * 64 + lane); zero beyond the filter's own taps
+  int gmax[8];            // taps walked for the 64 filters of group j (= the widest filter of the group): wave-uniform trip counts
+  int n_wpad;             // floats in fb_wpad
   int n_mels;
   int hop;
 };
@@ -103,11 +105,11 @@ constexpr int DPP_XOR2 = 0x4E;  // quad_perm [2,3,0,1]
 __device__ inline int zidx(int k) { return k + 4 * (k >> 8); }  // bank-spread layout of Z[0..1023]
 
 constexpr int FE_MAXJ = 8;          // mel filters per lane (n_mels <= 512)
-constexpr int FE_FBW_LDS = 4096;    // filter taps kept in LDS when the sparse filterbank has at most this many
+constexpr int FE_FBW_LDS = 6144;    // padded tap table kept in LDS when it has at most this many floats (24 KB), else read from memory
 
 __global__ __launch_bounds__(FE_THREADS, 2) void logmel_kernel(
     const float* __restrict__ wav, int T, int F, FrontendDev fe, float* __restrict__ out,
-    int64_t out_bstride, int row_offset, int FR, int nnz) {
+    int64_t out_bstride, int row_offset, int FR, int NCH) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -121,27 +123,12 @@ __global__ __launch_bounds__(FE_THREADS, 2) void logmel_kernel(
   float2* cbuf = cbase + wave * WAVE_C2;
   float* pbuf = reinterpret_cast<float*>(cbuf);          // aliases cbuf: written only after every Z read of the wave
   float* fbw_s = reinterpret_cast<float*>(cbase + FE_WAVES * WAVE_C2);
+  const int nnz = fe.n_wpad;
   const bool fbw_in_lds = nnz <= FE_FBW_LDS;
 
   const int b = blockIdx.y;
-  const int f0 = blockIdx.x * FR;
-  const int nfr = min(FR, F - f0);
-  const int span = (nfr - 1) * hop + NFFT;
-
-  // ---- stage the padded samples (reflect, as torch.stft center=True pad_mode="reflect") ----
-  {
-    const float* w = wav + (int64_t)b * T;
-    const int base = f0 * hop - NFFT / 2;
-    for (int i = tid; i < span; i += FE_THREADS) {
-      int j = base + i;
-      if (j < 0) j = -j;
-      else if (j >= T) j = 2 * (T - 1) - j;
-      samples[i] = w[j];
-    }
-    if (fbw_in_lds)
-      for (int i = tid; i < nnz; i += FE_THREADS) fbw_s[i] = fe.fb_w[i];
-  }
-  const float* fbw = fbw_in_lds ? fbw_s : fe.fb_w;
+  if (fbw_in_lds)
+    for (int i = tid; i < nnz; i += FE_THREADS) fbw_s[i] = fe.fb_wpad[i];
 
   // ---- per-lane constants, loaded once ----
   float2 win[16];   // window[2n], window[2n+1] for n = 64*n1 + lane
@@ -157,20 +144,41 @@ __global__ __launch_bounds__(FE_THREADS, 2) void logmel_kernel(
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i) tw_p[i] = fe.tw2048[lane + 64 * i];
-  // this lane's mel filters: m = lane + 64 j (first tap bin, tap count, offset of the first weight)
+  // this lane's mel filters: m = lane + 64 j (first tap bin; the taps come from the padded per-group table)
   const int n_mels = fe.n_mels;
-  int fb_s[FE_MAXJ], fb_c[FE_MAXJ], fb_o[FE_MAXJ];
+  int fb_s[FE_MAXJ];
 #pragma unroll
-  for (int j = 0; j < FE_MAXJ; ++j) {
-    const int m = min(lane + 64 * j, n_mels - 1);
-    fb_s[j] = fe.fb_start[m];
-    fb_c[j] = (lane + 64 * j < n_mels) ? fe.fb_count[m] : 0;
-    fb_o[j] = fe.fb_off[m];
-  }
+  for (int j = 0; j < FE_MAXJ; ++j) fb_s[j] = fe.fb_start[min(lane + 64 * j, n_mels - 1)];
 
   const float sg2 = (m2 & 2) ? -1.f : 1.f, sg1 = (m2 & 1) ? -1.f : 1.f;
   const float rc = (m2 == 3) ? 0.f : 1.f, rs_ = (m2 == 3) ? 1.f : 0.f;
 
+  // A workgroup walks NCH consecutive chunks of FR frames: the ~110 table loads per lane above and the launch are
+  // paid once per NCH * FR frames instead of once per FR.
+  for (int ch = 0; ch < NCH; ++ch) {
+  const int f0 = (blockIdx.x * NCH + ch) * FR;
+  if (f0 >= F) break;                          // uniform
+  const int nfr = min(FR, F - f0);
+  const int span = (nfr - 1) * hop + NFFT;
+  __syncthreads();                             // every wave is done with the previous chunk's samples
+  // ---- stage the padded samples (reflect, as torch.stft center=True pad_mode="reflect") ----
+  {
+    const float* w = wav + (int64_t)b * T;
+    const int base = f0 * hop - NFFT / 2;
+    if (base >= 0 && base + span <= T && (span & 3) == 0 && ((reinterpret_cast<uintptr_t>(w + base) & 15) == 0)) {
+      // interior chunk: no reflection, 16-byte loads, all of a thread's loads in flight at once (one round trip)
+      const float4* src = reinterpret_cast<const float4*>(w + base);
+      float4* dst = reinterpret_cast<float4*>(samples);
+      for (int i = tid; i < span / 4; i += FE_THREADS) dst[i] = src[i];
+    } else {
+      for (int i = tid; i < span; i += FE_THREADS) {
+        int j = base + i;
+        if (j < 0) j = -j;
+        else if (j >= T) j = 2 * (T - 1) - j;
+        samples[i] = w[j];
+      }
+    }
+  }
   __syncthreads();
 
   // Each WAVE now runs on its own: frame -> FFT -> power bins -> mel -> store, with wave-level
@@ -178,6 +186,15 @@ __global__ __launch_bounds__(FE_THREADS, 2) void logmel_kernel(
   for (int fl = wave; fl < nfr; fl += FE_WAVES) {
     const float* fs = samples + fl * hop;   // 8-byte aligned: hop is even (checked on the host)
     float2 z[16];
+#ifdef M2M_FE_SKIP_FFT     // diagnostic builds only: time everything but the transform
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) z[n1] = *reinterpret_cast<const float2*>(fs + 2 * (64 * n1 + lane));
+    {
+      const int q2 = ((m2 & 1) << 1) | (m2 >> 1);
+#pragma unroll
+      for (int q1 = 0; q1 < 16; ++q1) cbuf[zidx(k1_lane + 16 * q1 + 256 * q2)] = z[q1];
+    }
+#else
     // stage 1: lane holds n = 64*n1 + lane
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) {
@@ -217,6 +234,7 @@ __global__ __launch_bounds__(FE_THREADS, 2) void logmel_kernel(
 #pragma unroll
       for (int q1 = 0; q1 < 16; ++q1) cbuf[zidx(k1_lane + 16 * q1 + 256 * q2)] = z[q1];
     }
+#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // post-process pairs (k, 1024-k): X[k] = E + W2048^k O, X[1024-k] = conj(E - W2048^k O).
@@ -244,28 +262,43 @@ __global__ __launch_bounds__(FE_THREADS, 2) void logmel_kernel(
       pbuf[HALF - k] = xm.x * xm.x + xm.y * xm.y;
     }
     if (lane == 0) pbuf[512] = z512.x * z512.x + z512.y * z512.y;  // k = 512: E = Re Z, O = Im Z, W2048^512 = -i
+    if (lane < 48) pbuf[1025 + lane] = 0.f;                          // the padded taps of the last filters read (and ignore) these
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // ---- mel filterbank (sparse contiguous taps) + clamp + log, this wave's frame ----
+    // ---- mel filterbank + clamp + log, this wave's frame.  The 64 filters of a group walk the SAME number of taps
+    //      (the widest filter of the group; the table is zero-padded), so the trip counts are wave-uniform scalars:
+    //      no exec masking, and the weights are read lane-contiguous (tap c of the group's 64 filters is one 256-byte row).
     {
       float* orow = out + (int64_t)b * out_bstride + (int64_t)(row_offset + f0 + fl) * n_mels;
+      int wrow = 0;
 #pragma unroll
       for (int j = 0; j < FE_MAXJ; ++j) {
-        const int m = lane + 64 * j;
-        if (m < n_mels) {
-          const float* p = pbuf + fb_s[j];
-          const float* fw = fbw + fb_o[j];
-          float acc = 0.f;
-          for (int c = 0; c < fb_c[j]; ++c) acc = fmaf(p[c], fw[c], acc);
-          // clamp(min=1e-6).log(): the floor is the correctly rounded fp32 ln(1e-6f), so silent
-          // (zero-padded) regions are bit-identical to the reference's constant.
-          orow[m] = (acc > 1e-6f) ? logf(acc) : -13.815510749816895f;
+        if (64 * j >= n_mels) break;                               // uniform
+#ifdef M2M_FE_SKIP_MEL     // diagnostic builds only
+        const int gm = 1;
+#else
+        const int gm = fe.gmax[j];
+#endif
+        const float* p = pbuf + fb_s[j];
+        float acc = 0.f;
+        if (fbw_in_lds) {
+          const float* fw = fbw_s + wrow * 64 + lane;
+          for (int c = 0; c < gm; ++c) acc = fmaf(p[c], fw[c * 64], acc);
+        } else {
+          const float* fw = fe.fb_wpad + wrow * 64 + lane;
+          for (int c = 0; c < gm; ++c) acc = fmaf(p[c], fw[c * 64], acc);
         }
+        wrow += gm;
+        const int m = lane + 64 * j;
+        // clamp(min=1e-6).log(): the floor is the correctly rounded fp32 ln(1e-6f), so silent
+        // (zero-padded) regions are bit-identical to the reference's constant.
+        if (m < n_mels) orow[m] = (acc > 1e-6f) ? logf(acc) : -13.815510749816895f;
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();   // the next frame's transpose writes reuse this buffer
   }
+  }  // chunks
 }
 
 struct CondArgs {
@@ -290,7 +323,7 @@ __global__ void cond_rows_kernel(CondArgs a, int n_tables, int n_dim, const int6
 using namespace m2m;
 
 struct m2m_frontend {
-  int n_fft, hop, n_freqs, n_mels, nnz;
+  int n_fft, hop, n_freqs, n_mels, nnz, n_wpad;
   void* dev_blob = nullptr;  // one allocation holding every table
   FrontendDev dev;
 };
@@ -305,44 +338,49 @@ extern "C" int m2m_frontend_create(const m2m_frontend_desc* d, m2m_frontend** ou
   M2M_REQUIRE(d->n_mels >= 1 && d->window_host && d->fb_host, "m2m_frontend_create: bad n_mels / null tables");
 
   const int n_mels = d->n_mels, n_freqs = d->n_freqs;
-  std::vector<int> start(n_mels), count(n_mels), off(n_mels);
-  std::vector<float> w;
+  std::vector<int> start(n_mels), count(n_mels);
+  int nnz_true = 0;
   for (int m = 0; m < n_mels; ++m) {
     int lo = -1, hi = -1;
     for (int k = 0; k < n_freqs; ++k)
-      if (d->fb_host[(size_t)k * n_mels + m] != 0.0f) { if (lo < 0) lo = k; hi = k; }
+      if (d->fb_host[(size_t)k * n_mels + m] != 0.0f) { if (lo < 0) lo = k; hi = k; nnz_true++; }
     start[m] = lo < 0 ? 0 : lo;
     count[m] = lo < 0 ? 0 : hi - lo + 1;
-    off[m] = (int)w.size();
-    for (int k = 0; k < count[m]; ++k) w.push_back(d->fb_host[(size_t)(lo + k) * n_mels + m]);
   }
+  // per group of 64 filters: the widest filter's tap count; the table holds tap c of filter 64 j + lane at
+  // ((goff[j] + c) * 64 + lane), zero where c is past the filter's own taps (interior zeros of a filter stay zeros)
+  int gmax[8] = {0, 0, 0, 0, 0, 0, 0, 0}, goff[9] = {0};
+  for (int m = 0; m < n_mels; ++m) gmax[m / 64] = std::max(gmax[m / 64], count[m]);
+  for (int j = 0; j < 8; ++j) goff[j + 1] = goff[j] + gmax[j];
+  M2M_REQUIRE(gmax[0] + 0 <= 48 && *std::max_element(gmax, gmax + 8) <= 48,
+              "m2m_frontend_create: a mel filter spans more than 48 frequency bins (the kernel keeps 48 spare power bins for the padded taps)");
+  std::vector<float> w((size_t)goff[8] * 64, 0.0f);
+  for (int m = 0; m < n_mels; ++m)
+    for (int c = 0; c < count[m]; ++c) w[((size_t)goff[m / 64] + c) * 64 + (m % 64)] = d->fb_host[(size_t)(start[m] + c) * n_mels + m];
   std::vector<float2> tw1(HALF), tw2(HALF);
   for (int k = 0; k < HALF; ++k) {
     double a1 = -2.0 * M_PI * k / 1024.0, a2 = -2.0 * M_PI * k / 2048.0;
     tw1[k] = make_float2((float)cos(a1), (float)sin(a1));
     tw2[k] = make_float2((float)cos(a2), (float)sin(a2));
   }
-  // one blob: window | tw1024 | tw2048 | start | count | off | weights
+  // one blob: window | tw1024 | tw2048 | start | padded weights
   size_t o_win = 0;
   size_t o_tw1 = o_win + NFFT * sizeof(float);
   size_t o_tw2 = o_tw1 + HALF * sizeof(float2);
   size_t o_st = o_tw2 + HALF * sizeof(float2);
-  size_t o_ct = o_st + (size_t)n_mels * sizeof(int);
-  size_t o_of = o_ct + (size_t)n_mels * sizeof(int);
-  size_t o_w = (size_t)align_up((int64_t)(o_of + (size_t)n_mels * sizeof(int)), 16);
+  size_t o_w = (size_t)align_up((int64_t)(o_st + (size_t)n_mels * sizeof(int)), 16);
   size_t total = o_w + (w.size() + 4) * sizeof(float);
   std::vector<unsigned char> host(total, 0);
   memcpy(host.data() + o_win, d->window_host, NFFT * sizeof(float));
   memcpy(host.data() + o_tw1, tw1.data(), HALF * sizeof(float2));
   memcpy(host.data() + o_tw2, tw2.data(), HALF * sizeof(float2));
   memcpy(host.data() + o_st, start.data(), (size_t)n_mels * sizeof(int));
-  memcpy(host.data() + o_ct, count.data(), (size_t)n_mels * sizeof(int));
-  memcpy(host.data() + o_of, off.data(), (size_t)n_mels * sizeof(int));
   if (!w.empty()) memcpy(host.data() + o_w, w.data(), w.size() * sizeof(float));
 
   m2m_frontend* fe = new m2m_frontend();
   fe->n_fft = d->n_fft; fe->hop = d->hop_length; fe->n_freqs = n_freqs; fe->n_mels = n_mels;
-  fe->nnz = (int)w.size();
+  fe->nnz = nnz_true;
+  fe->n_wpad = (int)w.size();
   hipError_t e = hipMalloc(&fe->dev_blob, total);
   if (e == hipSuccess) e = hipMemcpy(fe->dev_blob, host.data(), total, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
@@ -356,9 +394,9 @@ extern "C" int m2m_frontend_create(const m2m_frontend_desc* d, m2m_frontend** ou
   fe->dev.tw1024 = (const float2*)(base + o_tw1);
   fe->dev.tw2048 = (const float2*)(base + o_tw2);
   fe->dev.fb_start = (const int*)(base + o_st);
-  fe->dev.fb_count = (const int*)(base + o_ct);
-  fe->dev.fb_off = (const int*)(base + o_of);
-  fe->dev.fb_w = (const float*)(base + o_w);
+  fe->dev.fb_wpad = (const float*)(base + o_w);
+  for (int j = 0; j < 8; ++j) fe->dev.gmax[j] = gmax[j];
+  fe->dev.n_wpad = (int)w.size();
   fe->dev.n_mels = n_mels;
   fe->dev.hop = d->hop_length;
   *out = fe;
@@ -399,12 +437,17 @@ extern "C" int m2m_logmel_f32(const m2m_frontend* fe, const float* wav_dev, int 
               "m2m_logmel_f32: out_batch_stride %lld smaller than (row_offset+frames)*n_mels", (long long)out_batch_stride);
   // 16 frames per workgroup: waveform re-read factor 1.44 at hop 256, two workgroups per CU.
   int FR = 16;
-  while (FR > 4 && frontend_smem_bytes(FR, fe->hop, fe->nnz) > 78 * 1024) FR -= 4;
-  const size_t smem = frontend_smem_bytes(FR, fe->hop, fe->nnz);
-  dim3 grid((unsigned)ceil_div(F, FR), (unsigned)B);
+  while (FR > 4 && frontend_smem_bytes(FR, fe->hop, fe->n_wpad) > 78 * 1024) FR -= 4;
+  const size_t smem = frontend_smem_bytes(FR, fe->hop, fe->n_wpad);
+  // chunks of FR frames per workgroup.  Measured on MI355X (B = 64 / 32, us per launch): 1 chunk 199.9 / 108.3,
+  // 2 chunks 196.0 / 112.5, 3 chunks 208.1 / 136.9: the table loads are not what bounds the kernel, so one chunk
+  // (most workgroups, best balance) unless a launch has thousands of workgroups to spare.
+  int NCH = ((int64_t)ceil_div(F, FR * 2) * B >= 1536) ? 2 : 1;
+  if (const char* v = getenv("M2M_FE_CHUNKS")) NCH = atoi(v) > 0 ? atoi(v) : NCH;
+  dim3 grid((unsigned)ceil_div(F, FR * NCH), (unsigned)B);
   M2M_OPT_IN_LDS(logmel_kernel, 160 * 1024);
   hipLaunchKernelGGL(logmel_kernel, grid, dim3(FE_THREADS), smem, (hipStream_t)stream, wav_dev, T, F, fe->dev,
-                     out_dev, out_batch_stride, row_offset, FR, fe->nnz);
+                     out_dev, out_batch_stride, row_offset, FR, NCH);
   M2M_CHECK_HIP(hipGetLastError());
   return M2M_OK;
 }

@@ -345,9 +345,13 @@ static bool use_graph() { return env_int("M2M_NO_GRAPH", 0) != 1; }
 // one 32-row MFMA tile of clips per chain), at most MAX_GROUPS chains.  Measured at B = 32 on
 // MI355X: 1 chain 322 ms, 2 chains 315 ms, 4 chains 666 ms (dispatch-bound) - see DESIGN.md.
 static int plan_groups(m2m_session* s) {
-  int rows = env_int("M2M_GROUP_ROWS", 32);
-  if (rows < 1) rows = 1;
-  int G = ceil_div(s->B, rows);
+  // Default: TWO chains once there are enough clips to split (B >= 24), one otherwise.  Two graph chains on two
+  // streams overlap one chain's latency phases (prologue, merge tail, feed-forward, lm_head / head) with the other's
+  // K/V stream: B = 32 -> 2 x 16 clips is +3.7 % over one chain of 32 (tools/chain_sweep.py); more than two chains do
+  // not help (the dependent-dispatch rate of the command processor becomes the limit: 4 x 8 = 1 x 32, 8 x 4 is 4x slower).
+  const int rows_env = env_int("M2M_GROUP_ROWS", 0);
+  int G = rows_env > 0 ? ceil_div(s->B, rows_env) : (s->B >= 24 ? 2 : 1);
+  if (G < 1) G = 1;
   if (G > MAX_GROUPS) G = MAX_GROUPS;
   const int base = s->B / G, extra = s->B % G;
   int b0 = 0;
@@ -573,28 +577,43 @@ extern "C" int m2m_bench_kernel(m2m_session* s, int which, int self_len, int ite
   for (int i = 0; i < G; ++i)
     M2M_CHECK_HIP(hipMemcpyAsync(s->groups[i].view.state, &hs, sizeof(hs), hipMemcpyHostToDevice, s->groups[i].stream));
   for (int i = 0; i < G; ++i) M2M_CHECK_HIP(hipStreamSynchronize(s->groups[i].stream));
-  hipStream_t st = s->groups[0].stream;
   hipEvent_t e0, e1;
   M2M_CHECK_HIP(hipEventCreate(&e0));
   M2M_CHECK_HIP(hipEventCreate(&e1));
-  const DecView all{0, s->B, s->groups[0].view.state};
   const int same_layer = env_int("M2M_BENCH_SAME_LAYER", 0);   // diagnostic: K/V working set small enough for the Infinity Cache
+  // the kernel exactly as the decode loop launches it: every chain launches ITS clips on ITS stream (the chains run
+  // side by side), back to back, cycling through the decoder layers so the K/V working set is the real loop's.
+  // One "launch" of the figures below = the co-scheduled launches of all G chains = all B clips.
   auto run = [&](int n) -> int {
     for (int i = 0; i < n; ++i) {
       const int layer = same_layer ? 0 : i % Ld;
-      if (which == M2M_KERNEL_DEC_CROSS_ATTN) { if ((rc = decode_launch_attn(s, all, false, layer, 0, st))) return rc; }
-      else if (which == M2M_KERNEL_DEC_SELF_ATTN) { if ((rc = decode_launch_attn(s, all, true, layer, self_len, st))) return rc; }
+      for (int c = 0; c < G; ++c) {
+        const DecGroup& gr = s->groups[c];
+        if (which == M2M_KERNEL_DEC_CROSS_ATTN) { if ((rc = decode_launch_attn(s, gr.view, false, layer, 0, gr.stream))) return rc; }
+        else if (which == M2M_KERNEL_DEC_SELF_ATTN) { if ((rc = decode_launch_attn(s, gr.view, true, layer, self_len, gr.stream))) return rc; }
+      }
     }
+    return M2M_OK;
+  };
+  auto fork = [&](hipEvent_t ev) -> int {
+    M2M_CHECK_HIP(hipEventRecord(ev, caller));
+    for (int c = 0; c < G; ++c) M2M_CHECK_HIP(hipStreamWaitEvent(s->groups[c].stream, ev, 0));
+    return M2M_OK;
+  };
+  auto join = [&](hipEvent_t ev) -> int {
+    for (int c = 0; c < G; ++c) {
+      M2M_CHECK_HIP(hipEventRecord(s->groups[c].ev_done, s->groups[c].stream));
+      M2M_CHECK_HIP(hipStreamWaitEvent(caller, s->groups[c].ev_done, 0));
+    }
+    M2M_CHECK_HIP(hipEventRecord(ev, caller));
     return M2M_OK;
   };
   float ms = 0.f;
   if (which != M2M_KERNEL_DEC_STEP) {
-    // ONE launch covering all B clips (B*H workgroups), back to back on one stream, cycling
-    // through the decoder layers so the K/V working set is the real loop's
     if ((rc = run(Ld))) return rc;  // warm-up
-    M2M_CHECK_HIP(hipEventRecord(e0, st));
+    if ((rc = fork(e0))) return rc;
     if ((rc = run(iters))) return rc;
-    M2M_CHECK_HIP(hipEventRecord(e1, st));
+    if ((rc = join(e1))) return rc;
     M2M_CHECK_HIP(hipEventSynchronize(e1));
     M2M_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
   } else {
