@@ -235,6 +235,13 @@ int m2m_train_forward_backward(m2m_trainer* t, const float* params_dev, const fl
                                const int64_t* cond_idx_dev, const int64_t* labels_dev, int B, int S, int Ld,
                                float* loss_out_dev, float* grads_dev, float* logits_out_dev, void* stream);
 
+/* Dropout of the teacher-forced pass (hf T5Config.dropout_rate, 0.1 in the reference's config; active because
+ * ref: train.py:33 puts the module in train() mode): on the embeddings, the attention probabilities, every
+ * residual branch, the gated activation and the final norms, as hf: modeling_t5.py places them.  Masks come from a
+ * counter-based hash of (seed, forward_backward call index since this call, site, element) and are regenerated in the
+ * backward pass.  p = 0 (the default after create) switches it off. */
+int m2m_trainer_set_dropout(m2m_trainer* t, float p, uint64_t seed);
+
 /* One transformers.optimization.Adafactor step with the reference's settings (lr=None, eps=(1e-30, 1e-3),
  * clip_threshold=1.0, decay_rate=-0.8, beta1=None, weight_decay=0, scale_parameter, relative_step,
  * warmup_init): params_dev is updated in place from grads_dev.  The step counter and the factored second

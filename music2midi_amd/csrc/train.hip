@@ -119,7 +119,11 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BGemmArgs g) {
     if constexpr (EPI == TG_STORE_T) reinterpret_cast<T*>(g.C)[at] = from_f32<T>(v);
     else if constexpr (EPI == TG_STORE_F32) reinterpret_cast<float*>(g.C)[at] = v;
     else if constexpr (EPI == TG_ACC_F32) reinterpret_cast<float*>(g.C)[at] += v;
-    else reinterpret_cast<float*>(g.C)[at] = g.R[at] + v;                        // TG_RESID_F32: C = R + acc
+    else {                                                                       // TG_RESID_F32: C = R + dropout(acc)
+      float u = v;
+      if (g.drop_thresh) u = drop_keep(g.drop_key, at, g.drop_thresh) ? v * g.drop_scale : 0.f;
+      reinterpret_cast<float*>(g.C)[at] = g.R[at] + u;
+    }
   }
 }
 
@@ -213,6 +217,20 @@ __global__ void cvt_kernel(const float* __restrict__ src, T* __restrict__ dst, i
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) dst[i] = from_f32<T>(src[i]);
 }
+// dst = T(keep(i) * scale * src)  (the gradient entering a dropped branch)
+template <typename T>
+__global__ void cvt_drop_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t n, uint64_t key, uint32_t thresh, float scale) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) dst[i] = from_f32<T>(drop_keep(key, i, thresh) ? src[i] * scale : 0.f);
+}
+// in-place dropout of an fp32 / T buffer
+template <typename T>
+__global__ void drop_inplace_kernel(T* __restrict__ x, int64_t n, uint64_t key, uint32_t thresh, float scale) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) x[i] = from_f32<T>(drop_keep(key, i, thresh) ? to_f32(x[i]) * scale : 0.f);
+}
 static inline int grid_1d(int64_t n, int per_block = 256) {
   int64_t g = (n + per_block - 1) / per_block;
   return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -227,10 +245,13 @@ int launch_cvt(int precision, const float* src, void* dst, int64_t n, hipStream_
 // ---- attention probabilities: P = softmax(scores + bias) row by row (hf: modeling_t5.py:159-170: no 1/sqrt(d)) ----
 // scores fp32 [BH][Sq][ldp]; bias_tab [H][tab_stride] by (key - query) + tab_center, or null; causal: keys > query masked.
 // One wave per row; P is written in T with the padding columns [Sk, ldp) zeroed (they are GEMM operand columns).
+// With dropout (hf: modeling_t5.py "attn_weights = dropout(attn_weights)") the kept-and-scaled copy Pd feeds the P.V product;
+// P itself is what the softmax backward needs.
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ sc, T* __restrict__ P, int rows_total, int H,
                                                           int Sq, int Sk, int ldp, const float* __restrict__ bias_tab,
-                                                          int tab_stride, int tab_center, int causal) {
+                                                          int tab_stride, int tab_center, int causal, T* __restrict__ Pd,
+                                                          uint64_t key, uint32_t thresh, float scale) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows_total) return;
@@ -246,24 +267,37 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restric
   for (int k = lane; k < kend; k += 64) sum += expf(s[k] + (bt ? bt[k] : 0.f) - mx);
   sum = wave_sum(sum);
   const float inv = 1.0f / sum;
-  for (int k = lane; k < ldp; k += 64)
-    p[k] = from_f32<T>(k < kend ? expf(s[k] + (bt ? bt[k] : 0.f) - mx) * inv : 0.f);
+  for (int k = lane; k < ldp; k += 64) {
+    const float pv = k < kend ? expf(s[k] + (bt ? bt[k] : 0.f) - mx) * inv : 0.f;
+    const T pt = from_f32<T>(pv);
+    p[k] = pt;
+    if (Pd) Pd[(int64_t)row * ldp + k] = drop_keep(key, (int64_t)row * ldp + k, thresh) ? from_f32<T>(to_f32(pt) * scale) : from_f32<T>(0.f);
+  }
+}
+// Pd = dropout(P) again (backward: the dV product needs it, it was a scratch buffer in the forward)
+template <typename T>
+__global__ void drop_copy_kernel(const T* __restrict__ P, T* __restrict__ Pd, int64_t n, uint64_t key, uint32_t thresh, float scale) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) Pd[i] = drop_keep(key, i, thresh) ? from_f32<T>(to_f32(P[i]) * scale) : from_f32<T>(0.f);
 }
 
 // dS = P o (dP - rowsum(P o dP))   (softmax backward; P in T as the forward stored it, dP fp32), dS in T, padding zeroed
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* __restrict__ P, const float* __restrict__ dP, T* __restrict__ dS,
-                                                          int rows_total, int Sk, int ldp) {
+                                                          int rows_total, int Sk, int ldp, uint64_t key, uint32_t thresh, float scale) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows_total) return;
   const T* p = P + (int64_t)row * ldp;
   const float* dp = dP + (int64_t)row * ldp;
   T* ds = dS + (int64_t)row * ldp;
+  // dP arrives for the DROPPED probabilities: through the mask first (thresh == 0: identity)
+  auto dpe = [&](int k) { return thresh ? (drop_keep(key, (int64_t)row * ldp + k, thresh) ? dp[k] * scale : 0.f) : dp[k]; };
   float t = 0.f;
-  for (int k = lane; k < Sk; k += 64) t += to_f32(p[k]) * dp[k];
+  for (int k = lane; k < Sk; k += 64) t += to_f32(p[k]) * dpe(k);
   t = wave_sum(t);
-  for (int k = lane; k < ldp; k += 64) ds[k] = from_f32<T>(k < Sk ? to_f32(p[k]) * (dp[k] - t) : 0.f);
+  for (int k = lane; k < ldp; k += 64) ds[k] = from_f32<T>(k < Sk ? to_f32(p[k]) * (dpe(k) - t) : 0.f);
 }
 
 // relative-position-bias gradient.  Stage 1: one block per (clip, head): part[b][h][rel] = sum over the diagonal
@@ -299,14 +333,16 @@ __global__ __launch_bounds__(256) void bias_bucket_kernel(const float* __restric
 
 // ---- gated GELU (hf: modeling_t5.py T5DenseGatedActDense: gelu_new(wi_0 x) * (wi_1 x)); ab = [a | b], [M, 2*dff] ----
 template <typename T>
-__global__ void gated_fwd_kernel(const T* __restrict__ ab, T* __restrict__ mid, int64_t M, int dff) {
+__global__ void gated_fwd_kernel(const T* __restrict__ ab, T* __restrict__ mid, int64_t M, int dff, uint64_t key, uint32_t thresh, float scale) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t n = M * dff, stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
     const int64_t row = i / dff;
     const int c = (int)(i - row * dff);
     const float a = to_f32(ab[row * 2 * dff + c]), b = to_f32(ab[row * 2 * dff + dff + c]);
-    mid[i] = from_f32<T>(gelu_new(a) * b);
+    float v = gelu_new(a) * b;
+    if (thresh) v = drop_keep(key, i, thresh) ? v * scale : 0.f;      // hf: T5DenseGatedActDense dropout before wo
+    mid[i] = from_f32<T>(v);
   }
 }
 __device__ inline float gelu_new_grad(float x) {
@@ -316,14 +352,16 @@ __device__ inline float gelu_new_grad(float x) {
   return 0.5f * (1.0f + th) + 0.5f * x * (1.0f - th * th) * k * (1.0f + 3.0f * 0.044715f * x * x);
 }
 template <typename T>
-__global__ void gated_bwd_kernel(const T* __restrict__ ab, const T* __restrict__ dmid, T* __restrict__ dab, int64_t M, int dff) {
+__global__ void gated_bwd_kernel(const T* __restrict__ ab, const T* __restrict__ dmid, T* __restrict__ dab, int64_t M, int dff, uint64_t key,
+                                 uint32_t thresh, float scale) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t n = M * dff, stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
     const int64_t row = i / dff;
     const int c = (int)(i - row * dff);
     const float a = to_f32(ab[row * 2 * dff + c]), b = to_f32(ab[row * 2 * dff + dff + c]);
-    const float dm = to_f32(dmid[i]);
+    float dm = to_f32(dmid[i]);
+    if (thresh) dm = drop_keep(key, i, thresh) ? dm * scale : 0.f;
     dab[row * 2 * dff + c] = from_f32<T>(dm * b * gelu_new_grad(a));
     dab[row * 2 * dff + dff + c] = from_f32<T>(dm * gelu_new(a));
   }
@@ -756,6 +794,10 @@ struct m2m_trainer {
   int64_t* cond_off_dev = nullptr;
   int* cond_rows_dev = nullptr;
   int tab_S = -1, tab_L = -1;            // geometry the bucket tables on the device were built for
+  // dropout (hf T5Config.dropout_rate; the reference trains in model.train() mode, ref train.py:33): off unless set
+  float drop_p = 0.f, drop_scale = 1.f;
+  uint32_t drop_thresh = 0;
+  uint64_t drop_seed = 0, fb_calls = 0, step_key = 0;
   // optimizer
   AfPlan af;
   unsigned char* af_mem = nullptr;
@@ -958,12 +1000,31 @@ struct Ops {
   const float* P;      // master parameters (fp32)
   const T* W(int64_t off) const { return (t->precision == M2M_PREC_BF16 ? reinterpret_cast<const T*>(t->Wc) : reinterpret_cast<const T*>(P)) + off; }
 
+  // dropout sites: one key per (layer, place); site < 0 or p == 0: no dropout
+  bool dropping(int site) const { return site >= 0 && t->drop_thresh != 0; }
+  uint64_t key(int site) const { return splitmix64(t->step_key + (uint64_t)site * 0x9E3779B97F4A7C15ull); }
+
   int mm(int epi, const void* A, int64_t lda, int akm, const void* B, int64_t ldb, int bkm, void* C, int64_t ldc, int M, int N, int K,
-         const float* R = nullptr) const {
+         const float* R = nullptr, int drop_site = -1) const {
     BGemmArgs g{};
     g.A = A; g.B = B; g.C = C; g.R = R; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.a_kmajor = akm; g.b_kmajor = bkm;
     g.nb1 = 1; g.nb2 = 1; g.alpha = 1.0f;
+    if (dropping(drop_site)) { g.drop_thresh = t->drop_thresh; g.drop_scale = t->drop_scale; g.drop_key = key(drop_site); }
     return launch_bgemm(t->precision, epi, g, st);
+  }
+  // gradient entering a (possibly dropped) branch, in the GEMM-input type
+  int cvt_branch(const float* src, void* dst, int64_t n, int site) const {
+    if (!dropping(site)) return launch_cvt(t->precision, src, dst, n, st);
+    hipLaunchKernelGGL(cvt_drop_kernel<T>, dim3(grid_1d(n)), dim3(256), 0, st, src, (T*)dst, n, key(site), t->drop_thresh, t->drop_scale);
+    M2M_CHECK_HIP(hipGetLastError());
+    return M2M_OK;
+  }
+  template <typename X>
+  int drop_inplace(X* x, int64_t n, int site) const {
+    if (!dropping(site)) return M2M_OK;
+    hipLaunchKernelGGL(drop_inplace_kernel<X>, dim3(grid_1d(n)), dim3(256), 0, st, x, n, key(site), t->drop_thresh, t->drop_scale);
+    M2M_CHECK_HIP(hipGetLastError());
+    return M2M_OK;
   }
   // batched over (clip b, head h): operand X of clip b / head h starts at X + b*s1 + h*s2 (elements of its own type)
   int mmbh(int epi, const T* A, int64_t lda, int akm, int64_t sA1, int64_t sA2, const T* B, int64_t ldb, int bkm, int64_t sB1, int64_t sB2,
@@ -1004,25 +1065,42 @@ struct Ops {
     M2M_CHECK_HIP(hipGetLastError());
     return M2M_OK;
   }
-  int softmax(const float* sc, void* Pm, int nB, int Sq, int Sk, int ldp, const float* tab, int causal) const {
+  // P (kept for the backward) and, with dropout, the dropped copy the P.V product reads (scratch: t->dS); returns it through *Puse
+  int softmax(const float* sc, void* Pm, int nB, int Sq, int Sk, int ldp, const float* tab, int causal, int site, const T** Puse) const {
     const int H = t->g.num_heads, rows = nB * H * Sq;
+    const bool dr = dropping(site);
     hipLaunchKernelGGL(softmax_fwd_kernel<T>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, sc, (T*)Pm, rows, H, Sq, Sk, ldp, tab, Sq + Sk - 1,
-                       Sq - 1, causal);
+                       Sq - 1, causal, dr ? (T*)t->dS : (T*)nullptr, dr ? key(site) : 0ull, dr ? t->drop_thresh : 0u, t->drop_scale);
+    M2M_CHECK_HIP(hipGetLastError());
+    *Puse = dr ? (const T*)t->dS : (const T*)Pm;
+    return M2M_OK;
+  }
+  // backward: the dropped probabilities again (into t->dS, consumed by the dV product before dS overwrites it)
+  int redrop(const void* Pm, int64_t n, int site, const T** Puse) const {
+    if (!dropping(site)) { *Puse = (const T*)Pm; return M2M_OK; }
+    hipLaunchKernelGGL(drop_copy_kernel<T>, dim3(grid_1d(n)), dim3(256), 0, st, (const T*)Pm, (T*)t->dS, n, key(site), t->drop_thresh, t->drop_scale);
+    M2M_CHECK_HIP(hipGetLastError());
+    *Puse = (const T*)t->dS;
+    return M2M_OK;
+  }
+  int softmax_bwd(const void* Pm, const float* dP, void* dS, int rows, int Sk, int ldp, int site) const {
+    const bool dr = dropping(site);
+    hipLaunchKernelGGL(softmax_bwd_kernel<T>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, (const T*)Pm, dP, (T*)dS, rows, Sk, ldp,
+                       dr ? key(site) : 0ull, dr ? t->drop_thresh : 0u, t->drop_scale);
     M2M_CHECK_HIP(hipGetLastError());
     return M2M_OK;
   }
-  int softmax_bwd(const void* Pm, const float* dP, void* dS, int rows, int Sk, int ldp) const {
-    hipLaunchKernelGGL(softmax_bwd_kernel<T>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, (const T*)Pm, dP, (T*)dS, rows, Sk, ldp);
+  int gated(const void* ab, void* mid, int64_t M, int site) const {
+    const bool dr = dropping(site);
+    hipLaunchKernelGGL(gated_fwd_kernel<T>, dim3(grid_1d(M * t->g.d_ff)), dim3(256), 0, st, (const T*)ab, (T*)mid, M, t->g.d_ff,
+                       dr ? key(site) : 0ull, dr ? t->drop_thresh : 0u, t->drop_scale);
     M2M_CHECK_HIP(hipGetLastError());
     return M2M_OK;
   }
-  int gated(const void* ab, void* mid, int64_t M) const {
-    hipLaunchKernelGGL(gated_fwd_kernel<T>, dim3(grid_1d(M * t->g.d_ff)), dim3(256), 0, st, (const T*)ab, (T*)mid, M, t->g.d_ff);
-    M2M_CHECK_HIP(hipGetLastError());
-    return M2M_OK;
-  }
-  int gated_bwd(const void* ab, const void* dmid, void* dab, int64_t M) const {
-    hipLaunchKernelGGL(gated_bwd_kernel<T>, dim3(grid_1d(M * t->g.d_ff)), dim3(256), 0, st, (const T*)ab, (const T*)dmid, (T*)dab, M, t->g.d_ff);
+  int gated_bwd(const void* ab, const void* dmid, void* dab, int64_t M, int site) const {
+    const bool dr = dropping(site);
+    hipLaunchKernelGGL(gated_bwd_kernel<T>, dim3(grid_1d(M * t->g.d_ff)), dim3(256), 0, st, (const T*)ab, (const T*)dmid, (T*)dab, M, t->g.d_ff,
+                       dr ? key(site) : 0ull, dr ? t->drop_thresh : 0u, t->drop_scale);
     M2M_CHECK_HIP(hipGetLastError());
     return M2M_OK;
   }
@@ -1037,10 +1115,16 @@ struct Ops {
 
 #define RC(expr) do { if ((rc = (expr)) != M2M_OK) return rc; } while (0)
 
+// dropout sites (hf: modeling_t5.py — T5Stack dropout on the embeddings and after the final norm, T5Attention on the
+// probabilities, T5LayerSelfAttention / CrossAttention / FF on the branch output, T5DenseGatedActDense before wo).
+// site = stack base + 16 * layer + place; oracle/train.py uses the same numbering.
+enum { SITE_ENC = 0, SITE_DEC = 1000, SITE_EMB = 900, SITE_FIN = 901,
+       PL_PROBS_SELF = 1, PL_SELF_OUT = 2, PL_PROBS_CROSS = 3, PL_CROSS_OUT = 4, PL_MID = 5, PL_FF_OUT = 6 };
+
 // self-attention block, forward: x_in -> x_out = x_in + Attn(norm(x_in)).  Buffers of this layer are passed in.
 template <typename T>
 int attn_self_fwd(const Ops<T>& o, const float* x_in, float* x_out, int64_t ln, int64_t wqkv, int64_t wo, void* h, void* qkv, void* Pm, void* ao,
-                  int nB, int S, const float* tab, int causal) {
+                  int nB, int S, const float* tab, int causal, int site0) {
   m2m_trainer* t = o.t;
   const int d = t->g.d_model, inner = t->inner, M = nB * S, ldp = (int)align_up(S, 8), H = t->g.num_heads;
   int rc;
@@ -1049,10 +1133,11 @@ int attn_self_fwd(const Ops<T>& o, const float* x_in, float* x_out, int64_t ln, 
   const T* q = (const T*)qkv;
   RC(o.mmbh(TG_STORE_F32, q, 3 * inner, 0, (int64_t)S * 3 * inner, DK, q + inner, 3 * inner, 0, (int64_t)S * 3 * inner, DK, t->sc, ldp,
             (int64_t)H * S * ldp, (int64_t)S * ldp, nB, S, S, DK));
-  RC(o.softmax(t->sc, Pm, nB, S, S, ldp, tab, causal));
-  RC(o.mmbh(TG_STORE_T, (const T*)Pm, ldp, 0, (int64_t)H * S * ldp, (int64_t)S * ldp, q + 2 * inner, 3 * inner, 1, (int64_t)S * 3 * inner, DK, ao,
+  const T* Pu;
+  RC(o.softmax(t->sc, Pm, nB, S, S, ldp, tab, causal, site0 + PL_PROBS_SELF, &Pu));
+  RC(o.mmbh(TG_STORE_T, Pu, ldp, 0, (int64_t)H * S * ldp, (int64_t)S * ldp, q + 2 * inner, 3 * inner, 1, (int64_t)S * 3 * inner, DK, ao,
             inner, (int64_t)S * inner, DK, nB, S, DK, S));
-  RC(o.mm(TG_RESID_F32, ao, inner, 0, o.W(wo), inner, 0, x_out, d, M, d, inner, x_in));
+  RC(o.mm(TG_RESID_F32, ao, inner, 0, o.W(wo), inner, 0, x_out, d, M, d, inner, x_in, site0 + PL_SELF_OUT));
   return M2M_OK;
 }
 
@@ -1060,20 +1145,22 @@ int attn_self_fwd(const Ops<T>& o, const float* x_in, float* x_out, int64_t ln, 
 template <typename T>
 int attn_self_bwd(const Ops<T>& o, const float* x_in, const float* dx_out, float* dx_in, float* G, int64_t ln, int64_t wqkv, int64_t wo,
                   const void* h, const void* qkv, const void* Pm, const void* ao, int nB, int S, const int* buckets, int64_t bias_off,
-                  int bias_accumulate) {
+                  int bias_accumulate, int site0) {
   m2m_trainer* t = o.t;
   const int d = t->g.d_model, inner = t->inner, M = nB * S, ldp = (int)align_up(S, 8), H = t->g.num_heads;
   int rc;
-  RC(o.cvt(dx_out, t->dxT, (int64_t)M * d));
+  RC(o.cvt_branch(dx_out, t->dxT, (int64_t)M * d, site0 + PL_SELF_OUT));
   RC(o.dW(t->dxT, d, d, ao, inner, inner, G + wo, M));                                            // dWo = dx^T . ao
   RC(o.dX(TG_STORE_T, t->dxT, d, wo, d, inner, t->dO, inner, M));                                 // dO = dx . Wo
   const T* q = (const T*)qkv;
   const T* dO = (const T*)t->dO;
   T* dq = (T*)t->dqkv;
   const int64_t sP1 = (int64_t)H * S * ldp, sP2 = (int64_t)S * ldp, sQ1 = (int64_t)S * 3 * inner, sO1 = (int64_t)S * inner;
-  RC(o.mmbh(TG_STORE_T, (const T*)Pm, ldp, 1, sP1, sP2, dO, inner, 1, sO1, DK, dq + 2 * inner, 3 * inner, sQ1, DK, nB, S, DK, S));   // dV = P^T dO
-  RC(o.mmbh(TG_STORE_F32, dO, inner, 0, sO1, DK, q + 2 * inner, 3 * inner, 0, sQ1, DK, t->sc, ldp, sP1, sP2, nB, S, S, DK));        // dP = dO V^T
-  RC(o.softmax_bwd(Pm, t->sc, t->dS, nB * H * S, S, ldp));
+  const T* Pu;
+  RC(o.redrop(Pm, (int64_t)nB * H * S * ldp, site0 + PL_PROBS_SELF, &Pu));
+  RC(o.mmbh(TG_STORE_T, Pu, ldp, 1, sP1, sP2, dO, inner, 1, sO1, DK, dq + 2 * inner, 3 * inner, sQ1, DK, nB, S, DK, S));             // dV = Pd^T dO
+  RC(o.mmbh(TG_STORE_F32, dO, inner, 0, sO1, DK, q + 2 * inner, 3 * inner, 0, sQ1, DK, t->sc, ldp, sP1, sP2, nB, S, S, DK));        // dPd = dO V^T
+  RC(o.softmax_bwd(Pm, t->sc, t->dS, nB * H * S, S, ldp, site0 + PL_PROBS_SELF));
   if (buckets) RC(o.bias_grad(t->dS, buckets, G + bias_off, nB, S, S, ldp, bias_accumulate));
   const T* dS = (const T*)t->dS;
   RC(o.mmbh(TG_STORE_T, dS, ldp, 0, sP1, sP2, q + inner, 3 * inner, 1, sQ1, DK, dq, 3 * inner, sQ1, DK, nB, S, DK, S));              // dQ = dS K
@@ -1085,26 +1172,26 @@ int attn_self_bwd(const Ops<T>& o, const float* x_in, const float* dx_out, float
 }
 
 template <typename T>
-int ff_fwd(const Ops<T>& o, const float* x_in, float* x_out, int64_t ln, int64_t wi, int64_t wo, void* h, void* ab, void* mid, int M) {
+int ff_fwd(const Ops<T>& o, const float* x_in, float* x_out, int64_t ln, int64_t wi, int64_t wo, void* h, void* ab, void* mid, int M, int site0) {
   m2m_trainer* t = o.t;
   const int d = t->g.d_model, dff = t->g.d_ff;
   int rc;
   RC(o.norm(x_in, ln, h, M));
   RC(o.mm(TG_STORE_T, h, d, 0, o.W(wi), d, 0, ab, 2 * dff, M, 2 * dff, d));
-  RC(o.gated(ab, mid, M));
-  RC(o.mm(TG_RESID_F32, mid, dff, 0, o.W(wo), dff, 0, x_out, d, M, d, dff, x_in));
+  RC(o.gated(ab, mid, M, site0 + PL_MID));
+  RC(o.mm(TG_RESID_F32, mid, dff, 0, o.W(wo), dff, 0, x_out, d, M, d, dff, x_in, site0 + PL_FF_OUT));
   return M2M_OK;
 }
 template <typename T>
 int ff_bwd(const Ops<T>& o, const float* x_in, const float* dx_out, float* dx_in, float* G, int64_t ln, int64_t wi, int64_t wo, const void* h,
-           const void* ab, const void* mid, int M) {
+           const void* ab, const void* mid, int M, int site0) {
   m2m_trainer* t = o.t;
   const int d = t->g.d_model, dff = t->g.d_ff;
   int rc;
-  RC(o.cvt(dx_out, t->dxT, (int64_t)M * d));
+  RC(o.cvt_branch(dx_out, t->dxT, (int64_t)M * d, site0 + PL_FF_OUT));
   RC(o.dW(t->dxT, d, d, mid, dff, dff, G + wo, M));                                               // dWo = dx^T . mid
   RC(o.dX(TG_STORE_T, t->dxT, d, wo, d, dff, t->dmid, dff, M));                                   // dmid = dx . Wo
-  RC(o.gated_bwd(ab, t->dmid, t->dab, M));
+  RC(o.gated_bwd(ab, t->dmid, t->dab, M, site0 + PL_MID));
   RC(o.dW(t->dab, 2 * dff, 2 * dff, h, d, d, G + wi, M));                                         // dWi = dab^T . h
   RC(o.dX(TG_STORE_F32, t->dab, 2 * dff, wi, 2 * dff, d, t->dh, d, M));                           // dh = dab . Wi
   RC(o.norm_bwd(x_in, ln, t->dh, dx_out, dx_in, G, M));
@@ -1135,6 +1222,8 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
   hipLaunchKernelGGL(bias_table_kernel, dim3(ceil_div(H * (2 * S - 1), 128)), dim3(128), 0, st, P + t->o_erb, t->ebucket, t->etab, H, 2 * S - 1);
   hipLaunchKernelGGL(bias_table_kernel, dim3(ceil_div(H * (2 * L - 1), 128)), dim3(128), 0, st, P + t->o_drb, t->dbucket, t->dtab, H, 2 * L - 1);
   M2M_CHECK_HIP(hipGetLastError());
+  t->step_key = splitmix64(t->drop_seed + t->fb_calls);
+  t->fb_calls += 1;
   if (t->precision == M2M_PREC_BF16) RC(o.cvt(P, t->Wc, t->n_floats));
   if (G) {
     hipLaunchKernelGGL(weights_transpose_kernel<T>, dim3(t->n_wt_blocks), dim3(256), 0, st, (const WtBlock*)t->wt_blocks, P, (T*)t->WT);
@@ -1147,19 +1236,24 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
   if (t->n_cond > 0)
     hipLaunchKernelGGL(cond_gather_kernel, dim3(B * t->n_cond), dim3(128), 0, st, P, t->cond_off_dev, t->cond_rows_dev, t->n_cond, cond_idx,
                        t->xe[0], S, d);
+  RC(o.drop_inplace(t->xe[0], (int64_t)Me * d, SITE_ENC + SITE_EMB));
   for (int l = 0; l < Le; ++l) {
     const EncOff& e = t->enc[l];
-    RC(attn_self_fwd<T>(o, t->xe[2 * l], t->xe[2 * l + 1], e.ln0, e.qkv, e.o, t->h0e[l], t->qkve[l], t->Pe[l], t->aoe[l], B, S, t->etab, 0));
-    RC(ff_fwd<T>(o, t->xe[2 * l + 1], t->xe[2 * l + 2], e.ln1, e.wi, e.wo, t->h1e[l], t->abe[l], t->mide[l], Me));
+    RC(attn_self_fwd<T>(o, t->xe[2 * l], t->xe[2 * l + 1], e.ln0, e.qkv, e.o, t->h0e[l], t->qkve[l], t->Pe[l], t->aoe[l], B, S, t->etab, 0,
+                        SITE_ENC + 16 * l));
+    RC(ff_fwd<T>(o, t->xe[2 * l + 1], t->xe[2 * l + 2], e.ln1, e.wi, e.wo, t->h1e[l], t->abe[l], t->mide[l], Me, SITE_ENC + 16 * l));
   }
   RC(o.norm(t->xe[2 * Le], t->o_eln, t->hE, Me));
+  RC(o.drop_inplace((T*)t->hE, (int64_t)Me * d, SITE_ENC + SITE_FIN));
   // decoder
   hipLaunchKernelGGL(shift_right_kernel, dim3(ceil_div(Md, 256)), dim3(256), 0, st, labels, t->dec_in, B, L, g.decoder_start_token_id, g.pad_token_id);
   RC(launch_embed_rows(t->dec_in, P + t->o_shared, t->xd[0], Md, d, V, g.pad_token_id, st));
+  RC(o.drop_inplace(t->xd[0], (int64_t)Md * d, SITE_DEC + SITE_EMB));
   const int64_t sPc1 = (int64_t)H * L * lps, sPc2 = (int64_t)L * lps;
   for (int l = 0; l < Ld; ++l) {
     const DecOff& e = t->dec[l];
-    RC(attn_self_fwd<T>(o, t->xd[3 * l], t->xd[3 * l + 1], e.ln0, e.qkv, e.o, t->h0d[l], t->qkvd[l], t->Pd[l], t->aod[l], B, L, t->dtab, 1));
+    RC(attn_self_fwd<T>(o, t->xd[3 * l], t->xd[3 * l + 1], e.ln0, e.qkv, e.o, t->h0d[l], t->qkvd[l], t->Pd[l], t->aod[l], B, L, t->dtab, 1,
+                        SITE_DEC + 16 * l));
     // cross-attention (hf: modeling_t5.py:319-342: K/V from the encoder output, zero bias, no mask)
     RC(o.norm(t->xd[3 * l + 1], e.ln1, t->h1d[l], Md));
     RC(o.mm(TG_STORE_T, t->h1d[l], d, 0, o.W(e.cq), d, 0, t->cqd[l], inner, Md, inner, d));
@@ -1167,13 +1261,16 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
     const T* cq = (const T*)t->cqd[l];
     const T* ckv = (const T*)t->ckvd[l];
     RC(o.mmbh(TG_STORE_F32, cq, inner, 0, (int64_t)L * inner, DK, ckv, 2 * inner, 0, (int64_t)S * 2 * inner, DK, t->sc, lps, sPc1, sPc2, B, L, S, DK));
-    RC(o.softmax(t->sc, t->Pcd[l], B, L, S, lps, nullptr, 0));
-    RC(o.mmbh(TG_STORE_T, (const T*)t->Pcd[l], lps, 0, sPc1, sPc2, ckv + inner, 2 * inner, 1, (int64_t)S * 2 * inner, DK, t->aocd[l], inner,
+    const T* Pu;
+    RC(o.softmax(t->sc, t->Pcd[l], B, L, S, lps, nullptr, 0, SITE_DEC + 16 * l + PL_PROBS_CROSS, &Pu));
+    RC(o.mmbh(TG_STORE_T, Pu, lps, 0, sPc1, sPc2, ckv + inner, 2 * inner, 1, (int64_t)S * 2 * inner, DK, t->aocd[l], inner,
               (int64_t)L * inner, DK, B, L, DK, S));
-    RC(o.mm(TG_RESID_F32, t->aocd[l], inner, 0, o.W(e.co), inner, 0, t->xd[3 * l + 2], d, Md, d, inner, t->xd[3 * l + 1]));
-    RC(ff_fwd<T>(o, t->xd[3 * l + 2], t->xd[3 * l + 3], e.ln2, e.wi, e.wo, t->h2d[l], t->abd[l], t->midd[l], Md));
+    RC(o.mm(TG_RESID_F32, t->aocd[l], inner, 0, o.W(e.co), inner, 0, t->xd[3 * l + 2], d, Md, d, inner, t->xd[3 * l + 1],
+            SITE_DEC + 16 * l + PL_CROSS_OUT));
+    RC(ff_fwd<T>(o, t->xd[3 * l + 2], t->xd[3 * l + 3], e.ln2, e.wi, e.wo, t->h2d[l], t->abd[l], t->midd[l], Md, SITE_DEC + 16 * l));
   }
   RC(o.norm(t->xd[3 * Ld], t->o_dln, t->hD, Md));
+  RC(o.drop_inplace((T*)t->hD, (int64_t)Md * d, SITE_DEC + SITE_FIN));
   RC(o.mm(TG_STORE_F32, t->hD, d, 0, o.W(t->o_lm), d, 0, t->logits, V, Md, V, d));
   if (logits_out) M2M_CHECK_HIP(hipMemcpyAsync(logits_out, t->logits, (size_t)Md * V * 4, hipMemcpyDeviceToDevice, st));
   // loss + gradient of the logits
@@ -1186,15 +1283,16 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
   // ================= backward =================
   RC(o.dW(t->dlog, ldv, V, t->hD, d, d, G + t->o_lm, Md));                                        // dW_lm = dlogits^T . hD
   RC(o.dX(TG_STORE_F32, t->dlog, ldv, t->o_lm, V, d, t->dh, d, Md));                              // dhD = dlogits . W_lm
+  RC(o.drop_inplace(t->dh, (int64_t)Md * d, SITE_DEC + SITE_FIN));
   float* dcur = t->dxa;
   float* dnext = t->dxb;
   RC(o.norm_bwd(t->xd[3 * Ld], t->o_dln, t->dh, nullptr, dcur, G, Md));
   for (int l = Ld - 1; l >= 0; --l) {
     const DecOff& e = t->dec[l];
-    RC(ff_bwd<T>(o, t->xd[3 * l + 2], dcur, dnext, G, e.ln2, e.wi, e.wo, t->h2d[l], t->abd[l], t->midd[l], Md));
+    RC(ff_bwd<T>(o, t->xd[3 * l + 2], dcur, dnext, G, e.ln2, e.wi, e.wo, t->h2d[l], t->abd[l], t->midd[l], Md, SITE_DEC + 16 * l));
     std::swap(dcur, dnext);
     // ---- cross-attention backward: dcur = d x[3l+2] ----
-    RC(o.cvt(dcur, t->dxT, (int64_t)Md * d));
+    RC(o.cvt_branch(dcur, t->dxT, (int64_t)Md * d, SITE_DEC + 16 * l + PL_CROSS_OUT));
     RC(o.dW(t->dxT, d, d, t->aocd[l], inner, inner, G + e.co, Md));
     RC(o.dX(TG_STORE_T, t->dxT, d, e.co, d, inner, t->dO, inner, Md));
     const T* cq = (const T*)t->cqd[l];
@@ -1203,9 +1301,11 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
     T* dckv = (T*)t->dckv;
     T* dcq = (T*)t->dcq;
     const int64_t sK1 = (int64_t)S * 2 * inner, sQ1 = (int64_t)L * inner;
-    RC(o.mmbh(TG_STORE_T, (const T*)t->Pcd[l], lps, 1, sPc1, sPc2, dO, inner, 1, sQ1, DK, dckv + inner, 2 * inner, sK1, DK, B, S, DK, L));   // dV = P^T dO
-    RC(o.mmbh(TG_STORE_F32, dO, inner, 0, sQ1, DK, ckv + inner, 2 * inner, 0, sK1, DK, t->sc, lps, sPc1, sPc2, B, L, S, DK));               // dP = dO V^T
-    RC(o.softmax_bwd(t->Pcd[l], t->sc, t->dS, B * H * L, S, lps));
+    const T* Pu;
+    RC(o.redrop(t->Pcd[l], (int64_t)B * H * L * lps, SITE_DEC + 16 * l + PL_PROBS_CROSS, &Pu));
+    RC(o.mmbh(TG_STORE_T, Pu, lps, 1, sPc1, sPc2, dO, inner, 1, sQ1, DK, dckv + inner, 2 * inner, sK1, DK, B, S, DK, L));                   // dV = Pd^T dO
+    RC(o.mmbh(TG_STORE_F32, dO, inner, 0, sQ1, DK, ckv + inner, 2 * inner, 0, sK1, DK, t->sc, lps, sPc1, sPc2, B, L, S, DK));               // dPd = dO V^T
+    RC(o.softmax_bwd(t->Pcd[l], t->sc, t->dS, B * H * L, S, lps, SITE_DEC + 16 * l + PL_PROBS_CROSS));
     const T* dS = (const T*)t->dS;
     RC(o.mmbh(TG_STORE_T, dS, lps, 0, sPc1, sPc2, ckv, 2 * inner, 1, sK1, DK, dcq, inner, sQ1, DK, B, L, DK, S));                            // dQ = dS K
     RC(o.mmbh(TG_STORE_T, dS, lps, 1, sPc1, sPc2, cq, inner, 1, sQ1, DK, dckv, 2 * inner, sK1, DK, B, S, DK, L));                            // dK = dS^T Q
@@ -1217,22 +1317,25 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
     RC(o.dX(l == Ld - 1 ? TG_STORE_F32 : TG_ACC_F32, dckv, 2 * inner, e.ckv, 2 * inner, d, t->dhE, d, Me));                  // dhE (+)= dckv . Wckv
     // ---- causal self-attention backward ----
     RC(attn_self_bwd<T>(o, t->xd[3 * l], dcur, dnext, G, e.ln0, e.qkv, e.o, t->h0d[l], t->qkvd[l], t->Pd[l], t->aod[l], B, L, t->dbucket, t->o_drb,
-                        l == Ld - 1 ? 0 : 1));
+                        l == Ld - 1 ? 0 : 1, SITE_DEC + 16 * l));
     std::swap(dcur, dnext);
   }
   // token embedding (decoder inputs; the encoder is fed inputs_embeds) — hf: modeling_t5.py embed_tokens = shared
+  RC(o.drop_inplace(dcur, (int64_t)Md * d, SITE_DEC + SITE_EMB));
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(V), dim3(256), 0, st, t->dec_in, Md, 1, 0, dcur, (int64_t)1, (int64_t)0, G + t->o_shared, d,
                      g.pad_token_id, V);
   // encoder
+  RC(o.drop_inplace(t->dhE, (int64_t)Me * d, SITE_ENC + SITE_FIN));
   RC(o.norm_bwd(t->xe[2 * Le], t->o_eln, t->dhE, nullptr, dcur, G, Me));
   for (int l = Le - 1; l >= 0; --l) {
     const EncOff& e = t->enc[l];
-    RC(ff_bwd<T>(o, t->xe[2 * l + 1], dcur, dnext, G, e.ln1, e.wi, e.wo, t->h1e[l], t->abe[l], t->mide[l], Me));
+    RC(ff_bwd<T>(o, t->xe[2 * l + 1], dcur, dnext, G, e.ln1, e.wi, e.wo, t->h1e[l], t->abe[l], t->mide[l], Me, SITE_ENC + 16 * l));
     std::swap(dcur, dnext);
     RC(attn_self_bwd<T>(o, t->xe[2 * l], dcur, dnext, G, e.ln0, e.qkv, e.o, t->h0e[l], t->qkve[l], t->Pe[l], t->aoe[l], B, S, t->ebucket, t->o_erb,
-                        l == Le - 1 ? 0 : 1));
+                        l == Le - 1 ? 0 : 1, SITE_ENC + 16 * l));
     std::swap(dcur, dnext);
   }
+  RC(o.drop_inplace(dcur, (int64_t)Me * d, SITE_ENC + SITE_EMB));
   // conditioning embeddings: rows 0 .. n_cond-1 of every clip's encoder input (ref: music2midi/input.py:57-59)
   for (int i = 0; i < t->n_cond; ++i)
     hipLaunchKernelGGL(embed_bwd_kernel, dim3(t->cond_rows[i]), dim3(256), 0, st, cond_idx, B, t->n_cond, i, dcur, (int64_t)S, (int64_t)i,
@@ -1296,6 +1399,16 @@ extern "C" int m2m_train_forward_backward(m2m_trainer* t, const float* params_de
   return t->precision == M2M_PREC_BF16
              ? forward_backward_t<bf16_t>(t, params_dev, enc_inputs_dev, cond_idx_dev, labels_dev, B, S, Ld, loss_out_dev, grads_dev, logits_out_dev, st)
              : forward_backward_t<float>(t, params_dev, enc_inputs_dev, cond_idx_dev, labels_dev, B, S, Ld, loss_out_dev, grads_dev, logits_out_dev, st);
+}
+
+extern "C" int m2m_trainer_set_dropout(m2m_trainer* t, float p, uint64_t seed) {
+  M2M_REQUIRE(t && p >= 0.f && p < 1.f, "m2m_trainer_set_dropout: p must be in [0, 1)");
+  t->drop_p = p;
+  t->drop_thresh = p > 0.f ? (uint32_t)((double)p * 4294967296.0) : 0u;
+  t->drop_scale = 1.0f / (1.0f - p);
+  t->drop_seed = seed;
+  t->fb_calls = 0;
+  return M2M_OK;
 }
 
 extern "C" int m2m_adafactor_step(m2m_trainer* t, float* params_dev, const float* grads_dev, void* stream) {

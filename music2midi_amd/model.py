@@ -68,6 +68,11 @@ class Music2MIDI(nn.Module):
             self._trainer = NativeTrainer(self.model, *limits, precision=getattr(self, "train_precision", None))
             if state is not None:
                 self._trainer.load_optimizer_state(state)
+        # dropout as the reference trains: model.train() (ref train.py:33) activates T5Config.dropout_rate (0.1 unless the
+        # config says otherwise); .eval() switches it off
+        want = float(self.config.model.t5.get("dropout_rate", 0.1)) if self.training else 0.0
+        if self._trainer.dropout != want:
+            self._trainer.set_dropout(want, seed=int(getattr(self, "seed", 0)) + self.global_step)
         return self._trainer
 
     def configure_optimizers(self):

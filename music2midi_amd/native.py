@@ -92,6 +92,7 @@ _SIGNATURES = {
     "m2m_trainer_workspace_bytes": (C.c_int64, [C.c_void_p]),
     "m2m_train_forward_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                              C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "m2m_trainer_set_dropout": (C.c_int, [C.c_void_p, C.c_float, C.c_uint64]),
     "m2m_adafactor_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "m2m_adafactor_get_step": (C.c_int, [C.c_void_p]),
     "m2m_adafactor_state_floats": (C.c_int64, [C.c_void_p]),

@@ -61,6 +61,12 @@ class NativeTrainer:
         self.grads = torch.zeros(self.n_floats, dtype=torch.float32, device=dev)
         self._adopt_parameters()
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.dropout = 0.0
+
+    def set_dropout(self, p: float, seed: int = 0):
+        """Dropout of the teacher-forced pass (hf T5Config.dropout_rate; 0 = off).  Restarts the mask sequence at `seed`."""
+        native.check(native.load().m2m_trainer_set_dropout(self.handle, float(p), int(seed) & 0xFFFFFFFFFFFFFFFF), "m2m_trainer_set_dropout")
+        self.dropout = float(p)
 
     # -- parameters <-> flat buffers ---------------------------------------------
     def _adopt_parameters(self):

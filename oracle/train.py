@@ -26,6 +26,40 @@ import torch
 
 from .t5 import gelu_new, relative_position_bucket
 
+_U64 = np.uint64
+_GOLDEN = 0x9E3779B97F4A7C15
+SITE_ENC, SITE_DEC, SITE_EMB, SITE_FIN = 0, 1000, 900, 901
+PL_PROBS_SELF, PL_SELF_OUT, PL_PROBS_CROSS, PL_CROSS_OUT, PL_MID, PL_FF_OUT = 1, 2, 3, 4, 5, 6
+
+
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        z = x + _U64(_GOLDEN)
+        z = (z ^ (z >> _U64(30))) * _U64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> _U64(27))) * _U64(0x94D049BB133111EB)
+        return z ^ (z >> _U64(31))
+
+
+class DropoutMasks:
+    """The device's counter-based dropout masks, regenerated on the host (csrc/train.h drop_keep): element i of a site is
+    kept iff the high 32 bits of splitmix64(key(site) + i) are >= p * 2^32; kept values are scaled by 1 / (1 - p)."""
+
+    def __init__(self, p: float, seed: int, call_index: int = 0):
+        self.p = float(p)
+        self.thresh = int(float(np.float32(p)) * 4294967296.0) if p > 0 else 0
+        self.scale = float(np.float32(1.0) / (np.float32(1.0) - np.float32(p)))
+        self.step_key = _splitmix64(np.asarray([(seed + call_index) & 0xFFFFFFFFFFFFFFFF], dtype=np.uint64))[0]
+
+    def mask(self, site: int, n: int) -> torch.Tensor:
+        """float tensor [n]: 0 or scale."""
+        if self.thresh == 0:
+            return torch.ones(n)
+        with np.errstate(over="ignore"):
+            key = _splitmix64(np.asarray([self.step_key + _U64((site * _GOLDEN) & 0xFFFFFFFFFFFFFFFF)], dtype=np.uint64))[0]
+            h = _splitmix64(key + np.arange(n, dtype=np.uint64))
+        keep = (h >> _U64(32)) >= _U64(self.thresh)
+        return torch.from_numpy(keep.astype(np.float32) * np.float32(self.scale))
+
 
 def leaf_params(sd: Dict[str, np.ndarray]) -> Dict[str, torch.Tensor]:
     """state dict (numpy, keys ``transformer.*`` / ``conditioning.*``) -> fp32 leaf tensors with requires_grad."""
@@ -38,6 +72,7 @@ class T5TrainOracle:
     def __init__(self, geom, params: Dict[str, torch.Tensor]):
         self.g = geom
         self.p = params
+        self.masks = None
 
     def w(self, name: str) -> torch.Tensor:
         return self.p["transformer." + name]
@@ -54,7 +89,13 @@ class T5TrainOracle:
         b = relative_position_bucket(rel, bidirectional, self.g.num_buckets, self.g.max_distance)
         return table[b].permute(2, 0, 1).unsqueeze(0)
 
-    def _attn(self, hq, hkv, prefix, bias):
+    def _drop(self, x, site):
+        """dropout at `site` with the device's mask (element index = flat index of the row-major activation)."""
+        if self.masks is None:
+            return x
+        return x * self.masks.mask(site, x.numel()).view(x.shape)
+
+    def _attn(self, hq, hkv, prefix, bias, site_probs=-1):
         B, Lq, _ = hq.shape
         q = self._heads(hq @ self.w(prefix + ".q.weight").T)
         k = self._heads(hkv @ self.w(prefix + ".k.weight").T)
@@ -62,51 +103,62 @@ class T5TrainOracle:
         s = q @ k.transpose(2, 3)                      # no 1/sqrt(d_kv) (hf: modeling_t5.py:197)
         if bias is not None:
             s = s + bias
-        o = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B, Lq, self.g.inner_dim)
+        pr = torch.softmax(s, dim=-1)
+        if self.masks is not None:                     # the device stores probabilities with a row pitch of ceil8(Sk)
+            Sk = pr.shape[-1]
+            ldp = (Sk + 7) // 8 * 8
+            m = self.masks.mask(site_probs, B * self.g.num_heads * Lq * ldp).view(B, self.g.num_heads, Lq, ldp)[..., :Sk]
+            pr = pr * m
+        o = (pr @ v).transpose(1, 2).reshape(B, Lq, self.g.inner_dim)
         return o @ self.w(prefix + ".o.weight").T
 
-    def _ffn(self, h, prefix):
-        return (gelu_new(h @ self.w(prefix + ".wi_0.weight").T) * (h @ self.w(prefix + ".wi_1.weight").T)) @ self.w(prefix + ".wo.weight").T
+    def _ffn(self, h, prefix, site_mid=-1):
+        mid = gelu_new(h @ self.w(prefix + ".wi_0.weight").T) * (h @ self.w(prefix + ".wi_1.weight").T)
+        return self._drop(mid, site_mid) @ self.w(prefix + ".wo.weight").T
 
     def encoder_inputs(self, feats: torch.Tensor, cond_idx: torch.Tensor) -> torch.Tensor:
         """ref: music2midi/input.py:57-59 — conditioning rows first, then the (constant) log-mel rows."""
         rows = [self.p[f"conditioning.embeds.{i}.weight"][cond_idx[:, i]] for i in range(cond_idx.shape[1])]
         return torch.cat([torch.stack(rows, dim=1), feats], dim=1)
 
-    def forward(self, feats: torch.Tensor, cond_idx: torch.Tensor, labels: torch.Tensor):
-        """-> (mean CE over labels != -100, logits [B, Ld, V])."""
+    def forward(self, feats: torch.Tensor, cond_idx: torch.Tensor, labels: torch.Tensor, masks: "DropoutMasks" = None):
+        """-> (mean CE over labels != -100, logits [B, Ld, V]).  `masks`: dropout as hf: modeling_t5.py places it
+        (embeddings, attention probabilities, every residual branch, gated activation, final norms) with the device's masks."""
         g = self.g
-        x = self.encoder_inputs(feats, cond_idx)
+        self.masks = masks
+        x = self._drop(self.encoder_inputs(feats, cond_idx), SITE_ENC + SITE_EMB)
         S = x.shape[1]
         ebias = self._bias(self.w("encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"), S, S, True)
         for i in range(g.num_layers):
             p = f"encoder.block.{i}.layer"
+            st = SITE_ENC + 16 * i
             h = self._norm(x, self.w(f"{p}.0.layer_norm.weight"))
-            x = x + self._attn(h, h, f"{p}.0.SelfAttention", ebias)
-            x = x + self._ffn(self._norm(x, self.w(f"{p}.1.layer_norm.weight")), f"{p}.1.DenseReluDense")
-        enc = self._norm(x, self.w("encoder.final_layer_norm.weight"))
+            x = x + self._drop(self._attn(h, h, f"{p}.0.SelfAttention", ebias, st + PL_PROBS_SELF), st + PL_SELF_OUT)
+            x = x + self._drop(self._ffn(self._norm(x, self.w(f"{p}.1.layer_norm.weight")), f"{p}.1.DenseReluDense", st + PL_MID), st + PL_FF_OUT)
+        enc = self._drop(self._norm(x, self.w("encoder.final_layer_norm.weight")), SITE_ENC + SITE_FIN)
         B, Ld = labels.shape
         dec_in = torch.full((B, Ld), g.decoder_start_token_id, dtype=torch.long)
         dec_in[:, 1:] = labels[:, :-1]
         dec_in[dec_in == -100] = g.pad_token_id
-        y = self.w("shared.weight")[dec_in]
+        y = self._drop(self.w("shared.weight")[dec_in], SITE_DEC + SITE_EMB)
         dbias = self._bias(self.w("decoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"), Ld, Ld, False)
         causal = torch.full((Ld, Ld), float("-inf")).triu(1)
         for i in range(g.num_decoder_layers):
             p = f"decoder.block.{i}.layer"
+            st = SITE_DEC + 16 * i
             h = self._norm(y, self.w(f"{p}.0.layer_norm.weight"))
-            y = y + self._attn(h, h, f"{p}.0.SelfAttention", dbias + causal)
+            y = y + self._drop(self._attn(h, h, f"{p}.0.SelfAttention", dbias + causal, st + PL_PROBS_SELF), st + PL_SELF_OUT)
             h = self._norm(y, self.w(f"{p}.1.layer_norm.weight"))
-            y = y + self._attn(h, enc, f"{p}.1.EncDecAttention", None)
-            y = y + self._ffn(self._norm(y, self.w(f"{p}.2.layer_norm.weight")), f"{p}.2.DenseReluDense")
-        logits = self._norm(y, self.w("decoder.final_layer_norm.weight")) @ self.w("lm_head.weight").T
+            y = y + self._drop(self._attn(h, enc, f"{p}.1.EncDecAttention", None, st + PL_PROBS_CROSS), st + PL_CROSS_OUT)
+            y = y + self._drop(self._ffn(self._norm(y, self.w(f"{p}.2.layer_norm.weight")), f"{p}.2.DenseReluDense", st + PL_MID), st + PL_FF_OUT)
+        logits = self._drop(self._norm(y, self.w("decoder.final_layer_norm.weight")), SITE_DEC + SITE_FIN) @ self.w("lm_head.weight").T
         loss = torch.nn.functional.cross_entropy(logits.reshape(-1, g.vocab_size), labels.reshape(-1), ignore_index=-100)
         return loss, logits
 
-    def loss_and_grads(self, feats, cond_idx, labels):
+    def loss_and_grads(self, feats, cond_idx, labels, masks: "DropoutMasks" = None):
         for t in self.p.values():
             t.grad = None
-        loss, logits = self.forward(feats, cond_idx, labels)
+        loss, logits = self.forward(feats, cond_idx, labels, masks)
         loss.backward()
         return loss.detach(), logits.detach(), {k: (v.grad.clone() if v.grad is not None else torch.zeros_like(v)) for k, v in self.p.items()}
 

@@ -170,9 +170,61 @@ def test_music2midi_training_surface_learns_and_serves_the_new_weights():
     assert losses[-1] < losses[0] - 0.05, (losses[0], losses[-1])
     assert m.global_step == 200 and m._trainer.step_count == 200 and 0 < sched.get_last_lr()[0] <= 2e-4
     assert not torch.equal(w0, m.model.transformer.lm_head.weight.detach())       # the module's parameters ARE the trained buffer
+    assert m._trainer.dropout == pytest.approx(0.1)            # train() mode: T5Config.dropout_rate, as the reference trains
+    m.eval()                                                   # eval(): dropout off -> the step's loss is the inference path's
     loss_eval = m.model(batch).loss                                                # inference-path forward on the new weights
     assert abs(loss_eval.item() - m.training_step(batch, 0).item()) < 1e-3 * max(1.0, loss_eval.item())
+    assert m._trainer.dropout == 0.0
     after = m.model.generate(batch, max_length=12)
     assert after.shape[0] == 3 and (after[:, 0] == 1).all()
     sd = m.state_dict()
     assert torch.equal(sd["model.transformer.lm_head.weight"], m.model.transformer.lm_head.weight.detach())
+
+
+@pytest.mark.parametrize("precision", ["fp32"])
+def test_dropout_step_matches_autograd_with_the_same_masks(precision):
+    """Dropout 0.1 at every place hf: modeling_t5.py has it.  The device's masks are a counter-based hash, so the oracle
+    regenerates exactly the same masks (oracle/train.py DropoutMasks) and autograd must give the same loss and gradients."""
+    from oracle.train import DropoutMasks
+    B, F, Ld = 3, 21, 14
+    model, tr, orc, params, geom, x, feats, cond, labels = _setup(tiny_config(), precision, B, F, Ld)
+    tr.set_dropout(0.1, seed=1234)
+    loss, logits = tr.forward_backward(x.cuda(), cond.cuda(), labels.cuda(), want_logits=True)
+    loss_o, logits_o, grads_o = orc.loss_and_grads(feats, cond, labels, DropoutMasks(0.1, 1234, 0))
+    loss_plain, _, _ = orc.loss_and_grads(feats, cond, labels)
+    assert abs(loss_plain.item() - loss_o.item()) > 1e-3                      # the masks do something
+    assert abs(loss.item() - loss_o.item()) < 1e-4 * abs(loss_o.item()), (loss.item(), loss_o.item(), loss_plain.item())
+    assert (logits.cpu() - logits_o).abs().max() < 3e-3
+    worst = max(_rel(tr.grads[off:off + int(np.prod(shape))].view(shape).cpu(), grads_o[name]) for name, (off, shape) in tr.layout.items())
+    print(f"dropout 0.1: loss {loss.item():.6f} (oracle with the same masks {loss_o.item():.6f}, without dropout {loss_plain.item():.6f}); "
+          f"worst gradient rel err {worst:.2e}")
+    assert worst < 1e-4
+    # the second call draws different masks (call index 1), reproducibly
+    loss2, _ = tr.forward_backward(x.cuda(), cond.cuda(), labels.cuda())
+    l2 = loss2.item()
+    loss2_o, _, _ = orc.loss_and_grads(feats, cond, labels, DropoutMasks(0.1, 1234, 1))
+    assert abs(l2 - loss2_o.item()) < 1e-4 * abs(loss2_o.item()) and abs(l2 - loss_o.item()) > 1e-4
+    tr.set_dropout(0.1, seed=1234)
+    loss3, _ = tr.forward_backward(x.cuda(), cond.cuda(), labels.cuda())
+    assert loss3.item() == pytest.approx(loss_o.item(), rel=1e-4)
+    # keep rate of a large mask is 1 - p
+    m = DropoutMasks(0.1, 7, 0).mask(5, 200000)
+    assert abs(float((m > 0).float().mean()) - 0.9) < 3e-3
+
+
+def test_dropout_bf16_full_model_statistics():
+    """bf16, full model, dropout on: the step runs, is reproducible for a fixed seed, differs between seeds, and its loss
+    is within the spread dropout causes (not an exact check: bf16 rounding points differ from the fp32 oracle's)."""
+    B, F, Ld = 4, 188, 48
+    model, tr, orc, params, geom, x, feats, cond, labels = _setup(copy.deepcopy(DEFAULT_CONFIG), "bf16", B, F, Ld)
+    from oracle.train import DropoutMasks
+    tr.set_dropout(0.1, seed=5)
+    a, _ = tr.forward_backward(x.cuda(), cond.cuda(), labels.cuda()); a = a.item(); ga = tr.grads.clone()
+    tr.set_dropout(0.1, seed=5)
+    b, _ = tr.forward_backward(x.cuda(), cond.cuda(), labels.cuda()); b = b.item()
+    assert a == b and torch.equal(ga, tr.grads)
+    tr.set_dropout(0.1, seed=6)
+    c, _ = tr.forward_backward(x.cuda(), cond.cuda(), labels.cuda()); c = c.item()
+    assert c != a
+    ref, _, _ = orc.loss_and_grads(feats, cond, labels, DropoutMasks(0.1, 5, 0))
+    assert abs(a - ref.item()) < 3e-2 * abs(ref.item())
