@@ -169,6 +169,19 @@ template <typename T> __device__ inline float gelu_new_t(float x) {
     }                                                                                                 \
   } while (0)
 
+// Counter-based dropout: element i of site `key` is KEPT iff the high 32 bits of splitmix64(key + i) are >= thresh
+// (thresh = p * 2^32), and kept values are scaled by 1 / (1 - p) — the same masks are regenerated in the backward pass,
+// nothing is stored.  (oracle/train.py mirrors the hash in numpy to reproduce the masks.)
+__host__ __device__ inline uint64_t splitmix64(uint64_t x) {
+  uint64_t z = x + 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__host__ __device__ inline bool drop_keep(uint64_t key, int64_t i, uint32_t thresh) {
+  return (uint32_t)(splitmix64(key + (uint64_t)i) >> 32) >= thresh;
+}
+
 __host__ __device__ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 

@@ -288,8 +288,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
               reinterpret_cast<T*>(g.out)[(int64_t)row * g.ldo + oc] = from_f32<T>(gelu_new_t<T>(v) * partner);
             }
           } else if constexpr (EPI == EPI_RESID) {
-            float* p = reinterpret_cast<float*>(g.out) + (int64_t)row * g.ldo + col;
-            *p += v;
+            const int64_t at = (int64_t)row * g.ldo + col;
+            float* p = reinterpret_cast<float*>(g.out) + at;
+            float u = v;
+            if (g.drop_thresh) u = drop_keep(g.drop_key, at, g.drop_thresh) ? v * g.drop_scale : 0.f;   // training only
+            *p = (g.resid ? g.resid[at] : *p) + u;
           } else {  // EPI_HEADS
             const int which = col / g.inner, rem = col - which * g.inner;
             const int hh = rem / DK, dd = rem - hh * DK;

@@ -140,6 +140,11 @@ struct GemmArgs {
   void* vt_out;
   int Sp;
   int ng;            // column tiles per group of the XCD-aware tile order (set by launch_gemm)
+  // EPI_RESID extras (training path; zero = the inference behaviour out += acc):
+  const float* resid;      // out = resid + acc instead of out += acc (same indexing as out)
+  uint32_t drop_thresh;    // dropout on acc before the add: keep(i) * drop_scale * acc, i = row * ldo + col (common.h drop_keep)
+  float drop_scale;
+  uint64_t drop_key;
 };
 
 int launch_gemm(int precision, int epi, const GemmArgs& a, hipStream_t st);
