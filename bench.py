@@ -147,19 +147,24 @@ def cpu_frontend_baseline(cfg, clips: int = 64, threads: int = 16):
             "sample": f"torch.stft + dense [1025x384] mel matmul + clamp/log on {clips} x {N_SAMPLES} samples, fp32"}
 
 
-def pmc_traffic_bytes(kernel_substr: str, batch: int):
-    """HBM bytes per launch of a kernel from the committed PMC summary (profiles/, collected by
-    tools/pmc_traffic.sh in separate FETCH_SIZE / WRITE_SIZE passes with 32-clip launches; FETCH_SIZE
-    doubled as MI355X_MICROARCH.md prescribes for gfx950).  None when no summary is present."""
+def pmc_traffic_bytes(kernel_substr: str, batch: int, n_chains: int = 1):
+    """HBM bytes of one co-scheduled launch set (all `batch` clips) of a kernel from the newest committed PMC summary
+    (profiles/*pmc_traffic_summary.txt, collected by tools/pmc_traffic.sh in separate FETCH_SIZE / WRITE_SIZE passes;
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  The summary lists bytes per KERNEL launch; a launch
+    covers `clips/launch` clips (header of the summary; 32 when absent = round 1), so the figure is scaled to `batch` clips.
+    None when no summary is present."""
     import re
     best = None
     for f in sorted((ROOT / "profiles").glob("*pmc_traffic_summary.txt")):
+        text = f.read_text()
+        m = re.search(r"clips/launch\s*=\s*(\d+)", text)
+        per_launch = int(m.group(1)) if m else 32
         vals = []
-        for line in f.read_text().splitlines():
+        for line in text.splitlines():
             if kernel_substr in line:
                 m = re.search(r"x2 corrected\s+([0-9.]+) MB\).*WRITE_SIZE/launch\s+[0-9.]+ KiB \(\s*([0-9.]+) MB\)", line)
                 if m:
-                    vals.append((float(m.group(1)) + float(m.group(2))) * 1e6 * batch / 32.0)
+                    vals.append((float(m.group(1)) + float(m.group(2))) * 1e6 * batch / per_launch)
         if vals:   # several template variants of the kernel (cache policy): mean per launch
             best = sum(vals) / len(vals)
     return best

@@ -4,15 +4,16 @@
 # other than the kernel trace.  Run on the GPU box from the repo root:  bash tools/pmc_traffic.sh
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/pmc_r1
+OUT=${PMC_OUT:-gpurun_out/pmc_traffic}
 mkdir -p $OUT
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT -o $C -- \
-    python3 bench.py --steps 1 --warmup 0 --no-roofline --cpu-tokens 0 --max-length 49 > $OUT/$C.log 2>&1 || tail -5 $OUT/$C.log
+    python3 bench.py --steps 1 --warmup 0 --no-roofline --no-parity --no-frontend --no-train --cpu-tokens 0 --max-length 49 > $OUT/$C.log 2>&1 || tail -5 $OUT/$C.log
 done
 python3 - <<'PY'
 import csv, collections, glob
-out = "gpurun_out/pmc_r1"
+import os
+out = os.environ.get("PMC_OUT", "gpurun_out/pmc_traffic")
 res = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(f"{out}/{c}_counter_collection.csv")
