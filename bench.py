@@ -338,7 +338,7 @@ def main():
     cond = torch.from_numpy(synth.cond_index_batch(first, B)).to(dev)
     inputs = ModelInputs(input_waveform=wav, cond_index=cond)
 
-    def step():
+    def step():     # each rank decodes its own 32 clips (weak scaling), ids all-gathered into global clip order
         toks = model.generate(inputs, max_length=args.max_length)
         return D.all_gather_tokens(toks, args.max_length, geom.pad_token_id)
 

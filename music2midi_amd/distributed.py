@@ -93,7 +93,7 @@ def all_gather_tokens(tokens: torch.Tensor, max_length: int, pad_id: int = 0) ->
     B, L = tokens.shape
     send = torch.full((B, max_length + 1), pad_id, dtype=torch.long, device=tokens.device)
     send[:, :L] = tokens
-    send[:, max_length] = L              # carry the local valid length in the last column
+    send[:, max_length] = L              # carry the local valid length in the last column (an empty shard carries nothing)
     counts = [torch.zeros(1, dtype=torch.long, device=tokens.device) for _ in range(world)]
     dist.all_gather(counts, torch.tensor([B], dtype=torch.long, device=tokens.device))
     sizes = [int(c.item()) for c in counts]
@@ -107,8 +107,29 @@ def all_gather_tokens(tokens: torch.Tensor, max_length: int, pad_id: int = 0) ->
         parts = [torch.empty_like(padded) for _ in range(world)]
         dist.all_gather(parts, padded)
         out = torch.cat([p[:n] for p, n in zip(parts, sizes)], dim=0)
-    L_global = int(out[:, max_length].max().item())
+    L_global = int(out[:, max_length].max().item()) if out.shape[0] else 1
     return out[:, :L_global].contiguous()
+
+
+def generate_sharded(generate_fn, inputs, max_length: int, pad_id: int = 0):
+    """Decode a batch of clips across all ranks: rank r runs ``generate_fn`` on its contiguous block of clips
+    (``shard_range``) and the token matrices are all-gathered back into clip order — what one process decoding the
+    whole batch would have returned.  ``inputs`` is a ``ModelInputs`` whose tensors have the FULL batch on every rank
+    (clips are cheap to replicate: 0.9 MB each); without a process group this is ``generate_fn(inputs, max_length=...)``.
+    Used by ``Music2MIDI.sample_tokens`` and by bench.py, so callers and the benchmark share one sharding path."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return generate_fn(inputs, max_length=max_length)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n = inputs.input_waveform.shape[0]
+    lo, hi = shard_range(n, rank, world)
+    if hi > lo:
+        local = type(inputs)(input_waveform=inputs.input_waveform[lo:hi],
+                             notes_batch=inputs.notes_batch[lo:hi] if inputs.notes_batch is not None else None,
+                             cond_index=inputs.cond_index[lo:hi] if inputs.cond_index is not None else None)
+        toks = generate_fn(local, max_length=max_length)
+    else:       # more ranks than clips: this rank contributes nothing
+        toks = torch.zeros((0, 1), dtype=torch.long, device=inputs.input_waveform.device)
+    return all_gather_tokens(toks, max_length, pad_id)
 
 
 def all_reduce_gradients(flat_grads: torch.Tensor) -> int:

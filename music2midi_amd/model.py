@@ -16,6 +16,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import distributed as D
 from .audio import load_audio as _load_audio
 from .checkpoint import load_t5_state, read_checkpoint
 from .config import load_config
@@ -98,7 +99,6 @@ class Music2MIDI(nn.Module):
 
     def fit_batches(self, batches, optimizer=None, world_size: int = 1):
         """Minimal stand-in for ``pl.Trainer.fit`` (ref train.py:40-41): step over an iterable of ModelInputs."""
-        from . import distributed as D
         if optimizer is None:
             optimizer = self.configure_optimizers()[0][0]
         losses = []
@@ -181,7 +181,9 @@ class Music2MIDI(nn.Module):
             wav = waveform.new_zeros((len(group), longest)).to(self.device)
             for row, piece in enumerate(group):                      # right-pad a ragged last piece with zeros
                 wav[row, : piece.shape[0]] = piece
-            ids = self.model.generate(ModelInputs(input_waveform=wav, cond_index=self._cond_rows(len(group), cond_index)),
-                                      max_length=1024)
+            # with a process group (one process per GPU) the chunk's segments are sharded over the ranks and the ids
+            # all-gathered back in segment order; a single process decodes the chunk itself
+            ids = D.generate_sharded(self.model.generate, ModelInputs(input_waveform=wav, cond_index=self._cond_rows(len(group), cond_index)),
+                                     max_length=1024, pad_id=self.model.geometry.pad_token_id)
             token_rows.extend(ids.unbind(0))
         return self.model.tokenizer.decode(token_rows, mode="sequential", duration_per_batch=split_duration)

@@ -95,3 +95,44 @@ def test_gloo_world2_gradient_all_reduce_averages_the_flat_buffer():
         assert p.exitcode == 0
     assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]
     assert D.all_reduce_gradients(torch.ones(4)) == 0          # single process: no-op
+
+
+def _shard_worker(rank, world, port, n_clips, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    D.init_process_group("gloo")
+    from music2midi_amd.input import ModelInputs
+    wav = torch.arange(n_clips, dtype=torch.float32)[:, None].repeat(1, 8)       # clip c carries the value c
+    cond = torch.stack([torch.arange(n_clips) % 6, torch.arange(n_clips) % 3], dim=1)
+    calls = []
+
+    def fake_generate(inp, max_length):                                           # ids encode (clip, cond) so order/pairing is visible
+        calls.append(inp.input_waveform.shape[0])
+        L = 3 + int(inp.input_waveform[0, 0].item()) % 4                           # shards stop at different lengths
+        out = torch.zeros((inp.input_waveform.shape[0], L), dtype=torch.long)
+        out[:, 0] = 1
+        out[:, 1] = inp.input_waveform[:, 0].long() + 10
+        out[:, 2] = inp.cond_index[:, 0] * 10 + inp.cond_index[:, 1] + 100
+        return out
+
+    ids = D.generate_sharded(fake_generate, ModelInputs(input_waveform=wav, cond_index=cond), max_length=16)
+    lo, hi = D.shard_range(n_clips, rank, world)
+    assert calls == ([hi - lo] if hi > lo else [])
+    assert ids.shape[0] == n_clips and torch.equal(ids[:, 1], torch.arange(n_clips) + 10)
+    assert torch.equal(ids[:, 2], cond[:, 0] * 10 + cond[:, 1] + 100)
+    dist.destroy_process_group()
+    q.put(rank)
+
+
+@pytest.mark.parametrize("n_clips", [5, 1])
+def test_gloo_world2_generate_sharded_returns_clip_order(n_clips):
+    """Music2MIDI.sample_tokens' multi-GPU path: clips sharded over the ranks, ids back in clip order, also when a rank has no clip."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, n_clips, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]
