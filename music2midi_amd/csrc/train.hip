@@ -306,16 +306,24 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* __restrict__ 
 // consecutive addresses.  Stage 2 sums the clips and the diagonals of each bucket.  Fixed order throughout.
 template <typename T>
 __global__ __launch_bounds__(256) void bias_diag_kernel(const T* __restrict__ dS, float* __restrict__ part, int H, int Sq, int Sk, int ldp) {
+  // block = (clip-head, 64 consecutive diagonals); thread = (quarter of the queries, diagonal): consecutive threads read
+  // consecutive addresses; the four partial sums of a diagonal are added in a fixed order through LDS
+  __shared__ float sred[4][64];
   const int nrel = Sq + Sk - 1;
-  const int bh = blockIdx.x;
+  const int bh = blockIdx.x, rl = threadIdx.x & 63, qg = threadIdx.x >> 6;
+  const int rel = blockIdx.y * 64 + rl;
   const T* base = dS + (int64_t)bh * Sq * ldp;
-  for (int rel = threadIdx.x; rel < nrel; rel += 256) {
+  float acc = 0.f;
+  if (rel < nrel) {
     const int off = rel - (Sq - 1);                              // key - query
     const int q_lo = max(0, -off), q_hi = min(Sq, Sk - off);     // q with 0 <= q + off < Sk
-    float acc = 0.f;
-    for (int q = q_lo; q < q_hi; ++q) acc += to_f32(base[(int64_t)q * ldp + q + off]);
-    part[(int64_t)bh * nrel + rel] = acc;
+    const int per = (Sq + 3) / 4;
+    const int a0 = max(q_lo, qg * per), a1 = min(q_hi, (qg + 1) * per);
+    for (int q = a0; q < a1; ++q) acc += to_f32(base[(int64_t)q * ldp + q + off]);
   }
+  sred[qg][rl] = acc;
+  __syncthreads();
+  if (qg == 0 && rel < nrel) part[(int64_t)bh * nrel + rel] = (sred[0][rl] + sred[1][rl]) + (sred[2][rl] + sred[3][rl]);
 }
 // stage 2: one block per (bucket, head): dtable[bucket][h] (+)= sum over clips b and the rels of that bucket of part[b][h][rel]
 __global__ __launch_bounds__(256) void bias_bucket_kernel(const float* __restrict__ part, const int* __restrict__ bucket_of_rel,
@@ -791,7 +799,7 @@ struct m2m_trainer {
   void *dlog = nullptr, *dxT = nullptr, *dmid = nullptr, *dab = nullptr, *dO = nullptr, *dqkv = nullptr, *dS = nullptr, *dcq = nullptr,
        *dckv = nullptr;
   int64_t* dec_in = nullptr;
-  int *ebucket = nullptr, *dbucket = nullptr;
+  int *ebucket = nullptr, *dbucket = nullptr, *counter = nullptr;
   int64_t* cond_off_dev = nullptr;
   int* cond_rows_dev = nullptr;
   int tab_S = -1, tab_L = -1;            // geometry the bucket tables on the device were built for
@@ -937,7 +945,7 @@ int build_arena(m2m_trainer* t) {
                 o_etab = F(H * (2 * S)), o_dtab = F(H * (2 * L)), o_dlog = T(Md * align_up(V, 8)), o_dxT = T(Mx * d), o_dmid = T(Mx * dff),
                 o_dab = T(Mx * 2 * dff), o_dO = T(Mx * inner), o_dqkv = T(Mx * 3 * inner), o_dS = T(B * H * Sm * lpm), o_dcq = T(Md * inner),
                 o_dckv = T(Me * 2 * inner), o_decin = c.take(Md * 8), o_eb = c.take(2 * S * 4), o_db = c.take(2 * L * 4),
-                o_co = c.take(64 * 8), o_cr = c.take(64 * 4), o_wc = (t->precision == M2M_PREC_BF16) ? T(t->n_floats) : 0,
+                o_co = c.take(64 * 8), o_cr = c.take(64 * 4), o_cnt = c.take(256), o_wc = (t->precision == M2M_PREC_BF16) ? T(t->n_floats) : 0,
                 o_wt = T(t->n_floats);
   const int64_t Mxp = align_up(Mx, 8), fmax = std::max<int64_t>(std::max<int64_t>(3 * inner, 2 * dff), align_up(V, 8));
   const int64_t o_tA = T(fmax * Mxp), o_tB = T(std::max<int64_t>(std::max<int64_t>(dff, inner), d) * Mxp);
@@ -976,7 +984,7 @@ int build_arena(m2m_trainer* t) {
   t->row_loss = (float*)(b + o_rl); t->inv_n = (float*)(b + o_inv); t->drel = (float*)(b + o_drel); t->etab = (float*)(b + o_etab);
   t->dtab = (float*)(b + o_dtab); t->dlog = b + o_dlog; t->dxT = b + o_dxT; t->dmid = b + o_dmid; t->dab = b + o_dab; t->dO = b + o_dO;
   t->dqkv = b + o_dqkv; t->dS = b + o_dS; t->dcq = b + o_dcq; t->dckv = b + o_dckv; t->dec_in = (int64_t*)(b + o_decin);
-  t->ebucket = (int*)(b + o_eb); t->dbucket = (int*)(b + o_db); t->cond_off_dev = (int64_t*)(b + o_co); t->cond_rows_dev = (int*)(b + o_cr);
+  t->ebucket = (int*)(b + o_eb); t->dbucket = (int*)(b + o_db); t->counter = (int*)(b + o_cnt); t->cond_off_dev = (int64_t*)(b + o_co); t->cond_rows_dev = (int*)(b + o_cr);
   t->Wc = (t->precision == M2M_PREC_BF16) ? (void*)(b + o_wc) : nullptr;
   t->WT = b + o_wt; t->tA = b + o_tA; t->tB = b + o_tB; t->kpart = (float*)(b + o_kp); t->wt_blocks = b + o_wtb; t->n_wt_blocks = (int)wtb.size();
   M2M_CHECK_HIP(hipMemcpy(t->wt_blocks, wtb.data(), wtb.size() * sizeof(WtBlock), hipMemcpyHostToDevice));
@@ -1081,6 +1089,8 @@ struct Ops {
   int norm(const float* x, int64_t w_off, void* out, int M) const { return launch_rmsnorm(t->precision, x, P + w_off, out, M, t->g.d_model, t->g.layer_norm_eps, st); }
   int norm_bwd(const float* x, int64_t w_off, const float* dy, const float* dx_res, float* dx_out, float* G, int M) const {
     const int d = t->g.d_model;
+    // (summing the partials in the last block to finish, behind a __threadfence() + counter, was measured: the agent-scope
+    //  fence of 256 blocks costs ~100 us per launch on this machine — 8.7 -> 12.3 ms per step; the second launch stays)
     hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(RN_BLOCKS), dim3(256), (size_t)4 * d * sizeof(float), st, x, P + w_off, dy, dx_res, dx_out,
                        t->dw_part, M, d, t->g.layer_norm_eps);
     hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(d, 64)), dim3(256), 0, st, t->dw_part, G + w_off, RN_BLOCKS, d, 0);
@@ -1128,7 +1138,7 @@ struct Ops {
   }
   int bias_grad(const void* dS, const int* buckets, float* Gtab, int nB, int Sq, int Sk, int ldp, int accumulate) const {
     const int H = t->g.num_heads, nrel = Sq + Sk - 1;
-    hipLaunchKernelGGL(bias_diag_kernel<T>, dim3(nB * H), dim3(256), 0, st, (const T*)dS, t->drel, H, Sq, Sk, ldp);
+    hipLaunchKernelGGL(bias_diag_kernel<T>, dim3(nB * H, ceil_div(nrel, 64)), dim3(256), 0, st, (const T*)dS, t->drel, H, Sq, Sk, ldp);
     hipLaunchKernelGGL(bias_bucket_kernel, dim3(t->g.num_buckets * H), dim3(256), 0, st, t->drel, buckets, Gtab, nB, H, nrel, accumulate);
     M2M_CHECK_HIP(hipGetLastError());
     return M2M_OK;
