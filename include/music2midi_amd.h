@@ -47,7 +47,9 @@ enum {
 
 enum {
   M2M_PREC_FP32 = 0,        /* fp32 weights / KV / GEMM inputs (f32 MFMA): parity mode */
-  M2M_PREC_BF16 = 1         /* bf16 weights / KV / GEMM inputs, fp32 accumulate: throughput mode */
+  M2M_PREC_BF16 = 1,        /* bf16 weights / KV / GEMM inputs, fp32 accumulate: throughput mode */
+  M2M_PREC_FP8 = 2          /* m2m_trainer_create only: as BF16, but the dense projection products (forward, dX, dW) run on
+                               block-scaled OCP FP8 (MXFP8: e4m3 forward operands, e5m2 gradients) — BASELINE configs[4] */
 };
 
 int m2m_abi_version(void);
@@ -251,6 +253,12 @@ int m2m_adafactor_get_step(const m2m_trainer* t);
 int64_t m2m_adafactor_state_floats(const m2m_trainer* t);
 int m2m_adafactor_state_export(const m2m_trainer* t, float* state_out_dev, void* stream);
 int m2m_adafactor_state_import(m2m_trainer* t, const float* state_in_dev, int step, void* stream);
+
+/* One MXFP8 product, C[M,N] = A[M,K] . B[N,K]^T (fp32 in and out, device pointers, row-major): both operands are quantised
+ * to OCP block-scaled FP8 — 32 elements along K per power-of-two E8M0 scale, e4m3 elements (e5m2 for A when a_is_e5m2, the
+ * gradient format) — and multiplied on gfx950's scaled MFMA (v_mfma_scale_f32_32x32x64_f8f6f4).  This is the arithmetic of
+ * the fp8 training mode (M2M_PREC_FP8 of m2m_trainer_create), exposed so it can be checked on its own.  Synchronises `stream`. */
+int m2m_mx8_matmul_f32(const float* a_dev, const float* b_dev, int M, int N, int K, int a_is_e5m2, float* c_dev, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Measurement hooks (bench.py): time one kernel of the decode step in isolation

@@ -32,6 +32,24 @@ struct BGemmArgs {
 
 int launch_bgemm(int precision, int epi, const BGemmArgs& g, hipStream_t st);
 
+// MXFP8 product (mx8.hip): C[M,N] (epi)= A[M,K] . B[N,K]^T, block-scaled fp8 operands (32 elements along K per E8M0 scale)
+struct MxGemmArgs {
+  const uint8_t *A, *B;      // fp8 bytes, [M][lda] / [N][ldb]; lda, ldb multiples of 128, zero-padded past K
+  const uint8_t *sA, *sB;    // E8M0 scales, [M][lda/32] / [N][ldb/32]
+  void* C;
+  const float* R;            // TG_RESID_F32
+  int M, N, K;
+  int64_t lda, ldb, ldc;
+  int ksplit, kchunk;
+  float* Cpart;
+  uint32_t drop_thresh;
+  float drop_scale;
+  uint64_t drop_key;
+};
+int launch_mxgemm(int fmt_a, int fmt_b, int epi, const MxGemmArgs& g, hipStream_t st);      // fmt: 0 = e4m3, 1 = e5m2
+int launch_mxq_rows(int src_kind, const void* src, int64_t ld_s, uint8_t* q, uint8_t* sc, int R, int C, int Cp, int fmt, hipStream_t st);
+int launch_mxq_cols(int src_kind, const void* src, int64_t ld_s, uint8_t* qt, uint8_t* sc, int R, int C, int Rp, int fmt, hipStream_t st);
+
 // Adafactor plan (device tables built once per trainer)
 struct AfTensor {
   int64_t offset;          // into the flat parameter / gradient buffers

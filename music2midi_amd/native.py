@@ -17,6 +17,7 @@ _lock = threading.Lock()
 
 PREC_FP32 = 0
 PREC_BF16 = 1
+PREC_FP8 = 2
 KERNEL_DEC_CROSS_ATTN = 0
 KERNEL_DEC_SELF_ATTN = 1
 KERNEL_DEC_STEP = 2
@@ -98,6 +99,7 @@ _SIGNATURES = {
     "m2m_adafactor_state_floats": (C.c_int64, [C.c_void_p]),
     "m2m_adafactor_state_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "m2m_adafactor_state_import": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "m2m_mx8_matmul_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "m2m_bench_kernel": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
                                    C.POINTER(C.c_int64), C.c_void_p]),
 }

@@ -214,3 +214,24 @@ def test_simple_midi_writer_roundtrip(tmp_path):
     assert raw[:4] == b"MThd" and raw[14:18] == b"MTrk" and raw.count(b"\x90") >= 2
     if isinstance(midi, SimpleMIDI):
         assert midi.note_array().shape == (2, 4)
+
+
+def test_training_surface_fails_loudly_without_gpu_and_binding_matches_header():
+    """The training entry points are part of the C ABI and have no CPU fallback either."""
+    import ctypes as C
+    from music2midi_amd.model import Music2MIDI
+    from music2midi_amd.input import ModelInputs
+    lib = native.load()
+    for name in ("m2m_trainer_create", "m2m_train_forward_backward", "m2m_adafactor_step", "m2m_trainer_set_dropout",
+                 "m2m_trainer_tensor_info", "m2m_adafactor_state_export"):
+        assert hasattr(lib, name)
+    assert C.sizeof(native.TensorInfo) == 160 + 8 + 4 + 4
+    assert lib.m2m_trainer_num_params(None) < 0 and lib.m2m_adafactor_step(None, None, None, None) < 0
+    assert b"null argument" in lib.m2m_last_error()
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    m = Music2MIDI(DEFAULT_CONFIG)
+    (opt,), (sched,) = m.configure_optimizers()
+    batch = ModelInputs(input_waveform=torch.zeros(1, 4096), notes_batch=(np.array([[0.0, 0.5, 60, 80]]),), cond_index=torch.zeros(1, 2, dtype=torch.long))
+    with pytest.raises(native.NativeError):
+        m.training_step(batch, 0)
