@@ -264,7 +264,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp8"],
+                    help="fp8 (block-scaled MXFP8 projection GEMMs) exists for --mode train only")
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
     ap.add_argument("--cpu-tokens", type=int, default=1023, help="greedy steps per clip of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
@@ -311,7 +312,7 @@ def main():
     S = N_FRAMES + 2
 
     # ---- weights: rank 0 owns them, everyone else receives them over RCCL ----
-    model = T5Transformer(cfg.to_dict(), precision=args.precision)
+    model = T5Transformer(cfg.to_dict(), precision="bf16" if args.precision == "fp8" else args.precision)
     state = None
     if rank == 0:
         state = synth.t5_state_dict(geom, seed=0)
@@ -319,6 +320,9 @@ def main():
     model = model.to(dev).eval()
     bcast_bytes = D.broadcast_module_state(model, src=0)
 
+    if args.precision == "fp8" and args.mode != "train":
+        print("[bench] --precision fp8 is a training mode (use --mode train)", file=sys.stderr)
+        sys.exit(2)
     if args.mode == "train":
         Bt = 16 if args.batch == 32 else args.batch
         rec = train_step_record(model, cfg, geom, dev, Bt, args.precision, args.steps, args.warmup, world)
@@ -484,7 +488,14 @@ def main():
     if rank == 0 and world == 1 and not args.no_train:
         mt = T5Transformer(cfg.to_dict(), precision="fp32")
         load_t5_state(mt, state, strict=False)
-        out["train_configs4"] = train_step_record(mt.to(dev), cfg, geom, dev, 16, "bf16", 10, 2)
+        mt = mt.to(dev)
+        out["train_configs4"] = train_step_record(mt, cfg, geom, dev, 16, "bf16", 10, 2)
+        fp8 = train_step_record(mt, cfg, geom, dev, 16, "fp8", 10, 2)          # configs[4] names fp8 GEMMs: MXFP8 projections, same step
+        out["train_configs4"]["fp8_mx_ms_per_step"] = fp8["ms_per_step"]
+        out["train_configs4"]["fp8_mx_clips_per_s"] = fp8["clips_per_s"]
+        out["train_configs4"]["fp8_note"] = ("projection products (forward, dX, dW) on block-scaled OCP FP8 (e4m3, 32 elements per E8M0 scale, "
+                                             "v_mfma_scale_f32_32x32x64_f8f6f4); at 16 clips/GPU the step is launch-bound, so the extra quantiser "
+                                             "launches cost more than the faster matrix instruction saves")
         del mt
 
     if rank == 0 and world == 1 and args.cpu_tokens > 0:

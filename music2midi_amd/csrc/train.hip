@@ -191,6 +191,62 @@ __global__ __launch_bounds__(256) void weights_transpose_kernel(const WtBlock* _
   }
 }
 
+// fp8 mode: every projection matrix W [N][K] (fp32 master) -> MXFP8 in BOTH layouts in one launch: row-major with blocks
+// along K (the forward's B operand) and transposed [K][Np] with blocks along N (the B operand of dX = dY . W).
+// One 64-thread workgroup per 32 x 64 tile (table entry); e4m3.
+struct W8Tile { int64_t off; int N, K, Np; int64_t q, qs, qt, qts; int tn, tk; };
+__device__ inline float w8_scale_exp(float amax) {
+  if (!(amax > 0.f)) return -127.f;
+  int e;
+  (void)frexpf(amax, &e);
+  int se = e - 1 - 8;
+  return (float)(se < -127 ? -127 : (se > 127 ? 127 : se));
+}
+__device__ inline uint32_t w8_pack4(float a, float b, float c, float d) {
+  a = fminf(fmaxf(a, -448.f), 448.f); b = fminf(fmaxf(b, -448.f), 448.f); c = fminf(fmaxf(c, -448.f), 448.f); d = fminf(fmaxf(d, -448.f), 448.f);
+  int w = 0;
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return (uint32_t)w;
+}
+__global__ __launch_bounds__(64) void mxq_weights_kernel(const W8Tile* __restrict__ tiles, const float* __restrict__ P, uint8_t* __restrict__ w8) {
+  __shared__ float tile[32][65];
+  const W8Tile tl = tiles[blockIdx.x];
+  const int n0 = tl.tn * 32, k0 = tl.tk * 64;
+  const float* src = P + tl.off;
+  for (int i = threadIdx.x; i < 32 * 64; i += 64) {
+    const int nl = i >> 6, kl = i & 63;
+    tile[nl][kl] = (n0 + nl < tl.N && k0 + kl < tl.K) ? src[(int64_t)(n0 + nl) * tl.K + k0 + kl] : 0.f;
+  }
+  __syncthreads();
+  {  // rows: thread -> (row, k-block)
+    const int nl = threadIdx.x >> 1, kb = threadIdx.x & 1;
+    if (n0 + nl < tl.N && k0 + 32 * kb < tl.K) {
+      float v[32], amax = 0.f;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) { v[j] = tile[nl][32 * kb + j]; amax = fmaxf(amax, fabsf(v[j])); }
+      const float se = w8_scale_exp(amax), inv = exp2f(-se);
+      uint32_t* dst = reinterpret_cast<uint32_t*>(w8 + tl.q + (int64_t)(n0 + nl) * tl.K + k0 + 32 * kb);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dst[j] = w8_pack4(v[4 * j] * inv, v[4 * j + 1] * inv, v[4 * j + 2] * inv, v[4 * j + 3] * inv);
+      w8[tl.qs + (int64_t)(n0 + nl) * (tl.K / 32) + (k0 + 32 * kb) / 32] = (uint8_t)((int)se + 127);
+    }
+  }
+  {  // columns: thread -> column k, block of 32 rows n0 .. n0 + 31
+    const int kl = threadIdx.x;
+    if (k0 + kl < tl.K) {
+      float v[32], amax = 0.f;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) { v[j] = tile[j][kl]; amax = fmaxf(amax, fabsf(v[j])); }
+      const float se = w8_scale_exp(amax), inv = exp2f(-se);
+      uint32_t* dst = reinterpret_cast<uint32_t*>(w8 + tl.qt + (int64_t)(k0 + kl) * tl.Np + n0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dst[j] = w8_pack4(v[4 * j] * inv, v[4 * j + 1] * inv, v[4 * j + 2] * inv, v[4 * j + 3] * inv);
+      w8[tl.qts + (int64_t)(k0 + kl) * (tl.Np / 32) + n0 / 32] = (uint8_t)((int)se + 127);
+    }
+  }
+}
+
 int launch_bgemm(int precision, int epi, const BGemmArgs& g, hipStream_t st) {
   const int E = precision == M2M_PREC_BF16 ? 8 : 4;
   M2M_REQUIRE(g.M >= 1 && g.N >= 1 && g.K >= 1 && g.nb1 >= 1 && g.nb2 >= 1, "bgemm: empty problem");
@@ -803,6 +859,16 @@ struct m2m_trainer {
   int64_t* cond_off_dev = nullptr;
   int* cond_rows_dev = nullptr;
   int tab_S = -1, tab_L = -1;            // geometry the bucket tables on the device were built for
+  // fp8 mode (M2M_PREC_FP8): storage type stays bf16, the projection products run on MXFP8 (mx8.hip)
+  bool fp8 = false;
+  bool fp8_fwd = true, fp8_dx = true, fp8_dw = true;   // diagnostic switches (M2M_FP8_PARTS=fwd,dx,dw subset)
+  int grad_fmt = 0;                      // element format of the gradient operands: 0 = e4m3 (default), 1 = e5m2 (M2M_FP8_GRAD=e5m2)
+  struct LinW { int64_t off; int N, K, Np; int64_t q, qs, qt, qts; };
+  std::vector<LinW> lin;                 // every projection matrix (fused groups), by parameter offset
+  uint8_t* w8 = nullptr;                 // fp8 weights, both layouts, + scales
+  void* w8_tiles = nullptr;
+  int n_w8_tiles = 0;
+  uint8_t *q8a = nullptr, *s8a = nullptr, *q8ta = nullptr, *s8ta = nullptr, *q8tb = nullptr, *s8tb = nullptr;
   // dropout (hf T5Config.dropout_rate; the reference trains in model.train() mode, ref train.py:33): off unless set
   float drop_p = 0.f, drop_scale = 1.f;
   uint32_t drop_thresh = 0;
@@ -964,6 +1030,30 @@ int build_arena(m2m_trainer* t) {
                                      add(e.ckv, 2 * (int)inner, (int)d); add(e.co, (int)d, (int)inner); add(e.wi, 2 * (int)dff, (int)d); add(e.wo, (int)d, (int)dff); }
   }
   const int64_t o_wtb = c.take((int64_t)wtb.size() * sizeof(WtBlock));
+  // fp8 mode: MXFP8 copies of every projection matrix (lm_head stays bf16) + quantised-activation scratch
+  std::vector<W8Tile> w8t;
+  int64_t w8_bytes = 0, o_w8 = 0, o_w8t = 0, o_q8a = 0, o_s8a = 0, o_q8ta = 0, o_s8ta = 0, o_q8tb = 0, o_s8tb = 0;
+  if (t->fp8) {
+    auto addl = [&](int64_t off, int N, int K) {
+      m2m_trainer::LinW w{off, N, K, (int)align_up(N, 128), 0, 0, 0, 0};
+      w.q = w8_bytes; w8_bytes = align_up(w8_bytes + (int64_t)N * K, 256);
+      w.qs = w8_bytes; w8_bytes = align_up(w8_bytes + (int64_t)N * (K / 32), 256);
+      w.qt = w8_bytes; w8_bytes = align_up(w8_bytes + (int64_t)K * w.Np, 256);
+      w.qts = w8_bytes; w8_bytes = align_up(w8_bytes + (int64_t)K * (w.Np / 32), 256);
+      t->lin.push_back(w);
+      for (int tn = 0; tn < ceil_div(N, 32); ++tn)
+        for (int tk = 0; tk < ceil_div(K, 64); ++tk) w8t.push_back({off, N, K, w.Np, w.q, w.qs, w.qt, w.qts, tn, tk});
+    };
+    for (const EncOff& e : t->enc) { addl(e.qkv, 3 * (int)inner, (int)d); addl(e.o, (int)d, (int)inner); addl(e.wi, 2 * (int)dff, (int)d); addl(e.wo, (int)d, (int)dff); }
+    for (const DecOff& e : t->dec) { addl(e.qkv, 3 * (int)inner, (int)d); addl(e.o, (int)d, (int)inner); addl(e.cq, (int)inner, (int)d);
+                                     addl(e.ckv, 2 * (int)inner, (int)d); addl(e.co, (int)d, (int)inner); addl(e.wi, 2 * (int)dff, (int)d); addl(e.wo, (int)d, (int)dff); }
+    const int64_t Mp128 = align_up(Mx, 128), f8 = align_up(fmax, 128);
+    o_w8 = c.take(w8_bytes); o_w8t = c.take((int64_t)w8t.size() * sizeof(W8Tile));
+    o_q8a = c.take(Mx * f8); o_s8a = c.take(Mx * (f8 / 32));
+    o_q8ta = c.take(f8 * Mp128); o_s8ta = c.take(f8 * (Mp128 / 32));
+    o_q8tb = c.take(align_up(std::max<int64_t>(std::max<int64_t>(dff, inner), d), 128) * Mp128);
+    o_s8tb = c.take(align_up(std::max<int64_t>(std::max<int64_t>(dff, inner), d), 128) * (Mp128 / 32));
+  }
   t->arena_bytes = c.off;
   hipError_t e = hipMalloc((void**)&t->arena, (size_t)c.off);
   if (e != hipSuccess) { set_error("m2m_trainer_create: hipMalloc(%lld) failed: %s", (long long)c.off, hipGetErrorString(e)); return M2M_ERR_NOMEM; }
@@ -988,6 +1078,11 @@ int build_arena(m2m_trainer* t) {
   t->Wc = (t->precision == M2M_PREC_BF16) ? (void*)(b + o_wc) : nullptr;
   t->WT = b + o_wt; t->tA = b + o_tA; t->tB = b + o_tB; t->kpart = (float*)(b + o_kp); t->wt_blocks = b + o_wtb; t->n_wt_blocks = (int)wtb.size();
   M2M_CHECK_HIP(hipMemcpy(t->wt_blocks, wtb.data(), wtb.size() * sizeof(WtBlock), hipMemcpyHostToDevice));
+  if (t->fp8) {
+    t->w8 = b + o_w8; t->w8_tiles = b + o_w8t; t->n_w8_tiles = (int)w8t.size();
+    t->q8a = b + o_q8a; t->s8a = b + o_s8a; t->q8ta = b + o_q8ta; t->s8ta = b + o_s8ta; t->q8tb = b + o_q8tb; t->s8tb = b + o_s8tb;
+    M2M_CHECK_HIP(hipMemcpy(t->w8_tiles, w8t.data(), w8t.size() * sizeof(W8Tile), hipMemcpyHostToDevice));
+  }
   M2M_CHECK_HIP(hipMemcpy(t->cond_off_dev, t->o_cond.data(), t->o_cond.size() * 8, hipMemcpyHostToDevice));
   M2M_CHECK_HIP(hipMemcpy(t->cond_rows_dev, t->cond_rows.data(), t->cond_rows.size() * 4, hipMemcpyHostToDevice));
   return M2M_OK;
@@ -1011,6 +1106,14 @@ struct Ops {
   int dw_kmajor = getenv("M2M_TRAIN_DW_KMAJOR") ? atoi(getenv("M2M_TRAIN_DW_KMAJOR")) : -1;   // -1 = by size, 0 / 1 = forced
   const T* W(int64_t off) const { return (t->precision == M2M_PREC_BF16 ? reinterpret_cast<const T*>(t->Wc) : reinterpret_cast<const T*>(P)) + off; }
 
+  // fp8 mode: the projection matrix that starts at parameter offset `off`, or null (lm_head, non-projection operands)
+  const m2m_trainer::LinW* lin8(int64_t off) const {
+    if (!t->fp8) return nullptr;
+    for (const auto& w : t->lin) if (w.off == off) return &w;
+    return nullptr;
+  }
+  float* Gbase = nullptr;     // flat gradient buffer of this call (dW recognises its weight by the output offset)
+
   // dropout sites: one key per (layer, place); site < 0 or p == 0: no dropout
   bool dropping(int site) const { return site >= 0 && t->drop_thresh != 0; }
   uint64_t key(int site) const { return splitmix64(t->step_key + (uint64_t)site * 0x9E3779B97F4A7C15ull); }
@@ -1021,6 +1124,17 @@ struct Ops {
     g.A = A; g.B = B; g.C = C; g.R = R; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.a_kmajor = akm; g.b_kmajor = bkm;
     g.nb1 = 1; g.nb2 = 1; g.alpha = 1.0f;
     if (dropping(drop_site)) { g.drop_thresh = t->drop_thresh; g.drop_scale = t->drop_scale; g.drop_key = key(drop_site); }
+    if (!akm && !bkm && t->fp8 && t->fp8_fwd) {          // a forward projection Y = X . W^T on MXFP8 operands
+      const int64_t off = reinterpret_cast<const T*>(B) - W(0);
+      if (const m2m_trainer::LinW* w = lin8(off)) {
+        int rc = launch_mxq_rows(1, A, lda, t->q8a, t->s8a, M, K, K, 0, st);
+        if (rc != M2M_OK) return rc;
+        MxGemmArgs m{};
+        m.A = t->q8a; m.sA = t->s8a; m.B = t->w8 + w->q; m.sB = t->w8 + w->qs; m.C = C; m.R = R; m.M = M; m.N = N; m.K = K;
+        m.lda = K; m.ldb = K; m.ldc = ldc; m.drop_thresh = g.drop_thresh; m.drop_scale = g.drop_scale; m.drop_key = g.drop_key;
+        return launch_mxgemm(0, 0, epi, m, st);
+      }
+    }
     // dense NT products with K % 64 == 0 go through the inference path's tuned kernel (128x128 tiles, register-prefetched
     // staging, XCD-aware tile order): every forward projection and every dX product qualifies
     if (!akm && !bkm && K % 64 == 0 && lda == K && ldb == K && use_tuned) {
@@ -1058,12 +1172,34 @@ struct Ops {
   }
   // dX[M, Kw] (epi) = dY[M, Nw] . W   for a weight stored [Nw][Kw]: an NT product against the transposed copy WT [Kw][Nw]
   int dX(int epi, const void* dY, int64_t ldy, int64_t w_off, int Nw, int Kw, void* C, int64_t ldc, int M) const {
+    if (const m2m_trainer::LinW* w = t->fp8_dx ? lin8(w_off) : nullptr) {    // fp8 mode: dY in e5m2 (gradient format), W^T in e4m3
+      int rc = launch_mxq_rows(1, dY, ldy, t->q8a, t->s8a, M, Nw, w->Np, t->grad_fmt, st);
+      if (rc != M2M_OK) return rc;
+      MxGemmArgs m{};
+      m.A = t->q8a; m.sA = t->s8a; m.B = t->w8 + w->qt; m.sB = t->w8 + w->qts; m.C = C; m.M = M; m.N = Kw; m.K = w->Np;
+      m.lda = w->Np; m.ldb = w->Np; m.ldc = ldc;
+      return launch_mxgemm(t->grad_fmt, 0, epi, m, st);
+    }
     return mm(epi, dY, ldy, 0, reinterpret_cast<const T*>(t->WT) + w_off, Nw, 0, C, ldc, M, Kw, Nw);
   }
   // G[Ny, Kx] = dY[M, Ny]^T . X[M, Kx]: both operands are transposed once (coalesced, through LDS) into [features][Mp]
   // scratch, then it is a plain NT product with the M rows as the reduction, split over k so that the few output tiles
   // of a weight gradient still fill the chip; the k-slices are summed in a fixed order.
   int dW(const void* dY, int64_t ldy, int Ny, const void* X, int64_t ldx, int Kx, float* Gout, int M) const {
+    if (Gbase && t->fp8_dw && lin8(Gout - Gbase)) {      // fp8 mode: dY^T (e5m2) . X^T (e4m3), blocks along the M rows
+      const int Mp8 = (int)align_up(M, 128);
+      int rc = launch_mxq_cols(1, dY, ldy, t->q8ta, t->s8ta, M, Ny, Mp8, t->grad_fmt, st);
+      if (rc == M2M_OK) rc = launch_mxq_cols(1, X, ldx, t->q8tb, t->s8tb, M, Kx, Mp8, 0, st);
+      if (rc != M2M_OK) return rc;
+      MxGemmArgs m{};
+      m.A = t->q8ta; m.sA = t->s8ta; m.B = t->q8tb; m.sB = t->s8tb; m.C = Gout; m.M = Ny; m.N = Kx; m.K = Mp8; m.lda = Mp8; m.ldb = Mp8; m.ldc = Kx;
+      const int tiles = ceil_div(Ny, 64) * ceil_div(Kx, 64);
+      int ks = 1024 / tiles;
+      if (ks > 32) ks = 32;
+      while (ks > 1 && ((int64_t)ks * Ny * Kx > t->kpart_floats || Mp8 / ks < 128)) --ks;
+      if (ks > 1) { m.kchunk = (int)align_up(ceil_div(Mp8, ks), 128); m.ksplit = ceil_div(Mp8, m.kchunk); m.Cpart = t->kpart; }
+      return launch_mxgemm(t->grad_fmt, 0, TG_STORE_F32, m, st);
+    }
     const int Mp = (int)align_up(M, 8);
     BGemmArgs g{};
     g.C = Gout; g.M = Ny; g.N = Kx; g.K = M; g.ldc = Kx; g.nb1 = 1; g.nb2 = 1; g.alpha = 1.0f;
@@ -1237,6 +1373,7 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
   const int d = g.d_model, inner = t->inner, V = g.vocab_size, H = g.num_heads, Le = g.num_layers, Ld = g.num_decoder_layers;
   const int Me = B * S, Md = B * L, lps = (int)align_up(S, 8), ldv = (int)align_up(V, 8);
   Ops<T> o{t, st, P};
+  o.Gbase = G;
   int rc;
   // ---- tables that depend on the geometry (host) and on the current bucket weights (device) ----
   if (t->tab_S != S) {
@@ -1259,6 +1396,10 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
   if (t->precision == M2M_PREC_BF16) RC(o.cvt(P, t->Wc, t->n_floats));
   if (G) {
     hipLaunchKernelGGL(weights_transpose_kernel<T>, dim3(t->n_wt_blocks), dim3(256), 0, st, (const WtBlock*)t->wt_blocks, P, (T*)t->WT);
+    M2M_CHECK_HIP(hipGetLastError());
+  }
+  if (t->fp8) {
+    hipLaunchKernelGGL(mxq_weights_kernel, dim3(t->n_w8_tiles), dim3(64), 0, st, (const W8Tile*)t->w8_tiles, P, t->w8);
     M2M_CHECK_HIP(hipGetLastError());
   }
   if (G) M2M_CHECK_HIP(hipMemsetAsync(G, 0, (size_t)t->n_floats * 4, st));
@@ -1382,13 +1523,27 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
 extern "C" int m2m_trainer_create(const m2m_t5_geometry* geom, int n_cond, const int* cond_rows, int precision, int max_batch,
                                   int max_enc_len, int max_dec_len, m2m_trainer** out) {
   M2M_REQUIRE(geom && out && (n_cond == 0 || cond_rows), "m2m_trainer_create: null argument");
-  M2M_REQUIRE(precision == M2M_PREC_FP32 || precision == M2M_PREC_BF16, "m2m_trainer_create: bad precision %d", precision);
+  M2M_REQUIRE(precision == M2M_PREC_FP32 || precision == M2M_PREC_BF16 || precision == M2M_PREC_FP8, "m2m_trainer_create: bad precision %d", precision);
+  const bool fp8 = precision == M2M_PREC_FP8;
+  if (fp8) {
+    precision = M2M_PREC_BF16;       // storage type and every non-projection product are the bf16 mode's
+    M2M_REQUIRE(geom->d_model % 128 == 0 && geom->d_ff % 128 == 0 && (geom->num_heads * geom->d_kv) % 128 == 0,
+                "m2m_trainer_create: fp8 mode needs d_model, d_ff and num_heads*d_kv to be multiples of 128 (MX blocks of 32 in 128-byte rows)");
+  }
   M2M_REQUIRE(geom->d_kv == DK, "m2m_trainer_create: d_kv=%d unsupported (64 only)", geom->d_kv);
   M2M_REQUIRE(geom->d_model % 64 == 0 && geom->d_model <= 512 && geom->d_ff % 8 == 0, "m2m_trainer_create: d_model must be a multiple of 64 (<= 512), d_ff of 8");
   M2M_REQUIRE(n_cond >= 0 && n_cond <= 8 && max_batch >= 1 && max_enc_len > n_cond && max_dec_len >= 1, "m2m_trainer_create: bad sizes");
   m2m_trainer* t = new m2m_trainer();
   t->g = *geom; t->precision = precision; t->inner = geom->num_heads * geom->d_kv; t->n_cond = n_cond;
   t->es = precision == M2M_PREC_BF16 ? 2 : 4;
+  t->fp8 = fp8;
+  // Gradient operands: e4m3 by default — with a scale per 32 elements the range of e5m2 is not needed, and its third
+  // mantissa bit halves the noise every backward product adds (measured on the full model, per-tensor gradient cosine
+  // against the fp32 oracle: e5m2 median 0.931 / min 0.908; e4m3: see tests/test_train_gpu.py).  M2M_FP8_GRAD=e5m2 selects e5m2.
+  t->grad_fmt = (getenv("M2M_FP8_GRAD") && strcmp(getenv("M2M_FP8_GRAD"), "e5m2") == 0) ? 1 : 0;
+  if (const char* parts = getenv("M2M_FP8_PARTS")) {
+    t->fp8_fwd = strstr(parts, "fwd") != nullptr; t->fp8_dx = strstr(parts, "dx") != nullptr; t->fp8_dw = strstr(parts, "dw") != nullptr;
+  }
   t->max_batch = max_batch; t->max_enc = max_enc_len; t->max_dec = max_dec_len;
   t->cond_rows.assign(cond_rows, cond_rows + n_cond);
   build_layout(t);

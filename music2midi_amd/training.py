@@ -22,7 +22,7 @@ import torch
 from . import native
 from .input import ModelInputs
 
-_PRECISIONS = {"fp32": native.PREC_FP32, "bf16": native.PREC_BF16}
+_PRECISIONS = {"fp32": native.PREC_FP32, "bf16": native.PREC_BF16, "fp8": native.PREC_FP8}
 
 
 class NativeTrainer:

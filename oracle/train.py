@@ -73,6 +73,7 @@ class T5TrainOracle:
         self.g = geom
         self.p = params
         self.masks = None
+        self.mx8 = False          # True: emulate the fp8 training mode's projection products (see _lin)
 
     def w(self, name: str) -> torch.Tensor:
         return self.p["transformer." + name]
@@ -95,11 +96,23 @@ class T5TrainOracle:
             return x
         return x * self.masks.mask(site, x.numel()).view(x.shape)
 
+    def _lin(self, x, wname):
+        """x @ W^T.  With ``self.mx8`` the product is the fp8 training mode's: both operands MXFP8-quantised along the
+        reduction dimension (oracle/mx8.py), straight-through in the backward — d/dx sees the quantised W, d/dW the
+        quantised x, exactly the operands the device's dX / dW products use (csrc/train.hip fp8 mode)."""
+        w = self.w(wname)
+        if getattr(self, "mx8", False):
+            from .mx8 import mx_quant_dequant
+            # the device quantises the activation from its bf16 storage, the weight from the fp32 master
+            x = x + (mx_quant_dequant(x.detach().bfloat16().float(), "e4m3") - x).detach()
+            w = w + (mx_quant_dequant(w.detach(), "e4m3") - w).detach()
+        return x @ w.T
+
     def _attn(self, hq, hkv, prefix, bias, site_probs=-1):
         B, Lq, _ = hq.shape
-        q = self._heads(hq @ self.w(prefix + ".q.weight").T)
-        k = self._heads(hkv @ self.w(prefix + ".k.weight").T)
-        v = self._heads(hkv @ self.w(prefix + ".v.weight").T)
+        q = self._heads(self._lin(hq, prefix + ".q.weight"))
+        k = self._heads(self._lin(hkv, prefix + ".k.weight"))
+        v = self._heads(self._lin(hkv, prefix + ".v.weight"))
         s = q @ k.transpose(2, 3)                      # no 1/sqrt(d_kv) (hf: modeling_t5.py:197)
         if bias is not None:
             s = s + bias
@@ -110,11 +123,11 @@ class T5TrainOracle:
             m = self.masks.mask(site_probs, B * self.g.num_heads * Lq * ldp).view(B, self.g.num_heads, Lq, ldp)[..., :Sk]
             pr = pr * m
         o = (pr @ v).transpose(1, 2).reshape(B, Lq, self.g.inner_dim)
-        return o @ self.w(prefix + ".o.weight").T
+        return self._lin(o, prefix + ".o.weight")
 
     def _ffn(self, h, prefix, site_mid=-1):
-        mid = gelu_new(h @ self.w(prefix + ".wi_0.weight").T) * (h @ self.w(prefix + ".wi_1.weight").T)
-        return self._drop(mid, site_mid) @ self.w(prefix + ".wo.weight").T
+        mid = gelu_new(self._lin(h, prefix + ".wi_0.weight")) * self._lin(h, prefix + ".wi_1.weight")
+        return self._lin(self._drop(mid, site_mid), prefix + ".wo.weight")
 
     def encoder_inputs(self, feats: torch.Tensor, cond_idx: torch.Tensor) -> torch.Tensor:
         """ref: music2midi/input.py:57-59 — conditioning rows first, then the (constant) log-mel rows."""

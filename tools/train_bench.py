@@ -10,7 +10,7 @@ from music2midi_amd.config import T5Geometry, default_config
 from music2midi_amd.training import NativeTrainer
 from music2midi_amd.transformer import T5Transformer
 
-prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"  # bf16 | fp32 | fp8
 cfg = default_config(); geom = T5Geometry(cfg.model.t5)
 sd = synth.t5_state_dict(geom, 0)
 model = T5Transformer(cfg.to_dict(), precision="fp32"); load_t5_state(model, sd, strict=False); model = model.cuda()
