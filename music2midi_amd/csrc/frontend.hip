@@ -107,7 +107,10 @@ __device__ inline int zidx(int k) { return k + 4 * (k >> 8); }  // bank-spread l
 constexpr int FE_MAXJ = 8;          // mel filters per lane (n_mels <= 512)
 constexpr int FE_FBW_LDS = 6144;    // padded tap table kept in LDS when it has at most this many floats (24 KB), else read from memory
 
-__global__ __launch_bounds__(FE_THREADS, 2) void logmel_kernel(
+#ifndef M2M_FE_WGS_PER_CU
+#define M2M_FE_WGS_PER_CU 2
+#endif
+__global__ __launch_bounds__(FE_THREADS, M2M_FE_WGS_PER_CU) void logmel_kernel(
     const float* __restrict__ wav, int T, int F, FrontendDev fe, float* __restrict__ out,
     int64_t out_bstride, int row_offset, int FR, int NCH) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -124,7 +127,11 @@ __global__ __launch_bounds__(FE_THREADS, 2) void logmel_kernel(
   float* pbuf = reinterpret_cast<float*>(cbuf);          // aliases cbuf: written only after every Z read of the wave
   float* fbw_s = reinterpret_cast<float*>(cbase + FE_WAVES * WAVE_C2);
   const int nnz = fe.n_wpad;
+#ifdef M2M_FE_TAPS_GLOBAL       // diagnostic builds only
+  const bool fbw_in_lds = false;
+#else
   const bool fbw_in_lds = nnz <= FE_FBW_LDS;
+#endif
 
   const int b = blockIdx.y;
   if (fbw_in_lds)
@@ -292,7 +299,13 @@ __global__ __launch_bounds__(FE_THREADS, 2) void logmel_kernel(
         const int m = lane + 64 * j;
         // clamp(min=1e-6).log(): the floor is the correctly rounded fp32 ln(1e-6f), so silent
         // (zero-padded) regions are bit-identical to the reference's constant.
+#ifdef M2M_FE_SKIP_LOG      // diagnostic builds only
+        if (m < n_mels) orow[m] = acc;
+#elif defined(M2M_FE_SKIP_STORE)
+        if (m < n_mels && acc == 12345.678f) orow[m] = acc;
+#else
         if (m < n_mels) orow[m] = (acc > 1e-6f) ? logf(acc) : -13.815510749816895f;
+#endif
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -422,6 +435,9 @@ extern "C" int m2m_frontend_fb_nnz(const m2m_frontend* fe) { return fe ? fe->nnz
 static size_t frontend_smem_bytes(int FR, int hop, int nnz) {
   size_t span = (size_t)(FR - 1) * hop + NFFT;
   span = (span + 3) & ~(size_t)3;
+#ifdef M2M_FE_TAPS_GLOBAL
+  nnz = FE_FBW_LDS + 1;
+#endif
   return span * sizeof(float) + (size_t)FE_WAVES * WAVE_C2 * sizeof(float2) +
          (nnz <= FE_FBW_LDS ? (size_t)nnz * sizeof(float) : 0);
 }
@@ -436,7 +452,7 @@ extern "C" int m2m_logmel_f32(const m2m_frontend* fe, const float* wav_dev, int 
   M2M_REQUIRE(out_batch_stride >= (int64_t)(row_offset + F) * fe->n_mels,
               "m2m_logmel_f32: out_batch_stride %lld smaller than (row_offset+frames)*n_mels", (long long)out_batch_stride);
   // 16 frames per workgroup: waveform re-read factor 1.44 at hop 256, two workgroups per CU.
-  int FR = 16;
+  int FR = getenv("M2M_FE_FR") ? atoi(getenv("M2M_FE_FR")) : 16;
   while (FR > 4 && frontend_smem_bytes(FR, fe->hop, fe->n_wpad) > 78 * 1024) FR -= 4;
   const size_t smem = frontend_smem_bytes(FR, fe->hop, fe->n_wpad);
   // chunks of FR frames per workgroup.  Measured on MI355X (B = 64 / 32, us per launch): 1 chunk 199.9 / 108.3,
