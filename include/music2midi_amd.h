@@ -257,7 +257,8 @@ int m2m_adafactor_state_import(m2m_trainer* t, const float* state_in_dev, int st
 /* One MXFP8 product, C[M,N] = A[M,K] . B[N,K]^T (fp32 in and out, device pointers, row-major): both operands are quantised
  * to OCP block-scaled FP8 — 32 elements along K per power-of-two E8M0 scale, e4m3 elements (e5m2 for A when a_is_e5m2, the
  * gradient format) — and multiplied on gfx950's scaled MFMA (v_mfma_scale_f32_32x32x64_f8f6f4).  This is the arithmetic of
- * the fp8 training mode (M2M_PREC_FP8 of m2m_trainer_create), exposed so it can be checked on its own.  Synchronises `stream`. */
+ * the fp8 training mode (M2M_PREC_FP8 of m2m_trainer_create), exposed so it can be checked on its own.  A test utility:
+ * unlike the hot-path entry points it allocates and frees its own device scratch, and it synchronises `stream`. */
 int m2m_mx8_matmul_f32(const float* a_dev, const float* b_dev, int M, int N, int K, int a_is_e5m2, float* c_dev, void* stream);
 
 /* ------------------------------------------------------------------------- *
