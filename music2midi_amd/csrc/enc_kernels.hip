@@ -516,20 +516,28 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
       }
       mx = fmaxf(mx, lane_xor<32>(mx));
       const float m_new = fmaxf(m_run, mx);
-      const float alpha = __expf(m_run - m_new);
+      // exp(x - m) as ONE fma + the hardware exp2: exp2(x * log2(e) - m * log2(e))  (the sub / mul / exp2 form of
+      // __expf(x - m) costs one more VALU op per score, and this loop is VALU-bound: ~3x its MFMA time)
+      constexpr float L2E = 1.4426950408889634f;
+      const float mneg = -m_new * L2E;
+      const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run, L2E, mneg));
       float psum = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        p[i] = __expf(p[i] - m_new);
+        p[i] = __builtin_amdgcn_exp2f(fmaf(p[i], L2E, mneg));
         psum += p[i];
       }
       psum += lane_xor<32>(psum);
       l_run = l_run * alpha + psum;
       m_run = m_new;
+      // the running maximum rarely moves after the first tiles: when no lane of the wave saw a new maximum every alpha
+      // is exactly 1 and the 32 rescaling multiplies are skipped (wave-uniform branch, results unchanged)
+      if (__ballot(alpha != 1.0f) != 0ull) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        o[0][i] *= alpha;
-        o[1][i] *= alpha;
+        for (int i = 0; i < 16; ++i) {
+          o[0][i] *= alpha;
+          o[1][i] *= alpha;
+        }
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {

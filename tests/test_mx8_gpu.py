@@ -25,7 +25,7 @@ def _device_mx(a, b, e5m2):
 
 @pytest.mark.parametrize("outliers", [False, True])
 @pytest.mark.parametrize("e5m2", [False, True])
-@pytest.mark.parametrize("M,N,K", [(64, 64, 128), (100, 37, 384), (261, 1536, 384), (33, 70, 1152), (5, 400, 200), (130, 66, 31)])
+@pytest.mark.parametrize("M,N,K", [(64, 64, 128), (100, 37, 384), (261, 1536, 384), (33, 70, 1152), (5, 400, 200), (130, 66, 31), (1100, 200, 256), (2048, 384, 512)])
 def test_mx8_product_matches_the_ocp_restatement(M, N, K, e5m2, outliers):
     from oracle.mx8 import mx_matmul
     a = torch.from_numpy(synth.normal(M + K, "a", (M, K), 1.0))
