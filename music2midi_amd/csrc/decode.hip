@@ -25,6 +25,8 @@
 
 namespace m2m {
 
+bool decode_headless();
+
 // ---- optional in-kernel wall-clock stamps (diagnostic builds only: -DM2M_STAMPS) ----
 // s_memrealtime runs at a constant 100 MHz and is the same clock on every CU, so stamps from
 // different kernels can be laid on one timeline.  Block 0 / thread 0 of every decode kernel logs
@@ -91,6 +93,27 @@ __device__ inline float4 xq_load4(const xq_t* p) {   // p 16-byte aligned
   return make_float4(xq_flt(a.x), xq_flt(a.y), xq_flt(b.x), xq_flt(b.y));
 }
 
+// ---- headless greedy loop: the arg-max travels as a packed 64-bit key ----
+// The lm_head workgroups reduce their 16 columns per row and atomicMax a key into keys[row]; the NEXT step's layer-0
+// self-attention workgroups decode it (token id -> embedding row = their input), the layer-0 cross-attention kernel
+// does the per-row bookkeeping (token matrix, finished flag, unfinished count) and clears the key, the layer-0
+// feed-forward kernel turns "no row unfinished" into done.  That removes dec_head_kernel (a kernel boundary + two
+// dependent memory round trips per step) from the greedy chain; teacher forcing keeps the head kernel.
+// key = (order-preserving image of the fp32 logit) << 32 | (0xFFFFFFFF - column): the largest key is the largest logit,
+// ties go to the lowest column (torch.argmax); 0 = "no key".
+__device__ inline unsigned long long amax_key(float v, int col) {
+  unsigned int u = __float_as_uint(v + 0.0f);                      // -0 -> +0: they must tie
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned int)col);
+}
+__device__ inline int amax_key_token(unsigned long long key, int fin, int V, int pad_id) {
+  int tok = (int)(0xFFFFFFFFu - (unsigned int)(key & 0xFFFFFFFFull));
+  if (fin || tok < 0 || tok >= V) tok = pad_id;                    // finished rows keep emitting pad (hf generation/utils.py:2929)
+  return tok;
+}
+// every kernel of a step: the chain is over when done is set OR the step counter has reached the step budget
+__device__ inline int chain_done(const DecState* st) { return st->done | (st->t >= st->max_steps); }
+
 // ===================================================== skinny projection ====
 // lm_head: logits[B, V] = RMSNorm(x) . W^T (untied, no d_model**-0.5 scaling: transformers 4.34 semantics).
 struct DecGemmArgs {
@@ -100,9 +123,10 @@ struct DecGemmArgs {
   float eps;
   const void* W;         // [Npad, K] T
   int K, N, B;
-  const DecState* state;
+  DecState* state;
   float* out;            // [B, ldo] logits
   int ldo;
+  unsigned long long* keys;   // headless greedy loop: [B] arg-max keys (the logits themselves are not stored)
 };
 
 // One 16-row x 16-column output tile per workgroup (MFMA 16x16x32 / 16x16x4), NW waves split K.
@@ -134,13 +158,15 @@ __device__ inline void mma32_16(f32x4_t& acc, const Frag<float>& a, const Frag<f
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi.w, b.hi.w, acc, 0, 0, 0);
 }
 
-template <typename T, int NS>
+template <typename T, int NS, bool HEADLESS>
 __global__ __launch_bounds__(64 * DG_MAXW) void dec_gemm_kernel(DecGemmArgs a) {
   M2M_STAMP_DECL
   __shared__ float ss_s[DG_MAXW][16];
   __shared__ float red[DG_MAXW][16 * 17];
   M2M_STAMP(2, 0);
-  const int done = a.state->done;   // consumed only before the stores
+  // headless: "live" comes from done and the STABLE copy of t (this kernel advances t itself at its end)
+  const int t_cur = HEADLESS ? a.state->t_copy : 0;
+  const int done = HEADLESS ? (a.state->done | (t_cur >= a.state->max_steps)) : chain_done(a.state);   // consumed only before the stores
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nw = blockDim.x >> 6;
   const int r = lane & 15, g = lane >> 4;
@@ -198,12 +224,37 @@ __global__ __launch_bounds__(64 * DG_MAXW) void dec_gemm_kernel(DecGemmArgs a) {
   for (int i = 0; i < 4; ++i) red[wave][(4 * g + i) * 17 + r] = acc[i];
   M2M_STAMP(2, 1);
   __syncthreads();
-  if (done || tid >= 256 || ob >= a.B || on >= a.N) return;
-  const int idx = orow * 17 + ocol;
-  float v = red[0][idx];
-  for (int w = 1; w < nw; ++w) v += red[w][idx];
-  a.out[(int64_t)ob * a.ldo + on] = v;
-  M2M_STAMP(2, 2);
+  if constexpr (HEADLESS) {
+    if (done || tid >= 256) return;                     // (wave-uniform: waves 0-3 hold the 256 outputs)
+    const int idx = orow * 17 + ocol;
+    float v = red[0][idx];
+    for (int w = 1; w < nw; ++w) v += red[w][idx];
+    const bool ok = ob < a.B && on < a.N;
+    if (ok && !(fabsf(v) <= 3.0e38f)) a.state->overflow = 1;        // non-finite logit: the reference would emit NaN, never a token
+    unsigned long long key = ok ? amax_key(v, on) : 0ull;
+    // max over the tile's 16 columns = the 16 lanes of this row's group (xor 8, 4, 2, 1 stay inside it)
+    auto kmax = [&](unsigned long long o) { key = o > key ? o : key; };
+    unsigned int lo = (unsigned int)key, hi = (unsigned int)(key >> 32);
+#define M2M_KEY_STEP(M)                                                                                     \
+    {                                                                                                       \
+      const unsigned int olo = __builtin_bit_cast(unsigned int, lane_xor<M>(__builtin_bit_cast(float, lo)));  \
+      const unsigned int ohi = __builtin_bit_cast(unsigned int, lane_xor<M>(__builtin_bit_cast(float, hi)));  \
+      kmax(((unsigned long long)ohi << 32) | olo);                                                          \
+      lo = (unsigned int)key; hi = (unsigned int)(key >> 32);                                               \
+    }
+    M2M_KEY_STEP(8) M2M_KEY_STEP(4) M2M_KEY_STEP(2) M2M_KEY_STEP(1)
+#undef M2M_KEY_STEP
+    if (ocol == 0 && ob < a.B) atomicMax(a.keys + ob, key);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) a.state->t = t_cur + 1;    // the step is over: advance the position
+    M2M_STAMP(2, 2);
+  } else {
+    if (done || tid >= 256 || ob >= a.B || on >= a.N) return;
+    const int idx = orow * 17 + ocol;
+    float v = red[0][idx];
+    for (int w = 1; w < nw; ++w) v += red[w][idx];
+    a.out[(int64_t)ob * a.ldo + on] = v;
+    M2M_STAMP(2, 2);
+  }
 }
 
 // waves x steps decomposition of the reduction length: K = 32 * NS * NW
@@ -226,8 +277,13 @@ static int launch_dec_gemm_t(const DecGemmArgs& a, hipStream_t st) {
   }
   dim3 grid((unsigned)ceil_div(a.N, 16), (unsigned)ceil_div(a.B, 16));
   dim3 block((unsigned)(64 * nw));
-  if (ns == 1) hipLaunchKernelGGL((dec_gemm_kernel<T, 1>), grid, block, 0, st, a);
-  else hipLaunchKernelGGL((dec_gemm_kernel<T, 2>), grid, block, 0, st, a);
+  if (a.keys) {
+    if (ns == 1) hipLaunchKernelGGL((dec_gemm_kernel<T, 1, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((dec_gemm_kernel<T, 2, true>), grid, block, 0, st, a);
+  } else {
+    if (ns == 1) hipLaunchKernelGGL((dec_gemm_kernel<T, 1, false>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((dec_gemm_kernel<T, 2, false>), grid, block, 0, st, a);
+  }
   M2M_CHECK_HIP(hipGetLastError());
   return M2M_OK;
 }
@@ -265,6 +321,7 @@ struct DecFfArgs {
   const void* Wo;        // [d, d_ff] T
   int d, d_ff, B;
   DecState* state;
+  int check_done;        // headless greedy loop, layer 0: the carry workgroup of row block 0 turns "no row unfinished" into done
 };
 
 #ifndef M2M_FF_ROWS
@@ -284,7 +341,7 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(1, 2)))
   __shared__ float red[KS][4][16 * 17];
   __shared__ __align__(16) T hs[16 * FF_HP];
   M2M_STAMP(4, 0);
-  const int done = a.state->done;
+  const int done = chain_done(a.state);
   const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   // XCD-aware order (workgroup id % 8 picks the XCD, each has its own L2): the row blocks that share a weight
@@ -303,6 +360,12 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(1, 2)))
 #pragma unroll
     for (int i = 0; i < FF_R; ++i) v[i] = a.x[(int64_t)min(b0 + i, a.B - 1) * K + tid];
     if (done) return;
+    if (a.check_done && b0 == 0 && tid == 0) {
+      // every row's layer-0 cross workgroup has counted itself in (the kernel before this one): none unfinished = the
+      // batch is complete.  The token fed THIS step (position t) was the last one: t + 1 valid columns.
+      if (a.state->n_unfinished == 0) { a.state->done = 1; a.state->out_len = a.state->t + 1; }
+      a.state->n_unfinished = 0;
+    }
 #pragma unroll
     for (int i = 0; i < FF_R; ++i) {
       if (b0 + i < a.B) {
@@ -482,6 +545,13 @@ struct DecAttnArgs {
   const void* Wo;        // [d, inner] T output projection of this sub-layer (this head uses columns [64h, 64h+64))
   int H, inner;
   DecState* state;
+  // headless greedy loop, layer 0 only (null / 0 elsewhere)
+  const float* emb;            // self: [V, d] token embedding — the input row is emb[token decoded from keys[b]]
+  unsigned long long* keys;    // [B] arg-max keys of the previous step (self: read; cross with `book`: read, then cleared)
+  int* finished;               // [B]
+  int64_t* tokens;             // [B, max_len]
+  int max_len, V, pad_id, eos_id;
+  int book;                    // cross: head 0's workgroup of every row does the row's bookkeeping at its end
 };
 
 // K/V rows are read once per step.  When the per-step K/V working set is larger than the 256 MB
@@ -532,8 +602,9 @@ template <typename T> __device__ inline void put_in(float* in_lds, int i, float 
   else in_lds[i] = v;
 }
 
-template <typename T, bool SELF, bool NT>
+template <typename T, bool SELF, bool NT, bool FETCH = false>
 __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
+  static_assert(!FETCH || SELF, "only the layer-0 self-attention fetches its input row from the embedding table");
   constexpr int E = 16 / sizeof(T);      // elements per 16-byte chunk: 8 (bf16) / 4 (fp32)
   constexpr int LPR = DK / E;            // lanes per key row (a "group"): 8 / 16
   constexpr int KPW = 64 / LPR;          // keys per wave-load: 8 / 4
@@ -574,8 +645,8 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
   // loop state: requested now, first consumed AFTER the prologue loads below have been issued, so
   // its round trip overlaps theirs instead of preceding it (every kernel of the step is latency-bound:
   // at B = 1 a step still takes 196 us, i.e. 7.5 us per kernel with nothing to stream)
-  const int st_done = a.state->done;
   const int st_t = a.state->t;
+  const int st_done = a.state->done | (st_t >= a.state->max_steps);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = blockIdx.x, b = blockIdx.y;   // grid (H, B): linear id = 8 b + h as before (a head's clips on one XCD), no division
@@ -590,14 +661,23 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
   //         would queue behind it in the fabric (measured: the norm then completes only after ~9 us).
   //         Only the first PF rounds of the stream follow them here. ----
   const int xc = min(tid * 4, a.d - 4);
+  const int on_ = min(tid >> 1, a.d - 1), opart = tid & 1;
   // RAW fixed-point words: converted only after every request below has been issued (the conversion needs the
   // data, and in program order it would put the wait for x in front of the K/V prefetch)
-  const longlong2 xr0 = *reinterpret_cast<const longlong2*>(a.x + (int64_t)b * a.d + xc);
-  const longlong2 xr1 = *reinterpret_cast<const longlong2*>(a.x + (int64_t)b * a.d + xc + 2);
+  longlong2 xr0 = make_longlong2(0, 0), xr1 = make_longlong2(0, 0);
+  xq_t xres = 0;
+  unsigned long long kraw = 0;
+  int fin0 = 0;
+  if constexpr (FETCH) {          // headless layer 0: the row is an embedding row, chosen by the previous step's arg-max key
+    kraw = a.keys[b];
+    fin0 = a.finished[b];
+  } else {
+    xr0 = *reinterpret_cast<const longlong2*>(a.x + (int64_t)b * a.d + xc);
+    xr1 = *reinterpret_cast<const longlong2*>(a.x + (int64_t)b * a.d + xc + 2);
+    // head 0 also carries the residual row into x_out: its raw fixed-point value, requested now
+    xres = a.x[(int64_t)b * a.d + on_];   // unconditional: a branch would split the block of loads
+  }
   const float4 gv = *reinterpret_cast<const float4*>(a.ln_w + xc);
-  // head 0 also carries the residual row into x_out: its raw fixed-point value, requested now
-  const int on_ = min(tid >> 1, a.d - 1), opart = tid & 1;
-  const xq_t xres = a.x[(int64_t)b * a.d + on_];   // unconditional: a branch would split the block of loads
   __builtin_amdgcn_sched_barrier(0);               // the latency-critical row goes out FIRST (loads retire in order)
   const int po = min(tid / LPO, NOUT - 1), part = tid % LPO;
   const int which = po / DK, dd = po - which * DK;
@@ -641,10 +721,19 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
   // duplicate work (waves are spread round-robin over the 4 SIMDs).
   const bool own_wave = wave * 256 < a.d;           // wave-uniform
   float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+  float eres = 0.f;
+  float4 e4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (FETCH) {          // second (dependent) round trip of the headless prologue: the embedding row
+    const int tok = amax_key_token(kraw, fin0, a.V, a.pad_id);
+    const float* er = a.emb + (int64_t)tok * a.d;
+    e4 = *reinterpret_cast<const float4*>(er + xc);
+    eres = er[on_];
+  }
   {
     const bool own = tid * 4 < a.d;
     if (own_wave) {
-      xv = make_float4(xq_flt(xr0.x), xq_flt(xr0.y), xq_flt(xr1.x), xq_flt(xr1.y));
+      if constexpr (FETCH) xv = e4;
+      else xv = make_float4(xq_flt(xr0.x), xq_flt(xr0.y), xq_flt(xr1.x), xq_flt(xr1.y));
       float ss = own ? (xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w) : 0.f;
       ss = wave_sum(ss);
       if (lane == 0) redw[wave] = ss;
@@ -875,17 +964,35 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
     accp += lane_xor<1>(accp);
     if (opart == 0 && tid < 2 * a.d && !st_done) {
       xq_t add = xq_fix_guarded(accp, a.state);
-      if (hh == 0) add += xres;                               // head 0 also carries the residual itself
+      if (hh == 0) add += FETCH ? xq_fix_guarded(eres, a.state) : xres;   // head 0 also carries the residual itself
       atomicAdd(reinterpret_cast<unsigned long long*>(a.x_out + (int64_t)b * a.d + on_), (unsigned long long)add);
       if (hh == a.H - 1) a.x_zero[(int64_t)b * a.d + on_] = 0;
     }
+  }
+  if (!SELF && a.book && hh == 0 && tid == 0) {
+    // headless bookkeeping of row b, after the layer-0 self-attention kernel (all 8 head workgroups of the row) has consumed
+    // the key: the token fed at this step goes into the token matrix, EOS finishes the row, the key is cleared for this
+    // step's lm_head.  (hf generation/utils.py:2925-2937.)
+    if (!st_done) {
+      const int fin = a.finished[b];
+      const int next = amax_key_token(a.keys[b], fin, a.V, a.pad_id);
+      if (st_t < a.max_len) a.tokens[(int64_t)b * a.max_len + st_t] = next;
+      const int nf = fin | (next == a.eos_id);
+      a.finished[b] = nf;
+      if (!nf) atomicAdd(&a.state->n_unfinished, 1);
+      a.keys[b] = 0ull;
+    }
+    if (b == 0) a.state->t_copy = st_t;      // ALWAYS (also in the no-op steps after the end): the lm_head kernel's "live" test reads it
   }
   M2M_STAMP(6 + (SELF ? 1 : 0), 3);
 }
 
 template <typename T>
 static void launch_dec_attn_t(bool self, bool nt, const DecAttnArgs& a, dim3 grid, size_t smem, hipStream_t st) {
-  if (self) {
+  if (self && a.emb) {
+    if (nt) hipLaunchKernelGGL((dec_attn_kernel<T, true, true, true>), grid, dim3(1024), smem, st, a);
+    else hipLaunchKernelGGL((dec_attn_kernel<T, true, false, true>), grid, dim3(1024), smem, st, a);
+  } else if (self) {
     if (nt) hipLaunchKernelGGL((dec_attn_kernel<T, true, true>), grid, dim3(1024), smem, st, a);
     else hipLaunchKernelGGL((dec_attn_kernel<T, true, false>), grid, dim3(1024), smem, st, a);
   } else {
@@ -916,6 +1023,7 @@ struct DecHeadArgs {
   int64_t* tokens;         // [B, max_len] generated ids (col 0 = start)
   int max_len;
   int* finished;           // [B]
+  unsigned long long* keys;// [B] (headless greedy loop; null otherwise)
   DecState* state;
   int pad_id, eos_id;
   // teacher forcing (nullptr for greedy)
@@ -931,8 +1039,8 @@ __global__ __launch_bounds__(1024) void dec_head_kernel(DecHeadArgs a) {
   DecState* stp = a.state;
   M2M_STAMP_DECL
   M2M_STAMP(8, 0);
-  const int st_done = stp->done;
   const int t = stp->t;
+  const int st_done = stp->done | (t >= stp->max_steps);
   const int tid = threadIdx.x, l32 = tid & 31, grp = tid >> 5;
   // first batch of logits of this lane group's first row: requested before the loop state is consumed
   constexpr int HK = 16;   // V <= 32 * HK columns are covered by the register batch (vocab 400 -> 13 used)
@@ -1024,9 +1132,12 @@ __global__ void dec_init_kernel(DecHeadArgs a, int start_id, int max_steps) {
   const int nthreads = gridDim.x * blockDim.x;
   if (tid == 0) {
     a.state->t = 0; a.state->done = (max_steps <= 0) ? 1 : 0; a.state->out_len = 1;
-    a.state->n_unfinished = a.B; a.state->max_steps = max_steps;
+    a.state->n_unfinished = a.keys ? 0 : a.B; a.state->max_steps = max_steps; a.state->t_copy = 0;
   }
-  for (int b = tid; b < a.B; b += nthreads) a.finished[b] = 0;
+  for (int b = tid; b < a.B; b += nthreads) {
+    a.finished[b] = 0;
+    if (a.keys) a.keys[b] = amax_key(0.f, start_id);         // headless: step 0 "decodes" the start token
+  }
   if (!a.forced)
     for (int i = tid; i < a.B * a.max_len; i += nthreads) a.tokens[i] = (i % a.max_len == 0) ? start_id : a.pad_id;
   for (int i = tid; i < a.B * a.d; i += nthreads) {
@@ -1036,6 +1147,27 @@ __global__ void dec_init_kernel(DecHeadArgs a, int start_id, int max_steps) {
     a.x[i] = xq_fix_guarded(a.shared[(int64_t)tok * a.d + c], a.state);
     a.x_zero[i] = 0;
   }
+}
+
+// after the loop: the last lm_head's keys are still pending (no later step consumed them) unless the chain ended on EOS
+__global__ void dec_final_kernel(DecHeadArgs a) {
+  DecState* st = a.state;
+  const int t = st->t;
+  if (st->done || !a.keys) return;
+  for (int b = threadIdx.x; b < a.B; b += blockDim.x) {
+    const int fin = a.finished[b];
+    const int next = amax_key_token(a.keys[b], fin, a.V, a.pad_id);
+    if (t < a.max_len) a.tokens[(int64_t)b * a.max_len + t] = next;
+    a.finished[b] = fin | (next == a.eos_id);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) { st->done = 1; st->out_len = t + 1; }
+}
+
+// M2M_HEADLESS=0 keeps dec_head_kernel in the greedy loop (the round-1 step: 20 kernels); default: folded away (19 kernels)
+bool decode_headless() {
+  static const bool on = [] { const char* v = getenv("M2M_HEADLESS"); return !(v && v[0] == '0'); }();
+  return on;
 }
 
 // ============================================================ step driver ====
@@ -1048,9 +1180,18 @@ static DecHeadArgs head_args(m2m_session* s, const DecView& v, bool forced, floa
   h.d = m->g.d_model; h.shared = m->shared; h.x = xbuf(s, v, 0); h.x_zero = xbuf(s, v, 1);
   h.tokens = s->tokens + (int64_t)v.b0 * s->max_dec; h.max_len = s->max_dec;
   h.finished = s->finished + v.b0; h.state = v.state; h.pad_id = m->g.pad_token_id; h.eos_id = m->g.eos_token_id;
+  h.keys = (!forced && decode_headless()) ? s->keys + v.b0 : nullptr;
   h.forced = forced ? s->forced_ids + (int64_t)v.b0 * Ld : nullptr; h.Ld = Ld;
   h.logits_out = logits_out ? logits_out + (int64_t)v.b0 * Ld * m->g.vocab_size : nullptr;
   return h;
+}
+
+int decode_finalize(m2m_session* s, const DecView& v, hipStream_t st) {
+  if (!decode_headless()) return M2M_OK;
+  DecHeadArgs h = head_args(s, v, false, nullptr, 0);
+  hipLaunchKernelGGL(dec_final_kernel, dim3(1), dim3(256), 0, st, h);
+  M2M_CHECK_HIP(hipGetLastError());
+  return M2M_OK;
 }
 
 int decode_init(m2m_session* s, const DecView& v, int max_steps, bool forced, hipStream_t st) {
@@ -1072,7 +1213,7 @@ static xq_t* xbuf(m2m_session* s, const DecView& v, int which) {
   return reinterpret_cast<xq_t*>(s->x_dec) + (size_t)which * stride + (size_t)v.b0 * s->m->g.d_model;
 }
 
-int decode_launch_attn(m2m_session* s, const DecView& v, bool self, int layer, int self_len, hipStream_t st) {
+int decode_launch_attn(m2m_session* s, const DecView& v, bool self, int layer, int self_len, hipStream_t st, bool headless) {
   const m2m_model* m = s->m;
   const m2m_t5_geometry& g = m->g;
   const size_t es = m->esize;
@@ -1095,6 +1236,11 @@ int decode_launch_attn(m2m_session* s, const DecView& v, bool self, int layer, i
   a.x = xbuf(s, v, self ? 0 : 1); a.x_out = xbuf(s, v, self ? 1 : 2); a.x_zero = xbuf(s, v, self ? 2 : 0);
   a.eps = g.layer_norm_eps; a.d = g.d_model;
   a.H = H; a.inner = m->inner; a.state = v.state;
+  if (headless && layer == 0) {            // the greedy loop without the head kernel: layer 0 takes over its work
+    a.keys = s->keys + v.b0; a.finished = s->finished + v.b0; a.tokens = s->tokens + (int64_t)v.b0 * s->max_dec;
+    a.max_len = s->max_dec; a.V = g.vocab_size; a.pad_id = g.pad_token_id; a.eos_id = g.eos_token_id;
+    if (self) a.emb = m->shared; else a.book = 1;
+  }
   if (self) {
     const size_t off = ((size_t)layer * kv_layer_elems(s, s->max_dec) + (size_t)v.b0 * H * s->max_dec * DK) * es;
     a.ln_w = L.ln0; a.Wp = L.wqkv; a.Wo = L.wo;
@@ -1122,19 +1268,21 @@ int decode_launch_step(m2m_session* s, const DecView& v, bool forced, float* log
   xq_t* xB = xbuf(s, v, 1);
   xq_t* xC = xbuf(s, v, 2);
   int rc;
+  const bool headless = !forced && decode_headless();
   for (int l = 0; l < g.num_decoder_layers; ++l) {
     const DecLayerPacked& L = m->dec[l];
     // 1. RMSNorm + per-head QKV projection + KV-cache append + causal self-attention + per-head
     //    output projection accumulated into the residual stream (one kernel)
-    if ((rc = decode_launch_attn(s, v, true, l, 0, st))) return rc;
+    if ((rc = decode_launch_attn(s, v, true, l, 0, st, headless))) return rc;
     // 2. the same for cross-attention over the S encoder positions (query projection only)
-    if ((rc = decode_launch_attn(s, v, false, l, 0, st))) return rc;
+    if ((rc = decode_launch_attn(s, v, false, l, 0, st, headless))) return rc;
     // 3. feed-forward sub-layer, one kernel: reads C (the stream after both attention sub-layers),
     //    accumulates C + FF(C) into A (zeroed by the cross-attention kernel) and leaves B zeroed for
     //    the next layer's self-attention
     DecFfArgs f{};
     f.x = xC; f.x_out = xA; f.x_zero = xB; f.ln_w = L.ln2; f.eps = g.layer_norm_eps;
     f.Wi = L.wi; f.Wo = L.wo_ff; f.d = g.d_model; f.d_ff = g.d_ff; f.B = v.nb; f.state = v.state;
+    f.check_done = (headless && l == 0) ? 1 : 0;
     if ((rc = launch_dec_ff(P, f, st))) return rc;
   }
   // final RMSNorm + lm_head (untied, no d_model**-0.5 scaling: transformers 4.34 semantics)
@@ -1142,7 +1290,9 @@ int decode_launch_step(m2m_session* s, const DecView& v, bool forced, float* log
   a.eps = g.layer_norm_eps; a.B = v.nb; a.state = v.state;
   a.x = xA; a.ldx = g.d_model; a.ln_w = m->dec_final_ln; a.W = m->lm_head; a.K = g.d_model; a.N = g.vocab_size;
   a.out = s->logits + (int64_t)v.b0 * m->vocab_pad; a.ldo = m->vocab_pad;
+  a.keys = headless ? s->keys + v.b0 : nullptr;
   if ((rc = launch_dec_gemm(P, a, st))) return rc;
+  if (headless) return M2M_OK;             // the arg-max key is consumed by the next step's layer 0 (or by decode_finalize)
   DecHeadArgs h = head_args(s, v, forced, logits_out, Ld);
   hipLaunchKernelGGL(dec_head_kernel, dim3(1), dim3(1024), 0, st, h);
   M2M_CHECK_HIP(hipGetLastError());

@@ -62,7 +62,9 @@ struct DecState {
   int n_unfinished;
   int max_steps;     // steps after which the loop must stop (max_length - 1)
   int overflow;      // sticky: a value outside the fixed-point residual range (|v| >= 2^21, Inf, NaN) was produced
-  int pad[2];
+  int t_copy;        // headless greedy loop: t of the current step, rewritten every step by the layer-0 cross kernel (the lm_head
+                     // kernel, which ADVANCES t at its end, reads this stable copy instead of t itself)
+  int pad[1];
 };
 
 }  // namespace m2m
@@ -110,6 +112,7 @@ struct m2m_session {
   float* logits;           // [B, vocab_pad]
   int64_t* tokens;         // [B, max_dec]
   int* finished;           // [B]
+  unsigned long long* keys;// [B] headless greedy loop: packed (logit, vocabulary index) arg-max keys of the previous step
   m2m::DecState* states;   // device [MAX_GROUPS]
   int64_t* forced_ids;     // [B, max_dec]
   // current problem
@@ -176,6 +179,8 @@ int launch_fill_zero(void* dst, int64_t bytes, hipStream_t st);
 // decoder-side (decode.hip)
 int decode_init(m2m_session* s, const DecView& v, int max_steps, bool forced, hipStream_t st);
 int decode_launch_step(m2m_session* s, const DecView& v, bool forced, float* logits_out, int Ld, hipStream_t st);
-int decode_launch_attn(m2m_session* s, const DecView& v, bool self, int layer, int self_len, hipStream_t st);
+int decode_launch_attn(m2m_session* s, const DecView& v, bool self, int layer, int self_len, hipStream_t st, bool headless = false);
+int decode_finalize(m2m_session* s, const DecView& v, hipStream_t st);   // headless greedy loop: write the last token, close the chain
+bool decode_headless();
 
 }  // namespace m2m

@@ -162,7 +162,7 @@ extern "C" int64_t m2m_model_param_bytes(const m2m_model* m) { return m ? m->blo
 namespace {
 struct WsLayout {
   int64_t x_enc, h_enc, qkv_enc, vt_enc, attn_enc, mid_enc, enc_bias, dec_bias, dec_bias_full, cross_vt, cross_kv, self_k, self_v;
-  int64_t x_dec, logits, tokens, finished, state, forced, total;
+  int64_t x_dec, logits, tokens, finished, keys, state, forced, total;
 };
 
 WsLayout ws_layout(const m2m_model* m, int B, int S, int L) {
@@ -190,6 +190,7 @@ WsLayout ws_layout(const m2m_model* m, int B, int S, int L) {
   w.logits = take(Bp * m->vocab_pad * 4);
   w.tokens = take((int64_t)B * L * 8);
   w.finished = take((int64_t)B * 4);
+  w.keys = take((int64_t)B * 8);
   w.state = take(sizeof(DecState) * MAX_GROUPS);
   w.forced = take((int64_t)B * L * 8);
   w.total = off;
@@ -229,7 +230,7 @@ extern "C" int m2m_session_create(const m2m_model* m, int max_batch, int max_enc
   s->dec_bias_full_tab = (float*)(b + w.dec_bias_full); s->cross_vt = b + w.cross_vt;
   s->x_dec = (b + w.x_dec);
   s->logits = (float*)(b + w.logits); s->tokens = (int64_t*)(b + w.tokens);
-  s->finished = (int*)(b + w.finished); s->states = (DecState*)(b + w.state); s->forced_ids = (int64_t*)(b + w.forced);
+  s->finished = (int*)(b + w.finished); s->keys = (unsigned long long*)(b + w.keys); s->states = (DecState*)(b + w.state); s->forced_ids = (int64_t*)(b + w.forced);
 
   // relative-position bias tables (fp32), built on the host from the bucket function
   const m2m_t5_geometry& g = m->g;
@@ -447,6 +448,10 @@ static int generate_greedy_impl(m2m_session* s, int max_length, int64_t* tokens_
       if (!gr.state_host->done) all_done = false;
     }
   }
+  // headless loop: the last step's arg-max is still a pending key (no later step consumed it)
+  if (steps > 0)
+    for (int i = 0; i < G; ++i)
+      if ((rc = decode_finalize(s, s->groups[i].view, s->groups[i].stream))) return rc;
   // valid length = the longest chain (one process decoding the whole batch stops when EVERY row has finished)
   int out_len = 1;
   bool range_error = false;
@@ -573,7 +578,7 @@ extern "C" int m2m_bench_kernel(m2m_session* s, int which, int self_len, int ite
   for (int i = 0; i < G; ++i) M2M_CHECK_HIP(hipStreamWaitEvent(s->groups[i].stream, s->ev_in, 0));
   int rc;
   // every chain sees a live loop in its (self_len)-th step
-  DecState hs{}; hs.t = self_len - 1; hs.done = 0; hs.out_len = 1; hs.n_unfinished = s->B; hs.max_steps = s->max_dec;
+  DecState hs{}; hs.t = self_len - 1; hs.t_copy = self_len - 1; hs.done = 0; hs.out_len = 1; hs.n_unfinished = 0; hs.max_steps = s->max_dec;
   for (int i = 0; i < G; ++i)
     M2M_CHECK_HIP(hipMemcpyAsync(s->groups[i].view.state, &hs, sizeof(hs), hipMemcpyHostToDevice, s->groups[i].stream));
   for (int i = 0; i < G; ++i) M2M_CHECK_HIP(hipStreamSynchronize(s->groups[i].stream));
@@ -589,8 +594,8 @@ extern "C" int m2m_bench_kernel(m2m_session* s, int which, int self_len, int ite
       const int layer = same_layer ? 0 : i % Ld;
       for (int c = 0; c < G; ++c) {
         const DecGroup& gr = s->groups[c];
-        if (which == M2M_KERNEL_DEC_CROSS_ATTN) { if ((rc = decode_launch_attn(s, gr.view, false, layer, 0, gr.stream))) return rc; }
-        else if (which == M2M_KERNEL_DEC_SELF_ATTN) { if ((rc = decode_launch_attn(s, gr.view, true, layer, self_len, gr.stream))) return rc; }
+        if (which == M2M_KERNEL_DEC_CROSS_ATTN) { if ((rc = decode_launch_attn(s, gr.view, false, layer, 0, gr.stream, decode_headless()))) return rc; }
+        else if (which == M2M_KERNEL_DEC_SELF_ATTN) { if ((rc = decode_launch_attn(s, gr.view, true, layer, self_len, gr.stream, decode_headless()))) return rc; }
       }
     }
     return M2M_OK;
