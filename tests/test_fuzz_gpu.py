@@ -1,0 +1,20 @@
+"""Differential fuzz of the greedy decode loop (tools/fuzz_decode.py): random batch / encoder length / max_length / EOS
+behaviour / chain split / graph length against the CPU oracle in fp32 — ids identical, near-ties excused only by the
+oracle's own top-2 margin."""
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+
+
+@pytest.mark.parametrize("seed", [3, 19])
+def test_decode_fuzz_against_oracle(seed):
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "fuzz_decode.py"), "100", str(seed)], capture_output=True, text=True, timeout=1500)
+    tail = "\n".join(r.stdout.splitlines()[-6:])
+    print(tail)
+    assert r.returncode == 0, tail + r.stderr[-2000:]
+    assert "FUZZ OK" in r.stdout
