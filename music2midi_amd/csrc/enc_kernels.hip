@@ -66,7 +66,10 @@ int launch_final_norm_f32(const float* x, const float* w, float* out_f32, void* 
 // ================================================================= GEMM ====
 // C[M,N] = A[M,K] * W[N,K]^T.  128x128 output tile per 256-thread workgroup, BK = 64 (bf16) / 32 (fp32),
 // 2x2 waves each owning 64x64 (2x2 MFMA 32x32 tiles), register-prefetched LDS staging.
-constexpr int BM = 128, BN = 128;
+// TF = 1 is the small-problem variant: 64x64 tiles (one 32x32 MFMA tile per wave, 18 KB of LDS, ~8 workgroups per CU).
+// A product whose 128x128 tiling gives fewer workgroups than two rounds of the 256 CUs (the N = 384 residual / dX
+// products of a 16-clip training step: 33 x 3 = 99 tiles) is bound by ONE workgroup's load -> LDS -> MFMA latency
+// chain per CU; four times the tiles at eight per CU hide it.  Same k order per output element: bit-identical results.
 
 template <typename T> struct TileCfg;
 template <> struct TileCfg<bf16_t> {
@@ -80,9 +83,11 @@ template <> struct TileCfg<float> {
   static constexpr int CPR = BK * 4 / 16;                    // 8
 };
 
-template <typename T, int EPI>
+template <typename T, int EPI, int TF = 2>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   using Cfg = TileCfg<T>;
+  constexpr int BM = 64 * TF, BN = 64 * TF, WT = 32 * TF;      // tile, and the square each of the 2x2 waves owns
+  static_assert(TF == 2 || EPI == EPI_STORE || EPI == EPI_STORE_F32 || EPI == EPI_RESID, "LDS-staged epilogues are written for 128x128 tiles");
   constexpr int BK = Cfg::BK;
   constexpr int EPC = 16 / sizeof(T);                          // elements per 16-byte chunk
   constexpr int CHUNKS = BM * Cfg::CPR;                        // per operand tile
@@ -114,6 +119,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   // register staging in NAMED scalars: arrays here (uint4 ra[PER_THREAD]) are demoted to scratch by
   // hipcc 7.2 across the k-loop even when every index is a compile-time constant
   static_assert(PER_THREAD == 2 || PER_THREAD == 4, "staging below is written for 2 or 4 chunks per thread");
+  static_assert(BM == BN, "one chunk table serves both operand tiles");
 #define M2M_CHUNK(i)                                                                         \
   const int c##i = tid + (i) * 256;                                                          \
   const T* ap##i = A + (int64_t)min(m0 + c##i / Cfg::CPR, g.M - 1) * K + (c##i % Cfg::CPR) * EPC; \
@@ -128,11 +134,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #define M2M_SSTORE() { M2M_ST(0) M2M_ST(1) if constexpr (PER_THREAD == 4) { M2M_ST(2) M2M_ST(3) } }
   ra2 = rb2 = ra3 = rb3 = make_uint4(0, 0, 0, 0);
 
-  f32x16 acc[2][2];
+  f32x16 acc[TF][TF];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TF; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = zero_acc();
+    for (int j = 0; j < TF; ++j) acc[i][j] = zero_acc();
 
   const int r = lane & 31, h = lane >> 5;
   const int nk = K / BK;
@@ -144,16 +150,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     if (kt + 1 < nk) { M2M_GLOAD((kt + 1) * BK) }
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
-      Frag<T> fa[2], fb[2];
+      Frag<T> fa[TF], fb[TF];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        fa[i] = load_frag(As + (wm * 64 + i * 32 + r) * Cfg::PITCH + s * 16 + 8 * h);
-        fb[i] = load_frag(Bs + (wn * 64 + i * 32 + r) * Cfg::PITCH + s * 16 + 8 * h);
+      for (int i = 0; i < TF; ++i) {
+        fa[i] = load_frag(As + (wm * WT + i * 32 + r) * Cfg::PITCH + s * 16 + 8 * h);
+        fb[i] = load_frag(Bs + (wn * WT + i * 32 + r) * Cfg::PITCH + s * 16 + 8 * h);
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TF; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) mma16(acc[i][j], fa[i], fb[j]);
+        for (int j = 0; j < TF; ++j) mma16(acc[i][j], fa[i], fb[j]);
     }
   }
 
@@ -255,22 +261,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     return;
   }
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
+  for (int mi = 0; mi < TF; ++mi) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int row = m0 + wm * 64 + mi * 32 + acc_row(e, lane);
+      const int row = m0 + wm * WT + mi * 32 + acc_row(e, lane);
       if (row >= g.M) continue;
       if constexpr (EPI == EPI_GATED) {
         // the wave's 64 columns are [32 of wi_0 | the matching 32 of wi_1]
         const int col = (n0 + wn * 64) / 2 + r;
         if (n0 + wn * 64 < g.N) {
-          const float v = gelu_new_t<T>(acc[mi][0][e]) * acc[mi][1][e];
+          const float v = gelu_new_t<T>(acc[mi][0][e]) * acc[mi][TF - 1][e];
           reinterpret_cast<T*>(g.out)[(int64_t)row * g.ldo + col] = from_f32<T>(v);
         }
       } else {
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          const int col = n0 + wn * 64 + ni * 32 + r;
+        for (int ni = 0; ni < TF; ++ni) {
+          const int col = n0 + wn * WT + ni * 32 + r;
           if constexpr (EPI != EPI_GATED16) {
             if (col >= g.N) continue;       // (GATED16: N is a multiple of 16 and every lane takes part in the exchange)
           }
@@ -308,8 +314,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   }
 }
 
-template <typename T>
-static int launch_gemm_t(int epi, const GemmArgs& a_in, hipStream_t st) {
+// Tile choice: the 128x128 kernel unless its grid is smaller than `M2M_GEMM_SMALL_BELOW` tiles (default 512 = two rounds
+// of the chip) and the epilogue is one of the plain ones; then 64x64 tiles (see the note above gemm_kernel).
+static int gemm_small_below() {
+  static const int v = [] { const char* e = getenv("M2M_GEMM_SMALL_BELOW"); return e ? atoi(e) : 512; }();
+  return v;
+}
+
+template <typename T, int TF>
+static int launch_gemm_tt(int epi, const GemmArgs& a_in, hipStream_t st) {
+  constexpr int BM = 64 * TF, BN = 64 * TF;
   GemmArgs a = a_in;
   const int ntn = ceil_div(a.N, BN);
   const int ng_max = (int)((2 << 20) / ((size_t)BN * a.K * sizeof(T)));          // column tiles whose weight rows fit 2 MB
@@ -317,16 +331,31 @@ static int launch_gemm_t(int epi, const GemmArgs& a_in, hipStream_t st) {
   a.ng = ceil_div(ntn, ngroups);
   dim3 grid((unsigned)(8 * ngroups * ceil_div(ceil_div(a.M, BM), 8) * a.ng));
   switch (epi) {
-    case EPI_STORE: hipLaunchKernelGGL((gemm_kernel<T, EPI_STORE>), grid, dim3(256), 0, st, a); break;
-    case EPI_RESID: hipLaunchKernelGGL((gemm_kernel<T, EPI_RESID>), grid, dim3(256), 0, st, a); break;
-    case EPI_GATED: hipLaunchKernelGGL((gemm_kernel<T, EPI_GATED>), grid, dim3(256), 0, st, a); break;
-    case EPI_HEADS: hipLaunchKernelGGL((gemm_kernel<T, EPI_HEADS>), grid, dim3(256), 0, st, a); break;
-    case EPI_STORE_F32: hipLaunchKernelGGL((gemm_kernel<T, EPI_STORE_F32>), grid, dim3(256), 0, st, a); break;
-    case EPI_GATED16: hipLaunchKernelGGL((gemm_kernel<T, EPI_GATED16>), grid, dim3(256), 0, st, a); break;
-    default: set_error("launch_gemm: bad epilogue %d", epi); return M2M_ERR_INVALID;
+    case EPI_STORE: hipLaunchKernelGGL((gemm_kernel<T, EPI_STORE, TF>), grid, dim3(256), 0, st, a); break;
+    case EPI_RESID: hipLaunchKernelGGL((gemm_kernel<T, EPI_RESID, TF>), grid, dim3(256), 0, st, a); break;
+    case EPI_STORE_F32: hipLaunchKernelGGL((gemm_kernel<T, EPI_STORE_F32, TF>), grid, dim3(256), 0, st, a); break;
+    default:
+      if constexpr (TF == 2) {
+        switch (epi) {
+          case EPI_GATED: hipLaunchKernelGGL((gemm_kernel<T, EPI_GATED, 2>), grid, dim3(256), 0, st, a); break;
+          case EPI_HEADS: hipLaunchKernelGGL((gemm_kernel<T, EPI_HEADS, 2>), grid, dim3(256), 0, st, a); break;
+          case EPI_GATED16: hipLaunchKernelGGL((gemm_kernel<T, EPI_GATED16, 2>), grid, dim3(256), 0, st, a); break;
+          default: set_error("launch_gemm: bad epilogue %d", epi); return M2M_ERR_INVALID;
+        }
+      } else {
+        set_error("launch_gemm: epilogue %d has no small-tile variant", epi); return M2M_ERR_INVALID;
+      }
   }
   M2M_CHECK_HIP(hipGetLastError());
   return M2M_OK;
+}
+
+template <typename T>
+static int launch_gemm_t(int epi, const GemmArgs& a, hipStream_t st) {
+  const bool plain = epi == EPI_STORE || epi == EPI_STORE_F32 || epi == EPI_RESID;
+  const int tiles128 = ceil_div(a.M, 128) * ceil_div(a.N, 128);
+  if (plain && tiles128 < gemm_small_below()) return launch_gemm_tt<T, 1>(epi, a, st);
+  return launch_gemm_tt<T, 2>(epi, a, st);
 }
 
 int launch_gemm(int precision, int epi, const GemmArgs& a, hipStream_t st) {

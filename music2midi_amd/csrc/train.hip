@@ -154,6 +154,177 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __re
   }
 }
 
+// ============================================================ weight-gradient GEMM ====
+// C[N1, N2] (fp32) = A[K, N1]^T . B[K, N2]: both operands row-major with the REDUCTION index as the row (a weight
+// gradient dW = dY^T . X reads dY [rows, N1] and X [rows, N2] exactly as the forward / backward passes left them).
+// The MFMA wants 8 consecutive k per lane, memory has 8 consecutive n: every thread loads an E x E block (E rows of k,
+// 16 bytes = E elements of n each; a wave's request is eight full 128-byte lines), transposes it IN REGISTERS (bf16:
+// 32 v_perm_b32 per 8x8 block; fp32: pure renaming) and writes E 16-byte rows of the usual [n][k] LDS tile — the same
+// number of LDS writes as a k-contiguous operand, where the generic kernel above scatters 2-byte elements.
+// Tiles 128x128 (TF = 2) or 64x64 (TF = 1), BK = 64 / 32, next k-step prefetched into registers, split over k on
+// blockIdx.z with fp32 partial tiles summed in z order by splitk_reduce_kernel (deterministic).
+struct DwGemmArgs {
+  const void *A, *B;
+  float* C;
+  float* Cpart;
+  int N1, N2, K;
+  int64_t lda, ldb, ldc;
+  int ksplit, kchunk;
+};
+
+template <typename T> struct DwCfg;
+template <> struct DwCfg<bf16_t> { static constexpr int BK = 64, E = 8; };
+template <> struct DwCfg<float> { static constexpr int BK = 32, E = 4; };
+
+__device__ inline uint32_t u4_get(const uint4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+
+template <typename T, int TF>
+__global__ __launch_bounds__(256) void dw_gemm_kernel(DwGemmArgs g) {
+  using Cfg = DwCfg<T>;
+  constexpr int BK = Cfg::BK, E = Cfg::E, PITCH = BK + E;
+  constexpr int BT = 64 * TF, WT = 32 * TF;
+  constexpr int KB = BK / E, NB = BT / E, BPO = KB * NB, TB = 2 * BPO, NBT = (TB + 255) / 256;
+  __shared__ __align__(16) T AB[2 * BT * PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int n1_0 = blockIdx.y * BT, n2_0 = blockIdx.x * BT;
+  const bool split = g.ksplit > 1;
+  const int kbeg = split ? blockIdx.z * g.kchunk : 0, kend = split ? min(g.K, kbeg + g.kchunk) : g.K;
+
+  // this thread's blocks: (operand, n block, k block); kb runs fastest over the lanes, so one store instruction of a wave
+  // covers whole 128-byte LDS rows and one load instruction whole 128-byte lines of 8 k-rows
+  const T* src[NBT];
+  int64_t ld[NBT];
+  int kofs[NBT], lds_off[NBT];
+  bool ok[NBT];
+#pragma unroll
+  for (int u = 0; u < NBT; ++u) {
+    const int bi = tid + 256 * u;
+    const int op = bi / BPO, id = bi - op * BPO;
+    const int kb = id % KB, nb = id / KB;
+    const int n0 = op ? n2_0 : n1_0, nlim = op ? g.N2 : g.N1;
+    ok[u] = bi < TB && n0 + nb * E + E <= nlim;
+    src[u] = reinterpret_cast<const T*>(op ? g.B : g.A) + (ok[u] ? n0 + nb * E : 0);
+    ld[u] = op ? g.ldb : g.lda;
+    kofs[u] = kb * E;
+    lds_off[u] = (min(op, 1) * BT + nb * E) * PITCH + kb * E;
+  }
+  uint4 rg[NBT][E];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < NBT; ++u)
+#pragma unroll
+      for (int kk = 0; kk < E; ++kk) {
+        const int k = k0 + kofs[u] + kk;
+        const uint4 v = *reinterpret_cast<const uint4*>(src[u] + (int64_t)min(k, kend - 1) * ld[u]);   // clamped, never predicated
+        rg[u][kk] = (ok[u] && k < kend) ? v : make_uint4(0, 0, 0, 0);
+      }
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int u = 0; u < NBT; ++u) {
+      if (TB < 256 && tid >= TB) continue;
+#pragma unroll
+      for (int j = 0; j < E; ++j) {
+        uint4 o;
+        if constexpr (sizeof(T) == 2) {          // o = column j of the 8x8 block: halves (2d, 2d+1) of dword j/2
+          const uint32_t sel = (j & 1) ? 0x07060302u : 0x05040100u;
+          o.x = __builtin_amdgcn_perm(u4_get(rg[u][1], j >> 1), u4_get(rg[u][0], j >> 1), sel);
+          o.y = __builtin_amdgcn_perm(u4_get(rg[u][3], j >> 1), u4_get(rg[u][2], j >> 1), sel);
+          o.z = __builtin_amdgcn_perm(u4_get(rg[u][5], j >> 1), u4_get(rg[u][4], j >> 1), sel);
+          o.w = __builtin_amdgcn_perm(u4_get(rg[u][7], j >> 1), u4_get(rg[u][6], j >> 1), sel);
+        } else {
+          o = make_uint4(u4_get(rg[u][0], j), u4_get(rg[u][1], j), u4_get(rg[u][2], j), u4_get(rg[u][3], j));
+        }
+        *reinterpret_cast<uint4*>(AB + lds_off[u] + j * PITCH) = o;
+      }
+    }
+  };
+
+  f32x16 acc[TF][TF];
+#pragma unroll
+  for (int i = 0; i < TF; ++i)
+#pragma unroll
+    for (int j = 0; j < TF; ++j) acc[i][j] = zero_acc();
+  const T* As = AB;
+  const T* Bs = AB + BT * PITCH;
+  gload(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    __syncthreads();
+    sstore();
+    __syncthreads();
+    if (k0 + BK < kend) gload(k0 + BK);
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      Frag<T> fa[TF], fb[TF];
+#pragma unroll
+      for (int i = 0; i < TF; ++i) {
+        fa[i] = load_frag(As + (wm * WT + i * 32 + r) * PITCH + s * 16 + 8 * h);
+        fb[i] = load_frag(Bs + (wn * WT + i * 32 + r) * PITCH + s * 16 + 8 * h);
+      }
+#pragma unroll
+      for (int i = 0; i < TF; ++i)
+#pragma unroll
+        for (int j = 0; j < TF; ++j) mma16(acc[i][j], fa[i], fb[j]);
+    }
+  }
+  float* out = split ? g.Cpart + (int64_t)blockIdx.z * g.N1 * g.N2 : g.C;
+  const int64_t ldo = split ? g.N2 : g.ldc;
+#pragma unroll
+  for (int mi = 0; mi < TF; ++mi)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = n1_0 + wm * WT + mi * 32 + acc_row(e, lane);
+      if (row >= g.N1) continue;
+#pragma unroll
+      for (int ni = 0; ni < TF; ++ni) {
+        const int col = n2_0 + wn * WT + ni * 32 + r;
+        if (col < g.N2) out[(int64_t)row * ldo + col] = acc[mi][ni][e];
+      }
+    }
+}
+
+// C = A^T . B with the split chosen here: enough workgroups to fill the chip, as few k-slices as that allows (every slice
+// writes and re-reads an fp32 image of C).
+int launch_dw_gemm(int precision, const void* A, int64_t lda, int N1, const void* B, int64_t ldb, int N2, int K, float* C, int64_t ldc,
+                   float* kpart, int64_t kpart_floats, hipStream_t st) {
+  const int E = precision == M2M_PREC_BF16 ? 8 : 4, BK = precision == M2M_PREC_BF16 ? 64 : 32;
+  M2M_REQUIRE(N1 % E == 0 && N2 % E == 0 && lda % E == 0 && ldb % E == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
+                  (reinterpret_cast<uintptr_t>(B) & 15) == 0,
+              "dw_gemm: operands must be 16-byte aligned with row lengths that are multiples of %d", E);
+  static const int force_tf = [] { const char* v = getenv("M2M_DW_TILE"); return v ? atoi(v) : 0; }();      // 64 / 128: diagnostic
+  static const int target = [] { const char* v = getenv("M2M_DW_WGS"); return v ? atoi(v) : 512; }();
+  const int t128 = ceil_div(N1, 128) * ceil_div(N2, 128);
+  const int tf = force_tf == 64 ? 1 : 2;   // 128x128 measured faster for every weight shape of the model (16 clips: 8.80 vs 9.90 ms per step)
+  (void)t128;
+  const int bt = 64 * tf;
+  const int tiles = ceil_div(N1, bt) * ceil_div(N2, bt);
+  int ks = ceil_div(target, tiles);
+  if (ks > 32) ks = 32;
+  while (ks > 1 && ((int64_t)ks * N1 * N2 > kpart_floats || K / ks < 2 * BK)) --ks;
+  DwGemmArgs g{};
+  g.A = A; g.B = B; g.C = C; g.Cpart = kpart; g.N1 = N1; g.N2 = N2; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.ksplit = 1; g.kchunk = K;
+  if (ks > 1) { g.kchunk = (int)align_up(ceil_div(K, ks), BK); g.ksplit = ceil_div(K, g.kchunk); }
+  dim3 grid((unsigned)ceil_div(N2, bt), (unsigned)ceil_div(N1, bt), (unsigned)g.ksplit);
+  if (precision == M2M_PREC_BF16) {
+    if (tf == 2) hipLaunchKernelGGL((dw_gemm_kernel<bf16_t, 2>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((dw_gemm_kernel<bf16_t, 1>), grid, dim3(256), 0, st, g);
+  } else {
+    if (tf == 2) hipLaunchKernelGGL((dw_gemm_kernel<float, 2>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((dw_gemm_kernel<float, 1>), grid, dim3(256), 0, st, g);
+  }
+  M2M_CHECK_HIP(hipGetLastError());
+  if (g.ksplit > 1) {
+    const int64_t n = (int64_t)N1 * N2;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, st, kpart, C, N1, N2,
+                       ldc, g.ksplit, 1.0f);
+    M2M_CHECK_HIP(hipGetLastError());
+  }
+  return M2M_OK;
+}
+
 // dst[c][r] = src[r][c]: src [R][C] (row stride ld_s) -> dst [C][ld_d]; the columns [R, Rpad) of dst are zeroed
 template <typename TS, typename TD>
 __global__ __launch_bounds__(256) void transpose_kernel(const TS* __restrict__ src, int64_t ld_s, TD* __restrict__ dst, int64_t ld_d, int R, int C,
@@ -1200,12 +1371,15 @@ struct Ops {
       if (ks > 1) { m.kchunk = (int)align_up(ceil_div(Mp8, ks), 128); m.ksplit = ceil_div(Mp8, m.kchunk); m.Cpart = t->kpart; }
       return launch_mxgemm(t->grad_fmt, 0, TG_STORE_F32, m, st);
     }
+    // (the generic kernel's k-major staging — 2-byte LDS scatters — and the transpose-then-NT route it replaced cost
+    //  ~30 us per weight gradient at 16 clips; M2M_TRAIN_DW_OLD=1 keeps them for comparison)
+    static const bool old_path = getenv("M2M_TRAIN_DW_OLD") != nullptr;
+    const int Ealign = t->precision == M2M_PREC_BF16 ? 8 : 4;
+    if (!old_path && Ny % Ealign == 0 && Kx % Ealign == 0 && ldy % Ealign == 0 && ldx % Ealign == 0)
+      return launch_dw_gemm(t->precision, dY, ldy, Ny, X, ldx, Kx, M, Gout, Kx, t->kpart, t->kpart_floats, st);
     const int Mp = (int)align_up(M, 8);
     BGemmArgs g{};
     g.C = Gout; g.M = Ny; g.N = Kx; g.K = M; g.ldc = Kx; g.nb1 = 1; g.nb2 = 1; g.alpha = 1.0f;
-    // Few rows (M < 8192, the per-GPU share of BASELINE configs[4]): read both operands k-major in place, transposed
-    // while they are staged — two launches fewer per weight gradient (bf16 16 clips: 9.28 -> 8.69 ms per step).  Many rows:
-    // the LDS-transposed staging costs more than two coalesced transposes (64 clips: 26.8 vs 28.9 ms).
     if (dw_kmajor == 1 || (dw_kmajor < 0 && M < 8192)) {
       g.A = dY; g.B = X; g.lda = ldy; g.ldb = ldx; g.a_kmajor = 1; g.b_kmajor = 1;
     } else {
