@@ -38,10 +38,30 @@ template <typename T> struct TgCfg;
 template <> struct TgCfg<bf16_t> { static constexpr int E = 8, PITCH = TG_BK + 8; };
 template <> struct TgCfg<float> { static constexpr int E = 4, PITCH = TG_BK + 4; };
 
-// one operand tile [64 rows][32 k] -> LDS (row-major, k contiguous), zero-filled outside (rows_valid, k_valid)
+__device__ inline uint32_t u4_get(const uint4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+// Column j of an E x E block held as E 16-byte rows (E = 8 bf16 / 4 fp32), as one 16-byte row of the transposed block.
+// bf16: halves (2d, 2d+1) of dword j/2 through v_perm_b32; fp32: register renaming.
+template <typename T, int E>
+__device__ inline uint4 tr_col(const uint4 (&rg)[E], int j) {
+  if constexpr (sizeof(T) == 2) {
+    const uint32_t sel = (j & 1) ? 0x07060302u : 0x05040100u;
+    return make_uint4(__builtin_amdgcn_perm(u4_get(rg[1], j >> 1), u4_get(rg[0], j >> 1), sel),
+                      __builtin_amdgcn_perm(u4_get(rg[3], j >> 1), u4_get(rg[2], j >> 1), sel),
+                      __builtin_amdgcn_perm(u4_get(rg[5], j >> 1), u4_get(rg[4], j >> 1), sel),
+                      __builtin_amdgcn_perm(u4_get(rg[7], j >> 1), u4_get(rg[6], j >> 1), sel));
+  } else {
+    return make_uint4(u4_get(rg[0], j), u4_get(rg[1], j), u4_get(rg[2], j), u4_get(rg[3], j));
+  }
+}
+
+// one operand tile [64 rows][32 k] -> LDS (row-major, k contiguous), zero-filled outside (rows_valid, k_valid).
+// k-major operands: E x E blocks transposed in registers (16-byte LDS rows instead of 2-byte scatters), threads
+// [tshift, tshift + blocks) do the work so that the A and the B tile of a step are staged by different waves; the row
+// (non-reduction) index may run past `rows` inside the 16-byte chunk: those tile rows only feed outputs that are never stored
+// (launch_bgemm checks that the padded row still lies inside the operand's row stride).
 template <typename T>
 __device__ inline void tg_stage(T* __restrict__ S, const T* __restrict__ G, int64_t ld, int kmajor, int row0, int k0,
-                                int rows, int K, int tid) {
+                                int rows, int K, int tid, int tshift) {
   using Cfg = TgCfg<T>;
   constexpr int E = Cfg::E;
   if (!kmajor) {
@@ -58,20 +78,19 @@ __device__ inline void tg_stage(T* __restrict__ S, const T* __restrict__ G, int6
       }
     }
   } else {
-    constexpr int CPK = TG_BM / E;                      // chunks per k-row (along the 64 "rows" of the tile)
-    for (int c = tid; c < TG_BK * CPK; c += 256) {
-      const int kl = c / CPK, rc = (c % CPK) * E;
-      const int k = k0 + kl, row = row0 + rc;
-      if (k < K && row + E <= rows) {
-        const uint4 v = *reinterpret_cast<const uint4*>(G + (int64_t)k * ld + row);
-        const T* ve = reinterpret_cast<const T*>(&v);
+    constexpr int KBn = TG_BK / E, RBn = TG_BM / E;     // blocks along k / along the tile rows
+    const int c = tid - tshift;
+    if (c >= 0 && c < KBn * RBn) {
+      const int kb = c % KBn, rb = c / KBn;
+      const int row = row0 + rb * E;
+      uint4 rg[E];
 #pragma unroll
-        for (int e = 0; e < E; ++e) S[(rc + e) * Cfg::PITCH + kl] = ve[e];
-      } else {
-#pragma unroll
-        for (int e = 0; e < E; ++e)
-          S[(rc + e) * Cfg::PITCH + kl] = (k < K && row + e < rows) ? G[(int64_t)k * ld + row + e] : from_f32<T>(0.f);
+      for (int kk = 0; kk < E; ++kk) {
+        const int k = k0 + kb * E + kk;
+        rg[kk] = (k < K && row < rows) ? *reinterpret_cast<const uint4*>(G + (int64_t)k * ld + row) : make_uint4(0, 0, 0, 0);
       }
+#pragma unroll
+      for (int j = 0; j < E; ++j) *reinterpret_cast<uint4*>(S + (rb * E + j) * Cfg::PITCH + kb * E) = tr_col<T, E>(rg, j);
     }
   }
 }
@@ -95,8 +114,8 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BGemmArgs g) {
   f32x16 acc = zero_acc();
   for (int k0 = kbeg; k0 < kend; k0 += TG_BK) {
     __syncthreads();
-    tg_stage<T>(As, A, g.lda, g.a_kmajor, m0, k0, g.M, kend, tid);
-    tg_stage<T>(Bs, B, g.ldb, g.b_kmajor, n0, k0, g.N, kend, tid);
+    tg_stage<T>(As, A, g.lda, g.a_kmajor, m0, k0, g.M, kend, tid, 0);
+    tg_stage<T>(Bs, B, g.ldb, g.b_kmajor, n0, k0, g.N, kend, tid, 128);
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < TG_BK / 16; ++s) {
@@ -176,8 +195,6 @@ template <typename T> struct DwCfg;
 template <> struct DwCfg<bf16_t> { static constexpr int BK = 64, E = 8; };
 template <> struct DwCfg<float> { static constexpr int BK = 32, E = 4; };
 
-__device__ inline uint32_t u4_get(const uint4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
-
 template <typename T, int TF>
 __global__ __launch_bounds__(256) void dw_gemm_kernel(DwGemmArgs g) {
   using Cfg = DwCfg<T>;
@@ -226,19 +243,7 @@ __global__ __launch_bounds__(256) void dw_gemm_kernel(DwGemmArgs g) {
     for (int u = 0; u < NBT; ++u) {
       if (TB < 256 && tid >= TB) continue;
 #pragma unroll
-      for (int j = 0; j < E; ++j) {
-        uint4 o;
-        if constexpr (sizeof(T) == 2) {          // o = column j of the 8x8 block: halves (2d, 2d+1) of dword j/2
-          const uint32_t sel = (j & 1) ? 0x07060302u : 0x05040100u;
-          o.x = __builtin_amdgcn_perm(u4_get(rg[u][1], j >> 1), u4_get(rg[u][0], j >> 1), sel);
-          o.y = __builtin_amdgcn_perm(u4_get(rg[u][3], j >> 1), u4_get(rg[u][2], j >> 1), sel);
-          o.z = __builtin_amdgcn_perm(u4_get(rg[u][5], j >> 1), u4_get(rg[u][4], j >> 1), sel);
-          o.w = __builtin_amdgcn_perm(u4_get(rg[u][7], j >> 1), u4_get(rg[u][6], j >> 1), sel);
-        } else {
-          o = make_uint4(u4_get(rg[u][0], j), u4_get(rg[u][1], j), u4_get(rg[u][2], j), u4_get(rg[u][3], j));
-        }
-        *reinterpret_cast<uint4*>(AB + lds_off[u] + j * PITCH) = o;
-      }
+      for (int j = 0; j < E; ++j) *reinterpret_cast<uint4*>(AB + lds_off[u] + j * PITCH) = tr_col<T, E>(rg[u], j);
     }
   };
 
@@ -425,6 +430,8 @@ int launch_bgemm(int precision, int epi, const BGemmArgs& g, hipStream_t st) {
               (long long)g.lda, (long long)g.ldb, E);
   M2M_REQUIRE(g.sA1 % E == 0 && g.sA2 % E == 0 && g.sB1 % E == 0 && g.sB2 % E == 0, "bgemm: batch strides must keep 16-byte alignment");
   M2M_REQUIRE((int64_t)g.nb1 * g.nb2 <= 65535, "bgemm: too many batch entries");
+  M2M_REQUIRE((!g.a_kmajor || g.lda >= align_up(g.M, E)) && (!g.b_kmajor || g.ldb >= align_up(g.N, E)),
+              "bgemm: a k-major operand's row stride must cover its rows padded to %d", E);
   if (g.ksplit > 1) {
     M2M_REQUIRE(g.nb1 == 1 && g.nb2 == 1 && epi == TG_STORE_F32 && g.Cpart && g.kchunk % TG_BK == 0, "bgemm: split-K is for plain fp32-store products");
     int rc = precision == M2M_PREC_BF16 ? launch_bgemm_t<bf16_t>(epi, g, st) : launch_bgemm_t<float>(epi, g, st);
@@ -615,35 +622,44 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
   float dwacc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) dwacc[j] = 0.f;
+  // d <= 512: a lane's (at most two) 4-column pieces of x, dy and the weight stay in registers between the statistics
+  // and the output pass (the first form read them twice, two dependent round trips per row)
+  float4 gv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) gv[j] = (lane * 4 + 256 * j < d) ? *reinterpret_cast<const float4*>(w + lane * 4 + 256 * j) : make_float4(0, 0, 0, 0);
   for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
     const float* xr = x + (int64_t)row * d;
     const float* dyr = dy + (int64_t)row * d;
+    float4 xv[2], dv[2], rv[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = lane * 4 + 256 * j;
+      const bool in = col < d;
+      xv[j] = in ? *reinterpret_cast<const float4*>(xr + col) : make_float4(0, 0, 0, 0);
+      dv[j] = in ? *reinterpret_cast<const float4*>(dyr + col) : make_float4(0, 0, 0, 0);
+      rv[j] = (in && dx_res) ? *reinterpret_cast<const float4*>(dx_res + (int64_t)row * d + col) : make_float4(0, 0, 0, 0);
+    }
     float ss = 0.f, c = 0.f;
-    for (int col = lane * 4; col < d; col += 256) {
-      const float4 xv = *reinterpret_cast<const float4*>(xr + col);
-      const float4 gv = *reinterpret_cast<const float4*>(w + col);
-      const float4 dv = *reinterpret_cast<const float4*>(dyr + col);
-      ss += xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w;
-      c += gv.x * dv.x * xv.x + gv.y * dv.y * xv.y + gv.z * dv.z * xv.z + gv.w * dv.w * xv.w;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {       // same association as the two-pass form: per piece, then pieces in order
+      ss += xv[j].x * xv[j].x + xv[j].y * xv[j].y + xv[j].z * xv[j].z + xv[j].w * xv[j].w;
+      c += gv[j].x * dv[j].x * xv[j].x + gv[j].y * dv[j].y * xv[j].y + gv[j].z * dv[j].z * xv[j].z + gv[j].w * dv[j].w * xv[j].w;
     }
     ss = wave_sum(ss);
     c = wave_sum(c);
     const float r = rsqrtf(ss / (float)d + eps);
     const float k2 = r * r * r * c / (float)d;
-    int j = 0;
-    for (int col = lane * 4; col < d; col += 256, ++j) {
-      const float4 xv = *reinterpret_cast<const float4*>(xr + col);
-      const float4 gv = *reinterpret_cast<const float4*>(w + col);
-      const float4 dv = *reinterpret_cast<const float4*>(dyr + col);
-      float4 o = make_float4(r * gv.x * dv.x - xv.x * k2, r * gv.y * dv.y - xv.y * k2, r * gv.z * dv.z - xv.z * k2,
-                             r * gv.w * dv.w - xv.w * k2);
-      if (dx_res) {
-        const float4 rv = *reinterpret_cast<const float4*>(dx_res + (int64_t)row * d + col);
-        o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = lane * 4 + 256 * j;
+      if (col < d) {
+        float4 o = make_float4(r * gv[j].x * dv[j].x - xv[j].x * k2, r * gv[j].y * dv[j].y - xv[j].y * k2, r * gv[j].z * dv[j].z - xv[j].z * k2,
+                               r * gv[j].w * dv[j].w - xv[j].w * k2);
+        if (dx_res) { o.x += rv[j].x; o.y += rv[j].y; o.z += rv[j].z; o.w += rv[j].w; }
+        *reinterpret_cast<float4*>(dx_out + (int64_t)row * d + col) = o;
+        dwacc[4 * j + 0] += dv[j].x * xv[j].x * r; dwacc[4 * j + 1] += dv[j].y * xv[j].y * r;
+        dwacc[4 * j + 2] += dv[j].z * xv[j].z * r; dwacc[4 * j + 3] += dv[j].w * xv[j].w * r;
       }
-      *reinterpret_cast<float4*>(dx_out + (int64_t)row * d + col) = o;
-      dwacc[4 * j + 0] += dv.x * xv.x * r; dwacc[4 * j + 1] += dv.y * xv.y * r;
-      dwacc[4 * j + 2] += dv.z * xv.z * r; dwacc[4 * j + 3] += dv.w * xv.w * r;
     }
   }
   int j = 0;
@@ -655,19 +671,31 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
   for (int col = threadIdx.x; col < d; col += 256)
     dw_part[(int64_t)blockIdx.x * d + col] = red[col] + red[d + col] + red[2 * d + col] + red[3 * d + col];
 }
-// out[col] (+)= sum over `parts` rows of part[p][col]   (second pass of every column reduction): 64 columns per block,
-// 4 row groups per column summed through LDS in a fixed order
+// out[col] (+)= sum over `parts` rows of part[p][col]   (second pass of every column reduction): 32 columns per block,
+// 8 row groups per column, each walking its rows 8 at a time (independent loads: the first form issued one dependent
+// round trip per row, 64 in a row = 16.7 us per launch), summed through LDS in a fixed order
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, float* __restrict__ out, int parts, int d, int accumulate) {
-  __shared__ float sred[4][64];
-  const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + cx;
+  __shared__ float sred[8][32];
+  const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + cx;
   float acc = 0.f;
-  if (col < d)
-    for (int p = py; p < parts; p += 4) acc += part[(int64_t)p * d + col];
+  if (col < d) {
+    int p = py;
+    for (; p + 56 < parts; p += 64) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(p + 8 * u) * d + col];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; p < parts; p += 8) acc += part[(int64_t)p * d + col];
+  }
   sred[py][cx] = acc;
   __syncthreads();
   if (py == 0 && col < d) {
-    const float v = (sred[0][cx] + sred[1][cx]) + (sred[2][cx] + sred[3][cx]);
+    float v = sred[0][cx];
+#pragma unroll
+    for (int u = 1; u < 8; ++u) v += sred[u][cx];
     out[col] = accumulate ? out[col] + v : v;
   }
 }
@@ -1403,7 +1431,7 @@ struct Ops {
     //  fence of 256 blocks costs ~100 us per launch on this machine — 8.7 -> 12.3 ms per step; the second launch stays)
     hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(RN_BLOCKS), dim3(256), (size_t)4 * d * sizeof(float), st, x, P + w_off, dy, dx_res, dx_out,
                        t->dw_part, M, d, t->g.layer_norm_eps);
-    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(d, 64)), dim3(256), 0, st, t->dw_part, G + w_off, RN_BLOCKS, d, 0);
+    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(d, 32)), dim3(256), 0, st, t->dw_part, G + w_off, RN_BLOCKS, d, 0);
     M2M_CHECK_HIP(hipGetLastError());
     return M2M_OK;
   }
