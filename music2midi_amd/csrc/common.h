@@ -182,6 +182,14 @@ __host__ __device__ inline bool drop_keep(uint64_t key, int64_t i, uint32_t thre
   return (uint32_t)(splitmix64(key + (uint64_t)i) >> 32) >= thresh;
 }
 
+// The key of a dropout site is splitmix64(*step + salt): `step` is a device word the trainer advances once per
+// forward/backward (so a captured HIP graph replays with fresh masks), `salt` identifies the site.
+struct DropKey {
+  const uint64_t* step;
+  uint64_t salt;
+};
+__device__ inline uint64_t drop_site_key(DropKey k) { return splitmix64(*k.step + k.salt); }
+
 __host__ __device__ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 

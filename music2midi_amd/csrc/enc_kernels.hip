@@ -260,6 +260,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
     return;
   }
+  uint64_t dkey = 0;
+  if constexpr (EPI == EPI_RESID) { if (g.drop_thresh) dkey = splitmix64(*g.drop_step + g.drop_key); }
 #pragma unroll
   for (int mi = 0; mi < TF; ++mi) {
 #pragma unroll
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
             const int64_t at = (int64_t)row * g.ldo + col;
             float* p = reinterpret_cast<float*>(g.out) + at;
             float u = v;
-            if (g.drop_thresh) u = drop_keep(g.drop_key, at, g.drop_thresh) ? v * g.drop_scale : 0.f;   // training only
+            if (g.drop_thresh) u = drop_keep(dkey, at, g.drop_thresh) ? v * g.drop_scale : 0.f;   // training only
             *p = (g.resid ? g.resid[at] : *p) + u;
           } else {  // EPI_HEADS
             const int which = col / g.inner, rem = col - which * g.inner;

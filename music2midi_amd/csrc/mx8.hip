@@ -137,6 +137,7 @@ __global__ __launch_bounds__(256) void mxgemm_kernel(MxGemmArgs g) {
   }
   const int col = n0 + wn * 32 + r;
   if (col >= g.N) return;
+  const uint64_t dkey = (EPI == TG_RESID_F32 && g.drop_thresh) ? splitmix64(*g.drop_step + g.drop_key) : 0ull;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int row = m0 + wm * 32 + acc_row(i, lane);
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void mxgemm_kernel(MxGemmArgs g) {
     else if constexpr (EPI == TG_ACC_F32) reinterpret_cast<float*>(g.C)[at] += v;
     else {
       float u = v;
-      if (g.drop_thresh) u = drop_keep(g.drop_key, at, g.drop_thresh) ? v * g.drop_scale : 0.f;
+      if (g.drop_thresh) u = drop_keep(dkey, at, g.drop_thresh) ? v * g.drop_scale : 0.f;
       reinterpret_cast<float*>(g.C)[at] = g.R[at] + u;
     }
   }

@@ -147,7 +147,8 @@ struct GemmArgs {
   const float* resid;      // out = resid + acc instead of out += acc (same indexing as out)
   uint32_t drop_thresh;    // dropout on acc before the add: keep(i) * drop_scale * acc, i = row * ldo + col (common.h drop_keep)
   float drop_scale;
-  uint64_t drop_key;
+  uint64_t drop_key;       // the site's salt: key = splitmix64(*drop_step + drop_key) (common.h DropKey)
+  const uint64_t* drop_step;
 };
 
 int launch_gemm(int precision, int epi, const GemmArgs& a, hipStream_t st);

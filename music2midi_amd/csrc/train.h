@@ -26,7 +26,8 @@ struct BGemmArgs {
   // TG_RESID_F32 only: dropout on the product before the residual add, C = R + keep(i) * drop_scale * acc  (drop_thresh == 0: off)
   uint32_t drop_thresh;
   float drop_scale;
-  uint64_t drop_key;
+  uint64_t drop_key;           // the site's salt: key = splitmix64(*drop_step + drop_key) (common.h DropKey)
+  const uint64_t* drop_step;
 };
 
 
@@ -44,7 +45,8 @@ struct MxGemmArgs {
   float* Cpart;
   uint32_t drop_thresh;
   float drop_scale;
-  uint64_t drop_key;
+  uint64_t drop_key;           // salt, as in BGemmArgs
+  const uint64_t* drop_step;
 };
 int launch_mxgemm(int fmt_a, int fmt_b, int epi, const MxGemmArgs& g, hipStream_t st);      // fmt: 0 = e4m3, 1 = e5m2
 int launch_mxq_rows(int src_kind, const void* src, int64_t ld_s, uint8_t* q, uint8_t* sc, int R, int C, int Cp, int fmt, hipStream_t st);

@@ -21,6 +21,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <functional>
 #include <string>
 #include <utility>
 #include <vector>
@@ -126,6 +127,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BGemmArgs g) {
   }
   const int col = n0 + wn * 32 + r;
   if (col >= g.N) return;
+  const uint64_t dkey = (EPI == TG_RESID_F32 && g.drop_thresh) ? splitmix64(*g.drop_step + g.drop_key) : 0ull;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int row = m0 + wm * 32 + acc_row(i, lane);
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BGemmArgs g) {
     else if constexpr (EPI == TG_ACC_F32) reinterpret_cast<float*>(g.C)[at] += v;
     else {                                                                       // TG_RESID_F32: C = R + dropout(acc)
       float u = v;
-      if (g.drop_thresh) u = drop_keep(g.drop_key, at, g.drop_thresh) ? v * g.drop_scale : 0.f;
+      if (g.drop_thresh) u = drop_keep(dkey, at, g.drop_thresh) ? v * g.drop_scale : 0.f;
       reinterpret_cast<float*>(g.C)[at] = g.R[at] + u;
     }
   }
@@ -454,14 +456,16 @@ __global__ void cvt_kernel(const float* __restrict__ src, T* __restrict__ dst, i
 }
 // dst = T(keep(i) * scale * src)  (the gradient entering a dropped branch)
 template <typename T>
-__global__ void cvt_drop_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t n, uint64_t key, uint32_t thresh, float scale) {
+__global__ void cvt_drop_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t n, DropKey dk, uint32_t thresh, float scale) {
+  const uint64_t key = thresh ? drop_site_key(dk) : 0ull;
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) dst[i] = from_f32<T>(drop_keep(key, i, thresh) ? src[i] * scale : 0.f);
 }
 // in-place dropout of an fp32 / T buffer
 template <typename T>
-__global__ void drop_inplace_kernel(T* __restrict__ x, int64_t n, uint64_t key, uint32_t thresh, float scale) {
+__global__ void drop_inplace_kernel(T* __restrict__ x, int64_t n, DropKey dk, uint32_t thresh, float scale) {
+  const uint64_t key = thresh ? drop_site_key(dk) : 0ull;
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) x[i] = from_f32<T>(drop_keep(key, i, thresh) ? to_f32(x[i]) * scale : 0.f);
@@ -486,7 +490,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ sc, T* __restrict__ P, int rows_total, int H,
                                                           int Sq, int Sk, int ldp, const float* __restrict__ bias_tab,
                                                           int tab_stride, int tab_center, int causal, T* __restrict__ Pd,
-                                                          uint64_t key, uint32_t thresh, float scale) {
+                                                          DropKey dk, uint32_t thresh, float scale) {
+  const uint64_t key = (Pd && thresh) ? drop_site_key(dk) : 0ull;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows_total) return;
@@ -511,7 +516,8 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restric
 }
 // Pd = dropout(P) again (backward: the dV product needs it, it was a scratch buffer in the forward)
 template <typename T>
-__global__ void drop_copy_kernel(const T* __restrict__ P, T* __restrict__ Pd, int64_t n, uint64_t key, uint32_t thresh, float scale) {
+__global__ void drop_copy_kernel(const T* __restrict__ P, T* __restrict__ Pd, int64_t n, DropKey dk, uint32_t thresh, float scale) {
+  const uint64_t key = thresh ? drop_site_key(dk) : 0ull;
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) Pd[i] = drop_keep(key, i, thresh) ? from_f32<T>(to_f32(P[i]) * scale) : from_f32<T>(0.f);
@@ -520,7 +526,8 @@ __global__ void drop_copy_kernel(const T* __restrict__ P, T* __restrict__ Pd, in
 // dS = P o (dP - rowsum(P o dP))   (softmax backward; P in T as the forward stored it, dP fp32), dS in T, padding zeroed
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* __restrict__ P, const float* __restrict__ dP, T* __restrict__ dS,
-                                                          int rows_total, int Sk, int ldp, uint64_t key, uint32_t thresh, float scale) {
+                                                          int rows_total, int Sk, int ldp, DropKey dk, uint32_t thresh, float scale) {
+  const uint64_t key = thresh ? drop_site_key(dk) : 0ull;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows_total) return;
@@ -576,7 +583,8 @@ __global__ __launch_bounds__(256) void bias_bucket_kernel(const float* __restric
 
 // ---- gated GELU (hf: modeling_t5.py T5DenseGatedActDense: gelu_new(wi_0 x) * (wi_1 x)); ab = [a | b], [M, 2*dff] ----
 template <typename T>
-__global__ void gated_fwd_kernel(const T* __restrict__ ab, T* __restrict__ mid, int64_t M, int dff, uint64_t key, uint32_t thresh, float scale) {
+__global__ void gated_fwd_kernel(const T* __restrict__ ab, T* __restrict__ mid, int64_t M, int dff, DropKey dk, uint32_t thresh, float scale) {
+  const uint64_t key = thresh ? drop_site_key(dk) : 0ull;
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t n = M * dff, stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
@@ -595,8 +603,9 @@ __device__ inline float gelu_new_grad(float x) {
   return 0.5f * (1.0f + th) + 0.5f * x * (1.0f - th * th) * k * (1.0f + 3.0f * 0.044715f * x * x);
 }
 template <typename T>
-__global__ void gated_bwd_kernel(const T* __restrict__ ab, const T* __restrict__ dmid, T* __restrict__ dab, int64_t M, int dff, uint64_t key,
+__global__ void gated_bwd_kernel(const T* __restrict__ ab, const T* __restrict__ dmid, T* __restrict__ dab, int64_t M, int dff, DropKey dk,
                                  uint32_t thresh, float scale) {
+  const uint64_t key = thresh ? drop_site_key(dk) : 0ull;
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t n = M * dff, stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
@@ -1071,7 +1080,26 @@ struct m2m_trainer {
   // dropout (hf T5Config.dropout_rate; the reference trains in model.train() mode, ref train.py:33): off unless set
   float drop_p = 0.f, drop_scale = 1.f;
   uint32_t drop_thresh = 0;
-  uint64_t drop_seed = 0, fb_calls = 0, step_key = 0;
+  uint64_t drop_seed = 0;
+  uint64_t *step_key_dev = nullptr, *step_ctr_dev = nullptr;   // key of the current pass / passes since set_dropout (device words:
+                                                               // a captured graph advances them itself, see step_key_kernel)
+  // Two scratch sets for the operands the weight-gradient products read (dxT, dab, dqkv, dcq, dckv): the products of
+  // sub-layer n run on the side stream while the main stream already writes sub-layer n + 1's operands into the other set
+  struct DwSet { void *dxT, *dab, *dqkv, *dcq, *dckv; };
+  DwSet dw_set[2];
+  // streams / graph of the step (trainer-owned: the caller's stream may be the legacy default stream, which cannot capture)
+  hipStream_t s_main = nullptr, s_side = nullptr;
+  hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_ready = nullptr, ev_free[2] = {nullptr, nullptr};
+  bool use_side = true, use_graph = true;
+  int64_t* labels_buf = nullptr;
+  int64_t* cond_buf = nullptr;
+  float* loss_dev = nullptr;
+  struct GraphKey {
+    const float* P = nullptr; float* G = nullptr; int B = 0, S = 0, L = 0; uint32_t thresh = 0; uint64_t seed = 0;
+    bool operator==(const GraphKey& o) const { return P == o.P && G == o.G && B == o.B && S == o.S && L == o.L && thresh == o.thresh && seed == o.seed; }
+  };
+  GraphKey last_key, graph_key;          // key of the previous call / of the instantiated graph
+  hipGraphExec_t gexec = nullptr;
   // optimizer
   AfPlan af;
   unsigned char* af_mem = nullptr;
@@ -1209,7 +1237,8 @@ int build_arena(m2m_trainer* t) {
                 o_dh = F(Mx * d), o_dhE = F(Me * d), o_dwp = F((int64_t)RN_BLOCKS * d), o_rl = F(Md), o_inv = F(64), o_drel = F(B * H * (2 * Sm)),
                 o_etab = F(H * (2 * S)), o_dtab = F(H * (2 * L)), o_dlog = T(Md * align_up(V, 8)), o_dxT = T(Mx * d), o_dmid = T(Mx * dff),
                 o_dab = T(Mx * 2 * dff), o_dO = T(Mx * inner), o_dqkv = T(Mx * 3 * inner), o_dS = T(B * H * Sm * lpm), o_dcq = T(Md * inner),
-                o_dckv = T(Me * 2 * inner), o_decin = c.take(Md * 8), o_eb = c.take(2 * S * 4), o_db = c.take(2 * L * 4),
+                o_dckv = T(Me * 2 * inner), o_dxT2 = T(Mx * d), o_dab2 = T(Mx * 2 * dff), o_dqkv2 = T(Mx * 3 * inner), o_dcq2 = T(Md * inner),
+                o_dckv2 = T(Me * 2 * inner), o_lab = c.take(Md * 8), o_cnd = c.take(B * 8 * 8), o_skey = c.take(256), o_decin = c.take(Md * 8), o_eb = c.take(2 * S * 4), o_db = c.take(2 * L * 4),
                 o_co = c.take(64 * 8), o_cr = c.take(64 * 4), o_cnt = c.take(256), o_wc = (t->precision == M2M_PREC_BF16) ? T(t->n_floats) : 0,
                 o_wt = T(t->n_floats);
   const int64_t Mxp = align_up(Mx, 8), fmax = std::max<int64_t>(std::max<int64_t>(3 * inner, 2 * dff), align_up(V, 8));
@@ -1273,6 +1302,10 @@ int build_arena(m2m_trainer* t) {
   t->row_loss = (float*)(b + o_rl); t->inv_n = (float*)(b + o_inv); t->drel = (float*)(b + o_drel); t->etab = (float*)(b + o_etab);
   t->dtab = (float*)(b + o_dtab); t->dlog = b + o_dlog; t->dxT = b + o_dxT; t->dmid = b + o_dmid; t->dab = b + o_dab; t->dO = b + o_dO;
   t->dqkv = b + o_dqkv; t->dS = b + o_dS; t->dcq = b + o_dcq; t->dckv = b + o_dckv; t->dec_in = (int64_t*)(b + o_decin);
+  t->dw_set[0] = {t->dxT, t->dab, t->dqkv, t->dcq, t->dckv};
+  t->dw_set[1] = {b + o_dxT2, b + o_dab2, b + o_dqkv2, b + o_dcq2, b + o_dckv2};
+  t->labels_buf = (int64_t*)(b + o_lab); t->cond_buf = (int64_t*)(b + o_cnd);
+  t->step_key_dev = (uint64_t*)(b + o_skey); t->step_ctr_dev = t->step_key_dev + 1; t->loss_dev = (float*)(t->step_key_dev + 4);
   t->ebucket = (int*)(b + o_eb); t->dbucket = (int*)(b + o_db); t->counter = (int*)(b + o_cnt); t->cond_off_dev = (int64_t*)(b + o_co); t->cond_rows_dev = (int*)(b + o_cr);
   t->Wc = (t->precision == M2M_PREC_BF16) ? (void*)(b + o_wc) : nullptr;
   t->WT = b + o_wt; t->tA = b + o_tA; t->tB = b + o_tB; t->kpart = (float*)(b + o_kp); t->wt_blocks = b + o_wtb; t->n_wt_blocks = (int)wtb.size();
@@ -1315,14 +1348,46 @@ struct Ops {
 
   // dropout sites: one key per (layer, place); site < 0 or p == 0: no dropout
   bool dropping(int site) const { return site >= 0 && t->drop_thresh != 0; }
-  uint64_t key(int site) const { return splitmix64(t->step_key + (uint64_t)site * 0x9E3779B97F4A7C15ull); }
+  DropKey key(int site) const { return DropKey{t->step_key_dev, (uint64_t)site * 0x9E3779B97F4A7C15ull}; }
+
+  // ---- weight-gradient products on the side stream.  A backward sub-layer brackets itself with begin_sub() / end_sub():
+  // dW() calls in between are queued, end_sub() hands them to the side stream behind everything the main stream has
+  // issued so far, and begin_sub() two sub-layers later waits for them before the operand set is written again.
+  hipStream_t st2 = nullptr;
+  mutable std::vector<std::function<int(hipStream_t)>> pending;
+  mutable int par = 0;
+  mutable bool used[2] = {false, false};
+  int begin_sub() const {
+    if (!st2) return M2M_OK;
+    if (used[par]) M2M_CHECK_HIP(hipStreamWaitEvent(st, t->ev_free[par], 0));
+    const m2m_trainer::DwSet& w = t->dw_set[par];
+    t->dxT = w.dxT; t->dab = w.dab; t->dqkv = w.dqkv; t->dcq = w.dcq; t->dckv = w.dckv;
+    return M2M_OK;
+  }
+  int end_sub() const {
+    if (!st2) return M2M_OK;
+    M2M_CHECK_HIP(hipEventRecord(t->ev_ready, st));
+    M2M_CHECK_HIP(hipStreamWaitEvent(st2, t->ev_ready, 0));
+    for (auto& f : pending) { const int rc = f(st2); if (rc != M2M_OK) { pending.clear(); return rc; } }
+    pending.clear();
+    M2M_CHECK_HIP(hipEventRecord(t->ev_free[par], st2));
+    used[par] = true;
+    par ^= 1;
+    return M2M_OK;
+  }
+  int join_side() const {                  // the main stream continues only after every queued product has finished
+    if (!st2) return M2M_OK;
+    for (int p = 0; p < 2; ++p)
+      if (used[p]) M2M_CHECK_HIP(hipStreamWaitEvent(st, t->ev_free[p], 0));
+    return M2M_OK;
+  }
 
   int mm(int epi, const void* A, int64_t lda, int akm, const void* B, int64_t ldb, int bkm, void* C, int64_t ldc, int M, int N, int K,
          const float* R = nullptr, int drop_site = -1) const {
     BGemmArgs g{};
     g.A = A; g.B = B; g.C = C; g.R = R; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.a_kmajor = akm; g.b_kmajor = bkm;
     g.nb1 = 1; g.nb2 = 1; g.alpha = 1.0f;
-    if (dropping(drop_site)) { g.drop_thresh = t->drop_thresh; g.drop_scale = t->drop_scale; g.drop_key = key(drop_site); }
+    if (dropping(drop_site)) { g.drop_thresh = t->drop_thresh; g.drop_scale = t->drop_scale; g.drop_key = key(drop_site).salt; g.drop_step = t->step_key_dev; }
     if (!akm && !bkm && t->fp8 && t->fp8_fwd) {          // a forward projection Y = X . W^T on MXFP8 operands
       const int64_t off = reinterpret_cast<const T*>(B) - W(0);
       if (const m2m_trainer::LinW* w = lin8(off)) {
@@ -1330,7 +1395,7 @@ struct Ops {
         if (rc != M2M_OK) return rc;
         MxGemmArgs m{};
         m.A = t->q8a; m.sA = t->s8a; m.B = t->w8 + w->q; m.sB = t->w8 + w->qs; m.C = C; m.R = R; m.M = M; m.N = N; m.K = K;
-        m.lda = K; m.ldb = K; m.ldc = ldc; m.drop_thresh = g.drop_thresh; m.drop_scale = g.drop_scale; m.drop_key = g.drop_key;
+        m.lda = K; m.ldb = K; m.ldc = ldc; m.drop_thresh = g.drop_thresh; m.drop_scale = g.drop_scale; m.drop_key = g.drop_key; m.drop_step = g.drop_step;
         return launch_mxgemm(0, 0, epi, m, st);
       }
     }
@@ -1342,7 +1407,7 @@ struct Ops {
       if (epi == TG_STORE_T) return launch_gemm(t->precision, EPI_STORE, a, st);
       if (epi == TG_STORE_F32) return launch_gemm(t->precision, EPI_STORE_F32, a, st);
       if (epi == TG_ACC_F32) return launch_gemm(t->precision, EPI_RESID, a, st);
-      a.resid = R; a.drop_thresh = g.drop_thresh; a.drop_scale = g.drop_scale; a.drop_key = g.drop_key;
+      a.resid = R; a.drop_thresh = g.drop_thresh; a.drop_scale = g.drop_scale; a.drop_key = g.drop_key; a.drop_step = g.drop_step;
       return launch_gemm(t->precision, EPI_RESID, a, st);
     }
     return launch_bgemm(t->precision, epi, g, st);
@@ -1385,6 +1450,11 @@ struct Ops {
   // scratch, then it is a plain NT product with the M rows as the reduction, split over k so that the few output tiles
   // of a weight gradient still fill the chip; the k-slices are summed in a fixed order.
   int dW(const void* dY, int64_t ldy, int Ny, const void* X, int64_t ldx, int Kx, float* Gout, int M) const {
+    if (!st2) return dW_on(st, dY, ldy, Ny, X, ldx, Kx, Gout, M);
+    pending.push_back([=](hipStream_t s) { return dW_on(s, dY, ldy, Ny, X, ldx, Kx, Gout, M); });
+    return M2M_OK;
+  }
+  int dW_on(hipStream_t st, const void* dY, int64_t ldy, int Ny, const void* X, int64_t ldx, int Kx, float* Gout, int M) const {
     if (Gbase && t->fp8_dw && lin8(Gout - Gbase)) {      // fp8 mode: dY^T (e5m2) . X^T (e4m3), blocks along the M rows
       const int Mp8 = (int)align_up(M, 128);
       int rc = launch_mxq_cols(1, dY, ldy, t->q8ta, t->s8ta, M, Ny, Mp8, t->grad_fmt, st);
@@ -1440,7 +1510,7 @@ struct Ops {
     const int H = t->g.num_heads, rows = nB * H * Sq;
     const bool dr = dropping(site);
     hipLaunchKernelGGL(softmax_fwd_kernel<T>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, sc, (T*)Pm, rows, H, Sq, Sk, ldp, tab, Sq + Sk - 1,
-                       Sq - 1, causal, dr ? (T*)t->dS : (T*)nullptr, dr ? key(site) : 0ull, dr ? t->drop_thresh : 0u, t->drop_scale);
+                       Sq - 1, causal, dr ? (T*)t->dS : (T*)nullptr, dr ? key(site) : DropKey{nullptr, 0}, dr ? t->drop_thresh : 0u, t->drop_scale);
     M2M_CHECK_HIP(hipGetLastError());
     *Puse = dr ? (const T*)t->dS : (const T*)Pm;
     return M2M_OK;
@@ -1456,21 +1526,21 @@ struct Ops {
   int softmax_bwd(const void* Pm, const float* dP, void* dS, int rows, int Sk, int ldp, int site) const {
     const bool dr = dropping(site);
     hipLaunchKernelGGL(softmax_bwd_kernel<T>, dim3(ceil_div(rows, 4)), dim3(256), 0, st, (const T*)Pm, dP, (T*)dS, rows, Sk, ldp,
-                       dr ? key(site) : 0ull, dr ? t->drop_thresh : 0u, t->drop_scale);
+                       dr ? key(site) : DropKey{nullptr, 0}, dr ? t->drop_thresh : 0u, t->drop_scale);
     M2M_CHECK_HIP(hipGetLastError());
     return M2M_OK;
   }
   int gated(const void* ab, void* mid, int64_t M, int site) const {
     const bool dr = dropping(site);
     hipLaunchKernelGGL(gated_fwd_kernel<T>, dim3(grid_1d(M * t->g.d_ff)), dim3(256), 0, st, (const T*)ab, (T*)mid, M, t->g.d_ff,
-                       dr ? key(site) : 0ull, dr ? t->drop_thresh : 0u, t->drop_scale);
+                       dr ? key(site) : DropKey{nullptr, 0}, dr ? t->drop_thresh : 0u, t->drop_scale);
     M2M_CHECK_HIP(hipGetLastError());
     return M2M_OK;
   }
   int gated_bwd(const void* ab, const void* dmid, void* dab, int64_t M, int site) const {
     const bool dr = dropping(site);
     hipLaunchKernelGGL(gated_bwd_kernel<T>, dim3(grid_1d(M * t->g.d_ff)), dim3(256), 0, st, (const T*)ab, (const T*)dmid, (T*)dab, M, t->g.d_ff,
-                       dr ? key(site) : 0ull, dr ? t->drop_thresh : 0u, t->drop_scale);
+                       dr ? key(site) : DropKey{nullptr, 0}, dr ? t->drop_thresh : 0u, t->drop_scale);
     M2M_CHECK_HIP(hipGetLastError());
     return M2M_OK;
   }
@@ -1519,6 +1589,7 @@ int attn_self_bwd(const Ops<T>& o, const float* x_in, const float* dx_out, float
   m2m_trainer* t = o.t;
   const int d = t->g.d_model, inner = t->inner, M = nB * S, ldp = (int)align_up(S, 8), H = t->g.num_heads;
   int rc;
+  RC(o.begin_sub());
   RC(o.cvt_branch(dx_out, t->dxT, (int64_t)M * d, site0 + PL_SELF_OUT));
   RC(o.dW(t->dxT, d, d, ao, inner, inner, G + wo, M));                                            // dWo = dx^T . ao
   RC(o.dX(TG_STORE_T, t->dxT, d, wo, d, inner, t->dO, inner, M));                                 // dO = dx . Wo
@@ -1538,6 +1609,7 @@ int attn_self_bwd(const Ops<T>& o, const float* x_in, const float* dx_out, float
   RC(o.dW(dq, 3 * inner, 3 * inner, h, d, d, G + wqkv, M));                                       // dWqkv = dqkv^T . h
   RC(o.dX(TG_STORE_F32, dq, 3 * inner, wqkv, 3 * inner, d, t->dh, d, M));                         // dh = dqkv . Wqkv
   RC(o.norm_bwd(x_in, ln, t->dh, dx_out, dx_in, G, M));
+  RC(o.end_sub());
   return M2M_OK;
 }
 
@@ -1558,6 +1630,7 @@ int ff_bwd(const Ops<T>& o, const float* x_in, const float* dx_out, float* dx_in
   m2m_trainer* t = o.t;
   const int d = t->g.d_model, dff = t->g.d_ff;
   int rc;
+  RC(o.begin_sub());
   RC(o.cvt_branch(dx_out, t->dxT, (int64_t)M * d, site0 + PL_FF_OUT));
   RC(o.dW(t->dxT, d, d, mid, dff, dff, G + wo, M));                                               // dWo = dx^T . mid
   RC(o.dX(TG_STORE_T, t->dxT, d, wo, d, dff, t->dmid, dff, M));                                   // dmid = dx . Wo
@@ -1565,36 +1638,32 @@ int ff_bwd(const Ops<T>& o, const float* x_in, const float* dx_out, float* dx_in
   RC(o.dW(t->dab, 2 * dff, 2 * dff, h, d, d, G + wi, M));                                         // dWi = dab^T . h
   RC(o.dX(TG_STORE_F32, t->dab, 2 * dff, wi, 2 * dff, d, t->dh, d, M));                           // dh = dab . Wi
   RC(o.norm_bwd(x_in, ln, t->dh, dx_out, dx_in, G, M));
+  RC(o.end_sub());
   return M2M_OK;
+}
+
+// key of this pass = splitmix64(seed + passes since set_dropout); the counter lives on the device so that a replayed graph advances it
+__global__ void step_key_kernel(uint64_t seed, uint64_t* __restrict__ ctr, uint64_t* __restrict__ key) {
+  const uint64_t c = *ctr;
+  *key = splitmix64(seed + c);
+  *ctr = c + 1;
 }
 
 template <typename T>
 int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, const int64_t* cond_idx, const int64_t* labels, int B, int S,
-                       int L, float* loss_out, float* G, float* logits_out, hipStream_t st) {
+                       int L, float* loss_out, float* G, float* logits_out, hipStream_t st, hipStream_t st_side) {
   const m2m_t5_geometry& g = t->g;
   const int d = g.d_model, inner = t->inner, V = g.vocab_size, H = g.num_heads, Le = g.num_layers, Ld = g.num_decoder_layers;
   const int Me = B * S, Md = B * L, lps = (int)align_up(S, 8), ldv = (int)align_up(V, 8);
   Ops<T> o{t, st, P};
   o.Gbase = G;
+  o.st2 = G ? st_side : nullptr;
   int rc;
-  // ---- tables that depend on the geometry (host) and on the current bucket weights (device) ----
-  if (t->tab_S != S) {
-    const std::vector<int> eb = bucket_table(g, S, S, true);
-    M2M_CHECK_HIP(hipMemcpyAsync(t->ebucket, eb.data(), eb.size() * 4, hipMemcpyHostToDevice, st));
-    M2M_CHECK_HIP(hipStreamSynchronize(st));   // eb is a stack object
-    t->tab_S = S;
-  }
-  if (t->tab_L != L) {
-    const std::vector<int> db = bucket_table(g, L, L, false);
-    M2M_CHECK_HIP(hipMemcpyAsync(t->dbucket, db.data(), db.size() * 4, hipMemcpyHostToDevice, st));
-    M2M_CHECK_HIP(hipStreamSynchronize(st));
-    t->tab_L = L;
-  }
+  // (the bucket tables of this geometry are on the device already: ensure_tables())
   hipLaunchKernelGGL(bias_table_kernel, dim3(ceil_div(H * (2 * S - 1), 128)), dim3(128), 0, st, P + t->o_erb, t->ebucket, t->etab, H, 2 * S - 1);
   hipLaunchKernelGGL(bias_table_kernel, dim3(ceil_div(H * (2 * L - 1), 128)), dim3(128), 0, st, P + t->o_drb, t->dbucket, t->dtab, H, 2 * L - 1);
   M2M_CHECK_HIP(hipGetLastError());
-  t->step_key = splitmix64(t->drop_seed + t->fb_calls);
-  t->fb_calls += 1;
+  hipLaunchKernelGGL(step_key_kernel, dim3(1), dim3(1), 0, st, t->drop_seed, t->step_ctr_dev, t->step_key_dev);
   if (t->precision == M2M_PREC_BF16) RC(o.cvt(P, t->Wc, t->n_floats));
   if (G) {
     hipLaunchKernelGGL(weights_transpose_kernel<T>, dim3(t->n_wt_blocks), dim3(256), 0, st, (const WtBlock*)t->wt_blocks, P, (T*)t->WT);
@@ -1607,7 +1676,7 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
   if (G) M2M_CHECK_HIP(hipMemsetAsync(G, 0, (size_t)t->n_floats * 4, st));
 
   // ================= forward =================
-  M2M_CHECK_HIP(hipMemcpyAsync(t->xe[0], enc_inputs, (size_t)Me * d * 4, hipMemcpyDeviceToDevice, st));
+  if (enc_inputs != t->xe[0]) M2M_CHECK_HIP(hipMemcpyAsync(t->xe[0], enc_inputs, (size_t)Me * d * 4, hipMemcpyDeviceToDevice, st));
   if (t->n_cond > 0)
     hipLaunchKernelGGL(cond_gather_kernel, dim3(B * t->n_cond), dim3(128), 0, st, P, t->cond_off_dev, t->cond_rows_dev, t->n_cond, cond_idx,
                        t->xe[0], S, d);
@@ -1656,7 +1725,9 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
   if (!G) return M2M_OK;
 
   // ================= backward =================
+  RC(o.begin_sub());
   RC(o.dW(t->dlog, ldv, V, t->hD, d, d, G + t->o_lm, Md));                                        // dW_lm = dlogits^T . hD
+  RC(o.end_sub());
   RC(o.dX(TG_STORE_F32, t->dlog, ldv, t->o_lm, V, d, t->dh, d, Md));                              // dhD = dlogits . W_lm
   RC(o.drop_inplace(t->dh, (int64_t)Md * d, SITE_DEC + SITE_FIN));
   float* dcur = t->dxa;
@@ -1667,6 +1738,7 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
     RC(ff_bwd<T>(o, t->xd[3 * l + 2], dcur, dnext, G, e.ln2, e.wi, e.wo, t->h2d[l], t->abd[l], t->midd[l], Md, SITE_DEC + 16 * l));
     std::swap(dcur, dnext);
     // ---- cross-attention backward: dcur = d x[3l+2] ----
+    RC(o.begin_sub());
     RC(o.cvt_branch(dcur, t->dxT, (int64_t)Md * d, SITE_DEC + 16 * l + PL_CROSS_OUT));
     RC(o.dW(t->dxT, d, d, t->aocd[l], inner, inner, G + e.co, Md));
     RC(o.dX(TG_STORE_T, t->dxT, d, e.co, d, inner, t->dO, inner, Md));
@@ -1690,6 +1762,7 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
     std::swap(dcur, dnext);
     RC(o.dW(dckv, 2 * inner, 2 * inner, t->hE, d, d, G + e.ckv, Me));                               // dWckv = dckv^T . hE
     RC(o.dX(l == Ld - 1 ? TG_STORE_F32 : TG_ACC_F32, dckv, 2 * inner, e.ckv, 2 * inner, d, t->dhE, d, Me));                  // dhE (+)= dckv . Wckv
+    RC(o.end_sub());
     // ---- causal self-attention backward ----
     RC(attn_self_bwd<T>(o, t->xd[3 * l], dcur, dnext, G, e.ln0, e.qkv, e.o, t->h0d[l], t->qkvd[l], t->Pd[l], t->aod[l], B, L, t->dbucket, t->o_drb,
                         l == Ld - 1 ? 0 : 1, SITE_DEC + 16 * l));
@@ -1716,12 +1789,15 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
     hipLaunchKernelGGL(embed_bwd_kernel, dim3(t->cond_rows[i]), dim3(256), 0, st, cond_idx, B, t->n_cond, i, dcur, (int64_t)S, (int64_t)i,
                        G + t->o_cond[i], d, 0, t->cond_rows[i]);
   M2M_CHECK_HIP(hipGetLastError());
+  RC(o.join_side());
   return M2M_OK;
 }
 
 }  // namespace
 
 // ------------------------------------------------------------------ C ABI ---
+namespace { void drop_graph(m2m_trainer* t); }
+
 extern "C" int m2m_trainer_create(const m2m_t5_geometry* geom, int n_cond, const int* cond_rows, int precision, int max_batch,
                                   int max_enc_len, int max_dec_len, m2m_trainer** out) {
   M2M_REQUIRE(geom && out && (n_cond == 0 || cond_rows), "m2m_trainer_create: null argument");
@@ -1752,12 +1828,30 @@ extern "C" int m2m_trainer_create(const m2m_t5_geometry* geom, int n_cond, const
   int rc = build_arena(t);
   if (rc == M2M_OK) rc = build_optimizer(t);
   if (rc != M2M_OK) { m2m_trainer_destroy(t); return rc; }
+  // streams / events of the step (M2M_TRAIN_SIDE=0: everything on the caller's stream; M2M_TRAIN_GRAPH=0: no graph replay)
+  { const char* v = getenv("M2M_TRAIN_SIDE"); t->use_side = !(v && v[0] == '0'); }
+  { const char* v = getenv("M2M_TRAIN_GRAPH"); t->use_graph = !(v && v[0] == '0'); }
+  if (t->use_side) {
+    hipError_t e = hipStreamCreateWithFlags(&t->s_main, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&t->s_side, hipStreamNonBlocking);
+    hipEvent_t* evs[] = {&t->ev_in, &t->ev_out, &t->ev_ready, &t->ev_free[0], &t->ev_free[1]};
+    for (hipEvent_t* ev : evs)
+      if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+    if (e != hipSuccess) { set_error("m2m_trainer_create: stream / event creation failed: %s", hipGetErrorString(e)); m2m_trainer_destroy(t); return M2M_ERR_HIP; }
+  }
   *out = t;
   return M2M_OK;
 }
 
 extern "C" void m2m_trainer_destroy(m2m_trainer* t) {
   if (!t) return;
+  (void)hipDeviceSynchronize();
+  drop_graph(t);
+  hipEvent_t evs[] = {t->ev_in, t->ev_out, t->ev_ready, t->ev_free[0], t->ev_free[1]};
+  for (hipEvent_t ev : evs)
+    if (ev) (void)hipEventDestroy(ev);
+  if (t->s_main) (void)hipStreamDestroy(t->s_main);
+  if (t->s_side) (void)hipStreamDestroy(t->s_side);
   if (t->arena) (void)hipFree(t->arena);
   if (t->af_mem) (void)hipFree(t->af_mem);
   delete t;
@@ -1777,6 +1871,46 @@ extern "C" int m2m_trainer_tensor_info(const m2m_trainer* t, int index, m2m_tens
   return M2M_OK;
 }
 
+namespace {
+
+// relative-position bucket tables of (S, L) on the device (host-built, uploaded synchronously: never inside a capture)
+int ensure_tables(m2m_trainer* t, int S, int L, hipStream_t st) {
+  const m2m_t5_geometry& g = t->g;
+  if (t->tab_S != S) {
+    const std::vector<int> eb = bucket_table(g, S, S, true);
+    M2M_CHECK_HIP(hipMemcpyAsync(t->ebucket, eb.data(), eb.size() * 4, hipMemcpyHostToDevice, st));
+    M2M_CHECK_HIP(hipStreamSynchronize(st));   // eb is a stack object
+    t->tab_S = S;
+  }
+  if (t->tab_L != L) {
+    const std::vector<int> db = bucket_table(g, L, L, false);
+    M2M_CHECK_HIP(hipMemcpyAsync(t->dbucket, db.data(), db.size() * 4, hipMemcpyHostToDevice, st));
+    M2M_CHECK_HIP(hipStreamSynchronize(st));
+    t->tab_L = L;
+  }
+  return M2M_OK;
+}
+
+int run_pass(m2m_trainer* t, const float* P, const float* x, const int64_t* cond, const int64_t* labels, int B, int S, int L, float* loss, float* G,
+             float* logits, hipStream_t st, hipStream_t side) {
+  return t->precision == M2M_PREC_BF16 ? forward_backward_t<bf16_t>(t, P, x, cond, labels, B, S, L, loss, G, logits, st, side)
+                                       : forward_backward_t<float>(t, P, x, cond, labels, B, S, L, loss, G, logits, st, side);
+}
+
+void drop_graph(m2m_trainer* t) {
+  if (t->gexec) { (void)hipGraphExecDestroy(t->gexec); t->gexec = nullptr; }
+  t->graph_key = m2m_trainer::GraphKey{};
+}
+
+}  // namespace
+
+// One forward (+ backward) pass.  Three ways to issue the same ~600 kernels, chosen here:
+//  * directly on the caller's stream (forward only, M2M_TRAIN_GRAPH=0 / M2M_TRAIN_SIDE=0, or the first call of a shape);
+//  * on the trainer's own two streams: the weight-gradient products of a sub-layer run beside the next sub-layer's
+//    gradient chain (they fill the CUs the small dX products leave idle);
+//  * as ONE captured HIP graph of those two streams, replayed from the second call with the same buffers and shapes on:
+//    inputs are staged into trainer-owned buffers first, so the graph never holds a caller pointer other than the flat
+//    parameter / gradient buffers (part of its key), and the dropout key advances on the device.
 extern "C" int m2m_train_forward_backward(m2m_trainer* t, const float* params_dev, const float* enc_inputs_dev, const int64_t* cond_idx_dev,
                                           const int64_t* labels_dev, int B, int S, int Ld, float* loss_out_dev, float* grads_dev,
                                           float* logits_out_dev, void* stream) {
@@ -1784,10 +1918,51 @@ extern "C" int m2m_train_forward_backward(m2m_trainer* t, const float* params_de
   M2M_REQUIRE(t->n_cond == 0 || cond_idx_dev, "m2m_train_forward_backward: cond_idx_dev is null");
   M2M_REQUIRE(B >= 1 && B <= t->max_batch && S > t->n_cond && S <= t->max_enc && Ld >= 1 && Ld <= t->max_dec,
               "m2m_train_forward_backward: (B=%d, S=%d, Ld=%d) outside the trainer's (%d, %d, %d)", B, S, Ld, t->max_batch, t->max_enc, t->max_dec);
-  hipStream_t st = (hipStream_t)stream;
-  return t->precision == M2M_PREC_BF16
-             ? forward_backward_t<bf16_t>(t, params_dev, enc_inputs_dev, cond_idx_dev, labels_dev, B, S, Ld, loss_out_dev, grads_dev, logits_out_dev, st)
-             : forward_backward_t<float>(t, params_dev, enc_inputs_dev, cond_idx_dev, labels_dev, B, S, Ld, loss_out_dev, grads_dev, logits_out_dev, st);
+  hipStream_t caller = (hipStream_t)stream;
+  int rc = ensure_tables(t, S, Ld, caller);
+  if (rc != M2M_OK) return rc;
+  const bool two = grads_dev && t->use_side && t->s_main && t->s_side;
+  if (!two) return run_pass(t, params_dev, enc_inputs_dev, cond_idx_dev, labels_dev, B, S, Ld, loss_out_dev, grads_dev, logits_out_dev, caller, nullptr);
+
+  // ---- stage the inputs (stream-ordered behind whatever produced them), then hand over to the trainer's streams ----
+  const m2m_t5_geometry& g = t->g;
+  M2M_CHECK_HIP(hipMemcpyAsync(t->xe[0], enc_inputs_dev, (size_t)B * S * g.d_model * 4, hipMemcpyDeviceToDevice, caller));
+  M2M_CHECK_HIP(hipMemcpyAsync(t->labels_buf, labels_dev, (size_t)B * Ld * 8, hipMemcpyDeviceToDevice, caller));
+  if (t->n_cond > 0) M2M_CHECK_HIP(hipMemcpyAsync(t->cond_buf, cond_idx_dev, (size_t)B * t->n_cond * 8, hipMemcpyDeviceToDevice, caller));
+  M2M_CHECK_HIP(hipEventRecord(t->ev_in, caller));
+  M2M_CHECK_HIP(hipStreamWaitEvent(t->s_main, t->ev_in, 0));
+
+  const m2m_trainer::GraphKey key{params_dev, grads_dev, B, S, Ld, t->drop_thresh, t->drop_seed};
+  const bool seen = key == t->last_key;
+  t->last_key = key;
+  if (t->use_graph && seen && !(t->gexec && key == t->graph_key)) {         // second call with this key: capture
+    drop_graph(t);
+    hipGraph_t graph = nullptr;
+    M2M_CHECK_HIP(hipStreamBeginCapture(t->s_main, hipStreamCaptureModeThreadLocal));
+    rc = run_pass(t, params_dev, t->xe[0], t->cond_buf, t->labels_buf, B, S, Ld, t->loss_dev, grads_dev, nullptr, t->s_main, t->s_side);
+    const hipError_t ce = hipStreamEndCapture(t->s_main, &graph);
+    if (rc != M2M_OK || ce != hipSuccess || !graph) {
+      if (graph) (void)hipGraphDestroy(graph);
+      if (rc == M2M_OK) { set_error("m2m_train_forward_backward: graph capture failed: %s", hipGetErrorString(ce)); rc = M2M_ERR_HIP; }
+      return rc;
+    }
+    const hipError_t ie = hipGraphInstantiate(&t->gexec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ie != hipSuccess) { t->gexec = nullptr; set_error("m2m_train_forward_backward: hipGraphInstantiate: %s", hipGetErrorString(ie)); return M2M_ERR_HIP; }
+    t->graph_key = key;
+  }
+  if (t->gexec && key == t->graph_key) {
+    M2M_CHECK_HIP(hipGraphLaunch(t->gexec, t->s_main));
+  } else {
+    rc = run_pass(t, params_dev, t->xe[0], t->cond_buf, t->labels_buf, B, S, Ld, t->loss_dev, grads_dev, nullptr, t->s_main, t->s_side);
+    if (rc != M2M_OK) return rc;
+  }
+  M2M_CHECK_HIP(hipEventRecord(t->ev_out, t->s_main));
+  M2M_CHECK_HIP(hipStreamWaitEvent(caller, t->ev_out, 0));
+  M2M_CHECK_HIP(hipMemcpyAsync(loss_out_dev, t->loss_dev, 4, hipMemcpyDeviceToDevice, caller));
+  if (logits_out_dev)
+    M2M_CHECK_HIP(hipMemcpyAsync(logits_out_dev, t->logits, (size_t)B * Ld * g.vocab_size * 4, hipMemcpyDeviceToDevice, caller));
+  return M2M_OK;
 }
 
 extern "C" int m2m_trainer_set_dropout(m2m_trainer* t, float p, uint64_t seed) {
@@ -1796,7 +1971,8 @@ extern "C" int m2m_trainer_set_dropout(m2m_trainer* t, float p, uint64_t seed) {
   t->drop_thresh = p > 0.f ? (uint32_t)((double)p * 4294967296.0) : 0u;
   t->drop_scale = 1.0f / (1.0f - p);
   t->drop_seed = seed;
-  t->fb_calls = 0;
+  M2M_CHECK_HIP(hipDeviceSynchronize());                               // nothing of an earlier pass still reads the counter
+  M2M_CHECK_HIP(hipMemset(t->step_ctr_dev, 0, 8));                     // the mask sequence restarts
   return M2M_OK;
 }
 
