@@ -511,6 +511,7 @@ int launch_cvt(int precision, const float* src, void* dst, int64_t n, hipStream_
 // One wave per row; P is written in T with the padding columns [Sk, ldp) zeroed (they are GEMM operand columns).
 // With dropout (hf: modeling_t5.py "attn_weights = dropout(attn_weights)") the kept-and-scaled copy Pd feeds the P.V product;
 // P itself is what the softmax backward needs.
+constexpr int SM_NR = 8;      // row elements per lane kept in registers (rows up to 512 keys)
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ sc, T* __restrict__ P, int rows_total, int H,
                                                           int Sq, int Sk, int ldp, const float* __restrict__ bias_tab,
@@ -525,6 +526,38 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restric
   T* p = P + (int64_t)row * ldp;
   const int kend = causal ? min(Sk, q + 1) : Sk;
   const float* bt = bias_tab ? bias_tab + (int64_t)hh * tab_stride + tab_center - q : nullptr;
+  if (ldp <= 64 * SM_NR) {
+    // rows of up to 512 keys (every shape of the model): the row lives in registers between the three passes — one read of
+    // the scores and one exponential per element instead of three reads and two exponentials; same values, same summation order
+    float v[SM_NR];
+    float mx = -1e30f;
+#pragma unroll
+    for (int u = 0; u < SM_NR; ++u) {
+      const int k = lane + 64 * u;
+      v[u] = k < kend ? s[k] + (bt ? bt[k] : 0.f) : -1e30f;
+      if (k < kend) mx = fmaxf(mx, v[u]);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int u = 0; u < SM_NR; ++u) {
+      const int k = lane + 64 * u;
+      v[u] = k < kend ? expf(v[u] - mx) : 0.f;
+      if (k < kend) sum += v[u];
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int u = 0; u < SM_NR; ++u) {
+      const int k = lane + 64 * u;
+      if (k < ldp) {
+        const T pt = from_f32<T>(v[u] * inv);
+        p[k] = pt;
+        if (Pd) Pd[(int64_t)row * ldp + k] = drop_keep(key, (int64_t)row * ldp + k, thresh) ? from_f32<T>(to_f32(pt) * scale) : from_f32<T>(0.f);
+      }
+    }
+    return;
+  }
   float mx = -1e30f;
   for (int k = lane; k < kend; k += 64) mx = fmaxf(mx, s[k] + (bt ? bt[k] : 0.f));
   mx = wave_max(mx);
@@ -561,11 +594,30 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* __restrict__ 
   T* ds = dS + (int64_t)row * ldp;
   // dP arrives for the DROPPED probabilities: through the mask first (thresh == 0: identity)
   auto dpe = [&](int k) { return thresh ? (drop_keep(key, (int64_t)row * ldp + k, thresh) ? dp[k] * scale : 0.f) : dp[k]; };
+  if (ldp <= 64 * SM_NR) {                 // P and dP of the row stay in registers between the two passes
+    float pv[SM_NR], dv[SM_NR];
+    float t = 0.f;
+#pragma unroll
+    for (int u = 0; u < SM_NR; ++u) {
+      const int k = lane + 64 * u;
+      pv[u] = k < Sk ? to_f32(p[k]) : 0.f;
+      dv[u] = k < Sk ? dpe(k) : 0.f;
+      if (k < Sk) t += pv[u] * dv[u];
+    }
+    t = wave_sum(t);
+#pragma unroll
+    for (int u = 0; u < SM_NR; ++u) {
+      const int k = lane + 64 * u;
+      if (k < ldp) ds[k] = from_f32<T>(k < Sk ? pv[u] * (dv[u] - t) : 0.f);
+    }
+    return;
+  }
   float t = 0.f;
   for (int k = lane; k < Sk; k += 64) t += to_f32(p[k]) * dpe(k);
   t = wave_sum(t);
   for (int k = lane; k < ldp; k += 64) ds[k] = from_f32<T>(k < Sk ? to_f32(p[k]) * (dpe(k) - t) : 0.f);
 }
+
 
 // relative-position-bias gradient.  Stage 1: one block per (clip, head): part[b][h][rel] = sum over the diagonal
 // key - query = rel - (Sq-1) of dS[b,h,q,k]; consecutive threads take consecutive diagonals, so every pass over q reads

@@ -86,8 +86,8 @@ __global__ __launch_bounds__(256) void persistent(Args a) {
         sacc.x += v.x; sacc.y += v.y; sacc.z += v.z; sacc.w += v.w;
       }
     }
-    // publish this member's partial row: value (ph * 8 + member) + col * 2^-10 (exact in fp32)
-    for (int c = threadIdx.x; c < D; c += blockDim.x) st_f32<S>(gpart + member * D + c, (float)(ph * 8 + member) + c * 0.0009765625f);
+    // publish this member's partial row: small integers (every partial sum below is exact in fp32)
+    for (int c = threadIdx.x; c < D; c += blockDim.x) st_f32<S>(gpart + member * D + c, (float)(ph * 8 + member + (c & 3)));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void persistent(Args a) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       float s = 0.f;
       for (int m = 0; m < MEMBERS; ++m) s += v[m];
-      const float want = (float)(ph * 64 + 28) + 8.f * (c * 0.0009765625f);
+      const float want = (float)(ph * 64 + 28 + 8 * (c & 3));
       if (s != want && !s_dead) a.err[1] = 1;
       acc += s;
     }
