@@ -273,3 +273,40 @@ def test_fp8_mode_matches_the_mx_emulating_oracle(cfg_name, B, F, Ld):
             tr.optimizer_step()
             l, _ = tr.forward_backward(x.cuda(), cond.cuda(), labels.cuda())
         assert l.item() < loss0 - 0.05, (loss0, l.item())
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_graph_replay_equals_direct_issue(precision, monkeypatch):
+    """The captured HIP graph of the step (second call with the same buffers and shapes onwards) must be the direct issue
+    bit for bit — fresh inputs every call, dropout on (the mask sequence advances on the device) — and the one grouped
+    weight-gradient launch must agree with the classic per-product split-K path to fp32 rounding."""
+    from music2midi_amd.training import NativeTrainer
+    B, F, Ld = 3, 21, 14
+    model, tr_graph, orc, params, geom, x, feats, cond, labels = _setup(tiny_config(), precision, B, F, Ld)
+    monkeypatch.setenv("M2M_TRAIN_GRAPH", "0")
+    tr_direct = NativeTrainer(model, B, F + 2, Ld, precision=precision)        # adopts the same parameter values
+    monkeypatch.setenv("M2M_TRAIN_DW_GROUP", "0")
+    monkeypatch.setenv("M2M_TRAIN_SIDE", "0")
+    tr_serial = NativeTrainer(model, B, F + 2, Ld, precision=precision)
+    for tr in (tr_graph, tr_direct, tr_serial):
+        tr.set_dropout(0.1, seed=77)
+    worst = 0.0
+    for call in range(5):                                                        # calls 1.. of tr_graph replay the graph
+        xi = (x + 0.01 * call * torch.from_numpy(synth.normal(40 + call, "dx", tuple(x.shape), 1.0))).cuda()
+        lab = labels.clone()
+        lab[0, call % Ld] = 5 + call
+        outs = []
+        for tr in (tr_graph, tr_direct, tr_serial):
+            loss, _ = tr.forward_backward(xi, cond.cuda(), lab.cuda())
+            outs.append((loss.item(), tr.grads.clone()))
+        assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1]), f"call {call}: graph replay differs from direct issue"
+        assert abs(outs[0][0] - outs[2][0]) <= 1e-6 * abs(outs[2][0])
+        tol = 1e-5 if precision == "fp32" else 1e-4
+        worst = max(worst, _rel(outs[0][1], outs[2][1]))
+        assert worst < tol, (call, worst)
+        if call:
+            assert outs[0][0] != first_loss                                      # inputs and masks did change
+        first_loss = outs[0][0]
+    print(f"{precision}: graph == direct over 5 calls; grouped vs split-K weight gradients {worst:.2e}")
+    for tr in (tr_graph, tr_direct, tr_serial):
+        tr.close()
