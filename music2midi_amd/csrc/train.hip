@@ -572,6 +572,217 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restric
     if (Pd) Pd[(int64_t)row * ldp + k] = drop_keep(key, (int64_t)row * ldp + k, thresh) ? from_f32<T>(to_f32(pt) * scale) : from_f32<T>(0.f);
   }
 }
+// ---- attention stripes: scores -> probabilities (forward) and dP -> dS (backward) WITHOUT the fp32 [Sq, Sk] image ----
+// Training sequences are short (S, L <= 320 here), so one wave can hold a whole stripe of 32 queries x all keys in MFMA
+// accumulators: T^T = X . Y^T with the KEYS as tile rows (X = K or V, [Sk, 64]) and the QUERIES as tile columns
+// (Y = Q or dO), so a lane owns ONE query (column l & 31) and its row reductions are in-lane plus one exchange with lane ^ 32
+// (the orientation of the inference flash kernel).  Forward: + T5 bias (per-head row of the (key - query) table, staged in
+// LDS), causal mask, softmax, P (and its dropped copy) written in T.  Backward: dP = V . dO^T, dS = P o (dP~ - sum P o dP~)
+// with dP~ the dropout-masked dP.  Replaces a batched GEMM that wrote the fp32 image + a row kernel that read it back
+// (35 MB each way per call at 16 clips): 15.6 + 25.7 us -> one launch (forward), 15.6 + 18 us -> one launch (backward).
+struct StripeArgs {
+  const void *X, *Y;                 // (key, d) at X + b*sX1 + h*sX2 + key*ldx + d;  (query, d) at Y + b*sY1 + h*sY2 + q*ldy + d
+  int64_t ldx, sX1, sX2, ldy, sY1, sY2;
+  void* P;                           // [nB*H][Sq][ldp] T: forward out / backward in
+  void* Pd;                          // forward: dropped copy of P, or null
+  void* dS;                          // backward out
+  const float* bias_tab;             // forward, self-attention: [H][tab_stride] by (key - query + tab_center); null: no bias
+  int tab_stride, tab_center;
+  int H, Sq, Sk, ldp, causal;
+  DropKey dk;
+  uint32_t thresh;
+  float scale;
+};
+constexpr int ST_NT = 16;            // key tiles per stripe: Sk <= 512 (the X operand of a (clip, head) is staged in LDS)
+// softmax exponential: accurate in the fp32 (parity) mode; multiply + v_exp_f32 where the result is rounded to bf16
+template <typename T> __device__ inline float m2m_exp_t(float x) {
+  if constexpr (sizeof(T) == 2) return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
+  else return expf(x);
+}
+
+template <typename T> __device__ inline void st_store4(T* p, float a, float b, float c, float d);
+template <> __device__ inline void st_store4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(pack2_bf16(a, b), pack2_bf16(c, d));
+}
+template <> __device__ inline void st_store4<float>(float* p, float a, float b, float c, float d) { *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d); }
+template <typename T> __device__ inline float4 st_load4(const T* p);
+template <> __device__ inline float4 st_load4<bf16_t>(const bf16_t* p) {
+  const uint2 v = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xFFFF0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xFFFF0000u));
+}
+template <> __device__ inline float4 st_load4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void attn_stripe_kernel(StripeArgs a) {
+  // LDS: [this head's bias row (forward with bias)] [X = the (clip, head)'s K or V, rows padded to the tile count, pitch 64 + E]:
+  // the four waves (128 queries) share it — read straight from memory, every key tile was a dependent round trip at the
+  // one wave per SIMD this kernel's accumulators allow (37 us per launch).
+  extern __shared__ __align__(16) unsigned char st_smem[];
+  constexpr int E = 16 / sizeof(T), XP = DK + E;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h2 = lane >> 5;
+  const int bh = blockIdx.y, b = bh / a.H, hh = bh - b * a.H;
+  const int q0 = blockIdx.x * 32;                    // all four waves work on the SAME 32 queries, wave w on key tiles w, w + 4, ...
+  __shared__ float red_a[4][32], red_b[4][32];       // per-wave partial row statistics
+  const bool has_bias = !BWD && a.bias_tab != nullptr;
+  float* st_bias = reinterpret_cast<float*>(st_smem);
+  T* xs = reinterpret_cast<T*>(st_smem + (has_bias ? ((size_t)a.tab_stride * 4 + 15) / 16 * 16 : 0));
+  const int nt = (a.Sk + 31) >> 5;
+  const T* X = reinterpret_cast<const T*>(a.X) + b * a.sX1 + hh * a.sX2;
+  {
+    constexpr int CPR = DK / E;
+    for (int c = threadIdx.x; c < nt * 32 * CPR; c += 256) {
+      const int row = c / CPR, col = (c % CPR) * E;
+      *reinterpret_cast<uint4*>(xs + row * XP + col) =
+          row < a.Sk ? *reinterpret_cast<const uint4*>(X + (int64_t)row * a.ldx + col) : make_uint4(0, 0, 0, 0);
+    }
+    if (has_bias)
+      for (int i = threadIdx.x; i < a.tab_stride; i += 256) st_bias[i] = a.bias_tab[(int64_t)hh * a.tab_stride + i];
+  }
+  __syncthreads();
+  const int q = q0 + r, qc = min(q, a.Sq - 1);
+  const T* Y = reinterpret_cast<const T*>(a.Y) + b * a.sY1 + hh * a.sY2;
+  Frag<T> yf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) yf[s] = load_frag(Y + (int64_t)qc * a.ldy + 16 * s + 8 * h2);
+  // One key tile at a time, the tile product RECOMPUTED in the second pass (4 MFMAs from LDS: cheaper than keeping ten
+  // accumulator tiles alive — that form needed 368 registers, one wave per SIMD, every accumulator moved through AGPRs).
+  // element i of a tile: key 32 kt + (i & 3) + 8 (i >> 2) + 4 h2, query q (this lane's column)
+  auto tile = [&](int kt) {
+    f32x16 acc = zero_acc();
+    const T* xr = xs + (kt * 32 + r) * XP + 8 * h2;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) mma16(acc, load_frag(xr + 16 * s), yf[s]);
+    return acc;
+  };
+  const int kend = BWD ? a.Sk : (a.causal ? min(a.Sk, q + 1) : a.Sk);
+  const int64_t prow = ((int64_t)bh * a.Sq + qc) * a.ldp;
+  const uint64_t key = a.thresh ? drop_site_key(a.dk) : 0ull;
+  if constexpr (!BWD) {
+    const float* bt = st_bias + a.tab_center - qc;
+    // pass 1: running (max, sum) of this lane's half of the keys
+    float m = -1e30f, l = 0.f;
+    for (int kt = wave; kt < nt; kt += 4) {
+      f32x16 acc = tile(kt);
+      float tm = -1e30f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int k = kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h2;
+        float v = acc[i];
+        if (has_bias) v += bt[min(k, a.Sk - 1)];
+        v = k < kend ? v : -1e30f;
+        acc[i] = v;
+        tm = fmaxf(tm, v);
+      }
+      const float mn = fmaxf(m, tm);
+      float ts = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) ts += acc[i] > -1e29f ? m2m_exp_t<T>(acc[i] - mn) : 0.f;
+      l = l * m2m_exp_t<T>(m - mn) + ts;
+      m = mn;
+    }
+    {
+      const float mo = lane_xor<32>(m), lo = lane_xor<32>(l);
+      const float mt = fmaxf(m, mo);
+      l = l * m2m_exp_t<T>(m - mt) + lo * m2m_exp_t<T>(mo - mt);
+      m = mt;
+    }
+    if (h2 == 0) { red_a[wave][r] = m; red_b[wave][r] = l; }
+    __syncthreads();
+    {                                                // the four waves' (max, sum) of this query, fixed order
+      const float m0 = red_a[0][r], m1 = red_a[1][r], m2 = red_a[2][r], m3 = red_a[3][r];
+      m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+      l = red_b[0][r] * m2m_exp_t<T>(m0 - m) + red_b[1][r] * m2m_exp_t<T>(m1 - m) + red_b[2][r] * m2m_exp_t<T>(m2 - m) + red_b[3][r] * m2m_exp_t<T>(m3 - m);
+    }
+    const float inv = 1.0f / l;
+    // pass 2: probabilities
+    T* prw = reinterpret_cast<T*>(a.P) + prow;
+    T* pdw = a.Pd ? reinterpret_cast<T*>(a.Pd) + prow : nullptr;
+    for (int kt = wave; kt < nt; kt += 4) {
+      const f32x16 acc = tile(kt);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int k0 = kt * 32 + 8 * g + 4 * h2;
+        float pv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k = k0 + e;
+          float v = acc[4 * g + e];
+          if (has_bias) v += bt[min(k, a.Sk - 1)];
+          pv[e] = k < kend ? to_f32(from_f32<T>(m2m_exp_t<T>(v - m) * inv)) : 0.f;
+        }
+        if (q < a.Sq && k0 < a.ldp) {                // ldp is a multiple of 8: the 4 keys are inside the row; keys >= kend are zeros
+          st_store4<T>(prw + k0, pv[0], pv[1], pv[2], pv[3]);
+          if (pdw) {
+            float dv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dv[e] = drop_keep(key, prow + k0 + e, a.thresh) ? pv[e] * a.scale : 0.f;
+            st_store4<T>(pdw + k0, dv[0], dv[1], dv[2], dv[3]);
+          }
+        }
+      }
+    }
+  } else {
+    const T* prd = reinterpret_cast<const T*>(a.P) + prow;
+    auto masked = [&](float dp, int k) {             // dP arrives for the DROPPED probabilities: through the mask first
+      if (a.thresh) dp = drop_keep(key, prow + k, a.thresh) ? dp * a.scale : 0.f;
+      return k < a.Sk ? dp : 0.f;
+    };
+    // pass 1: t = sum_k P dP~
+    float t = 0.f;
+    for (int kt = wave; kt < nt; kt += 4) {
+      const f32x16 acc = tile(kt);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int k0 = kt * 32 + 8 * g + 4 * h2;
+        float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k0 < a.ldp) pv = st_load4<T>(prd + k0);
+        const float pe[4] = {pv.x, pv.y, pv.z, pv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t += (k0 + e < a.Sk ? pe[e] : 0.f) * masked(acc[4 * g + e], k0 + e);
+      }
+    }
+    t += lane_xor<32>(t);
+    if (h2 == 0) red_a[wave][r] = t;
+    __syncthreads();
+    t = (red_a[0][r] + red_a[1][r]) + (red_a[2][r] + red_a[3][r]);
+    // pass 2: dS = P (dP~ - t)
+    T* dsw = reinterpret_cast<T*>(a.dS) + prow;
+    for (int kt = wave; kt < nt; kt += 4) {
+      const f32x16 acc = tile(kt);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int k0 = kt * 32 + 8 * g + 4 * h2;
+        if (q < a.Sq && k0 < a.ldp) {
+          const float4 pv = st_load4<T>(prd + k0);
+          const float pe[4] = {pv.x, pv.y, pv.z, pv.w};
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (k0 + e < a.Sk) ? pe[e] * (masked(acc[4 * g + e], k0 + e) - t) : 0.f;
+          st_store4<T>(dsw + k0, o[0], o[1], o[2], o[3]);
+        }
+      }
+    }
+  }
+}
+
+template <typename T>
+static int launch_attn_stripe(bool bwd, const StripeArgs& a, int nB, hipStream_t st) {
+  dim3 grid((unsigned)ceil_div(a.Sq, 32), (unsigned)(nB * a.H));
+  constexpr int E = 16 / sizeof(T);
+  const size_t bias_bytes = (!bwd && a.bias_tab) ? ((size_t)a.tab_stride * 4 + 15) / 16 * 16 : 0;
+  const size_t smem = bias_bytes + (size_t)ceil_div(a.Sk, 32) * 32 * (DK + E) * sizeof(T);
+  if (bwd) {
+    M2M_OPT_IN_LDS((attn_stripe_kernel<T, true>), 158 * 1024);    // + 1 KB of static LDS (the per-wave row statistics)
+    hipLaunchKernelGGL((attn_stripe_kernel<T, true>), grid, dim3(256), smem, st, a);
+  } else {
+    M2M_OPT_IN_LDS((attn_stripe_kernel<T, false>), 158 * 1024);
+    hipLaunchKernelGGL((attn_stripe_kernel<T, false>), grid, dim3(256), smem, st, a);
+  }
+  M2M_CHECK_HIP(hipGetLastError());
+  return M2M_OK;
+}
+
 // Pd = dropout(P) again (backward: the dV product needs it, it was a scratch buffer in the forward)
 template <typename T>
 __global__ void drop_copy_kernel(const T* __restrict__ P, T* __restrict__ Pd, int64_t n, DropKey dk, uint32_t thresh, float scale) {
@@ -1643,6 +1854,32 @@ struct Ops {
     M2M_CHECK_HIP(hipGetLastError());
     return M2M_OK;
   }
+  // Fused scores + softmax (attn_stripe_kernel) when a wave can hold all keys; K = (key, d) operand, Q = (query, d) operand.
+  static bool stripes_on() { static const bool on = [] { const char* v = getenv("M2M_TRAIN_STRIPES"); return !(v && v[0] == '0'); }(); return on; }
+  bool stripe_ok(int Sk) const {          // all keys of a (clip, head) in LDS beside the bias row
+    return stripes_on() && Sk <= 32 * ST_NT && (size_t)ceil_div(Sk, 32) * 32 * (DK + 16 / sizeof(T)) * sizeof(T) + 16384 <= 158 * 1024;
+  }
+  int attn_probs(const T* K, int64_t ldk, int64_t sK1, int64_t sK2, const T* Q, int64_t ldq, int64_t sQ1, int64_t sQ2, void* Pm, int nB, int Sq, int Sk,
+            int ldp, const float* tab, int causal, int site, const T** Puse) const {
+    const bool dr = dropping(site);
+    StripeArgs a{};
+    a.X = K; a.ldx = ldk; a.sX1 = sK1; a.sX2 = sK2; a.Y = Q; a.ldy = ldq; a.sY1 = sQ1; a.sY2 = sQ2;
+    a.P = Pm; a.Pd = dr ? t->dS : nullptr; a.bias_tab = tab; a.tab_stride = Sq + Sk - 1; a.tab_center = Sq - 1;
+    a.H = t->g.num_heads; a.Sq = Sq; a.Sk = Sk; a.ldp = ldp; a.causal = causal;
+    a.dk = dr ? key(site) : DropKey{nullptr, 0}; a.thresh = dr ? t->drop_thresh : 0u; a.scale = t->drop_scale;
+    *Puse = dr ? (const T*)t->dS : (const T*)Pm;
+    return launch_attn_stripe<T>(false, a, nB, st);
+  }
+  // Fused dP + softmax backward: V = (key, d) operand, dO = (query, d) operand; dS out
+  int dscores(const T* V, int64_t ldv, int64_t sV1, int64_t sV2, const T* dO, int64_t ldo, int64_t sO1, int64_t sO2, const void* Pm, void* dS, int nB,
+              int Sq, int Sk, int ldp, int site) const {
+    const bool dr = dropping(site);
+    StripeArgs a{};
+    a.X = V; a.ldx = ldv; a.sX1 = sV1; a.sX2 = sV2; a.Y = dO; a.ldy = ldo; a.sY1 = sO1; a.sY2 = sO2;
+    a.P = const_cast<void*>(Pm); a.dS = dS; a.H = t->g.num_heads; a.Sq = Sq; a.Sk = Sk; a.ldp = ldp;
+    a.dk = dr ? key(site) : DropKey{nullptr, 0}; a.thresh = dr ? t->drop_thresh : 0u; a.scale = t->drop_scale;
+    return launch_attn_stripe<T>(true, a, nB, st);
+  }
   // P (kept for the backward) and, with dropout, the dropped copy the P.V product reads (scratch: t->dS); returns it through *Puse
   int softmax(const float* sc, void* Pm, int nB, int Sq, int Sk, int ldp, const float* tab, int causal, int site, const T** Puse) const {
     const int H = t->g.num_heads, rows = nB * H * Sq;
@@ -1709,10 +1946,15 @@ int attn_self_fwd(const Ops<T>& o, const float* x_in, float* x_out, int64_t ln, 
   RC(o.norm(x_in, ln, h, M));
   RC(o.mm(TG_STORE_T, h, d, 0, o.W(wqkv), d, 0, qkv, 3 * inner, M, 3 * inner, d));
   const T* q = (const T*)qkv;
-  RC(o.mmbh(TG_STORE_F32, q, 3 * inner, 0, (int64_t)S * 3 * inner, DK, q + inner, 3 * inner, 0, (int64_t)S * 3 * inner, DK, t->sc, ldp,
-            (int64_t)H * S * ldp, (int64_t)S * ldp, nB, S, S, DK));
   const T* Pu;
-  RC(o.softmax(t->sc, Pm, nB, S, S, ldp, tab, causal, site0 + PL_PROBS_SELF, &Pu));
+  if (o.stripe_ok(S)) {
+    RC(o.attn_probs(q + inner, 3 * inner, (int64_t)S * 3 * inner, DK, q, 3 * inner, (int64_t)S * 3 * inner, DK, Pm, nB, S, S, ldp, tab, causal,
+               site0 + PL_PROBS_SELF, &Pu));
+  } else {
+    RC(o.mmbh(TG_STORE_F32, q, 3 * inner, 0, (int64_t)S * 3 * inner, DK, q + inner, 3 * inner, 0, (int64_t)S * 3 * inner, DK, t->sc, ldp,
+              (int64_t)H * S * ldp, (int64_t)S * ldp, nB, S, S, DK));
+    RC(o.softmax(t->sc, Pm, nB, S, S, ldp, tab, causal, site0 + PL_PROBS_SELF, &Pu));
+  }
   RC(o.mmbh(TG_STORE_T, Pu, ldp, 0, (int64_t)H * S * ldp, (int64_t)S * ldp, q + 2 * inner, 3 * inner, 1, (int64_t)S * 3 * inner, DK, ao,
             inner, (int64_t)S * inner, DK, nB, S, DK, S));
   RC(o.mm(TG_RESID_F32, ao, inner, 0, o.W(wo), inner, 0, x_out, d, M, d, inner, x_in, site0 + PL_SELF_OUT));
@@ -1738,8 +1980,12 @@ int attn_self_bwd(const Ops<T>& o, const float* x_in, const float* dx_out, float
   const T* Pu;
   RC(o.redrop(Pm, (int64_t)nB * H * S * ldp, site0 + PL_PROBS_SELF, &Pu));
   RC(o.mmbh(TG_STORE_T, Pu, ldp, 1, sP1, sP2, dO, inner, 1, sO1, DK, dq + 2 * inner, 3 * inner, sQ1, DK, nB, S, DK, S));             // dV = Pd^T dO
-  RC(o.mmbh(TG_STORE_F32, dO, inner, 0, sO1, DK, q + 2 * inner, 3 * inner, 0, sQ1, DK, t->sc, ldp, sP1, sP2, nB, S, S, DK));        // dPd = dO V^T
-  RC(o.softmax_bwd(Pm, t->sc, t->dS, nB * H * S, S, ldp, site0 + PL_PROBS_SELF));
+  if (o.stripe_ok(S)) {
+    RC(o.dscores(q + 2 * inner, 3 * inner, sQ1, DK, dO, inner, sO1, DK, Pm, t->dS, nB, S, S, ldp, site0 + PL_PROBS_SELF));       // dS from dPd = dO V^T
+  } else {
+    RC(o.mmbh(TG_STORE_F32, dO, inner, 0, sO1, DK, q + 2 * inner, 3 * inner, 0, sQ1, DK, t->sc, ldp, sP1, sP2, nB, S, S, DK));      // dPd = dO V^T
+    RC(o.softmax_bwd(Pm, t->sc, t->dS, nB * H * S, S, ldp, site0 + PL_PROBS_SELF));
+  }
   if (buckets) RC(o.bias_grad(t->dS, buckets, G + bias_off, nB, S, S, ldp, bias_accumulate));
   const T* dS = (const T*)t->dS;
   RC(o.mmbh(TG_STORE_T, dS, ldp, 0, sP1, sP2, q + inner, 3 * inner, 1, sQ1, DK, dq, 3 * inner, sQ1, DK, nB, S, DK, S));              // dQ = dS K
@@ -1843,9 +2089,14 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
     RC(o.mm(TG_STORE_T, t->hE, d, 0, o.W(e.ckv), d, 0, t->ckvd[l], 2 * inner, Me, 2 * inner, d));
     const T* cq = (const T*)t->cqd[l];
     const T* ckv = (const T*)t->ckvd[l];
-    RC(o.mmbh(TG_STORE_F32, cq, inner, 0, (int64_t)L * inner, DK, ckv, 2 * inner, 0, (int64_t)S * 2 * inner, DK, t->sc, lps, sPc1, sPc2, B, L, S, DK));
     const T* Pu;
-    RC(o.softmax(t->sc, t->Pcd[l], B, L, S, lps, nullptr, 0, SITE_DEC + 16 * l + PL_PROBS_CROSS, &Pu));
+    if (o.stripe_ok(S)) {
+      RC(o.attn_probs(ckv, 2 * inner, (int64_t)S * 2 * inner, DK, cq, inner, (int64_t)L * inner, DK, t->Pcd[l], B, L, S, lps, nullptr, 0,
+                 SITE_DEC + 16 * l + PL_PROBS_CROSS, &Pu));
+    } else {
+      RC(o.mmbh(TG_STORE_F32, cq, inner, 0, (int64_t)L * inner, DK, ckv, 2 * inner, 0, (int64_t)S * 2 * inner, DK, t->sc, lps, sPc1, sPc2, B, L, S, DK));
+      RC(o.softmax(t->sc, t->Pcd[l], B, L, S, lps, nullptr, 0, SITE_DEC + 16 * l + PL_PROBS_CROSS, &Pu));
+    }
     RC(o.mmbh(TG_STORE_T, Pu, lps, 0, sPc1, sPc2, ckv + inner, 2 * inner, 1, (int64_t)S * 2 * inner, DK, t->aocd[l], inner,
               (int64_t)L * inner, DK, B, L, DK, S));
     RC(o.mm(TG_RESID_F32, t->aocd[l], inner, 0, o.W(e.co), inner, 0, t->xd[3 * l + 2], d, Md, d, inner, t->xd[3 * l + 1],
@@ -1890,8 +2141,12 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
     const T* Pu;
     RC(o.redrop(t->Pcd[l], (int64_t)B * H * L * lps, SITE_DEC + 16 * l + PL_PROBS_CROSS, &Pu));
     RC(o.mmbh(TG_STORE_T, Pu, lps, 1, sPc1, sPc2, dO, inner, 1, sQ1, DK, dckv + inner, 2 * inner, sK1, DK, B, S, DK, L));                   // dV = Pd^T dO
-    RC(o.mmbh(TG_STORE_F32, dO, inner, 0, sQ1, DK, ckv + inner, 2 * inner, 0, sK1, DK, t->sc, lps, sPc1, sPc2, B, L, S, DK));               // dPd = dO V^T
-    RC(o.softmax_bwd(t->Pcd[l], t->sc, t->dS, B * H * L, S, lps, SITE_DEC + 16 * l + PL_PROBS_CROSS));
+    if (o.stripe_ok(S)) {
+      RC(o.dscores(ckv + inner, 2 * inner, sK1, DK, dO, inner, sQ1, DK, t->Pcd[l], t->dS, B, L, S, lps, SITE_DEC + 16 * l + PL_PROBS_CROSS));
+    } else {
+      RC(o.mmbh(TG_STORE_F32, dO, inner, 0, sQ1, DK, ckv + inner, 2 * inner, 0, sK1, DK, t->sc, lps, sPc1, sPc2, B, L, S, DK));             // dPd = dO V^T
+      RC(o.softmax_bwd(t->Pcd[l], t->sc, t->dS, B * H * L, S, lps, SITE_DEC + 16 * l + PL_PROBS_CROSS));
+    }
     const T* dS = (const T*)t->dS;
     RC(o.mmbh(TG_STORE_T, dS, lps, 0, sPc1, sPc2, ckv, 2 * inner, 1, sK1, DK, dcq, inner, sQ1, DK, B, L, DK, S));                            // dQ = dS K
     RC(o.mmbh(TG_STORE_T, dS, lps, 1, sPc1, sPc2, cq, inner, 1, sQ1, DK, dckv, 2 * inner, sK1, DK, B, S, DK, L));                            // dK = dS^T Q
