@@ -612,64 +612,92 @@ template <> __device__ inline float4 st_load4<bf16_t>(const bf16_t* p) {
 }
 template <> __device__ inline float4 st_load4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-template <typename T, bool BWD>
+template <typename T, bool BWD, bool DROP, bool BIAS>
 __global__ __launch_bounds__(256) void attn_stripe_kernel(StripeArgs a) {
-  // LDS: [this head's bias row (forward with bias)] [X = the (clip, head)'s K or V, rows padded to the tile count, pitch 64 + E]:
-  // the four waves (128 queries) share it — read straight from memory, every key tile was a dependent round trip at the
-  // one wave per SIMD this kernel's accumulators allow (37 us per launch).
+  // A workgroup = 32 queries of one (clip, head); its four waves split the key tiles (wave w: tiles w, w + 4, ...), so the
+  // dependent chain of a wave is at most ST_NT / 4 tiles per pass and a 16-clip launch has > 1 000 workgroups.  Operand
+  // fragments come straight from memory, all of a wave's loads in flight at once (bf16: kept in registers for both passes);
+  // LDS holds only this head's bias row and the per-wave row statistics.  (First forms: all tiles' accumulators alive in
+  // one wave — 368 registers, 37 us per launch; K / V staged in LDS for 128 queries per workgroup — 25 us.)
   extern __shared__ __align__(16) unsigned char st_smem[];
-  constexpr int E = 16 / sizeof(T), XP = DK + E;
+  constexpr int TPW = ST_NT / 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h2 = lane >> 5;
   const int bh = blockIdx.y, b = bh / a.H, hh = bh - b * a.H;
-  const int q0 = blockIdx.x * 32;                    // all four waves work on the SAME 32 queries, wave w on key tiles w, w + 4, ...
+  const int q0 = blockIdx.x * 32;
   __shared__ float red_a[4][32], red_b[4][32];       // per-wave partial row statistics
-  const bool has_bias = !BWD && a.bias_tab != nullptr;
+  constexpr bool has_bias = !BWD && BIAS;
   float* st_bias = reinterpret_cast<float*>(st_smem);
-  T* xs = reinterpret_cast<T*>(st_smem + (has_bias ? ((size_t)a.tab_stride * 4 + 15) / 16 * 16 : 0));
   const int nt = (a.Sk + 31) >> 5;
-  const T* X = reinterpret_cast<const T*>(a.X) + b * a.sX1 + hh * a.sX2;
-  {
-    constexpr int CPR = DK / E;
-    for (int c = threadIdx.x; c < nt * 32 * CPR; c += 256) {
-      const int row = c / CPR, col = (c % CPR) * E;
-      *reinterpret_cast<uint4*>(xs + row * XP + col) =
-          row < a.Sk ? *reinterpret_cast<const uint4*>(X + (int64_t)row * a.ldx + col) : make_uint4(0, 0, 0, 0);
-    }
-    if (has_bias)
-      for (int i = threadIdx.x; i < a.tab_stride; i += 256) st_bias[i] = a.bias_tab[(int64_t)hh * a.tab_stride + i];
-  }
-  __syncthreads();
+  // row staging: the 32 x ldp block of P / dS this workgroup produces (or consumes) goes through LDS, so memory sees whole
+  // rows in 16-byte chunks instead of 8-byte pieces of 32 different rows per store (forward 18.7 -> us, backward 25.3 -> us)
+  const int LP = nt * 32 + 16 / (int)sizeof(T);                                   // row pitch, elements
+  T* pl = reinterpret_cast<T*>(st_smem + (has_bias ? ((size_t)(a.tab_stride + 32) * 4 + 15) / 16 * 16 : 0));
+  T* pl2 = pl + 32 * LP;                                                          // forward with dropout: the dropped copy
   const int q = q0 + r, qc = min(q, a.Sq - 1);
+  const T* X = reinterpret_cast<const T*>(a.X) + b * a.sX1 + hh * a.sX2;
   const T* Y = reinterpret_cast<const T*>(a.Y) + b * a.sY1 + hh * a.sY2;
   Frag<T> yf[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) yf[s] = load_frag(Y + (int64_t)qc * a.ldy + 16 * s + 8 * h2);
-  // One key tile at a time, the tile product RECOMPUTED in the second pass (4 MFMAs from LDS: cheaper than keeping ten
-  // accumulator tiles alive — that form needed 368 registers, one wave per SIMD, every accumulator moved through AGPRs).
-  // element i of a tile: key 32 kt + (i & 3) + 8 (i >> 2) + 4 h2, query q (this lane's column)
-  auto tile = [&](int kt) {
-    f32x16 acc = zero_acc();
-    const T* xr = xs + (kt * 32 + r) * XP + 8 * h2;
+  constexpr bool KEEP = sizeof(T) == 2;              // fp32 fragments are twice the registers: reloaded per pass instead
+  Frag<T> xf[KEEP ? TPW : 1][4];
+  if constexpr (KEEP) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) mma16(acc, load_frag(xr + 16 * s), yf[s]);
+    for (int j = 0; j < TPW; ++j) {
+      const T* xr = X + (int64_t)min((wave + 4 * j) * 32 + r, a.Sk - 1) * a.ldx + 8 * h2;      // clamped: keys >= Sk are masked below
+#pragma unroll
+      for (int s = 0; s < 4; ++s) xf[j][s] = load_frag(xr + 16 * s);
+    }
+  }
+  constexpr int EC = 16 / sizeof(T);
+  const int cpr = a.ldp / EC;                        // 16-byte chunks per row (ldp is a multiple of 8)
+  const int64_t blk = ((int64_t)bh * a.Sq + q0) * a.ldp;
+  if constexpr (BWD) {                               // P rows -> LDS (read twice below), coalesced
+    const T* src = reinterpret_cast<const T*>(a.P) + blk;
+    for (int c = threadIdx.x; c < 32 * cpr; c += 256) {
+      const int row = c / cpr, col = (c - row * cpr) * EC;
+      *reinterpret_cast<uint4*>(pl + row * LP + col) =
+          q0 + row < a.Sq ? *reinterpret_cast<const uint4*>(src + (int64_t)row * a.ldp + col) : make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  if (has_bias) {
+    for (int i = threadIdx.x; i < a.tab_stride + 32; i += 256) st_bias[i] = i < a.tab_stride ? a.bias_tab[(int64_t)hh * a.tab_stride + i] : 0.f;
+    __syncthreads();
+  }
+  // element i of a tile: key 32 kt + (i & 3) + 8 (i >> 2) + 4 h2, query q (this lane's column); the tile product is
+  // RECOMPUTED in the second pass (4 MFMAs) instead of being kept
+  auto tile = [&](int j) {
+    f32x16 acc = zero_acc();
+    if constexpr (KEEP) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) mma16(acc, xf[j][s], yf[s]);
+    } else {
+      const T* xr = X + (int64_t)min((wave + 4 * j) * 32 + r, a.Sk - 1) * a.ldx + 8 * h2;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) mma16(acc, load_frag(xr + 16 * s), yf[s]);
+    }
     return acc;
   };
   const int kend = BWD ? a.Sk : (a.causal ? min(a.Sk, q + 1) : a.Sk);
   const int64_t prow = ((int64_t)bh * a.Sq + qc) * a.ldp;
-  const uint64_t key = a.thresh ? drop_site_key(a.dk) : 0ull;
+  const uint64_t key = DROP ? drop_site_key(a.dk) : 0ull;
   if constexpr (!BWD) {
     const float* bt = st_bias + a.tab_center - qc;
     // pass 1: running (max, sum) of this lane's half of the keys
     float m = -1e30f, l = 0.f;
-    for (int kt = wave; kt < nt; kt += 4) {
-      f32x16 acc = tile(kt);
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+      const int kt = wave + 4 * j;
+      if (kt >= nt) break;                             // wave-uniform
+      f32x16 acc = tile(j);
       float tm = -1e30f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int k = kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h2;
         float v = acc[i];
-        if (has_bias) v += bt[min(k, a.Sk - 1)];
+        if (has_bias) v += bt[k];                      // the LDS row is padded by 32 entries: no clamp
         v = k < kend ? v : -1e30f;
         acc[i] = v;
         tm = fmaxf(tm, v);
@@ -677,7 +705,7 @@ __global__ __launch_bounds__(256) void attn_stripe_kernel(StripeArgs a) {
       const float mn = fmaxf(m, tm);
       float ts = 0.f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) ts += acc[i] > -1e29f ? m2m_exp_t<T>(acc[i] - mn) : 0.f;
+      for (int i = 0; i < 16; ++i) ts += m2m_exp_t<T>(acc[i] - mn);      // masked entries are -1e30: exp gives exactly 0, no branch
       l = l * m2m_exp_t<T>(m - mn) + ts;
       m = mn;
     }
@@ -696,10 +724,11 @@ __global__ __launch_bounds__(256) void attn_stripe_kernel(StripeArgs a) {
     }
     const float inv = 1.0f / l;
     // pass 2: probabilities
-    T* prw = reinterpret_cast<T*>(a.P) + prow;
-    T* pdw = a.Pd ? reinterpret_cast<T*>(a.Pd) + prow : nullptr;
-    for (int kt = wave; kt < nt; kt += 4) {
-      const f32x16 acc = tile(kt);
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+      const int kt = wave + 4 * j;
+      if (kt >= nt) break;                             // wave-uniform
+      const f32x16 acc = tile(j);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int k0 = kt * 32 + 8 * g + 4 * h2;
@@ -708,35 +737,48 @@ __global__ __launch_bounds__(256) void attn_stripe_kernel(StripeArgs a) {
         for (int e = 0; e < 4; ++e) {
           const int k = k0 + e;
           float v = acc[4 * g + e];
-          if (has_bias) v += bt[min(k, a.Sk - 1)];
-          pv[e] = k < kend ? to_f32(from_f32<T>(m2m_exp_t<T>(v - m) * inv)) : 0.f;
+          if (has_bias) v += bt[k];
+          v = k < kend ? v : -1e30f;
+          pv[e] = to_f32(from_f32<T>(m2m_exp_t<T>(v - m) * inv));
         }
-        if (q < a.Sq && k0 < a.ldp) {                // ldp is a multiple of 8: the 4 keys are inside the row; keys >= kend are zeros
-          st_store4<T>(prw + k0, pv[0], pv[1], pv[2], pv[3]);
-          if (pdw) {
-            float dv[4];
+        st_store4<T>(pl + r * LP + k0, pv[0], pv[1], pv[2], pv[3]);          // keys >= kend are zeros
+        if constexpr (DROP) {
+          float dv[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dv[e] = drop_keep(key, prow + k0 + e, a.thresh) ? pv[e] * a.scale : 0.f;
-            st_store4<T>(pdw + k0, dv[0], dv[1], dv[2], dv[3]);
-          }
+          for (int e = 0; e < 4; ++e) dv[e] = drop_keep(key, prow + k0 + e, a.thresh) ? pv[e] * a.scale : 0.f;
+          st_store4<T>(pl2 + r * LP + k0, dv[0], dv[1], dv[2], dv[3]);
+        }
+      }
+    }
+    __syncthreads();
+    {
+      T* dst = reinterpret_cast<T*>(a.P) + blk;
+      T* dst2 = DROP ? reinterpret_cast<T*>(a.Pd) + blk : nullptr;
+      for (int c = threadIdx.x; c < 32 * cpr; c += 256) {
+        const int row = c / cpr, col = (c - row * cpr) * EC;
+        if (q0 + row < a.Sq) {
+          *reinterpret_cast<uint4*>(dst + (int64_t)row * a.ldp + col) = *reinterpret_cast<const uint4*>(pl + row * LP + col);
+          if constexpr (DROP) *reinterpret_cast<uint4*>(dst2 + (int64_t)row * a.ldp + col) = *reinterpret_cast<const uint4*>(pl2 + row * LP + col);
         }
       }
     }
   } else {
-    const T* prd = reinterpret_cast<const T*>(a.P) + prow;
+    T* prd = pl + r * LP;                            // this lane's query row of P, in LDS
     auto masked = [&](float dp, int k) {             // dP arrives for the DROPPED probabilities: through the mask first
-      if (a.thresh) dp = drop_keep(key, prow + k, a.thresh) ? dp * a.scale : 0.f;
+      if constexpr (DROP) dp = drop_keep(key, prow + k, a.thresh) ? dp * a.scale : 0.f;
       return k < a.Sk ? dp : 0.f;
     };
     // pass 1: t = sum_k P dP~
     float t = 0.f;
-    for (int kt = wave; kt < nt; kt += 4) {
-      const f32x16 acc = tile(kt);
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+      const int kt = wave + 4 * j;
+      if (kt >= nt) break;                             // wave-uniform
+      const f32x16 acc = tile(j);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int k0 = kt * 32 + 8 * g + 4 * h2;
-        float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k0 < a.ldp) pv = st_load4<T>(prd + k0);
+        const float4 pv = st_load4<T>(prd + k0);
         const float pe[4] = {pv.x, pv.y, pv.z, pv.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) t += (k0 + e < a.Sk ? pe[e] : 0.f) * masked(acc[4 * g + e], k0 + e);
@@ -747,20 +789,28 @@ __global__ __launch_bounds__(256) void attn_stripe_kernel(StripeArgs a) {
     __syncthreads();
     t = (red_a[0][r] + red_a[1][r]) + (red_a[2][r] + red_a[3][r]);
     // pass 2: dS = P (dP~ - t)
-    T* dsw = reinterpret_cast<T*>(a.dS) + prow;
-    for (int kt = wave; kt < nt; kt += 4) {
-      const f32x16 acc = tile(kt);
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+      const int kt = wave + 4 * j;
+      if (kt >= nt) break;                             // wave-uniform
+      const f32x16 acc = tile(j);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int k0 = kt * 32 + 8 * g + 4 * h2;
-        if (q < a.Sq && k0 < a.ldp) {
-          const float4 pv = st_load4<T>(prd + k0);
-          const float pe[4] = {pv.x, pv.y, pv.z, pv.w};
-          float o[4];
+        const float4 pv = st_load4<T>(prd + k0);
+        const float pe[4] = {pv.x, pv.y, pv.z, pv.w};
+        float o[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (k0 + e < a.Sk) ? pe[e] * (masked(acc[4 * g + e], k0 + e) - t) : 0.f;
-          st_store4<T>(dsw + k0, o[0], o[1], o[2], o[3]);
-        }
+        for (int e = 0; e < 4; ++e) o[e] = (k0 + e < a.Sk) ? pe[e] * (masked(acc[4 * g + e], k0 + e) - t) : 0.f;
+        st_store4<T>(prd + k0, o[0], o[1], o[2], o[3]);                        // in place: the same lane read these four
+      }
+    }
+    __syncthreads();
+    {
+      T* dst = reinterpret_cast<T*>(a.dS) + blk;
+      for (int c = threadIdx.x; c < 32 * cpr; c += 256) {
+        const int row = c / cpr, col = (c - row * cpr) * EC;
+        if (q0 + row < a.Sq) *reinterpret_cast<uint4*>(dst + (int64_t)row * a.ldp + col) = *reinterpret_cast<const uint4*>(pl + row * LP + col);
       }
     }
   }
@@ -769,16 +819,23 @@ __global__ __launch_bounds__(256) void attn_stripe_kernel(StripeArgs a) {
 template <typename T>
 static int launch_attn_stripe(bool bwd, const StripeArgs& a, int nB, hipStream_t st) {
   dim3 grid((unsigned)ceil_div(a.Sq, 32), (unsigned)(nB * a.H));
-  constexpr int E = 16 / sizeof(T);
-  const size_t bias_bytes = (!bwd && a.bias_tab) ? ((size_t)a.tab_stride * 4 + 15) / 16 * 16 : 0;
-  const size_t smem = bias_bytes + (size_t)ceil_div(a.Sk, 32) * 32 * (DK + E) * sizeof(T);
+  const bool drop = a.thresh != 0, bias = !bwd && a.bias_tab != nullptr;
+  const size_t bias_bytes = bias ? ((size_t)(a.tab_stride + 32) * 4 + 15) / 16 * 16 : 0;
+  const size_t row_bytes = (size_t)32 * (ceil_div(a.Sk, 32) * 32 + 16 / sizeof(T)) * sizeof(T);
+  const size_t smem = bias_bytes + row_bytes * ((!bwd && drop) ? 2 : 1);
+#define M2M_ST_LAUNCH(B_, D_, I_)                                                                              \
+  do {                                                                                                         \
+    M2M_OPT_IN_LDS((attn_stripe_kernel<T, B_, D_, I_>), 158 * 1024);      /* + 1 KB of static LDS */              \
+    hipLaunchKernelGGL((attn_stripe_kernel<T, B_, D_, I_>), grid, dim3(256), smem, st, a);                     \
+  } while (0)
   if (bwd) {
-    M2M_OPT_IN_LDS((attn_stripe_kernel<T, true>), 158 * 1024);    // + 1 KB of static LDS (the per-wave row statistics)
-    hipLaunchKernelGGL((attn_stripe_kernel<T, true>), grid, dim3(256), smem, st, a);
+    if (drop) M2M_ST_LAUNCH(true, true, false); else M2M_ST_LAUNCH(true, false, false);
+  } else if (bias) {
+    if (drop) M2M_ST_LAUNCH(false, true, true); else M2M_ST_LAUNCH(false, false, true);
   } else {
-    M2M_OPT_IN_LDS((attn_stripe_kernel<T, false>), 158 * 1024);
-    hipLaunchKernelGGL((attn_stripe_kernel<T, false>), grid, dim3(256), smem, st, a);
+    if (drop) M2M_ST_LAUNCH(false, true, false); else M2M_ST_LAUNCH(false, false, false);
   }
+#undef M2M_ST_LAUNCH
   M2M_CHECK_HIP(hipGetLastError());
   return M2M_OK;
 }
@@ -1856,8 +1913,8 @@ struct Ops {
   }
   // Fused scores + softmax (attn_stripe_kernel) when a wave can hold all keys; K = (key, d) operand, Q = (query, d) operand.
   static bool stripes_on() { static const bool on = [] { const char* v = getenv("M2M_TRAIN_STRIPES"); return !(v && v[0] == '0'); }(); return on; }
-  bool stripe_ok(int Sk) const {          // all keys of a (clip, head) in LDS beside the bias row
-    return stripes_on() && Sk <= 32 * ST_NT && (size_t)ceil_div(Sk, 32) * 32 * (DK + 16 / sizeof(T)) * sizeof(T) + 16384 <= 158 * 1024;
+  bool stripe_ok(int Sk) const {      // the bias row + (two, with dropout) 32-row blocks of P must fit the LDS
+    return stripes_on() && Sk <= 32 * ST_NT && 2 * (size_t)32 * (ceil_div(Sk, 32) * 32 + 8) * sizeof(T) + 8192 <= 158 * 1024;
   }
   int attn_probs(const T* K, int64_t ldk, int64_t sK1, int64_t sK2, const T* Q, int64_t ldq, int64_t sQ1, int64_t sQ2, void* Pm, int nB, int Sq, int Sk,
             int ldp, const float* tab, int causal, int site, const T** Puse) const {
