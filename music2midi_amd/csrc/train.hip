@@ -2098,7 +2098,7 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
   const int Me = B * S, Md = B * L, lps = (int)align_up(S, 8), ldv = (int)align_up(V, 8);
   Ops<T> o{t, st, P};
   o.Gbase = G;
-  o.group = G && t->use_group && !t->fp8;
+  o.group = G && t->use_group && !(t->fp8 && t->fp8_dw);
   o.st2 = (G && !o.group) ? st_side : nullptr;
   int rc;
   // (the bucket tables of this geometry are on the device already: ensure_tables())
