@@ -33,11 +33,14 @@ namespace m2m {
 // 64x64 output tile per 256-thread workgroup (2x2 waves, one 32x32 MFMA tile each), BK = 32.
 // Operand storage: a_kmajor == 0: element (m, k) at A[m*lda + k]; a_kmajor == 1: at A[k*lda + m]
 // (the transposed product reads the buffer as it is: the tile is transposed on its way into LDS).
-constexpr int TG_BM = 64, TG_BN = 64, TG_BK = 32;
+constexpr int TG_BM = 64, TG_BN = 64;
+// k extent staged per step: 128 (bf16) / 64 (fp32) — 35 KB of LDS either way.  The attention products reduce over <= ~360
+// keys / queries, so the dependent load -> LDS -> MFMA chain of a workgroup is 3 steps instead of the 9 of BK = 32 (16 -> us per launch)
+constexpr int TG_BK_MAX = 128;
 
 template <typename T> struct TgCfg;
-template <> struct TgCfg<bf16_t> { static constexpr int E = 8, PITCH = TG_BK + 8; };
-template <> struct TgCfg<float> { static constexpr int E = 4, PITCH = TG_BK + 4; };
+template <> struct TgCfg<bf16_t> { static constexpr int E = 8, BK = 128, PITCH = BK + 8; };
+template <> struct TgCfg<float> { static constexpr int E = 4, BK = 64, PITCH = BK + 4; };
 
 __device__ inline uint32_t u4_get(const uint4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 // Column j of an E x E block held as E 16-byte rows (E = 8 bf16 / 4 fp32), as one 16-byte row of the transposed block.
@@ -66,6 +69,7 @@ __device__ inline void tg_stage(T* __restrict__ S, const T* __restrict__ G, int6
   using Cfg = TgCfg<T>;
   constexpr int E = Cfg::E;
   if (!kmajor) {
+    constexpr int TG_BK = Cfg::BK;
     constexpr int CPR = TG_BK / E;                      // chunks per row
     for (int c = tid; c < TG_BM * CPR; c += 256) {
       const int rl = c / CPR, kc = (c % CPR) * E;
@@ -79,9 +83,9 @@ __device__ inline void tg_stage(T* __restrict__ S, const T* __restrict__ G, int6
       }
     }
   } else {
-    constexpr int KBn = TG_BK / E, RBn = TG_BM / E;     // blocks along k / along the tile rows
-    const int c = tid - tshift;
-    if (c >= 0 && c < KBn * RBn) {
+    constexpr int KBn = Cfg::BK / E, RBn = TG_BM / E;   // blocks along k / along the tile rows
+    const int c0 = tid - tshift;                                             // 128 threads per operand
+    for (int c = c0; c0 >= 0 && c0 < 128 && c < KBn * RBn; c += 128) {
       const int kb = c % KBn, rb = c / KBn;
       const int row = row0 + rb * E;
       uint4 rg[E];
@@ -113,6 +117,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BGemmArgs g) {
   const int kbeg = split ? blockIdx.z * g.kchunk : 0, kend = split ? min(g.K, kbeg + g.kchunk) : g.K;
 
   f32x16 acc = zero_acc();
+  constexpr int TG_BK = Cfg::BK;
   for (int k0 = kbeg; k0 < kend; k0 += TG_BK) {
     __syncthreads();
     tg_stage<T>(As, A, g.lda, g.a_kmajor, m0, k0, g.M, kend, tid, 0);
@@ -460,7 +465,7 @@ int launch_bgemm(int precision, int epi, const BGemmArgs& g, hipStream_t st) {
   M2M_REQUIRE((!g.a_kmajor || g.lda >= align_up(g.M, E)) && (!g.b_kmajor || g.ldb >= align_up(g.N, E)),
               "bgemm: a k-major operand's row stride must cover its rows padded to %d", E);
   if (g.ksplit > 1) {
-    M2M_REQUIRE(g.nb1 == 1 && g.nb2 == 1 && epi == TG_STORE_F32 && g.Cpart && g.kchunk % TG_BK == 0, "bgemm: split-K is for plain fp32-store products");
+    M2M_REQUIRE(g.nb1 == 1 && g.nb2 == 1 && epi == TG_STORE_F32 && g.Cpart && g.kchunk % TG_BK_MAX == 0, "bgemm: split-K is for plain fp32-store products");
     int rc = precision == M2M_PREC_BF16 ? launch_bgemm_t<bf16_t>(epi, g, st) : launch_bgemm_t<float>(epi, g, st);
     if (rc != M2M_OK) return rc;
     const int64_t n = (int64_t)g.M * g.N;
@@ -1054,6 +1059,36 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ p
   }
 }
 
+// every RMSNorm weight gradient of a step in one launch: partial image j ([parts][d]) -> out_base + off[j]
+__global__ __launch_bounds__(256) void colsum_group_kernel(const float* __restrict__ part_all, const int64_t* __restrict__ offs, float* __restrict__ out_base,
+                                                           int parts, int d) {
+  __shared__ float sred[8][32];
+  const int j = blockIdx.y;
+  const float* part = part_all + (int64_t)j * parts * d;
+  const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + cx;
+  float acc = 0.f;
+  if (col < d) {
+    int p = py;
+    for (; p + 56 < parts; p += 64) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(p + 8 * u) * d + col];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; p < parts; p += 8) acc += part[(int64_t)p * d + col];
+  }
+  sred[py][cx] = acc;
+  __syncthreads();
+  if (py == 0 && col < d) {
+    float v = sred[0][cx];
+#pragma unroll
+    for (int u = 1; u < 8; ++u) v += sred[u][cx];
+    out_base[offs[j] + col] = v;
+  }
+}
+
 // ---- cross entropy (mean over labels != -100, hf: modeling_t5.py:1049-1054) + gradient of the logits ----
 __global__ void count_valid_kernel(const int64_t* __restrict__ labels, int n, float* __restrict__ inv_n) {
   __shared__ int cnt[256];
@@ -1437,6 +1472,8 @@ struct m2m_trainer {
   void* dw_probs_dev = nullptr;          // DwProb table on the device
   std::vector<unsigned char> dw_probs_host;   // ... and its host image (re-uploaded only when it changes)
   int dw_tiles = 0;
+  int64_t* norm_offs_dev = nullptr;      // parameter offsets of the RMSNorm weights, in the order the backward pass meets them
+  std::vector<int64_t> norm_offs_host;
   // streams / graph of the step (trainer-owned: the caller's stream may be the legacy default stream, which cannot capture)
   hipStream_t s_main = nullptr, s_side = nullptr;
   hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_ready = nullptr, ev_free[2] = {nullptr, nullptr};
@@ -1584,7 +1621,7 @@ int build_arena(m2m_trainer* t) {
                                   o.push_back(T(B * H * L * lpl)); o.push_back(T(Md * inner)); o.push_back(T(Md * inner)); o.push_back(T(Me * 2 * inner));
                                   o.push_back(T(B * H * L * lps)); o.push_back(T(Md * inner)); o.push_back(T(Md * 2 * dff)); o.push_back(T(Md * dff)); }
   const int64_t o_hE = T(Me * d), o_hD = T(Md * d), o_logits = F(Md * V), o_sc = F(B * H * Sm * lpm), o_dxa = F(Mx * d), o_dxb = F(Mx * d),
-                o_dh = F(Mx * d), o_dhE = F(Me * d), o_dwp = F((int64_t)RN_BLOCKS * d), o_rl = F(Md), o_inv = F(64), o_drel = F(B * H * (2 * Sm)),
+                o_dh = F(Mx * d), o_dhE = F(Me * d), o_dwp = F((int64_t)RN_BLOCKS * d * (2 * Le + 3 * Ld + 2)), o_nofs = c.take(64 * 8), o_rl = F(Md), o_inv = F(64), o_drel = F(B * H * (2 * Sm)),
                 o_etab = F(H * (2 * S)), o_dtab = F(H * (2 * L)), o_dlog = T(Md * align_up(V, 8)), o_dxT = T(Mx * d), o_dmid = T(Mx * dff),
                 o_dab = T(Mx * 2 * dff), o_dO = T(Mx * inner), o_dqkv = T(Mx * 3 * inner), o_dS = T(B * H * Sm * lpm), o_dcq = T(Md * inner),
                 o_dckv = T(Me * 2 * inner), o_lab = c.take(Md * 8), o_cnd = c.take(B * 8 * 8), o_skey = c.take(256), o_decin = c.take(Md * 8), o_eb = c.take(2 * S * 4), o_db = c.take(2 * L * 4),
@@ -1652,7 +1689,7 @@ int build_arena(m2m_trainer* t) {
                                   t->Pd.push_back(nextT()); t->aod.push_back(nextT()); t->cqd.push_back(nextT()); t->ckvd.push_back(nextT());
                                   t->Pcd.push_back(nextT()); t->aocd.push_back(nextT()); t->abd.push_back(nextT()); t->midd.push_back(nextT()); }
   t->hE = b + o_hE; t->hD = b + o_hD; t->logits = (float*)(b + o_logits); t->sc = (float*)(b + o_sc); t->dxa = (float*)(b + o_dxa);
-  t->dxb = (float*)(b + o_dxb); t->dh = (float*)(b + o_dh); t->dhE = (float*)(b + o_dhE); t->dw_part = (float*)(b + o_dwp);
+  t->dxb = (float*)(b + o_dxb); t->dh = (float*)(b + o_dh); t->dhE = (float*)(b + o_dhE); t->dw_part = (float*)(b + o_dwp); t->norm_offs_dev = (int64_t*)(b + o_nofs);
   t->row_loss = (float*)(b + o_rl); t->inv_n = (float*)(b + o_inv); t->drel = (float*)(b + o_drel); t->etab = (float*)(b + o_etab);
   t->dtab = (float*)(b + o_dtab); t->dlog = b + o_dlog; t->dxT = b + o_dxT; t->dmid = b + o_dmid; t->dab = b + o_dab; t->dO = b + o_dO;
   t->dqkv = b + o_dqkv; t->dS = b + o_dS; t->dcq = b + o_dcq; t->dckv = b + o_dckv; t->dec_in = (int64_t*)(b + o_decin);
@@ -1718,6 +1755,7 @@ struct Ops {
   bool group = false;
   mutable std::vector<std::function<int(hipStream_t)>> pending;
   mutable std::vector<DwProb> probs;
+  mutable std::vector<int64_t> norm_offs;
   mutable int pos[m2m_trainer::K_KINDS] = {0, 0, 0, 0, 0};
   mutable int sub = 0;
   mutable bool used[2] = {false, false};
@@ -1753,6 +1791,23 @@ struct Ops {
     if (!st2) return M2M_OK;
     for (int p = 0; p < 2; ++p)
       if (used[p]) M2M_CHECK_HIP(hipStreamWaitEvent(st, t->ev_free[p], 0));
+    return M2M_OK;
+  }
+  int flush_norms() const {
+    if (!group || norm_offs.empty()) return M2M_OK;
+    M2M_REQUIRE(norm_offs.size() <= 64 && (int)norm_offs.size() <= 2 * t->g.num_layers + 3 * t->g.num_decoder_layers + 2, "training: too many norms");
+    if (t->norm_offs_host != norm_offs) {
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      (void)hipStreamIsCapturing(st, &cs);
+      M2M_REQUIRE(cs == hipStreamCaptureStatusNone, "training: the norm table changed inside a graph capture");
+      M2M_CHECK_HIP(hipStreamSynchronize(st));
+      M2M_CHECK_HIP(hipMemcpy(t->norm_offs_dev, norm_offs.data(), norm_offs.size() * 8, hipMemcpyHostToDevice));
+      t->norm_offs_host = norm_offs;
+    }
+    const int d = t->g.d_model;
+    hipLaunchKernelGGL(colsum_group_kernel, dim3(ceil_div(d, 32), (unsigned)norm_offs.size()), dim3(256), 0, st, t->dw_part, t->norm_offs_dev, Gbase,
+                       RN_BLOCKS, d);
+    M2M_CHECK_HIP(hipGetLastError());
     return M2M_OK;
   }
   int flush_group() const {
@@ -1896,7 +1951,7 @@ struct Ops {
     int ks = 1024 / tiles;
     if (ks > 32) ks = 32;
     while (ks > 1 && ((int64_t)ks * Ny * Kx > t->kpart_floats || ceil_div(M, ks) < 64)) --ks;
-    if (ks > 1) { g.ksplit = ks; g.kchunk = (int)align_up(ceil_div(M, ks), TG_BK); g.ksplit = ceil_div(M, g.kchunk); g.Cpart = t->kpart; }
+    if (ks > 1) { g.ksplit = ks; g.kchunk = (int)align_up(ceil_div(M, ks), TG_BK_MAX); g.ksplit = ceil_div(M, g.kchunk); g.Cpart = t->kpart; }
     return launch_bgemm(t->precision, TG_STORE_F32, g, st);
   }
   int cvt(const float* src, void* dst, int64_t n) const { return launch_cvt(t->precision, src, dst, n, st); }
@@ -1905,9 +1960,14 @@ struct Ops {
     const int d = t->g.d_model;
     // (summing the partials in the last block to finish, behind a __threadfence() + counter, was measured: the agent-scope
     //  fence of 256 blocks costs ~100 us per launch on this machine — 8.7 -> 12.3 ms per step; the second launch stays)
+    // grouped mode: the partial image of every norm goes to a slice of its own and ONE launch sums them all after the backward
+    // pass (flush_norms); otherwise the column sum follows right away
+    const int slot = group ? (int)norm_offs.size() : 0;
+    float* part = t->dw_part + (int64_t)slot * RN_BLOCKS * d;
     hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(RN_BLOCKS), dim3(256), (size_t)4 * d * sizeof(float), st, x, P + w_off, dy, dx_res, dx_out,
-                       t->dw_part, M, d, t->g.layer_norm_eps);
-    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(d, 32)), dim3(256), 0, st, t->dw_part, G + w_off, RN_BLOCKS, d, 0);
+                       part, M, d, t->g.layer_norm_eps);
+    if (group) norm_offs.push_back(w_off);
+    else hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(d, 32)), dim3(256), 0, st, part, G + w_off, RN_BLOCKS, d, 0);
     M2M_CHECK_HIP(hipGetLastError());
     return M2M_OK;
   }
@@ -2242,6 +2302,7 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
   M2M_CHECK_HIP(hipGetLastError());
   RC(o.join_side());
   RC(o.flush_group());
+  RC(o.flush_norms());
   return M2M_OK;
 }
 
