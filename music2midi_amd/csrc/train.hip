@@ -1233,23 +1233,43 @@ __global__ __launch_bounds__(256) void af_pass_a(const AfBlock* __restrict__ blo
   const float* g = G + t.offset;
   float p2 = 0.f;
   const int r1 = min(bk.row0 + AF_ROWS, t.rows);
-  // thread tid owns columns tid, tid + 256, ... ; rows are walked in order -> fixed summation order per column
+  // thread tid owns columns tid, tid + 256, ... ; rows are walked in order -> fixed summation order per column.  ONE read of
+  // g and p (the first form read g a second time for the row sums, one dependent load per row: 157 us per step): the per-row
+  // partial sums of this thread's columns stay in registers and are reduced by wave, then over the four waves, in a fixed order
+  __shared__ float rred[4][AF_ROWS];
+  float rs[AF_ROWS];
+#pragma unroll
+  for (int j = 0; j < AF_ROWS; ++j) rs[j] = 0.f;
   for (int c = threadIdx.x; c < t.cols; c += 256) {
+    float gv[AF_ROWS], pv[AF_ROWS];
+#pragma unroll
+    for (int j = 0; j < AF_ROWS; ++j) {
+      const int r = min(bk.row0 + j, r1 - 1);          // clamped: every load of the tile is in flight at once
+      gv[j] = g[(int64_t)r * t.cols + c];
+      pv[j] = p[(int64_t)r * t.cols + c];
+    }
     float cs = 0.f;
-    for (int r = bk.row0; r < r1; ++r) {
-      const float gv = g[(int64_t)r * t.cols + c], pv = p[(int64_t)r * t.cols + c];
-      cs += gv * gv + 1e-30f;
-      p2 += pv * pv;
+#pragma unroll
+    for (int j = 0; j < AF_ROWS; ++j) {
+      if (bk.row0 + j < r1) {
+        const float q = gv[j] * gv[j] + 1e-30f;
+        cs += q;
+        rs[j] += q;
+        p2 += pv[j] * pv[j];
+      }
     }
     colpart[bk.col_off + c] = cs;
   }
-  // row sums: one wave per row at a time
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int r = bk.row0 + wave; r < r1; r += 4) {
-    float rs = 0.f;
-    for (int c = lane; c < t.cols; c += 64) { const float gv = g[(int64_t)r * t.cols + c]; rs += gv * gv + 1e-30f; }
-    rs = wave_sum(rs);
-    if (lane == 0) rowsum[t.row_off + r] = rs;
+  {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < AF_ROWS; ++j) {
+      const float v = wave_sum(rs[j]);
+      if (lane == 0) rred[wave][j] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < AF_ROWS && bk.row0 + (int)threadIdx.x < r1)
+      rowsum[t.row_off + bk.row0 + threadIdx.x] = (rred[0][threadIdx.x] + rred[1][threadIdx.x]) + (rred[2][threadIdx.x] + rred[3][threadIdx.x]);
   }
   sred[threadIdx.x] = p2;
   __syncthreads();
@@ -1320,9 +1340,15 @@ __global__ __launch_bounds__(256) void af_pass_b(const AfBlock* __restrict__ blo
   float u2 = 0.f;
   for (int c = threadIdx.x; c < t.cols; c += 256) {
     const float cf = cfac[t.cfac_off + c];
-    for (int r = bk.row0; r < r1; ++r) {
-      const float u = g[(int64_t)r * t.cols + c] * rfac[t.row_off + r] * cf;
-      u2 += u * u;
+    float gv[AF_ROWS];
+#pragma unroll
+    for (int j = 0; j < AF_ROWS; ++j) gv[j] = g[(int64_t)min(bk.row0 + j, r1 - 1) * t.cols + c];
+#pragma unroll
+    for (int j = 0; j < AF_ROWS; ++j) {
+      if (bk.row0 + j < r1) {
+        const float u = gv[j] * rfac[t.row_off + bk.row0 + j] * cf;
+        u2 += u * u;
+      }
     }
   }
   sred[threadIdx.x] = u2;
@@ -1356,12 +1382,18 @@ __global__ __launch_bounds__(256) void af_pass_c(const AfBlock* __restrict__ blo
   const float* g = G + t.offset;
   const float step = tstat[2 * bk.tensor + 1];
   const int r1 = min(bk.row0 + AF_ROWS, t.rows);
-  for (int r = bk.row0; r < r1; ++r) {
-    const float rf = rfac[t.row_off + r] * step;
-    for (int c = threadIdx.x; c < t.cols; c += 256) {
-      const int64_t at = (int64_t)r * t.cols + c;
-      p[at] -= g[at] * rf * cfac[t.cfac_off + c];
+  for (int c = threadIdx.x; c < t.cols; c += 256) {          // column-outer: the 32 rows' loads of a column are in flight together
+    const float cf = cfac[t.cfac_off + c];
+    float gv[AF_ROWS], pv[AF_ROWS];
+#pragma unroll
+    for (int j = 0; j < AF_ROWS; ++j) {
+      const int64_t at = (int64_t)min(bk.row0 + j, r1 - 1) * t.cols + c;
+      gv[j] = g[at];
+      pv[j] = p[at];
     }
+#pragma unroll
+    for (int j = 0; j < AF_ROWS; ++j)
+      if (bk.row0 + j < r1) p[(int64_t)(bk.row0 + j) * t.cols + c] = pv[j] - gv[j] * (rfac[t.row_off + bk.row0 + j] * step) * cf;
   }
 }
 
