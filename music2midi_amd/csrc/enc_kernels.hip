@@ -83,9 +83,17 @@ template <> struct TileCfg<float> {
   static constexpr int CPR = BK * 4 / 16;                    // 8
 };
 
+// k extent per step: the small-tile variant stages twice the k of the big one (same 35 KB of LDS): its products are the
+// latency-bound ones, and half the steps halve the dependent load -> LDS -> MFMA chain of a workgroup
+template <typename T, int TF> struct TileCfgT {
+  static constexpr int BK = TileCfg<T>::BK * (TF == 1 ? 2 : 1);
+  static constexpr int PITCH = BK + (TileCfg<T>::PITCH - TileCfg<T>::BK);
+  static constexpr int CPR = BK * (int)sizeof(T) / 16;
+};
+
 template <typename T, int EPI, int TF = 2>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-  using Cfg = TileCfg<T>;
+  using Cfg = TileCfgT<T, TF>;
   constexpr int BM = 64 * TF, BN = 64 * TF, WT = 32 * TF;      // tile, and the square each of the 2x2 waves owns
   static_assert(TF == 2 || EPI == EPI_STORE || EPI == EPI_STORE_F32 || EPI == EPI_RESID, "LDS-staged epilogues are written for 128x128 tiles");
   constexpr int BK = Cfg::BK;
@@ -356,7 +364,7 @@ template <typename T>
 static int launch_gemm_t(int epi, const GemmArgs& a, hipStream_t st) {
   const bool plain = epi == EPI_STORE || epi == EPI_STORE_F32 || epi == EPI_RESID;
   const int tiles128 = ceil_div(a.M, 128) * ceil_div(a.N, 128);
-  if (plain && tiles128 < gemm_small_below()) return launch_gemm_tt<T, 1>(epi, a, st);
+  if (plain && tiles128 < gemm_small_below() && a.K % TileCfgT<T, 1>::BK == 0) return launch_gemm_tt<T, 1>(epi, a, st);
   return launch_gemm_tt<T, 2>(epi, a, st);
 }
 

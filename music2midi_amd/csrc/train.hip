@@ -1382,18 +1382,12 @@ __global__ __launch_bounds__(256) void af_pass_c(const AfBlock* __restrict__ blo
   const float* g = G + t.offset;
   const float step = tstat[2 * bk.tensor + 1];
   const int r1 = min(bk.row0 + AF_ROWS, t.rows);
-  for (int c = threadIdx.x; c < t.cols; c += 256) {          // column-outer: the 32 rows' loads of a column are in flight together
-    const float cf = cfac[t.cfac_off + c];
-    float gv[AF_ROWS], pv[AF_ROWS];
-#pragma unroll
-    for (int j = 0; j < AF_ROWS; ++j) {
-      const int64_t at = (int64_t)min(bk.row0 + j, r1 - 1) * t.cols + c;
-      gv[j] = g[at];
-      pv[j] = p[at];
+  for (int r = bk.row0; r < r1; ++r) {
+    const float rf = rfac[t.row_off + r] * step;
+    for (int c = threadIdx.x; c < t.cols; c += 256) {
+      const int64_t at = (int64_t)r * t.cols + c;
+      p[at] -= g[at] * rf * cfac[t.cfac_off + c];
     }
-#pragma unroll
-    for (int j = 0; j < AF_ROWS; ++j)
-      if (bk.row0 + j < r1) p[(int64_t)(bk.row0 + j) * t.cols + c] = pv[j] - gv[j] * (rfac[t.row_off + bk.row0 + j] * step) * cf;
   }
 }
 
