@@ -591,6 +591,7 @@ struct StripeArgs {
   void* P;                           // [nB*H][Sq][ldp] T: forward out / backward in
   void* Pd;                          // forward: dropped copy of P, or null
   void* dS;                          // backward out
+  float* diag_part;                  // backward, self-attention with bias: [nB*H][stripes][Sk + 31] diagonal sums of dS per stripe, or null
   const float* bias_tab;             // forward, self-attention: [H][tab_stride] by (key - query + tab_center); null: no bias
   int tab_stride, tab_center;
   int H, Sq, Sk, ldp, causal;
@@ -818,6 +819,20 @@ __global__ __launch_bounds__(256) void attn_stripe_kernel(StripeArgs a) {
         if (q0 + row < a.Sq) *reinterpret_cast<uint4*>(dst + (int64_t)row * a.ldp + col) = *reinterpret_cast<const uint4*>(pl + row * LP + col);
       }
     }
+    // relative-position-bias gradient, stage 1 (replaces bias_diag_kernel's pass over dS in memory): the sums of this stripe's
+    // dS along the diagonals key - row = i - 31, i in [0, Sk + 31), rows in fixed order; bias_bucket2_kernel adds the stripes
+    if (a.diag_part) {
+      const int dl = a.Sk + 31, rows = min(32, a.Sq - q0);
+      float* out = a.diag_part + ((int64_t)bh * gridDim.x + blockIdx.x) * dl;
+      for (int i = threadIdx.x; i < dl; i += 256) {
+        float acc = 0.f;
+        for (int rr = 0; rr < rows; ++rr) {
+          const int k = i - 31 + rr;
+          if (k >= 0 && k < a.Sk) acc += to_f32(pl[rr * LP + k]);
+        }
+        out[i] = acc;
+      }
+    }
   }
 }
 
@@ -929,6 +944,31 @@ __global__ __launch_bounds__(256) void bias_bucket_kernel(const float* __restric
   __syncthreads();
   for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) sred[threadIdx.x] += sred[threadIdx.x + st]; __syncthreads(); }
   if (threadIdx.x == 0) dtable[blockIdx.x] = accumulate ? dtable[blockIdx.x] + sred[0] : sred[0];
+}
+
+// stage 1b for the per-stripe diagonal sums of attn_stripe_kernel: part2 [B*H][stripes][Sk + 31] -> tmp [H][nrel], summed over
+// clips and stripes in a fixed order; the diagonal with global index rel (= key - query + Sq - 1) is entry
+// rel + 31 + 32 s - (Sq - 1) of stripe s.  Block = (head, 64 consecutive rels) x 4 clip groups; bias_bucket_kernel (B = 1) follows.
+__global__ __launch_bounds__(256) void bias_stripes_sum_kernel(const float* __restrict__ part2, float* __restrict__ tmp, int B, int H, int stripes,
+                                                               int Sq, int Sk) {
+  __shared__ float sred[4][64];
+  const int nrel = Sq + Sk - 1, dl = Sk + 31;
+  const int hh = blockIdx.x, rl = threadIdx.x & 63, bg = threadIdx.x >> 6;
+  const int rel = blockIdx.y * 64 + rl;
+  float acc = 0.f;
+  if (rel < nrel) {
+    const int per = (B + 3) / 4;
+    for (int b = bg * per; b < min(B, (bg + 1) * per); ++b) {
+      const float* pb = part2 + ((int64_t)b * H + hh) * stripes * dl;
+      for (int sidx = 0; sidx < stripes; ++sidx) {
+        const int loc = rel + 31 + 32 * sidx - (Sq - 1);
+        if (loc >= 0 && loc < dl) acc += pb[(int64_t)sidx * dl + loc];
+      }
+    }
+  }
+  sred[bg][rl] = acc;
+  __syncthreads();
+  if (bg == 0 && rel < nrel) tmp[(int64_t)hh * nrel + rel] = (sred[0][rl] + sred[1][rl]) + (sred[2][rl] + sred[3][rl]);
 }
 
 // ---- gated GELU (hf: modeling_t5.py T5DenseGatedActDense: gelu_new(wi_0 x) * (wi_1 x)); ab = [a | b], [M, 2*dff] ----
@@ -1647,7 +1687,7 @@ int build_arena(m2m_trainer* t) {
                                   o.push_back(T(B * H * L * lpl)); o.push_back(T(Md * inner)); o.push_back(T(Md * inner)); o.push_back(T(Me * 2 * inner));
                                   o.push_back(T(B * H * L * lps)); o.push_back(T(Md * inner)); o.push_back(T(Md * 2 * dff)); o.push_back(T(Md * dff)); }
   const int64_t o_hE = T(Me * d), o_hD = T(Md * d), o_logits = F(Md * V), o_sc = F(B * H * Sm * lpm), o_dxa = F(Mx * d), o_dxb = F(Mx * d),
-                o_dh = F(Mx * d), o_dhE = F(Me * d), o_dwp = F((int64_t)RN_BLOCKS * d * (2 * Le + 3 * Ld + 2)), o_nofs = c.take(64 * 8), o_rl = F(Md), o_inv = F(64), o_drel = F(B * H * (2 * Sm)),
+                o_dh = F(Mx * d), o_dhE = F(Me * d), o_dwp = F((int64_t)RN_BLOCKS * d * (2 * Le + 3 * Ld + 2)), o_nofs = c.take(64 * 8), o_rl = F(Md), o_inv = F(64), o_drel = F(B * H * std::max<int64_t>(2 * Sm, ((Sm + 31) / 32) * (Sm + 32)) + H * 2 * Sm),
                 o_etab = F(H * (2 * S)), o_dtab = F(H * (2 * L)), o_dlog = T(Md * align_up(V, 8)), o_dxT = T(Mx * d), o_dmid = T(Mx * dff),
                 o_dab = T(Mx * 2 * dff), o_dO = T(Mx * inner), o_dqkv = T(Mx * 3 * inner), o_dS = T(B * H * Sm * lpm), o_dcq = T(Md * inner),
                 o_dckv = T(Me * 2 * inner), o_lab = c.take(Md * 8), o_cnd = c.take(B * 8 * 8), o_skey = c.take(256), o_decin = c.take(Md * 8), o_eb = c.take(2 * S * 4), o_db = c.take(2 * L * 4),
@@ -2015,11 +2055,12 @@ struct Ops {
   }
   // Fused dP + softmax backward: V = (key, d) operand, dO = (query, d) operand; dS out
   int dscores(const T* V, int64_t ldv, int64_t sV1, int64_t sV2, const T* dO, int64_t ldo, int64_t sO1, int64_t sO2, const void* Pm, void* dS, int nB,
-              int Sq, int Sk, int ldp, int site) const {
+              int Sq, int Sk, int ldp, int site, bool want_diag = false) const {
     const bool dr = dropping(site);
     StripeArgs a{};
     a.X = V; a.ldx = ldv; a.sX1 = sV1; a.sX2 = sV2; a.Y = dO; a.ldy = ldo; a.sY1 = sO1; a.sY2 = sO2;
     a.P = const_cast<void*>(Pm); a.dS = dS; a.H = t->g.num_heads; a.Sq = Sq; a.Sk = Sk; a.ldp = ldp;
+    a.diag_part = want_diag ? t->drel : nullptr;
     a.dk = dr ? key(site) : DropKey{nullptr, 0}; a.thresh = dr ? t->drop_thresh : 0u; a.scale = t->drop_scale;
     return launch_attn_stripe<T>(true, a, nB, st);
   }
@@ -2059,6 +2100,15 @@ struct Ops {
     const bool dr = dropping(site);
     hipLaunchKernelGGL(gated_bwd_kernel<T>, dim3(grid_1d(M * t->g.d_ff)), dim3(256), 0, st, (const T*)ab, (const T*)dmid, (T*)dab, M, t->g.d_ff,
                        dr ? key(site) : DropKey{nullptr, 0}, dr ? t->drop_thresh : 0u, t->drop_scale);
+    M2M_CHECK_HIP(hipGetLastError());
+    return M2M_OK;
+  }
+  // bias gradient from the per-stripe diagonal sums the backward stripe kernel left in t->drel
+  int bias_grad_stripes(const int* buckets, float* Gtab, int nB, int Sq, int Sk, int accumulate) const {
+    const int H = t->g.num_heads, nrel = Sq + Sk - 1, stripes = ceil_div(Sq, 32);
+    float* tmp = t->drel + (int64_t)nB * H * stripes * (Sk + 31);
+    hipLaunchKernelGGL(bias_stripes_sum_kernel, dim3(H, ceil_div(nrel, 64)), dim3(256), 0, st, t->drel, tmp, nB, H, stripes, Sq, Sk);
+    hipLaunchKernelGGL(bias_bucket_kernel, dim3(t->g.num_buckets * H), dim3(256), 0, st, tmp, buckets, Gtab, 1, H, nrel, accumulate);
     M2M_CHECK_HIP(hipGetLastError());
     return M2M_OK;
   }
@@ -2124,12 +2174,13 @@ int attn_self_bwd(const Ops<T>& o, const float* x_in, const float* dx_out, float
   RC(o.redrop(Pm, (int64_t)nB * H * S * ldp, site0 + PL_PROBS_SELF, &Pu));
   RC(o.mmbh(TG_STORE_T, Pu, ldp, 1, sP1, sP2, dO, inner, 1, sO1, DK, dq + 2 * inner, 3 * inner, sQ1, DK, nB, S, DK, S));             // dV = Pd^T dO
   if (o.stripe_ok(S)) {
-    RC(o.dscores(q + 2 * inner, 3 * inner, sQ1, DK, dO, inner, sO1, DK, Pm, t->dS, nB, S, S, ldp, site0 + PL_PROBS_SELF));       // dS from dPd = dO V^T
+    RC(o.dscores(q + 2 * inner, 3 * inner, sQ1, DK, dO, inner, sO1, DK, Pm, t->dS, nB, S, S, ldp, site0 + PL_PROBS_SELF, buckets != nullptr));   // dS from dPd = dO V^T
+    if (buckets) RC(o.bias_grad_stripes(buckets, G + bias_off, nB, S, S, bias_accumulate));
   } else {
     RC(o.mmbh(TG_STORE_F32, dO, inner, 0, sO1, DK, q + 2 * inner, 3 * inner, 0, sQ1, DK, t->sc, ldp, sP1, sP2, nB, S, S, DK));      // dPd = dO V^T
     RC(o.softmax_bwd(Pm, t->sc, t->dS, nB * H * S, S, ldp, site0 + PL_PROBS_SELF));
+    if (buckets) RC(o.bias_grad(t->dS, buckets, G + bias_off, nB, S, S, ldp, bias_accumulate));
   }
-  if (buckets) RC(o.bias_grad(t->dS, buckets, G + bias_off, nB, S, S, ldp, bias_accumulate));
   const T* dS = (const T*)t->dS;
   RC(o.mmbh(TG_STORE_T, dS, ldp, 0, sP1, sP2, q + inner, 3 * inner, 1, sQ1, DK, dq, 3 * inner, sQ1, DK, nB, S, DK, S));              // dQ = dS K
   RC(o.mmbh(TG_STORE_T, dS, ldp, 1, sP1, sP2, q, 3 * inner, 1, sQ1, DK, dq + inner, 3 * inner, sQ1, DK, nB, S, DK, S));              // dK = dS^T Q
