@@ -949,8 +949,10 @@ __global__ __launch_bounds__(256) void bias_bucket_kernel(const float* __restric
 // stage 1b for the per-stripe diagonal sums of attn_stripe_kernel: part2 [B*H][stripes][Sk + 31] -> tmp [H][nrel], summed over
 // clips and stripes in a fixed order; the diagonal with global index rel (= key - query + Sq - 1) is entry
 // rel + 31 + 32 s - (Sq - 1) of stripe s.  Block = (head, 64 consecutive rels) x 4 clip groups; bias_bucket_kernel (B = 1) follows.
-__global__ __launch_bounds__(256) void bias_stripes_sum_kernel(const float* __restrict__ part2, float* __restrict__ tmp, int B, int H, int stripes,
-                                                               int Sq, int Sk) {
+__global__ __launch_bounds__(256) void bias_stripes_sum_kernel(const float* __restrict__ part2_all, float* __restrict__ tmp_all, int B, int H, int stripes,
+                                                               int Sq, int Sk, int64_t layer_stride) {
+  const float* part2 = part2_all + (int64_t)blockIdx.z * layer_stride;        // blockIdx.z: layer (grouped mode: all layers of a stack in one launch)
+  float* tmp = tmp_all + (int64_t)blockIdx.z * H * (Sq + Sk - 1);
   __shared__ float sred[4][64];
   const int nrel = Sq + Sk - 1, dl = Sk + 31;
   const int hh = blockIdx.x, rl = threadIdx.x & 63, bg = threadIdx.x >> 6;
@@ -1538,6 +1540,7 @@ struct m2m_trainer {
   void* dw_probs_dev = nullptr;          // DwProb table on the device
   std::vector<unsigned char> dw_probs_host;   // ... and its host image (re-uploaded only when it changes)
   int dw_tiles = 0;
+  int64_t drel_slot_floats = 0;          // one self-attention layer's per-stripe diagonal sums (t->drel holds Le + Ld of them, then the scratch)
   int64_t* norm_offs_dev = nullptr;      // parameter offsets of the RMSNorm weights, in the order the backward pass meets them
   std::vector<int64_t> norm_offs_host;
   // streams / graph of the step (trainer-owned: the caller's stream may be the legacy default stream, which cannot capture)
@@ -1687,7 +1690,7 @@ int build_arena(m2m_trainer* t) {
                                   o.push_back(T(B * H * L * lpl)); o.push_back(T(Md * inner)); o.push_back(T(Md * inner)); o.push_back(T(Me * 2 * inner));
                                   o.push_back(T(B * H * L * lps)); o.push_back(T(Md * inner)); o.push_back(T(Md * 2 * dff)); o.push_back(T(Md * dff)); }
   const int64_t o_hE = T(Me * d), o_hD = T(Md * d), o_logits = F(Md * V), o_sc = F(B * H * Sm * lpm), o_dxa = F(Mx * d), o_dxb = F(Mx * d),
-                o_dh = F(Mx * d), o_dhE = F(Me * d), o_dwp = F((int64_t)RN_BLOCKS * d * (2 * Le + 3 * Ld + 2)), o_nofs = c.take(64 * 8), o_rl = F(Md), o_inv = F(64), o_drel = F(B * H * std::max<int64_t>(2 * Sm, ((Sm + 31) / 32) * (Sm + 32)) + H * 2 * Sm),
+                o_dh = F(Mx * d), o_dhE = F(Me * d), o_dwp = F((int64_t)RN_BLOCKS * d * (2 * Le + 3 * Ld + 2)), o_nofs = c.take(64 * 8), o_rl = F(Md), o_inv = F(64), o_drel = F((int64_t)(Le + Ld) * B * H * std::max<int64_t>(2 * Sm, ((Sm + 31) / 32) * (Sm + 32)) + (int64_t)std::max(Le, Ld) * H * 2 * Sm),
                 o_etab = F(H * (2 * S)), o_dtab = F(H * (2 * L)), o_dlog = T(Md * align_up(V, 8)), o_dxT = T(Mx * d), o_dmid = T(Mx * dff),
                 o_dab = T(Mx * 2 * dff), o_dO = T(Mx * inner), o_dqkv = T(Mx * 3 * inner), o_dS = T(B * H * Sm * lpm), o_dcq = T(Md * inner),
                 o_dckv = T(Me * 2 * inner), o_lab = c.take(Md * 8), o_cnd = c.take(B * 8 * 8), o_skey = c.take(256), o_decin = c.take(Md * 8), o_eb = c.take(2 * S * 4), o_db = c.take(2 * L * 4),
@@ -1756,7 +1759,7 @@ int build_arena(m2m_trainer* t) {
                                   t->Pcd.push_back(nextT()); t->aocd.push_back(nextT()); t->abd.push_back(nextT()); t->midd.push_back(nextT()); }
   t->hE = b + o_hE; t->hD = b + o_hD; t->logits = (float*)(b + o_logits); t->sc = (float*)(b + o_sc); t->dxa = (float*)(b + o_dxa);
   t->dxb = (float*)(b + o_dxb); t->dh = (float*)(b + o_dh); t->dhE = (float*)(b + o_dhE); t->dw_part = (float*)(b + o_dwp); t->norm_offs_dev = (int64_t*)(b + o_nofs);
-  t->row_loss = (float*)(b + o_rl); t->inv_n = (float*)(b + o_inv); t->drel = (float*)(b + o_drel); t->etab = (float*)(b + o_etab);
+  t->row_loss = (float*)(b + o_rl); t->inv_n = (float*)(b + o_inv); t->drel = (float*)(b + o_drel); t->drel_slot_floats = B * H * std::max<int64_t>(2 * Sm, ((Sm + 31) / 32) * (Sm + 32)); t->etab = (float*)(b + o_etab);
   t->dtab = (float*)(b + o_dtab); t->dlog = b + o_dlog; t->dxT = b + o_dxT; t->dmid = b + o_dmid; t->dab = b + o_dab; t->dO = b + o_dO;
   t->dqkv = b + o_dqkv; t->dS = b + o_dS; t->dcq = b + o_dcq; t->dckv = b + o_dckv; t->dec_in = (int64_t*)(b + o_decin);
   {
@@ -1822,6 +1825,9 @@ struct Ops {
   mutable std::vector<std::function<int(hipStream_t)>> pending;
   mutable std::vector<DwProb> probs;
   mutable std::vector<int64_t> norm_offs;
+  struct BiasJob { const int* buckets; float* Gtab; int nB, Sq, Sk, first_slot, layers; };
+  mutable std::vector<BiasJob> bias_jobs;          // grouped mode: per stack, the self-attention layers whose diagonal sums wait in t->drel slots
+  mutable int drel_slots = 0;
   mutable int pos[m2m_trainer::K_KINDS] = {0, 0, 0, 0, 0};
   mutable int sub = 0;
   mutable bool used[2] = {false, false};
@@ -2060,7 +2066,7 @@ struct Ops {
     StripeArgs a{};
     a.X = V; a.ldx = ldv; a.sX1 = sV1; a.sX2 = sV2; a.Y = dO; a.ldy = ldo; a.sY1 = sO1; a.sY2 = sO2;
     a.P = const_cast<void*>(Pm); a.dS = dS; a.H = t->g.num_heads; a.Sq = Sq; a.Sk = Sk; a.ldp = ldp;
-    a.diag_part = want_diag ? t->drel : nullptr;
+    a.diag_part = want_diag ? drel_slot() : nullptr;
     a.dk = dr ? key(site) : DropKey{nullptr, 0}; a.thresh = dr ? t->drop_thresh : 0u; a.scale = t->drop_scale;
     return launch_attn_stripe<T>(true, a, nB, st);
   }
@@ -2104,12 +2110,28 @@ struct Ops {
     return M2M_OK;
   }
   // bias gradient from the per-stripe diagonal sums the backward stripe kernel left in t->drel
-  int bias_grad_stripes(const int* buckets, float* Gtab, int nB, int Sq, int Sk, int accumulate) const {
-    const int H = t->g.num_heads, nrel = Sq + Sk - 1, stripes = ceil_div(Sq, 32);
-    float* tmp = t->drel + (int64_t)nB * H * stripes * (Sk + 31);
-    hipLaunchKernelGGL(bias_stripes_sum_kernel, dim3(H, ceil_div(nrel, 64)), dim3(256), 0, st, t->drel, tmp, nB, H, stripes, Sq, Sk);
-    hipLaunchKernelGGL(bias_bucket_kernel, dim3(t->g.num_buckets * H), dim3(256), 0, st, tmp, buckets, Gtab, 1, H, nrel, accumulate);
+  float* drel_slot() const { return t->drel + (int64_t)(group ? drel_slots : 0) * t->drel_slot_floats; }      // where the next stripe launch leaves its sums
+  int bias_reduce(const BiasJob& j, int accumulate) const {
+    const int H = t->g.num_heads, nrel = j.Sq + j.Sk - 1, stripes = ceil_div(j.Sq, 32);
+    float* tmp = t->drel + (int64_t)(t->g.num_layers + t->g.num_decoder_layers) * t->drel_slot_floats;
+    hipLaunchKernelGGL(bias_stripes_sum_kernel, dim3(H, ceil_div(nrel, 64), j.layers), dim3(256), 0, st, t->drel + (int64_t)j.first_slot * t->drel_slot_floats,
+                       tmp, j.nB, H, stripes, j.Sq, j.Sk, t->drel_slot_floats);
+    hipLaunchKernelGGL(bias_bucket_kernel, dim3(t->g.num_buckets * H), dim3(256), 0, st, tmp, j.buckets, j.Gtab, j.layers, H, nrel, accumulate);
     M2M_CHECK_HIP(hipGetLastError());
+    return M2M_OK;
+  }
+  // grouped mode: the layers of a stack share one table, so their sums are reduced together after the backward pass (two
+  // launches per stack instead of two per layer); otherwise right away
+  int bias_grad_stripes(const int* buckets, float* Gtab, int nB, int Sq, int Sk, int accumulate) const {
+    if (!group) return bias_reduce(BiasJob{buckets, Gtab, nB, Sq, Sk, 0, 1}, accumulate);
+    if (!bias_jobs.empty() && bias_jobs.back().buckets == buckets && bias_jobs.back().Gtab == Gtab) bias_jobs.back().layers += 1;
+    else bias_jobs.push_back(BiasJob{buckets, Gtab, nB, Sq, Sk, drel_slots, 1});
+    drel_slots += 1;
+    return M2M_OK;
+  }
+  int flush_bias() const {
+    for (const BiasJob& j : bias_jobs) { const int rc = bias_reduce(j, 0); if (rc != M2M_OK) return rc; }
+    bias_jobs.clear();
     return M2M_OK;
   }
   int bias_grad(const void* dS, const int* buckets, float* Gtab, int nB, int Sq, int Sk, int ldp, int accumulate) const {
@@ -2380,6 +2402,7 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
   RC(o.join_side());
   RC(o.flush_group());
   RC(o.flush_norms());
+  RC(o.flush_bias());
   return M2M_OK;
 }
 
