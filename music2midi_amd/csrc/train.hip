@@ -1015,9 +1015,14 @@ __global__ void gated_bwd_kernel(const T* __restrict__ ab, const T* __restrict__
 // dx_out[row] = dx_res[row] (gradient arriving over the residual connection, may be null)
 //             + r * (w o dy) - x * r^3 * mean(w o dy o x);   dw partial per block (fixed order), reduced by colsum_kernel.
 constexpr int RN_BLOCKS = 256;
+// out_t (optional): the gradient again in the GEMM-input type, through the dropout mask of the branch that consumes it next
+// (what cvt_kernel / cvt_drop_kernel would produce in a launch of its own)
+template <typename T>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ dy, const float* __restrict__ dx_res,
-                                                          float* __restrict__ dx_out, float* __restrict__ dw_part, int M, int d, float eps) {
+                                                          float* __restrict__ dx_out, float* __restrict__ dw_part, int M, int d, float eps,
+                                                          T* __restrict__ out_t, DropKey dk, uint32_t thresh, float scale) {
+  const uint64_t key = (out_t && thresh) ? drop_site_key(dk) : 0ull;
   extern __shared__ float red[];          // [4][d]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float dwacc[8];
@@ -1058,6 +1063,15 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
                                r * gv[j].w * dv[j].w - xv[j].w * k2);
         if (dx_res) { o.x += rv[j].x; o.y += rv[j].y; o.z += rv[j].z; o.w += rv[j].w; }
         *reinterpret_cast<float4*>(dx_out + (int64_t)row * d + col) = o;
+        if (out_t) {
+          const int64_t at = (int64_t)row * d + col;
+          float v[4] = {o.x, o.y, o.z, o.w};
+          if (thresh) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = drop_keep(key, at + e, thresh) ? v[e] * scale : 0.f;
+          }
+          st_store4<T>(out_t + at, v[0], v[1], v[2], v[3]);
+        }
         dwacc[4 * j + 0] += dv[j].x * xv[j].x * r; dwacc[4 * j + 1] += dv[j].y * xv[j].y * r;
         dwacc[4 * j + 2] += dv[j].z * xv[j].z * r; dwacc[4 * j + 3] += dv[j].w * xv[j].w * r;
       }
@@ -1828,6 +1842,11 @@ struct Ops {
   struct BiasJob { const int* buckets; float* Gtab; int nB, Sq, Sk, first_slot, layers; };
   mutable std::vector<BiasJob> bias_jobs;          // grouped mode: per stack, the self-attention layers whose diagonal sums wait in t->drel slots
   mutable int drel_slots = 0;
+  // grouped mode: the RMSNorm backward of a sub-layer also emits its dx in the GEMM-input type for the sub-layer that runs next
+  // (site = that sub-layer's branch-output dropout site; -2: nobody), straight into that sub-layer's dxT ring entry
+  mutable int after_site = -2;
+  struct PreCvt { const float* src = nullptr; const void* dst = nullptr; int site = -2; };
+  mutable PreCvt pre;
   mutable int pos[m2m_trainer::K_KINDS] = {0, 0, 0, 0, 0};
   mutable int sub = 0;
   mutable bool used[2] = {false, false};
@@ -1935,6 +1954,8 @@ struct Ops {
   }
   // gradient entering a (possibly dropped) branch, in the GEMM-input type
   int cvt_branch(const float* src, void* dst, int64_t n, int site) const {
+    if (pre.src == src && pre.dst == dst && pre.site == site) { pre = PreCvt{}; return M2M_OK; }      // the producing norm already wrote it
+    pre = PreCvt{};
     if (!dropping(site)) return launch_cvt(t->precision, src, dst, n, st);
     hipLaunchKernelGGL(cvt_drop_kernel<T>, dim3(grid_1d(n)), dim3(256), 0, st, src, (T*)dst, n, key(site), t->drop_thresh, t->drop_scale);
     M2M_CHECK_HIP(hipGetLastError());
@@ -2036,8 +2057,16 @@ struct Ops {
     // pass (flush_norms); otherwise the column sum follows right away
     const int slot = group ? (int)norm_offs.size() : 0;
     float* part = t->dw_part + (int64_t)slot * RN_BLOCKS * d;
-    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(RN_BLOCKS), dim3(256), (size_t)4 * d * sizeof(float), st, x, P + w_off, dy, dx_res, dx_out,
-                       part, M, d, t->g.layer_norm_eps);
+    T* out_t = nullptr;
+    DropKey dk{nullptr, 0};
+    uint32_t thr = 0;
+    if (group && after_site != -2) {
+      out_t = (T*)t->ring[m2m_trainer::K_DXT][pos[m2m_trainer::K_DXT] % t->ring[m2m_trainer::K_DXT].size()];      // what the next begin_sub() selects
+      if (dropping(after_site)) { dk = key(after_site); thr = t->drop_thresh; }
+      pre.src = dx_out; pre.dst = out_t; pre.site = after_site;
+    }
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel<T>, dim3(RN_BLOCKS), dim3(256), (size_t)4 * d * sizeof(float), st, x, P + w_off, dy, dx_res, dx_out,
+                       part, M, d, t->g.layer_norm_eps, out_t, dk, thr, t->drop_scale);
     if (group) norm_offs.push_back(w_off);
     else hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(d, 32)), dim3(256), 0, st, part, G + w_off, RN_BLOCKS, d, 0);
     M2M_CHECK_HIP(hipGetLastError());
@@ -2338,9 +2367,11 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
   RC(o.drop_inplace(t->dh, (int64_t)Md * d, SITE_DEC + SITE_FIN));
   float* dcur = t->dxa;
   float* dnext = t->dxb;
+  o.after_site = SITE_DEC + 16 * (Ld - 1) + PL_FF_OUT;
   RC(o.norm_bwd(t->xd[3 * Ld], t->o_dln, t->dh, nullptr, dcur, G, Md));
   for (int l = Ld - 1; l >= 0; --l) {
     const DecOff& e = t->dec[l];
+    o.after_site = SITE_DEC + 16 * l + PL_CROSS_OUT;
     RC(ff_bwd<T>(o, t->xd[3 * l + 2], dcur, dnext, G, e.ln2, e.wi, e.wo, t->h2d[l], t->abd[l], t->midd[l], Md, SITE_DEC + 16 * l));
     std::swap(dcur, dnext);
     // ---- cross-attention backward: dcur = d x[3l+2] ----
@@ -2368,12 +2399,14 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
     RC(o.mmbh(TG_STORE_T, dS, lps, 1, sPc1, sPc2, cq, inner, 1, sQ1, DK, dckv, 2 * inner, sK1, DK, B, S, DK, L));                            // dK = dS^T Q
     RC(o.dW(dcq, inner, inner, t->h1d[l], d, d, G + e.cq, Md));
     RC(o.dX(TG_STORE_F32, dcq, inner, e.cq, inner, d, t->dh, d, Md));
+    o.after_site = SITE_DEC + 16 * l + PL_SELF_OUT;
     RC(o.norm_bwd(t->xd[3 * l + 1], e.ln1, t->dh, dcur, dnext, G, Md));
     std::swap(dcur, dnext);
     RC(o.dW(dckv, 2 * inner, 2 * inner, t->hE, d, d, G + e.ckv, Me));                               // dWckv = dckv^T . hE
     RC(o.dX(l == Ld - 1 ? TG_STORE_F32 : TG_ACC_F32, dckv, 2 * inner, e.ckv, 2 * inner, d, t->dhE, d, Me));                  // dhE (+)= dckv . Wckv
     RC(o.end_sub());
     // ---- causal self-attention backward ----
+    o.after_site = l > 0 ? SITE_DEC + 16 * (l - 1) + PL_FF_OUT : -2;
     RC(attn_self_bwd<T>(o, t->xd[3 * l], dcur, dnext, G, e.ln0, e.qkv, e.o, t->h0d[l], t->qkvd[l], t->Pd[l], t->aod[l], B, L, t->dbucket, t->o_drb,
                         l == Ld - 1 ? 0 : 1, SITE_DEC + 16 * l));
     std::swap(dcur, dnext);
@@ -2384,11 +2417,14 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
                      g.pad_token_id, V);
   // encoder
   RC(o.drop_inplace(t->dhE, (int64_t)Me * d, SITE_ENC + SITE_FIN));
+  o.after_site = SITE_ENC + 16 * (Le - 1) + PL_FF_OUT;
   RC(o.norm_bwd(t->xe[2 * Le], t->o_eln, t->dhE, nullptr, dcur, G, Me));
   for (int l = Le - 1; l >= 0; --l) {
     const EncOff& e = t->enc[l];
+    o.after_site = SITE_ENC + 16 * l + PL_SELF_OUT;
     RC(ff_bwd<T>(o, t->xe[2 * l + 1], dcur, dnext, G, e.ln1, e.wi, e.wo, t->h1e[l], t->abe[l], t->mide[l], Me, SITE_ENC + 16 * l));
     std::swap(dcur, dnext);
+    o.after_site = l > 0 ? SITE_ENC + 16 * (l - 1) + PL_FF_OUT : -2;
     RC(attn_self_bwd<T>(o, t->xe[2 * l], dcur, dnext, G, e.ln0, e.qkv, e.o, t->h0e[l], t->qkve[l], t->Pe[l], t->aoe[l], B, S, t->ebucket, t->o_erb,
                         l == Le - 1 ? 0 : 1, SITE_ENC + 16 * l));
     std::swap(dcur, dnext);
