@@ -577,6 +577,26 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restric
     if (Pd) Pd[(int64_t)row * ldp + k] = drop_keep(key, (int64_t)row * ldp + k, thresh) ? from_f32<T>(to_f32(pt) * scale) : from_f32<T>(0.f);
   }
 }
+// K and V of every (clip, head) transposed for the fused products of the stripe kernels: src element (b, s, h, d) at
+// src + (b*S + s)*ld + which*wstride + h*64 + d  ->  dst[which][(b*H + h)*64 + d][s], row pitch Sp (a multiple of 32), zero in [S, Sp).
+template <typename T>
+__global__ __launch_bounds__(256) void kv_transpose_kernel(const T* __restrict__ src, int64_t ld, int64_t wstride, T* __restrict__ dst, int S, int Sp, int H,
+                                                           int64_t dst_wstride) {
+  __shared__ T tile[64][64 + 2];
+  const int s0 = blockIdx.x * 64, bh = blockIdx.y, which = blockIdx.z, b = bh / H, hh = bh - b * H;
+  const T* sp = src + (int64_t)b * S * ld + which * wstride + hh * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int sl = i >> 6, dd = i & 63;
+    tile[sl][dd] = (s0 + sl < S) ? sp[(int64_t)(s0 + sl) * ld + dd] : from_f32<T>(0.f);
+  }
+  __syncthreads();
+  T* dp = dst + which * dst_wstride + (int64_t)bh * 64 * Sp;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int dd = i >> 6, sl = i & 63;
+    if (s0 + sl < Sp) dp[(int64_t)dd * Sp + s0 + sl] = tile[sl][dd];
+  }
+}
+
 // ---- attention stripes: scores -> probabilities (forward) and dP -> dS (backward) WITHOUT the fp32 [Sq, Sk] image ----
 // Training sequences are short (S, L <= 320 here), so one wave can hold a whole stripe of 32 queries x all keys in MFMA
 // accumulators: T^T = X . Y^T with the KEYS as tile rows (X = K or V, [Sk, 64]) and the QUERIES as tile columns
@@ -592,6 +612,13 @@ struct StripeArgs {
   void* Pd;                          // forward: dropped copy of P, or null
   void* dS;                          // backward out
   float* diag_part;                  // backward, self-attention with bias: [nB*H][stripes][Sk + 31] diagonal sums of dS per stripe, or null
+  // optional fused product with the rows this workgroup has just formed: forward O = P~ . V, backward dQ = dS . K.  Xt is the
+  // second operand TRANSPOSED ([nB*H][64][xt_ld], zero beyond Sk: kv_transpose_kernel), (query, d) of the result at
+  // O + b*sO1 + h*sO2 + q*ldo + d; null: the product is a launch of its own
+  const void* Xt;
+  int64_t xt_ld;
+  void* O;
+  int64_t ldo, sO1, sO2;
   const float* bias_tab;             // forward, self-attention: [H][tab_stride] by (key - query + tab_center); null: no bias
   int tab_stride, tab_center;
   int H, Sq, Sk, ldp, causal;
@@ -686,6 +713,27 @@ __global__ __launch_bounds__(256) void attn_stripe_kernel(StripeArgs a) {
     }
     return acc;
   };
+  // fused product rows . Xt^T (see StripeArgs): waves 0 and 1 take the two 32-wide halves of d, 8 k-steps' fragments in flight at a time
+  auto rows_times_xt = [&](const T* rows) {
+    if (!a.Xt || wave >= 2) return;
+    const T* xt = reinterpret_cast<const T*>(a.Xt) + ((int64_t)bh * DK + wave * 32 + r) * a.xt_ld + 8 * h2;
+    f32x16 acc = zero_acc();
+    const int nks = nt * 2;                           // k-steps of 16 keys
+    for (int k8 = 0; k8 < nks; k8 += 8) {
+      Frag<T> bf[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) bf[u] = load_frag(xt + 16 * min(k8 + u, nks - 1));
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (k8 + u < nks) mma16(acc, load_frag(rows + r * LP + 16 * (k8 + u) + 8 * h2), bf[u]);
+    }
+    T* o = reinterpret_cast<T*>(a.O) + b * a.sO1 + hh * a.sO2 + wave * 32 + r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int qq = q0 + acc_row(i, lane);
+      if (qq < a.Sq) o[(int64_t)qq * a.ldo] = from_f32<T>(acc[i]);
+    }
+  };
   const int kend = BWD ? a.Sk : (a.causal ? min(a.Sk, q + 1) : a.Sk);
   const int64_t prow = ((int64_t)bh * a.Sq + qc) * a.ldp;
   const uint64_t key = DROP ? drop_site_key(a.dk) : 0ull;
@@ -768,6 +816,7 @@ __global__ __launch_bounds__(256) void attn_stripe_kernel(StripeArgs a) {
         }
       }
     }
+    rows_times_xt(DROP ? pl2 : pl);                   // O = P~ . V
   } else {
     T* prd = pl + r * LP;                            // this lane's query row of P, in LDS
     auto masked = [&](float dp, int k) {             // dP arrives for the DROPPED probabilities: through the mask first
@@ -833,6 +882,7 @@ __global__ __launch_bounds__(256) void attn_stripe_kernel(StripeArgs a) {
         out[i] = acc;
       }
     }
+    rows_times_xt(pl);                               // dQ = dS . K
   }
 }
 
@@ -1519,6 +1569,7 @@ struct m2m_trainer {
   std::vector<float*> xe, xd;            // residual streams: 2*Le + 1 and 3*Ld + 1 buffers
   std::vector<void*> h0e, h1e, qkve, Pe, aoe, abe, mide;
   std::vector<void*> h0d, h1d, h2d, qkvd, Pd, aod, cqd, ckvd, Pcd, aocd, abd, midd;
+  std::vector<void*> kte, ktd, ktc;      // per layer: K and V transposed, [2][B*H][64][Sp] (kv_transpose_kernel), for the fused stripe products
   void *hE = nullptr, *hD = nullptr;
   float *logits = nullptr, *sc = nullptr, *dxa = nullptr, *dxb = nullptr, *dh = nullptr, *dhE = nullptr, *dw_part = nullptr,
         *row_loss = nullptr, *inv_n = nullptr, *drel = nullptr, *etab = nullptr, *dtab = nullptr;
@@ -1703,6 +1754,10 @@ int build_arena(m2m_trainer* t) {
   for (int l = 0; l < Ld; ++l) { o.push_back(T(Md * d)); o.push_back(T(Md * d)); o.push_back(T(Md * d)); o.push_back(T(Md * 3 * inner));
                                   o.push_back(T(B * H * L * lpl)); o.push_back(T(Md * inner)); o.push_back(T(Md * inner)); o.push_back(T(Me * 2 * inner));
                                   o.push_back(T(B * H * L * lps)); o.push_back(T(Md * inner)); o.push_back(T(Md * 2 * dff)); o.push_back(T(Md * dff)); }
+  const int64_t Sp32 = align_up(S, 32), Lp32 = align_up(L, 32);
+  std::vector<int64_t> o_kte, o_ktd, o_ktc;
+  for (int l = 0; l < Le; ++l) o_kte.push_back(T(2 * B * H * 64 * Sp32));
+  for (int l = 0; l < Ld; ++l) { o_ktd.push_back(T(2 * B * H * 64 * Lp32)); o_ktc.push_back(T(2 * B * H * 64 * Sp32)); }
   const int64_t o_hE = T(Me * d), o_hD = T(Md * d), o_logits = F(Md * V), o_sc = F(B * H * Sm * lpm), o_dxa = F(Mx * d), o_dxb = F(Mx * d),
                 o_dh = F(Mx * d), o_dhE = F(Me * d), o_dwp = F((int64_t)RN_BLOCKS * d * (2 * Le + 3 * Ld + 2)), o_nofs = c.take(64 * 8), o_rl = F(Md), o_inv = F(64), o_drel = F((int64_t)(Le + Ld) * B * H * std::max<int64_t>(2 * Sm, ((Sm + 31) / 32) * (Sm + 32)) + (int64_t)std::max(Le, Ld) * H * 2 * Sm),
                 o_etab = F(H * (2 * S)), o_dtab = F(H * (2 * L)), o_dlog = T(Md * align_up(V, 8)), o_dxT = T(Mx * d), o_dmid = T(Mx * dff),
@@ -1771,6 +1826,9 @@ int build_arena(m2m_trainer* t) {
   for (int l = 0; l < Ld; ++l) { t->h0d.push_back(nextT()); t->h1d.push_back(nextT()); t->h2d.push_back(nextT()); t->qkvd.push_back(nextT());
                                   t->Pd.push_back(nextT()); t->aod.push_back(nextT()); t->cqd.push_back(nextT()); t->ckvd.push_back(nextT());
                                   t->Pcd.push_back(nextT()); t->aocd.push_back(nextT()); t->abd.push_back(nextT()); t->midd.push_back(nextT()); }
+  for (int64_t off : o_kte) t->kte.push_back(b + off);
+  for (int64_t off : o_ktd) t->ktd.push_back(b + off);
+  for (int64_t off : o_ktc) t->ktc.push_back(b + off);
   t->hE = b + o_hE; t->hD = b + o_hD; t->logits = (float*)(b + o_logits); t->sc = (float*)(b + o_sc); t->dxa = (float*)(b + o_dxa);
   t->dxb = (float*)(b + o_dxb); t->dh = (float*)(b + o_dh); t->dhE = (float*)(b + o_dhE); t->dw_part = (float*)(b + o_dwp); t->norm_offs_dev = (int64_t*)(b + o_nofs);
   t->row_loss = (float*)(b + o_rl); t->inv_n = (float*)(b + o_inv); t->drel = (float*)(b + o_drel); t->drel_slot_floats = B * H * std::max<int64_t>(2 * Sm, ((Sm + 31) / 32) * (Sm + 32)); t->etab = (float*)(b + o_etab);
@@ -2077,25 +2135,39 @@ struct Ops {
   bool stripe_ok(int Sk) const {      // the bias row + (two, with dropout) 32-row blocks of P must fit the LDS
     return stripes_on() && Sk <= 32 * ST_NT && 2 * (size_t)32 * (ceil_div(Sk, 32) * 32 + 8) * sizeof(T) + 8192 <= 158 * 1024;
   }
+  // K | V of a layer ([rows, ld], K at column 0 and V at column `inner` of `kv`) -> kt [2][nB*H][64][Sp]
+  int kv_transpose(const T* kv, int64_t ld, void* kt, int nB, int S) const {
+    const int H = t->g.num_heads, Sp = (int)align_up(S, 32);
+    hipLaunchKernelGGL(kv_transpose_kernel<T>, dim3(ceil_div(Sp, 64), nB * H, 2), dim3(256), 0, st, kv, ld, (int64_t)t->inner, (T*)kt, S, Sp, H,
+                       (int64_t)nB * H * DK * Sp);
+    M2M_CHECK_HIP(hipGetLastError());
+    return M2M_OK;
+  }
+  static bool fuse_on() { static const bool on = [] { const char* v = getenv("M2M_TRAIN_FUSE_PV"); return !(v && v[0] == '0'); }(); return on; }
+  // Xt / O: the fused product of the stripe kernel (StripeArgs), or null
   int attn_probs(const T* K, int64_t ldk, int64_t sK1, int64_t sK2, const T* Q, int64_t ldq, int64_t sQ1, int64_t sQ2, void* Pm, int nB, int Sq, int Sk,
-            int ldp, const float* tab, int causal, int site, const T** Puse) const {
+            int ldp, const float* tab, int causal, int site, const T** Puse, const T* Xt = nullptr, void* O = nullptr, int64_t ldo = 0, int64_t sO1 = 0,
+            int64_t sO2 = 0) const {
     const bool dr = dropping(site);
     StripeArgs a{};
     a.X = K; a.ldx = ldk; a.sX1 = sK1; a.sX2 = sK2; a.Y = Q; a.ldy = ldq; a.sY1 = sQ1; a.sY2 = sQ2;
     a.P = Pm; a.Pd = dr ? t->dS : nullptr; a.bias_tab = tab; a.tab_stride = Sq + Sk - 1; a.tab_center = Sq - 1;
     a.H = t->g.num_heads; a.Sq = Sq; a.Sk = Sk; a.ldp = ldp; a.causal = causal;
     a.dk = dr ? key(site) : DropKey{nullptr, 0}; a.thresh = dr ? t->drop_thresh : 0u; a.scale = t->drop_scale;
+    a.Xt = Xt; a.xt_ld = align_up(Sk, 32); a.O = O; a.ldo = ldo; a.sO1 = sO1; a.sO2 = sO2;
     *Puse = dr ? (const T*)t->dS : (const T*)Pm;
     return launch_attn_stripe<T>(false, a, nB, st);
   }
   // Fused dP + softmax backward: V = (key, d) operand, dO = (query, d) operand; dS out
   int dscores(const T* V, int64_t ldv, int64_t sV1, int64_t sV2, const T* dO, int64_t ldo, int64_t sO1, int64_t sO2, const void* Pm, void* dS, int nB,
-              int Sq, int Sk, int ldp, int site, bool want_diag = false) const {
+              int Sq, int Sk, int ldp, int site, bool want_diag = false, const T* Xt = nullptr, void* Out = nullptr, int64_t ld_out = 0, int64_t s1_out = 0,
+              int64_t s2_out = 0) const {
     const bool dr = dropping(site);
     StripeArgs a{};
     a.X = V; a.ldx = ldv; a.sX1 = sV1; a.sX2 = sV2; a.Y = dO; a.ldy = ldo; a.sY1 = sO1; a.sY2 = sO2;
     a.P = const_cast<void*>(Pm); a.dS = dS; a.H = t->g.num_heads; a.Sq = Sq; a.Sk = Sk; a.ldp = ldp;
     a.diag_part = want_diag ? drel_slot() : nullptr;
+    a.Xt = Xt; a.xt_ld = align_up(Sk, 32); a.O = Out; a.ldo = ld_out; a.sO1 = s1_out; a.sO2 = s2_out;
     a.dk = dr ? key(site) : DropKey{nullptr, 0}; a.thresh = dr ? t->drop_thresh : 0u; a.scale = t->drop_scale;
     return launch_attn_stripe<T>(true, a, nB, st);
   }
@@ -2183,7 +2255,7 @@ enum { SITE_ENC = 0, SITE_DEC = 1000, SITE_EMB = 900, SITE_FIN = 901,
 // self-attention block, forward: x_in -> x_out = x_in + Attn(norm(x_in)).  Buffers of this layer are passed in.
 template <typename T>
 int attn_self_fwd(const Ops<T>& o, const float* x_in, float* x_out, int64_t ln, int64_t wqkv, int64_t wo, void* h, void* qkv, void* Pm, void* ao,
-                  int nB, int S, const float* tab, int causal, int site0) {
+                  int nB, int S, const float* tab, int causal, int site0, void* kt) {
   m2m_trainer* t = o.t;
   const int d = t->g.d_model, inner = t->inner, M = nB * S, ldp = (int)align_up(S, 8), H = t->g.num_heads;
   int rc;
@@ -2191,16 +2263,20 @@ int attn_self_fwd(const Ops<T>& o, const float* x_in, float* x_out, int64_t ln, 
   RC(o.mm(TG_STORE_T, h, d, 0, o.W(wqkv), d, 0, qkv, 3 * inner, M, 3 * inner, d));
   const T* q = (const T*)qkv;
   const T* Pu;
+  const bool fuse = o.stripe_ok(S) && o.fuse_on() && kt;         // P . V inside the stripe kernel, against the transposed V
+  const T* vt = (const T*)kt + (int64_t)nB * H * DK * align_up(S, 32);
+  if (fuse) RC(o.kv_transpose(q + inner, 3 * inner, kt, nB, S));
   if (o.stripe_ok(S)) {
     RC(o.attn_probs(q + inner, 3 * inner, (int64_t)S * 3 * inner, DK, q, 3 * inner, (int64_t)S * 3 * inner, DK, Pm, nB, S, S, ldp, tab, causal,
-               site0 + PL_PROBS_SELF, &Pu));
+               site0 + PL_PROBS_SELF, &Pu, fuse ? vt : nullptr, ao, inner, (int64_t)S * inner, DK));
   } else {
     RC(o.mmbh(TG_STORE_F32, q, 3 * inner, 0, (int64_t)S * 3 * inner, DK, q + inner, 3 * inner, 0, (int64_t)S * 3 * inner, DK, t->sc, ldp,
               (int64_t)H * S * ldp, (int64_t)S * ldp, nB, S, S, DK));
     RC(o.softmax(t->sc, Pm, nB, S, S, ldp, tab, causal, site0 + PL_PROBS_SELF, &Pu));
   }
-  RC(o.mmbh(TG_STORE_T, Pu, ldp, 0, (int64_t)H * S * ldp, (int64_t)S * ldp, q + 2 * inner, 3 * inner, 1, (int64_t)S * 3 * inner, DK, ao,
-            inner, (int64_t)S * inner, DK, nB, S, DK, S));
+  if (!fuse)
+    RC(o.mmbh(TG_STORE_T, Pu, ldp, 0, (int64_t)H * S * ldp, (int64_t)S * ldp, q + 2 * inner, 3 * inner, 1, (int64_t)S * 3 * inner, DK, ao,
+              inner, (int64_t)S * inner, DK, nB, S, DK, S));
   RC(o.mm(TG_RESID_F32, ao, inner, 0, o.W(wo), inner, 0, x_out, d, M, d, inner, x_in, site0 + PL_SELF_OUT));
   return M2M_OK;
 }
@@ -2209,7 +2285,7 @@ int attn_self_fwd(const Ops<T>& o, const float* x_in, float* x_out, int64_t ln, 
 template <typename T>
 int attn_self_bwd(const Ops<T>& o, const float* x_in, const float* dx_out, float* dx_in, float* G, int64_t ln, int64_t wqkv, int64_t wo,
                   const void* h, const void* qkv, const void* Pm, const void* ao, int nB, int S, const int* buckets, int64_t bias_off,
-                  int bias_accumulate, int site0) {
+                  int bias_accumulate, int site0, const void* kt) {
   m2m_trainer* t = o.t;
   const int d = t->g.d_model, inner = t->inner, M = nB * S, ldp = (int)align_up(S, 8), H = t->g.num_heads;
   int rc;
@@ -2224,8 +2300,10 @@ int attn_self_bwd(const Ops<T>& o, const float* x_in, const float* dx_out, float
   const T* Pu;
   RC(o.redrop(Pm, (int64_t)nB * H * S * ldp, site0 + PL_PROBS_SELF, &Pu));
   RC(o.mmbh(TG_STORE_T, Pu, ldp, 1, sP1, sP2, dO, inner, 1, sO1, DK, dq + 2 * inner, 3 * inner, sQ1, DK, nB, S, DK, S));             // dV = Pd^T dO
+  const bool fuse = o.stripe_ok(S) && o.fuse_on() && kt;         // dQ = dS . K inside the stripe kernel, against the transposed K
   if (o.stripe_ok(S)) {
-    RC(o.dscores(q + 2 * inner, 3 * inner, sQ1, DK, dO, inner, sO1, DK, Pm, t->dS, nB, S, S, ldp, site0 + PL_PROBS_SELF, buckets != nullptr));   // dS from dPd = dO V^T
+    RC(o.dscores(q + 2 * inner, 3 * inner, sQ1, DK, dO, inner, sO1, DK, Pm, t->dS, nB, S, S, ldp, site0 + PL_PROBS_SELF, buckets != nullptr,   // dS from dPd = dO V^T
+                 fuse ? (const T*)kt : nullptr, dq, 3 * inner, sQ1, DK));
     if (buckets) RC(o.bias_grad_stripes(buckets, G + bias_off, nB, S, S, bias_accumulate));
   } else {
     RC(o.mmbh(TG_STORE_F32, dO, inner, 0, sO1, DK, q + 2 * inner, 3 * inner, 0, sQ1, DK, t->sc, ldp, sP1, sP2, nB, S, S, DK));      // dPd = dO V^T
@@ -2233,7 +2311,7 @@ int attn_self_bwd(const Ops<T>& o, const float* x_in, const float* dx_out, float
     if (buckets) RC(o.bias_grad(t->dS, buckets, G + bias_off, nB, S, S, ldp, bias_accumulate));
   }
   const T* dS = (const T*)t->dS;
-  RC(o.mmbh(TG_STORE_T, dS, ldp, 0, sP1, sP2, q + inner, 3 * inner, 1, sQ1, DK, dq, 3 * inner, sQ1, DK, nB, S, DK, S));              // dQ = dS K
+  if (!fuse) RC(o.mmbh(TG_STORE_T, dS, ldp, 0, sP1, sP2, q + inner, 3 * inner, 1, sQ1, DK, dq, 3 * inner, sQ1, DK, nB, S, DK, S));   // dQ = dS K
   RC(o.mmbh(TG_STORE_T, dS, ldp, 1, sP1, sP2, q, 3 * inner, 1, sQ1, DK, dq + inner, 3 * inner, sQ1, DK, nB, S, DK, S));              // dK = dS^T Q
   RC(o.dW(dq, 3 * inner, 3 * inner, h, d, d, G + wqkv, M));                                       // dWqkv = dqkv^T . h
   RC(o.dX(TG_STORE_F32, dq, 3 * inner, wqkv, 3 * inner, d, t->dh, d, M));                         // dh = dqkv . Wqkv
@@ -2314,7 +2392,7 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
   for (int l = 0; l < Le; ++l) {
     const EncOff& e = t->enc[l];
     RC(attn_self_fwd<T>(o, t->xe[2 * l], t->xe[2 * l + 1], e.ln0, e.qkv, e.o, t->h0e[l], t->qkve[l], t->Pe[l], t->aoe[l], B, S, t->etab, 0,
-                        SITE_ENC + 16 * l));
+                        SITE_ENC + 16 * l, t->kte[l]));
     RC(ff_fwd<T>(o, t->xe[2 * l + 1], t->xe[2 * l + 2], e.ln1, e.wi, e.wo, t->h1e[l], t->abe[l], t->mide[l], Me, SITE_ENC + 16 * l));
   }
   RC(o.norm(t->xe[2 * Le], t->o_eln, t->hE, Me));
@@ -2324,10 +2402,11 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
   RC(launch_embed_rows(t->dec_in, P + t->o_shared, t->xd[0], Md, d, V, g.pad_token_id, st));
   RC(o.drop_inplace(t->xd[0], (int64_t)Md * d, SITE_DEC + SITE_EMB));
   const int64_t sPc1 = (int64_t)H * L * lps, sPc2 = (int64_t)L * lps;
+  const bool fuse_c = o.stripe_ok(S) && o.fuse_on();       // cross-attention: P . V and dQ = dS . K inside the stripe kernels
   for (int l = 0; l < Ld; ++l) {
     const DecOff& e = t->dec[l];
     RC(attn_self_fwd<T>(o, t->xd[3 * l], t->xd[3 * l + 1], e.ln0, e.qkv, e.o, t->h0d[l], t->qkvd[l], t->Pd[l], t->aod[l], B, L, t->dtab, 1,
-                        SITE_DEC + 16 * l));
+                        SITE_DEC + 16 * l, t->ktd[l]));
     // cross-attention (hf: modeling_t5.py:319-342: K/V from the encoder output, zero bias, no mask)
     RC(o.norm(t->xd[3 * l + 1], e.ln1, t->h1d[l], Md));
     RC(o.mm(TG_STORE_T, t->h1d[l], d, 0, o.W(e.cq), d, 0, t->cqd[l], inner, Md, inner, d));
@@ -2336,14 +2415,17 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
     const T* ckv = (const T*)t->ckvd[l];
     const T* Pu;
     if (o.stripe_ok(S)) {
+      if (fuse_c) RC(o.kv_transpose(ckv, 2 * inner, t->ktc[l], B, S));          // serves P . V here and dQ = dS . K in the backward pass
       RC(o.attn_probs(ckv, 2 * inner, (int64_t)S * 2 * inner, DK, cq, inner, (int64_t)L * inner, DK, t->Pcd[l], B, L, S, lps, nullptr, 0,
-                 SITE_DEC + 16 * l + PL_PROBS_CROSS, &Pu));
+                 SITE_DEC + 16 * l + PL_PROBS_CROSS, &Pu, fuse_c ? (const T*)t->ktc[l] + (int64_t)B * H * DK * align_up(S, 32) : nullptr, t->aocd[l], inner,
+                 (int64_t)L * inner, DK));
     } else {
       RC(o.mmbh(TG_STORE_F32, cq, inner, 0, (int64_t)L * inner, DK, ckv, 2 * inner, 0, (int64_t)S * 2 * inner, DK, t->sc, lps, sPc1, sPc2, B, L, S, DK));
       RC(o.softmax(t->sc, t->Pcd[l], B, L, S, lps, nullptr, 0, SITE_DEC + 16 * l + PL_PROBS_CROSS, &Pu));
     }
-    RC(o.mmbh(TG_STORE_T, Pu, lps, 0, sPc1, sPc2, ckv + inner, 2 * inner, 1, (int64_t)S * 2 * inner, DK, t->aocd[l], inner,
-              (int64_t)L * inner, DK, B, L, DK, S));
+    if (!fuse_c)
+      RC(o.mmbh(TG_STORE_T, Pu, lps, 0, sPc1, sPc2, ckv + inner, 2 * inner, 1, (int64_t)S * 2 * inner, DK, t->aocd[l], inner,
+                (int64_t)L * inner, DK, B, L, DK, S));
     RC(o.mm(TG_RESID_F32, t->aocd[l], inner, 0, o.W(e.co), inner, 0, t->xd[3 * l + 2], d, Md, d, inner, t->xd[3 * l + 1],
             SITE_DEC + 16 * l + PL_CROSS_OUT));
     RC(ff_fwd<T>(o, t->xd[3 * l + 2], t->xd[3 * l + 3], e.ln2, e.wi, e.wo, t->h2d[l], t->abd[l], t->midd[l], Md, SITE_DEC + 16 * l));
@@ -2389,13 +2471,14 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
     RC(o.redrop(t->Pcd[l], (int64_t)B * H * L * lps, SITE_DEC + 16 * l + PL_PROBS_CROSS, &Pu));
     RC(o.mmbh(TG_STORE_T, Pu, lps, 1, sPc1, sPc2, dO, inner, 1, sQ1, DK, dckv + inner, 2 * inner, sK1, DK, B, S, DK, L));                   // dV = Pd^T dO
     if (o.stripe_ok(S)) {
-      RC(o.dscores(ckv + inner, 2 * inner, sK1, DK, dO, inner, sQ1, DK, t->Pcd[l], t->dS, B, L, S, lps, SITE_DEC + 16 * l + PL_PROBS_CROSS));
+      RC(o.dscores(ckv + inner, 2 * inner, sK1, DK, dO, inner, sQ1, DK, t->Pcd[l], t->dS, B, L, S, lps, SITE_DEC + 16 * l + PL_PROBS_CROSS, false,
+                   fuse_c ? (const T*)t->ktc[l] : nullptr, dcq, inner, sQ1, DK));
     } else {
       RC(o.mmbh(TG_STORE_F32, dO, inner, 0, sQ1, DK, ckv + inner, 2 * inner, 0, sK1, DK, t->sc, lps, sPc1, sPc2, B, L, S, DK));             // dPd = dO V^T
       RC(o.softmax_bwd(t->Pcd[l], t->sc, t->dS, B * H * L, S, lps, SITE_DEC + 16 * l + PL_PROBS_CROSS));
     }
     const T* dS = (const T*)t->dS;
-    RC(o.mmbh(TG_STORE_T, dS, lps, 0, sPc1, sPc2, ckv, 2 * inner, 1, sK1, DK, dcq, inner, sQ1, DK, B, L, DK, S));                            // dQ = dS K
+    if (!fuse_c) RC(o.mmbh(TG_STORE_T, dS, lps, 0, sPc1, sPc2, ckv, 2 * inner, 1, sK1, DK, dcq, inner, sQ1, DK, B, L, DK, S));               // dQ = dS K
     RC(o.mmbh(TG_STORE_T, dS, lps, 1, sPc1, sPc2, cq, inner, 1, sQ1, DK, dckv, 2 * inner, sK1, DK, B, S, DK, L));                            // dK = dS^T Q
     RC(o.dW(dcq, inner, inner, t->h1d[l], d, d, G + e.cq, Md));
     RC(o.dX(TG_STORE_F32, dcq, inner, e.cq, inner, d, t->dh, d, Md));
@@ -2408,7 +2491,7 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
     // ---- causal self-attention backward ----
     o.after_site = l > 0 ? SITE_DEC + 16 * (l - 1) + PL_FF_OUT : -2;
     RC(attn_self_bwd<T>(o, t->xd[3 * l], dcur, dnext, G, e.ln0, e.qkv, e.o, t->h0d[l], t->qkvd[l], t->Pd[l], t->aod[l], B, L, t->dbucket, t->o_drb,
-                        l == Ld - 1 ? 0 : 1, SITE_DEC + 16 * l));
+                        l == Ld - 1 ? 0 : 1, SITE_DEC + 16 * l, t->ktd[l]));
     std::swap(dcur, dnext);
   }
   // token embedding (decoder inputs; the encoder is fed inputs_embeds) — hf: modeling_t5.py embed_tokens = shared
@@ -2426,7 +2509,7 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
     std::swap(dcur, dnext);
     o.after_site = l > 0 ? SITE_ENC + 16 * (l - 1) + PL_FF_OUT : -2;
     RC(attn_self_bwd<T>(o, t->xe[2 * l], dcur, dnext, G, e.ln0, e.qkv, e.o, t->h0e[l], t->qkve[l], t->Pe[l], t->aoe[l], B, S, t->ebucket, t->o_erb,
-                        l == Le - 1 ? 0 : 1, SITE_ENC + 16 * l));
+                        l == Le - 1 ? 0 : 1, SITE_ENC + 16 * l, t->kte[l]));
     std::swap(dcur, dnext);
   }
   RC(o.drop_inplace(dcur, (int64_t)Me * d, SITE_ENC + SITE_EMB));
