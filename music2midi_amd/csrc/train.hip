@@ -1582,7 +1582,10 @@ struct m2m_trainer {
   int tab_S = -1, tab_L = -1;            // geometry the bucket tables on the device were built for
   // fp8 mode (M2M_PREC_FP8): storage type stays bf16, the projection products run on MXFP8 (mx8.hip)
   bool fp8 = false;
-  bool fp8_fwd = true, fp8_dx = true, fp8_dw = true;   // diagnostic switches (M2M_FP8_PARTS=fwd,dx,dw subset)
+  // which projection products run on MXFP8 (M2M_FP8_PARTS = subset of fwd,dx,dw).  Default: forward and dX; the weight gradients
+  // take the grouped bf16 launch — on fp8 they need two transposing quantiser launches + a split-K product + a reduce EACH
+  // (16 clips: 8.9 ms per step against 7.5 ms), for the least accuracy-critical third of the products
+  bool fp8_fwd = true, fp8_dx = true, fp8_dw = false;
   int grad_fmt = 0;                      // element format of the gradient operands: 0 = e4m3 (default), 1 = e5m2 (M2M_FP8_GRAD=e5m2)
   struct LinW { int64_t off; int N, K, Np; int64_t q, qs, qt, qts; };
   std::vector<LinW> lin;                 // every projection matrix (fused groups), by parameter offset

@@ -230,9 +230,11 @@ def test_dropout_bf16_full_model_statistics():
     assert abs(a - ref.item()) < 3e-2 * abs(ref.item())
 
 
+@pytest.mark.parametrize("parts", [None, "fwd,dx,dw"])
 @pytest.mark.parametrize("cfg_name,B,F,Ld", [("tiny", 3, 21, 14), ("full", 4, 188, 48)])
-def test_fp8_mode_matches_the_mx_emulating_oracle(cfg_name, B, F, Ld):
-    """fp8 mode (BASELINE configs[4]'s dtype): the projection products — forward, dX and dW — on block-scaled OCP FP8
+def test_fp8_mode_matches_the_mx_emulating_oracle(cfg_name, B, F, Ld, parts, monkeypatch):
+    """fp8 mode (BASELINE configs[4]'s dtype): the projection products — forward and dX by default, dW with M2M_FP8_PARTS=fwd,dx,dw
+    (second parametrisation) — on block-scaled OCP FP8
     (MXFP8 e4m3, 32 elements per power-of-two scale; csrc/mx8.hip), everything else as the bf16 mode.  The product itself
     is pinned by tests/test_mx8_gpu.py.  The step is compared with autograd over an oracle whose projections quantise
     their operands the same way (oracle/train.py mx8 + straight-through): that is the function the device differentiates.
@@ -240,6 +242,8 @@ def test_fp8_mode_matches_the_mx_emulating_oracle(cfg_name, B, F, Ld):
     turns by cos ~0.93 — a property of the perturbed forward, which the ablation (forward-only fp8: 0.937; dX-only 0.995;
     dW-only 0.9988) and the emulating oracle both show."""
     cfg = tiny_config() if cfg_name == "tiny" else copy.deepcopy(DEFAULT_CONFIG)
+    if parts:
+        monkeypatch.setenv("M2M_FP8_PARTS", parts)
     model, tr, orc, params, geom, x, feats, cond, labels = _setup(cfg, "fp8", B, F, Ld)
     loss, _ = tr.forward_backward(x.cuda(), cond.cuda(), labels.cuda())
     g1 = tr.grads.clone()
