@@ -745,6 +745,7 @@ __global__ __launch_bounds__(256) void attn_stripe_kernel(StripeArgs a) {
     for (int j = 0; j < TPW; ++j) {
       const int kt = wave + 4 * j;
       if (kt >= nt) break;                             // wave-uniform
+      if (a.causal && kt * 32 > q0 + 31) break;        // causal: this and every later tile of the wave lie above the stripe's diagonal
       f32x16 acc = tile(j);
       float tm = -1e30f;
 #pragma unroll
@@ -782,6 +783,14 @@ __global__ __launch_bounds__(256) void attn_stripe_kernel(StripeArgs a) {
     for (int j = 0; j < TPW; ++j) {
       const int kt = wave + 4 * j;
       if (kt >= nt) break;                             // wave-uniform
+      if (a.causal && kt * 32 > q0 + 31) {             // fully masked tile: zeros, no product, no exponentials
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          st_store4<T>(pl + r * LP + kt * 32 + 8 * g + 4 * h2, 0.f, 0.f, 0.f, 0.f);
+          if constexpr (DROP) st_store4<T>(pl2 + r * LP + kt * 32 + 8 * g + 4 * h2, 0.f, 0.f, 0.f, 0.f);
+        }
+        continue;
+      }
       const f32x16 acc = tile(j);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -829,6 +838,7 @@ __global__ __launch_bounds__(256) void attn_stripe_kernel(StripeArgs a) {
     for (int j = 0; j < TPW; ++j) {
       const int kt = wave + 4 * j;
       if (kt >= nt) break;                             // wave-uniform
+      if (a.causal && kt * 32 > q0 + 31) break;        // causal: P is zero there
       const f32x16 acc = tile(j);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -848,6 +858,9 @@ __global__ __launch_bounds__(256) void attn_stripe_kernel(StripeArgs a) {
     for (int j = 0; j < TPW; ++j) {
       const int kt = wave + 4 * j;
       if (kt >= nt) break;                             // wave-uniform
+      if (a.causal && kt * 32 > q0 + 31) {             // dS = P (...) = 0: the staged P rows already hold zeros there
+        continue;
+      }
       const f32x16 acc = tile(j);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -1024,40 +1037,56 @@ __global__ __launch_bounds__(256) void bias_stripes_sum_kernel(const float* __re
 }
 
 // ---- gated GELU (hf: modeling_t5.py T5DenseGatedActDense: gelu_new(wi_0 x) * (wi_1 x)); ab = [a | b], [M, 2*dff] ----
+// four consecutive columns per thread (8- / 16-byte accesses; the first form moved 2-byte elements: 11.4 / 16.5 us per launch)
 template <typename T>
 __global__ void gated_fwd_kernel(const T* __restrict__ ab, T* __restrict__ mid, int64_t M, int dff, DropKey dk, uint32_t thresh, float scale) {
   const uint64_t key = thresh ? drop_site_key(dk) : 0ull;
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t n = M * dff, stride = (int64_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) {
-    const int64_t row = i / dff;
-    const int c = (int)(i - row * dff);
-    const float a = to_f32(ab[row * 2 * dff + c]), b = to_f32(ab[row * 2 * dff + dff + c]);
-    float v = gelu_new(a) * b;
-    if (thresh) v = drop_keep(key, i, thresh) ? v * scale : 0.f;      // hf: T5DenseGatedActDense dropout before wo
-    mid[i] = from_f32<T>(v);
+  int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = dff >> 2;
+  const int64_t n4 = M * q, stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i4 < n4; i4 += stride) {
+    const int64_t row = i4 / q;
+    const int c = (int)(i4 - row * q) * 4;
+    const float4 a = st_load4<T>(ab + row * 2 * dff + c), b = st_load4<T>(ab + row * 2 * dff + dff + c);
+    float v[4] = {gelu_new(a.x) * b.x, gelu_new(a.y) * b.y, gelu_new(a.z) * b.z, gelu_new(a.w) * b.w};
+    if (thresh) {                                                       // hf: T5DenseGatedActDense dropout before wo
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = drop_keep(key, row * dff + c + e, thresh) ? v[e] * scale : 0.f;
+    }
+    st_store4<T>(mid + row * dff + c, v[0], v[1], v[2], v[3]);
   }
 }
-__device__ inline float gelu_new_grad(float x) {
+// gelu_new(x) and its derivative from one tanh
+__device__ inline void gelu_new_both(float x, float* g, float* dg) {
   const float k = 0.7978845608028654f;
   const float u = k * (x + 0.044715f * x * x * x);
   const float th = tanhf(u);
-  return 0.5f * (1.0f + th) + 0.5f * x * (1.0f - th * th) * k * (1.0f + 3.0f * 0.044715f * x * x);
+  *g = 0.5f * x * (1.0f + th);
+  *dg = 0.5f * (1.0f + th) + 0.5f * x * (1.0f - th * th) * k * (1.0f + 3.0f * 0.044715f * x * x);
 }
 template <typename T>
 __global__ void gated_bwd_kernel(const T* __restrict__ ab, const T* __restrict__ dmid, T* __restrict__ dab, int64_t M, int dff, DropKey dk,
                                  uint32_t thresh, float scale) {
   const uint64_t key = thresh ? drop_site_key(dk) : 0ull;
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t n = M * dff, stride = (int64_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) {
-    const int64_t row = i / dff;
-    const int c = (int)(i - row * dff);
-    const float a = to_f32(ab[row * 2 * dff + c]), b = to_f32(ab[row * 2 * dff + dff + c]);
-    float dm = to_f32(dmid[i]);
-    if (thresh) dm = drop_keep(key, i, thresh) ? dm * scale : 0.f;
-    dab[row * 2 * dff + c] = from_f32<T>(dm * b * gelu_new_grad(a));
-    dab[row * 2 * dff + dff + c] = from_f32<T>(dm * gelu_new(a));
+  int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = dff >> 2;
+  const int64_t n4 = M * q, stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i4 < n4; i4 += stride) {
+    const int64_t row = i4 / q;
+    const int c = (int)(i4 - row * q) * 4;
+    const float4 a4 = st_load4<T>(ab + row * 2 * dff + c), b4 = st_load4<T>(ab + row * 2 * dff + dff + c), d4 = st_load4<T>(dmid + row * dff + c);
+    const float a[4] = {a4.x, a4.y, a4.z, a4.w}, b[4] = {b4.x, b4.y, b4.z, b4.w};
+    float dm[4] = {d4.x, d4.y, d4.z, d4.w}, da[4], db[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (thresh) dm[e] = drop_keep(key, row * dff + c + e, thresh) ? dm[e] * scale : 0.f;
+      float g, dg;
+      gelu_new_both(a[e], &g, &dg);
+      da[e] = dm[e] * b[e] * dg;
+      db[e] = dm[e] * g;
+    }
+    st_store4<T>(dab + row * 2 * dff + c, da[0], da[1], da[2], da[3]);
+    st_store4<T>(dab + row * 2 * dff + dff + c, db[0], db[1], db[2], db[3]);
   }
 }
 
@@ -2164,11 +2193,12 @@ struct Ops {
   // Fused dP + softmax backward: V = (key, d) operand, dO = (query, d) operand; dS out
   int dscores(const T* V, int64_t ldv, int64_t sV1, int64_t sV2, const T* dO, int64_t ldo, int64_t sO1, int64_t sO2, const void* Pm, void* dS, int nB,
               int Sq, int Sk, int ldp, int site, bool want_diag = false, const T* Xt = nullptr, void* Out = nullptr, int64_t ld_out = 0, int64_t s1_out = 0,
-              int64_t s2_out = 0) const {
+              int64_t s2_out = 0, int causal = 0) const {
     const bool dr = dropping(site);
     StripeArgs a{};
     a.X = V; a.ldx = ldv; a.sX1 = sV1; a.sX2 = sV2; a.Y = dO; a.ldy = ldo; a.sY1 = sO1; a.sY2 = sO2;
     a.P = const_cast<void*>(Pm); a.dS = dS; a.H = t->g.num_heads; a.Sq = Sq; a.Sk = Sk; a.ldp = ldp;
+    a.causal = causal;                   // only lets the kernel skip key tiles above the diagonal (P is zero there anyway)
     a.diag_part = want_diag ? drel_slot() : nullptr;
     a.Xt = Xt; a.xt_ld = align_up(Sk, 32); a.O = Out; a.ldo = ld_out; a.sO1 = s1_out; a.sO2 = s2_out;
     a.dk = dr ? key(site) : DropKey{nullptr, 0}; a.thresh = dr ? t->drop_thresh : 0u; a.scale = t->drop_scale;
@@ -2201,14 +2231,14 @@ struct Ops {
   }
   int gated(const void* ab, void* mid, int64_t M, int site) const {
     const bool dr = dropping(site);
-    hipLaunchKernelGGL(gated_fwd_kernel<T>, dim3(grid_1d(M * t->g.d_ff)), dim3(256), 0, st, (const T*)ab, (T*)mid, M, t->g.d_ff,
+    hipLaunchKernelGGL(gated_fwd_kernel<T>, dim3(grid_1d(M * t->g.d_ff / 4)), dim3(256), 0, st, (const T*)ab, (T*)mid, M, t->g.d_ff,
                        dr ? key(site) : DropKey{nullptr, 0}, dr ? t->drop_thresh : 0u, t->drop_scale);
     M2M_CHECK_HIP(hipGetLastError());
     return M2M_OK;
   }
   int gated_bwd(const void* ab, const void* dmid, void* dab, int64_t M, int site) const {
     const bool dr = dropping(site);
-    hipLaunchKernelGGL(gated_bwd_kernel<T>, dim3(grid_1d(M * t->g.d_ff)), dim3(256), 0, st, (const T*)ab, (const T*)dmid, (T*)dab, M, t->g.d_ff,
+    hipLaunchKernelGGL(gated_bwd_kernel<T>, dim3(grid_1d(M * t->g.d_ff / 4)), dim3(256), 0, st, (const T*)ab, (const T*)dmid, (T*)dab, M, t->g.d_ff,
                        dr ? key(site) : DropKey{nullptr, 0}, dr ? t->drop_thresh : 0u, t->drop_scale);
     M2M_CHECK_HIP(hipGetLastError());
     return M2M_OK;
@@ -2306,7 +2336,7 @@ int attn_self_bwd(const Ops<T>& o, const float* x_in, const float* dx_out, float
   const bool fuse = o.stripe_ok(S) && o.fuse_on() && kt;         // dQ = dS . K inside the stripe kernel, against the transposed K
   if (o.stripe_ok(S)) {
     RC(o.dscores(q + 2 * inner, 3 * inner, sQ1, DK, dO, inner, sO1, DK, Pm, t->dS, nB, S, S, ldp, site0 + PL_PROBS_SELF, buckets != nullptr,   // dS from dPd = dO V^T
-                 fuse ? (const T*)kt : nullptr, dq, 3 * inner, sQ1, DK));
+                 fuse ? (const T*)kt : nullptr, dq, 3 * inner, sQ1, DK, buckets == t->dbucket ? 1 : 0));
     if (buckets) RC(o.bias_grad_stripes(buckets, G + bias_off, nB, S, S, bias_accumulate));
   } else {
     RC(o.mmbh(TG_STORE_F32, dO, inner, 0, sO1, DK, q + 2 * inner, 3 * inner, 0, sQ1, DK, t->sc, ldp, sP1, sP2, nB, S, S, DK));      // dPd = dO V^T

@@ -44,7 +44,9 @@ def _rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-20))
 
 
-@pytest.mark.parametrize("cfg_name,B,F,Ld", [("tiny", 3, 21, 14), ("tiny", 2, 70, 33), ("tiny", 1, 9, 1), ("full", 2, 40, 20)])
+# (F = 400: 13 key tiles per stripe, the fused attention kernels near their largest shape; F = 530: past it, the unfused path)
+@pytest.mark.parametrize("cfg_name,B,F,Ld", [("tiny", 3, 21, 14), ("tiny", 2, 70, 33), ("tiny", 1, 9, 1), ("full", 2, 40, 20), ("tiny", 2, 400, 37),
+                                             ("tiny", 1, 530, 5)])
 def test_fp32_loss_logits_and_every_gradient_match_autograd(cfg_name, B, F, Ld):
     cfg = tiny_config() if cfg_name == "tiny" else copy.deepcopy(DEFAULT_CONFIG)
     model, tr, orc, params, geom, x, feats, cond, labels = _setup(cfg, "fp32", B, F, Ld)
