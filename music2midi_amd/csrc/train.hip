@@ -688,10 +688,11 @@ __global__ __launch_bounds__(256) void attn_stripe_kernel(StripeArgs a) {
   const int64_t blk = ((int64_t)bh * a.Sq + q0) * a.ldp;
   if constexpr (BWD) {                               // P rows -> LDS (read twice below), coalesced
     const T* src = reinterpret_cast<const T*>(a.P) + blk;
-    for (int c = threadIdx.x; c < 32 * cpr; c += 256) {
-      const int row = c / cpr, col = (c - row * cpr) * EC;
+    const int cpl = nt * 32 / EC;                      // the WHOLE LDS row: a causal stripe never rewrites the tiles above its diagonal,
+    for (int c = threadIdx.x; c < 32 * cpl; c += 256) {          // and the fused product reads them (uninitialised LDS x 0 is not 0)
+      const int row = c / cpl, col = (c - row * cpl) * EC;
       *reinterpret_cast<uint4*>(pl + row * LP + col) =
-          q0 + row < a.Sq ? *reinterpret_cast<const uint4*>(src + (int64_t)row * a.ldp + col) : make_uint4(0, 0, 0, 0);
+          (q0 + row < a.Sq && col < a.ldp) ? *reinterpret_cast<const uint4*>(src + (int64_t)row * a.ldp + col) : make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
   }
@@ -1791,7 +1792,7 @@ int build_arena(m2m_trainer* t) {
   for (int l = 0; l < Le; ++l) o_kte.push_back(T(2 * B * H * 64 * Sp32));
   for (int l = 0; l < Ld; ++l) { o_ktd.push_back(T(2 * B * H * 64 * Lp32)); o_ktc.push_back(T(2 * B * H * 64 * Sp32)); }
   const int64_t o_hE = T(Me * d), o_hD = T(Md * d), o_logits = F(Md * V), o_sc = F(B * H * Sm * lpm), o_dxa = F(Mx * d), o_dxb = F(Mx * d),
-                o_dh = F(Mx * d), o_dhE = F(Me * d), o_dwp = F((int64_t)RN_BLOCKS * d * (2 * Le + 3 * Ld + 2)), o_nofs = c.take(64 * 8), o_rl = F(Md), o_inv = F(64), o_drel = F((int64_t)(Le + Ld) * B * H * std::max<int64_t>(2 * Sm, ((Sm + 31) / 32) * (Sm + 32)) + (int64_t)std::max(Le, Ld) * H * 2 * Sm),
+                o_dh = F(Mx * d), o_dhE = F(Me * d), o_dwp = F((int64_t)RN_BLOCKS * d * (2 * Le + 3 * Ld + 2)), o_nofs = c.take(64 * 8), o_rl = F(Md), o_inv = F(64), o_drel = F((int64_t)(Le + Ld) * B * H * std::max<int64_t>(2 * Sm, ((Sm + 31) / 32) * (Sm + 32)) + (int64_t)std::max(Le, Ld) * H * 2 * Sm + B * H * 2 * Sm),
                 o_etab = F(H * (2 * S)), o_dtab = F(H * (2 * L)), o_dlog = T(Md * align_up(V, 8)), o_dxT = T(Mx * d), o_dmid = T(Mx * dff),
                 o_dab = T(Mx * 2 * dff), o_dO = T(Mx * inner), o_dqkv = T(Mx * 3 * inner), o_dS = T(B * H * Sm * lpm), o_dcq = T(Md * inner),
                 o_dckv = T(Me * 2 * inner), o_lab = c.take(Md * 8), o_cnd = c.take(B * 8 * 8), o_skey = c.take(256), o_decin = c.take(Md * 8), o_eb = c.take(2 * S * 4), o_db = c.take(2 * L * 4),
@@ -2175,7 +2176,9 @@ struct Ops {
     M2M_CHECK_HIP(hipGetLastError());
     return M2M_OK;
   }
-  static bool fuse_on() { static const bool on = [] { const char* v = getenv("M2M_TRAIN_FUSE_PV"); return !(v && v[0] == '0'); }(); return on; }
+  // M2M_TRAIN_FUSE_PV: 0 = off, fwd / bwd = only that pass (diagnostics), default both
+  static int fuse_mode() { static const int m = [] { const char* v = getenv("M2M_TRAIN_FUSE_PV"); return !v ? 3 : v[0] == '0' ? 0 : v[0] == 'f' ? 1 : v[0] == 'b' ? 2 : 3; }(); return m; }
+  static bool fuse_on() { return fuse_mode() != 0; }
   // Xt / O: the fused product of the stripe kernel (StripeArgs), or null
   int attn_probs(const T* K, int64_t ldk, int64_t sK1, int64_t sK2, const T* Q, int64_t ldq, int64_t sQ1, int64_t sQ2, void* Pm, int nB, int Sq, int Sk,
             int ldp, const float* tab, int causal, int site, const T** Puse, const T* Xt = nullptr, void* O = nullptr, int64_t ldo = 0, int64_t sO1 = 0,
@@ -2270,8 +2273,12 @@ struct Ops {
   }
   int bias_grad(const void* dS, const int* buckets, float* Gtab, int nB, int Sq, int Sk, int ldp, int accumulate) const {
     const int H = t->g.num_heads, nrel = Sq + Sk - 1;
-    hipLaunchKernelGGL(bias_diag_kernel<T>, dim3(nB * H, ceil_div(nrel, 64)), dim3(256), 0, st, (const T*)dS, t->drel, H, Sq, Sk, ldp);
-    hipLaunchKernelGGL(bias_bucket_kernel, dim3(t->g.num_buckets * H), dim3(256), 0, st, t->drel, buckets, Gtab, nB, H, nrel, accumulate);
+    // scratch of its own, behind the stripe kernels' slots and their reduction scratch: those may hold other layers' sums
+    // that wait for the end of the pass (a model whose encoder is past the stripe kernels' reach and whose decoder is not)
+    float* part = t->drel + (int64_t)(t->g.num_layers + t->g.num_decoder_layers) * t->drel_slot_floats +
+                  (int64_t)std::max(t->g.num_layers, t->g.num_decoder_layers) * H * 2 * std::max(t->max_enc, t->max_dec);
+    hipLaunchKernelGGL(bias_diag_kernel<T>, dim3(nB * H, ceil_div(nrel, 64)), dim3(256), 0, st, (const T*)dS, part, H, Sq, Sk, ldp);
+    hipLaunchKernelGGL(bias_bucket_kernel, dim3(t->g.num_buckets * H), dim3(256), 0, st, part, buckets, Gtab, nB, H, nrel, accumulate);
     M2M_CHECK_HIP(hipGetLastError());
     return M2M_OK;
   }
@@ -2297,17 +2304,18 @@ int attn_self_fwd(const Ops<T>& o, const float* x_in, float* x_out, int64_t ln, 
   const T* q = (const T*)qkv;
   const T* Pu;
   const bool fuse = o.stripe_ok(S) && o.fuse_on() && kt;         // P . V inside the stripe kernel, against the transposed V
+  const bool fuse_pv = fuse && (o.fuse_mode() & 1);
   const T* vt = (const T*)kt + (int64_t)nB * H * DK * align_up(S, 32);
   if (fuse) RC(o.kv_transpose(q + inner, 3 * inner, kt, nB, S));
   if (o.stripe_ok(S)) {
     RC(o.attn_probs(q + inner, 3 * inner, (int64_t)S * 3 * inner, DK, q, 3 * inner, (int64_t)S * 3 * inner, DK, Pm, nB, S, S, ldp, tab, causal,
-               site0 + PL_PROBS_SELF, &Pu, fuse ? vt : nullptr, ao, inner, (int64_t)S * inner, DK));
+               site0 + PL_PROBS_SELF, &Pu, fuse_pv ? vt : nullptr, ao, inner, (int64_t)S * inner, DK));
   } else {
     RC(o.mmbh(TG_STORE_F32, q, 3 * inner, 0, (int64_t)S * 3 * inner, DK, q + inner, 3 * inner, 0, (int64_t)S * 3 * inner, DK, t->sc, ldp,
               (int64_t)H * S * ldp, (int64_t)S * ldp, nB, S, S, DK));
     RC(o.softmax(t->sc, Pm, nB, S, S, ldp, tab, causal, site0 + PL_PROBS_SELF, &Pu));
   }
-  if (!fuse)
+  if (!fuse_pv)
     RC(o.mmbh(TG_STORE_T, Pu, ldp, 0, (int64_t)H * S * ldp, (int64_t)S * ldp, q + 2 * inner, 3 * inner, 1, (int64_t)S * 3 * inner, DK, ao,
               inner, (int64_t)S * inner, DK, nB, S, DK, S));
   RC(o.mm(TG_RESID_F32, ao, inner, 0, o.W(wo), inner, 0, x_out, d, M, d, inner, x_in, site0 + PL_SELF_OUT));
@@ -2333,7 +2341,7 @@ int attn_self_bwd(const Ops<T>& o, const float* x_in, const float* dx_out, float
   const T* Pu;
   RC(o.redrop(Pm, (int64_t)nB * H * S * ldp, site0 + PL_PROBS_SELF, &Pu));
   RC(o.mmbh(TG_STORE_T, Pu, ldp, 1, sP1, sP2, dO, inner, 1, sO1, DK, dq + 2 * inner, 3 * inner, sQ1, DK, nB, S, DK, S));             // dV = Pd^T dO
-  const bool fuse = o.stripe_ok(S) && o.fuse_on() && kt;         // dQ = dS . K inside the stripe kernel, against the transposed K
+  const bool fuse = o.stripe_ok(S) && (o.fuse_mode() & 2) && kt;  // dQ = dS . K inside the stripe kernel, against the transposed K
   if (o.stripe_ok(S)) {
     RC(o.dscores(q + 2 * inner, 3 * inner, sQ1, DK, dO, inner, sO1, DK, Pm, t->dS, nB, S, S, ldp, site0 + PL_PROBS_SELF, buckets != nullptr,   // dS from dPd = dO V^T
                  fuse ? (const T*)kt : nullptr, dq, 3 * inner, sQ1, DK, buckets == t->dbucket ? 1 : 0));
@@ -2436,6 +2444,7 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
   RC(o.drop_inplace(t->xd[0], (int64_t)Md * d, SITE_DEC + SITE_EMB));
   const int64_t sPc1 = (int64_t)H * L * lps, sPc2 = (int64_t)L * lps;
   const bool fuse_c = o.stripe_ok(S) && o.fuse_on();       // cross-attention: P . V and dQ = dS . K inside the stripe kernels
+  const bool fuse_c_pv = fuse_c && (o.fuse_mode() & 1), fuse_c_dq = fuse_c && (o.fuse_mode() & 2);
   for (int l = 0; l < Ld; ++l) {
     const DecOff& e = t->dec[l];
     RC(attn_self_fwd<T>(o, t->xd[3 * l], t->xd[3 * l + 1], e.ln0, e.qkv, e.o, t->h0d[l], t->qkvd[l], t->Pd[l], t->aod[l], B, L, t->dtab, 1,
@@ -2450,13 +2459,13 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
     if (o.stripe_ok(S)) {
       if (fuse_c) RC(o.kv_transpose(ckv, 2 * inner, t->ktc[l], B, S));          // serves P . V here and dQ = dS . K in the backward pass
       RC(o.attn_probs(ckv, 2 * inner, (int64_t)S * 2 * inner, DK, cq, inner, (int64_t)L * inner, DK, t->Pcd[l], B, L, S, lps, nullptr, 0,
-                 SITE_DEC + 16 * l + PL_PROBS_CROSS, &Pu, fuse_c ? (const T*)t->ktc[l] + (int64_t)B * H * DK * align_up(S, 32) : nullptr, t->aocd[l], inner,
+                 SITE_DEC + 16 * l + PL_PROBS_CROSS, &Pu, fuse_c_pv ? (const T*)t->ktc[l] + (int64_t)B * H * DK * align_up(S, 32) : nullptr, t->aocd[l], inner,
                  (int64_t)L * inner, DK));
     } else {
       RC(o.mmbh(TG_STORE_F32, cq, inner, 0, (int64_t)L * inner, DK, ckv, 2 * inner, 0, (int64_t)S * 2 * inner, DK, t->sc, lps, sPc1, sPc2, B, L, S, DK));
       RC(o.softmax(t->sc, t->Pcd[l], B, L, S, lps, nullptr, 0, SITE_DEC + 16 * l + PL_PROBS_CROSS, &Pu));
     }
-    if (!fuse_c)
+    if (!fuse_c_pv)
       RC(o.mmbh(TG_STORE_T, Pu, lps, 0, sPc1, sPc2, ckv + inner, 2 * inner, 1, (int64_t)S * 2 * inner, DK, t->aocd[l], inner,
                 (int64_t)L * inner, DK, B, L, DK, S));
     RC(o.mm(TG_RESID_F32, t->aocd[l], inner, 0, o.W(e.co), inner, 0, t->xd[3 * l + 2], d, Md, d, inner, t->xd[3 * l + 1],
@@ -2505,13 +2514,13 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
     RC(o.mmbh(TG_STORE_T, Pu, lps, 1, sPc1, sPc2, dO, inner, 1, sQ1, DK, dckv + inner, 2 * inner, sK1, DK, B, S, DK, L));                   // dV = Pd^T dO
     if (o.stripe_ok(S)) {
       RC(o.dscores(ckv + inner, 2 * inner, sK1, DK, dO, inner, sQ1, DK, t->Pcd[l], t->dS, B, L, S, lps, SITE_DEC + 16 * l + PL_PROBS_CROSS, false,
-                   fuse_c ? (const T*)t->ktc[l] : nullptr, dcq, inner, sQ1, DK));
+                   fuse_c_dq ? (const T*)t->ktc[l] : nullptr, dcq, inner, sQ1, DK));
     } else {
       RC(o.mmbh(TG_STORE_F32, dO, inner, 0, sQ1, DK, ckv + inner, 2 * inner, 0, sK1, DK, t->sc, lps, sPc1, sPc2, B, L, S, DK));             // dPd = dO V^T
       RC(o.softmax_bwd(t->Pcd[l], t->sc, t->dS, B * H * L, S, lps, SITE_DEC + 16 * l + PL_PROBS_CROSS));
     }
     const T* dS = (const T*)t->dS;
-    if (!fuse_c) RC(o.mmbh(TG_STORE_T, dS, lps, 0, sPc1, sPc2, ckv, 2 * inner, 1, sK1, DK, dcq, inner, sQ1, DK, B, L, DK, S));               // dQ = dS K
+    if (!fuse_c_dq) RC(o.mmbh(TG_STORE_T, dS, lps, 0, sPc1, sPc2, ckv, 2 * inner, 1, sK1, DK, dcq, inner, sQ1, DK, B, L, DK, S));               // dQ = dS K
     RC(o.mmbh(TG_STORE_T, dS, lps, 1, sPc1, sPc2, cq, inner, 1, sQ1, DK, dckv, 2 * inner, sK1, DK, B, S, DK, L));                            // dK = dS^T Q
     RC(o.dW(dcq, inner, inner, t->h1d[l], d, d, G + e.cq, Md));
     RC(o.dX(TG_STORE_F32, dcq, inner, e.cq, inner, d, t->dh, d, Md));
