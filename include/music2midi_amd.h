@@ -232,6 +232,10 @@ int64_t m2m_trainer_workspace_bytes(const m2m_trainer* t);   /* device bytes the
  * grads_dev      flat fp32, OVERWRITTEN with d loss / d params; NULL = forward only.
  * logits_out_dev optional [B, Ld, V] fp32.
  * Deterministic: every reduction has a fixed order, two calls give bit-identical results.
+ * Streams: with gradients the pass runs on the trainer's own streams — stream-ordered behind everything already on `stream`
+ * (the inputs are copied into trainer-owned buffers first) and `stream` waits for its end, so for the caller it behaves like
+ * work on `stream`.  From the second call with the same (params_dev, grads_dev, B, S, Ld, dropout) on, the pass is replayed as
+ * one captured HIP graph (M2M_TRAIN_GRAPH=0 disables that); params_dev / grads_dev must stay valid while the trainer lives.
  */
 int m2m_train_forward_backward(m2m_trainer* t, const float* params_dev, const float* enc_inputs_dev,
                                const int64_t* cond_idx_dev, const int64_t* labels_dev, int B, int S, int Ld,
