@@ -47,8 +47,13 @@ struct MxGemmArgs {
   float drop_scale;
   uint64_t drop_key;           // salt, as in BGemmArgs
   const uint64_t* drop_step;
+  // launch_mxgemm_q: A is given as bf16 [M][ld_src] (columns >= Kvalid count as zero) and quantised while it is staged
+  const void* Asrc;
+  int64_t ld_src;
+  int Kvalid;
 };
 int launch_mxgemm(int fmt_a, int fmt_b, int epi, const MxGemmArgs& g, hipStream_t st);      // fmt: 0 = e4m3, 1 = e5m2
+int launch_mxgemm_q(int fmt_a, int epi, const MxGemmArgs& g, hipStream_t st);               // A quantised in the product's own staging
 int launch_mxq_rows(int src_kind, const void* src, int64_t ld_s, uint8_t* q, uint8_t* sc, int R, int C, int Cp, int fmt, hipStream_t st);
 int launch_mxq_cols(int src_kind, const void* src, int64_t ld_s, uint8_t* qt, uint8_t* sc, int R, int C, int Rp, int fmt, hipStream_t st);
 

@@ -1909,6 +1909,7 @@ struct Ops {
   int dw_kmajor = getenv("M2M_TRAIN_DW_KMAJOR") ? atoi(getenv("M2M_TRAIN_DW_KMAJOR")) : -1;   // -1 = by size, 0 / 1 = forced
   const T* W(int64_t off) const { return (t->precision == M2M_PREC_BF16 ? reinterpret_cast<const T*>(t->Wc) : reinterpret_cast<const T*>(P)) + off; }
 
+  static bool mxq_fused() { static const bool on = [] { const char* v = getenv("M2M_FP8_FUSED_Q"); return !(v && v[0] == '0'); }(); return on; }
   // fp8 mode: the projection matrix that starts at parameter offset `off`, or null (lm_head, non-projection operands)
   const m2m_trainer::LinW* lin8(int64_t off) const {
     if (!t->fp8) return nullptr;
@@ -2022,11 +2023,15 @@ struct Ops {
     if (!akm && !bkm && t->fp8 && t->fp8_fwd) {          // a forward projection Y = X . W^T on MXFP8 operands
       const int64_t off = reinterpret_cast<const T*>(B) - W(0);
       if (const m2m_trainer::LinW* w = lin8(off)) {
-        int rc = launch_mxq_rows(1, A, lda, t->q8a, t->s8a, M, K, K, 0, st);
-        if (rc != M2M_OK) return rc;
         MxGemmArgs m{};
         m.A = t->q8a; m.sA = t->s8a; m.B = t->w8 + w->q; m.sB = t->w8 + w->qs; m.C = C; m.R = R; m.M = M; m.N = N; m.K = K;
         m.lda = K; m.ldb = K; m.ldc = ldc; m.drop_thresh = g.drop_thresh; m.drop_scale = g.drop_scale; m.drop_key = g.drop_key; m.drop_step = g.drop_step;
+        if (mxq_fused() && K % 128 == 0 && lda % 8 == 0) {      // activations quantised inside the product's staging: one launch
+          m.Asrc = A; m.ld_src = lda; m.Kvalid = K;
+          return launch_mxgemm_q(0, epi, m, st);
+        }
+        int rc = launch_mxq_rows(1, A, lda, t->q8a, t->s8a, M, K, K, 0, st);
+        if (rc != M2M_OK) return rc;
         return launch_mxgemm(0, 0, epi, m, st);
       }
     }
@@ -2070,11 +2075,15 @@ struct Ops {
   // dX[M, Kw] (epi) = dY[M, Nw] . W   for a weight stored [Nw][Kw]: an NT product against the transposed copy WT [Kw][Nw]
   int dX(int epi, const void* dY, int64_t ldy, int64_t w_off, int Nw, int Kw, void* C, int64_t ldc, int M) const {
     if (const m2m_trainer::LinW* w = t->fp8_dx ? lin8(w_off) : nullptr) {    // fp8 mode: dY in e5m2 (gradient format), W^T in e4m3
-      int rc = launch_mxq_rows(1, dY, ldy, t->q8a, t->s8a, M, Nw, w->Np, t->grad_fmt, st);
-      if (rc != M2M_OK) return rc;
       MxGemmArgs m{};
       m.A = t->q8a; m.sA = t->s8a; m.B = t->w8 + w->qt; m.sB = t->w8 + w->qts; m.C = C; m.M = M; m.N = Kw; m.K = w->Np;
       m.lda = w->Np; m.ldb = w->Np; m.ldc = ldc;
+      if (mxq_fused() && Nw % 8 == 0 && ldy % 8 == 0) {
+        m.Asrc = dY; m.ld_src = ldy; m.Kvalid = Nw;
+        return launch_mxgemm_q(t->grad_fmt, epi, m, st);
+      }
+      int rc = launch_mxq_rows(1, dY, ldy, t->q8a, t->s8a, M, Nw, w->Np, t->grad_fmt, st);
+      if (rc != M2M_OK) return rc;
       return launch_mxgemm(t->grad_fmt, 0, epi, m, st);
     }
     return mm(epi, dY, ldy, 0, reinterpret_cast<const T*>(t->WT) + w_off, Nw, 0, C, ldc, M, Kw, Nw);
