@@ -264,6 +264,11 @@ int m2m_adafactor_state_import(m2m_trainer* t, const float* state_in_dev, int st
  * the fp8 training mode (M2M_PREC_FP8 of m2m_trainer_create), exposed so it can be checked on its own.  A test utility:
  * unlike the hot-path entry points it allocates and frees its own device scratch, and it synchronises `stream`. */
 int m2m_mx8_matmul_f32(const float* a_dev, const float* b_dev, int M, int N, int K, int a_is_e5m2, float* c_dev, void* stream);
+/* The same with A in bf16, as the training step feeds it (K a multiple of 8): fused != 0 quantises A inside the product's operand
+ * staging (one launch per product, what the fp8 mode runs), 0 through the separate row quantiser; bit-identical by construction
+ * and by test.  Test utility like the above. */
+int m2m_mx8_matmul_bf16a(const uint16_t* a_bf16_dev, const float* b_dev, int M, int N, int K, int a_is_e5m2, int fused, float* c_dev,
+                         void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Measurement hooks (bench.py): time one kernel of the decode step in isolation

@@ -205,13 +205,26 @@ __global__ __launch_bounds__(256) void mxgemm_q_kernel(MxGemmArgs g) {
         amax = fmaxf(amax, fmaxf(fabsf(v[2 * j]), fabsf(v[2 * j + 1])));
       }
       amax = mxq_quad_max(amax);
-      const float se = mx_block_scale_exp(amax, FA == 0 ? 8 : 15);
-      const float inv = exp2f(-se);
-      uint2 q;
-      q.x = mx_pack4<FA>(v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv);
-      q.y = mx_pack4<FA>(v[4] * inv, v[5] * inv, v[6] * inv, v[7] * inv);
-      *reinterpret_cast<uint2*>(As + rl * MX_PITCH + kc * 8) = q;
-      if ((kc & 3) == 0) Asc[rl * 4 + (kc >> 2)] = (uint8_t)((int)se + 127);
+      // floor(log2 amax) - emax from the exponent field (== mx_block_scale_exp's frexpf form for every finite amax: subnormals
+      // and zero clamp to -127 either way), 2^-se built from its bits: ~45 instructions per chunk instead of ~70 — every
+      // column tile of the product re-quantises its rows, so this is the kernel's VALU time
+      int se = (int)((__float_as_uint(amax) >> 23) & 0xFF) - 127 - (FA == 0 ? 8 : 15);
+      se = se < -127 ? -127 : se;                                  // (the upper clamp cannot bind: amax is a finite bf16)
+      const float inv = __uint_as_float((uint32_t)(127 - se) << 23);
+      constexpr float LIM = FA == 0 ? 448.0f : 57344.0f;
+      float w[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[j] = __builtin_amdgcn_fmed3f(v[j] * inv, -LIM, LIM);
+      int q0 = 0, q1 = 0;
+      if constexpr (FA == 0) {
+        q0 = __builtin_amdgcn_cvt_pk_fp8_f32(w[0], w[1], q0, false); q0 = __builtin_amdgcn_cvt_pk_fp8_f32(w[2], w[3], q0, true);
+        q1 = __builtin_amdgcn_cvt_pk_fp8_f32(w[4], w[5], q1, false); q1 = __builtin_amdgcn_cvt_pk_fp8_f32(w[6], w[7], q1, true);
+      } else {
+        q0 = __builtin_amdgcn_cvt_pk_bf8_f32(w[0], w[1], q0, false); q0 = __builtin_amdgcn_cvt_pk_bf8_f32(w[2], w[3], q0, true);
+        q1 = __builtin_amdgcn_cvt_pk_bf8_f32(w[4], w[5], q1, false); q1 = __builtin_amdgcn_cvt_pk_bf8_f32(w[6], w[7], q1, true);
+      }
+      *reinterpret_cast<uint2*>(As + rl * MX_PITCH + kc * 8) = make_uint2((uint32_t)q0, (uint32_t)q1);
+      if ((kc & 3) == 0) Asc[rl * 4 + (kc >> 2)] = (uint8_t)(se + 127);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -377,5 +390,34 @@ extern "C" int m2m_mx8_matmul_f32(const float* a_dev, const float* b_dev, int M,
   hipError_t e = hipStreamSynchronize(st);
   (void)hipFree(buf);
   if (rc == M2M_OK && e != hipSuccess) { set_error("m2m_mx8_matmul_f32: %s", hipGetErrorString(e)); rc = M2M_ERR_HIP; }
+  return rc;
+}
+
+// The same product with A given in bf16 (what the training path feeds it): `fused` != 0 quantises A inside the product's operand
+// staging (mxgemm_q_kernel), 0 through the separate row quantiser — the two must agree bit for bit (tests/test_mx8_gpu.py).
+extern "C" int m2m_mx8_matmul_bf16a(const uint16_t* a_bf16_dev, const float* b_dev, int M, int N, int K, int a_is_e5m2, int fused, float* c_dev,
+                                    void* stream) {
+  M2M_REQUIRE(a_bf16_dev && b_dev && c_dev && M >= 1 && N >= 1 && K >= 8 && K % 8 == 0, "m2m_mx8_matmul_bf16a: bad argument (K must be a multiple of 8)");
+  hipStream_t st = (hipStream_t)stream;
+  const int Kp = (int)align_up(K, 128);
+  uint8_t* buf = nullptr;
+  const size_t qa = (size_t)M * Kp, qb = (size_t)N * Kp, sa = (size_t)M * (Kp / 32), sb = (size_t)N * (Kp / 32);
+  M2M_CHECK_HIP(hipMalloc((void**)&buf, qa + qb + align_up((int64_t)sa, 256) + align_up((int64_t)sb, 256) + 1024));
+  uint8_t *A8 = buf, *B8 = buf + qa, *SA = B8 + qb, *SB = SA + align_up((int64_t)sa, 256);
+  int rc = launch_mxq_rows(0, b_dev, K, B8, SB, N, K, Kp, 0, st);
+  MxGemmArgs g{};
+  g.A = A8; g.B = B8; g.sA = SA; g.sB = SB; g.C = c_dev; g.M = M; g.N = N; g.K = Kp; g.lda = Kp; g.ldb = Kp; g.ldc = N;
+  if (rc == M2M_OK) {
+    if (fused) {
+      g.Asrc = a_bf16_dev; g.ld_src = K; g.Kvalid = K;
+      rc = launch_mxgemm_q(a_is_e5m2 ? 1 : 0, TG_STORE_F32, g, st);
+    } else {
+      rc = launch_mxq_rows(1, a_bf16_dev, K, A8, SA, M, K, Kp, a_is_e5m2 ? 1 : 0, st);
+      if (rc == M2M_OK) rc = launch_mxgemm(a_is_e5m2 ? 1 : 0, 0, TG_STORE_F32, g, st);
+    }
+  }
+  hipError_t e = hipStreamSynchronize(st);
+  (void)hipFree(buf);
+  if (rc == M2M_OK && e != hipSuccess) { set_error("m2m_mx8_matmul_bf16a: %s", hipGetErrorString(e)); rc = M2M_ERR_HIP; }
   return rc;
 }

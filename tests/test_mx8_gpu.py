@@ -77,3 +77,29 @@ def test_mx8_integer_data_is_exact():
     b[3] *= 0.125
     assert torch.equal(_device_mx(a, b, False), a @ b.T)
     assert torch.equal(_device_mx(a, b, True), a @ b.T) or (_device_mx(a, b, True) - a @ b.T).abs().max() == 0
+
+
+@pytest.mark.parametrize("e5m2", [False, True])
+@pytest.mark.parametrize("M,N,K", [(64, 64, 128), (100, 37, 384), (261, 1536, 384), (33, 70, 1152), (70, 130, 200), (1100, 200, 256), (4176, 384, 2304)])
+def test_mx8_fused_quantisation_equals_the_separate_quantiser(M, N, K, e5m2):
+    """The fp8 training products quantise their bf16 activations INSIDE the product's operand staging (mxgemm_q_kernel: exponent-field
+    scale, bit-built 2^-se, v_med3 clamp); the row quantiser (frexpf / exp2f form, pinned above against the OCP restatement) must
+    give the same product bit for bit — zero blocks, FP8 subnormals, clamped outliers, bf16 subnormals and a ragged K included."""
+    lib = native.load()
+    a = torch.from_numpy(synth.normal(3 * M + K, "a", (M, K), 1.0))
+    a = a * torch.exp2(torch.from_numpy((synth.uniform01(2, "ra", M) * 40 - 20).astype(np.float32)))[:, None]
+    a[0, :32] = 0.0
+    a[M // 2, K // 2] = 3.0e4
+    a[M // 3, :8] = 1e-39                                   # bf16 subnormals
+    a[M - 1] *= 1e-30
+    b = torch.from_numpy(synth.normal(N + K, "b", (N, K), 0.05))
+    a16 = a.to(torch.bfloat16).cuda().contiguous()
+    b_d = b.cuda().contiguous()
+    outs = []
+    for fused in (0, 1):
+        c_d = torch.empty((M, N), dtype=torch.float32, device="cuda")
+        native.check(lib.m2m_mx8_matmul_bf16a(a16.data_ptr(), b_d.data_ptr(), M, N, K, int(e5m2), fused, c_d.data_ptr(), native.stream_handle()),
+                     "m2m_mx8_matmul_bf16a")
+        outs.append(c_d.cpu())
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
