@@ -494,8 +494,8 @@ def main():
         out["train_configs4"]["fp8_mx_ms_per_step"] = fp8["ms_per_step"]
         out["train_configs4"]["fp8_mx_clips_per_s"] = fp8["clips_per_s"]
         out["train_configs4"]["fp8_note"] = ("projection products (forward and dX; the weight gradients take the grouped bf16 launch) on block-scaled OCP FP8 (e4m3, 32 elements per E8M0 scale, "
-                                             "v_mfma_scale_f32_32x32x64_f8f6f4); at 16 clips/GPU the products are latency-bound, not MFMA-bound, so the extra "
-                                             "quantiser launches cost more than the faster matrix instruction saves")
+                                             "v_mfma_scale_f32_32x32x64_f8f6f4); activations quantised inside the product's operand staging; at 16 clips/GPU the products are latency- and "
+                                             "VALU-bound, not MFMA-bound, so the faster matrix instruction does not show")
         del mt
 
     if rank == 0 and world == 1 and args.cpu_tokens > 0:

@@ -165,20 +165,24 @@ __device__ inline float mxq_quad_max(float v) {
   v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));   // lane ^ 2
   return v;
 }
-template <int FA, int EPI>
+// TN = 2: 64 x 128 tile (each wave 32 x 64): a workgroup's quantised rows serve twice the columns — every column tile of a product
+// re-quantises its rows, so for the wide products (N >= 512) this halves the kernel's VALU time
+template <int FA, int EPI, int TN>
 __global__ __launch_bounds__(256) void mxgemm_q_kernel(MxGemmArgs g) {
+  constexpr int BN = 64 * TN;
   __shared__ __align__(16) uint8_t As[64 * MX_PITCH];
-  __shared__ __align__(16) uint8_t Bs[64 * MX_PITCH];
+  __shared__ __align__(16) uint8_t Bs[BN * MX_PITCH];
   __shared__ __align__(4) uint8_t Asc[64 * 4];                 // scale bytes of the A tile: [row][k-block of this step]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-  const int brow = min(n0 + wn * 32 + r, g.N - 1);
-  const uint32_t* sB = reinterpret_cast<const uint32_t*>(g.sB) + (int64_t)brow * (g.ldb / 128);
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * BN;
+  const uint32_t* sB[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) sB[j] = reinterpret_cast<const uint32_t*>(g.sB) + (int64_t)min(n0 + (wn * TN + j) * 32 + r, g.N - 1) * (g.ldb / 128);
   const bf16_t* A = reinterpret_cast<const bf16_t*>(g.Asrc);
   // staging assignments: A: 64 rows x 16 chunks of 8 bf16 = 4 per thread (chunk c: row c / 16, k chunk c % 16: the 4 lanes of a
   // quad hold one 32-element block); B: 64 rows x 8 chunks of 16 fp8 bytes = 2 per thread
-  uint4 ra[4], rb[2];
+  uint4 ra[4], rb[2 * TN];
   auto gload = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(256) void mxgemm_q_kernel(MxGemmArgs g) {
       ra[i] = (row < g.M && k < g.Kvalid) ? *reinterpret_cast<const uint4*>(A + (int64_t)row * g.ld_src + k) : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 2 * TN; ++i) {
       const int c = tid + 256 * i, row = n0 + c / 8, kc = (c % 8) * 16;
       rb[i] = row < g.N ? *reinterpret_cast<const uint4*>(g.B + (int64_t)row * g.ldb + k0 + kc) : make_uint4(0, 0, 0, 0);
     }
@@ -227,64 +231,80 @@ __global__ __launch_bounds__(256) void mxgemm_q_kernel(MxGemmArgs g) {
       if ((kc & 3) == 0) Asc[rl * 4 + (kc >> 2)] = (uint8_t)(se + 127);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 2 * TN; ++i) {
       const int c = tid + 256 * i;
       *reinterpret_cast<uint4*>(Bs + (c / 8) * MX_PITCH + (c % 8) * 16) = rb[i];
     }
   };
-  f32x16 acc = zero_acc();
+  f32x16 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) acc[j] = zero_acc();
   gload(0);
   for (int k0 = 0; k0 < g.K; k0 += MX_BK) {
     __syncthreads();
     sstore();
-    const uint32_t sb4 = sB[k0 / 128];
+    uint32_t sb4[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) sb4[j] = sB[j][k0 / 128];
     __syncthreads();
     if (k0 + MX_BK < g.K) gload(k0 + MX_BK);
     const uint32_t sa4 = *reinterpret_cast<const uint32_t*>(Asc + (wm * 32 + r) * 4);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const uint8_t* ap = As + (wm * 32 + r) * MX_PITCH + s * 64 + h * 16;
-      const uint8_t* bp = Bs + (wn * 32 + r) * MX_PITCH + s * 64 + h * 16;
       const uint4 a0 = *reinterpret_cast<const uint4*>(ap), a1 = *reinterpret_cast<const uint4*>(ap + 32);
-      const uint4 b0 = *reinterpret_cast<const uint4*>(bp), b1 = *reinterpret_cast<const uint4*>(bp + 32);
       const v8i_t av = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
-      const v8i_t bv = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
-      const int sa = (int)((sa4 >> (8 * (2 * s + h))) & 0xFF), sb = (int)((sb4 >> (8 * (2 * s + h))) & 0xFF);
-      acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc, FA, 0, 0, sa, 0, sb);
+      const int sa = (int)((sa4 >> (8 * (2 * s + h))) & 0xFF);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const uint8_t* bp = Bs + ((wn * TN + j) * 32 + r) * MX_PITCH + s * 64 + h * 16;
+        const uint4 b0 = *reinterpret_cast<const uint4*>(bp), b1 = *reinterpret_cast<const uint4*>(bp + 32);
+        const v8i_t bv = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
+        const int sb = (int)((sb4[j] >> (8 * (2 * s + h))) & 0xFF);
+        acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc[j], FA, 0, 0, sa, 0, sb);
+      }
     }
   }
-  const int col = n0 + wn * 32 + r;
-  if (col >= g.N) return;
   const uint64_t dkey = (EPI == TG_RESID_F32 && g.drop_thresh) ? splitmix64(*g.drop_step + g.drop_key) : 0ull;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int row = m0 + wm * 32 + acc_row(i, lane);
-    if (row >= g.M) continue;
-    const int64_t at = (int64_t)row * g.ldc + col;
-    const float v = acc[i];
-    if constexpr (EPI == TG_STORE_T) reinterpret_cast<bf16_t*>(g.C)[at] = f32_to_bf16(v);
-    else if constexpr (EPI == TG_STORE_F32) reinterpret_cast<float*>(g.C)[at] = v;
-    else if constexpr (EPI == TG_ACC_F32) reinterpret_cast<float*>(g.C)[at] += v;
-    else {
-      float u = v;
-      if (g.drop_thresh) u = drop_keep(dkey, at, g.drop_thresh) ? v * g.drop_scale : 0.f;
-      reinterpret_cast<float*>(g.C)[at] = g.R[at] + u;
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + (wn * TN + j) * 32 + r;
+    if (col >= g.N) continue;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = m0 + wm * 32 + acc_row(i, lane);
+      if (row >= g.M) continue;
+      const int64_t at = (int64_t)row * g.ldc + col;
+      const float v = acc[j][i];
+      if constexpr (EPI == TG_STORE_T) reinterpret_cast<bf16_t*>(g.C)[at] = f32_to_bf16(v);
+      else if constexpr (EPI == TG_STORE_F32) reinterpret_cast<float*>(g.C)[at] = v;
+      else if constexpr (EPI == TG_ACC_F32) reinterpret_cast<float*>(g.C)[at] += v;
+      else {
+        float u = v;
+        if (g.drop_thresh) u = drop_keep(dkey, at, g.drop_thresh) ? v * g.drop_scale : 0.f;
+        reinterpret_cast<float*>(g.C)[at] = g.R[at] + u;
+      }
     }
   }
 }
 
-template <int FA>
-static int launch_mxgemm_q_f(int epi, const MxGemmArgs& g, hipStream_t st) {
-  dim3 grid((unsigned)ceil_div(g.N, 64), (unsigned)ceil_div(g.M, 64));
+template <int FA, int TN>
+static int launch_mxgemm_q_ft(int epi, const MxGemmArgs& g, hipStream_t st) {
+  dim3 grid((unsigned)ceil_div(g.N, 64 * TN), (unsigned)ceil_div(g.M, 64));
   switch (epi) {
-    case TG_STORE_T: hipLaunchKernelGGL((mxgemm_q_kernel<FA, TG_STORE_T>), grid, dim3(256), 0, st, g); break;
-    case TG_STORE_F32: hipLaunchKernelGGL((mxgemm_q_kernel<FA, TG_STORE_F32>), grid, dim3(256), 0, st, g); break;
-    case TG_ACC_F32: hipLaunchKernelGGL((mxgemm_q_kernel<FA, TG_ACC_F32>), grid, dim3(256), 0, st, g); break;
-    case TG_RESID_F32: hipLaunchKernelGGL((mxgemm_q_kernel<FA, TG_RESID_F32>), grid, dim3(256), 0, st, g); break;
+    case TG_STORE_T: hipLaunchKernelGGL((mxgemm_q_kernel<FA, TG_STORE_T, TN>), grid, dim3(256), 0, st, g); break;
+    case TG_STORE_F32: hipLaunchKernelGGL((mxgemm_q_kernel<FA, TG_STORE_F32, TN>), grid, dim3(256), 0, st, g); break;
+    case TG_ACC_F32: hipLaunchKernelGGL((mxgemm_q_kernel<FA, TG_ACC_F32, TN>), grid, dim3(256), 0, st, g); break;
+    case TG_RESID_F32: hipLaunchKernelGGL((mxgemm_q_kernel<FA, TG_RESID_F32, TN>), grid, dim3(256), 0, st, g); break;
     default: set_error("mxgemm_q: bad epilogue %d", epi); return M2M_ERR_INVALID;
   }
   M2M_CHECK_HIP(hipGetLastError());
   return M2M_OK;
+}
+template <int FA>
+static int launch_mxgemm_q_f(int epi, const MxGemmArgs& g, hipStream_t st) {
+  static const int wide_from = [] { const char* v = getenv("M2M_MXQ_WIDE_FROM"); return v ? atoi(v) : 512; }();      // N from which the 64 x 128 tile is used
+  return g.N >= wide_from ? launch_mxgemm_q_ft<FA, 2>(epi, g, st) : launch_mxgemm_q_ft<FA, 1>(epi, g, st);
 }
 int launch_mxgemm_q(int fmt_a, int epi, const MxGemmArgs& g, hipStream_t st) {
   M2M_REQUIRE(g.Asrc && g.M >= 1 && g.N >= 1 && g.K >= 128 && g.K % 128 == 0 && g.ldb % 128 == 0 && g.K <= g.ldb && g.Kvalid <= g.K && g.ld_src % 8 == 0 &&
