@@ -28,6 +28,11 @@ struct BGemmArgs {
   float drop_scale;
   uint64_t drop_key;           // the site's salt: key = splitmix64(*drop_step + drop_key) (common.h DropKey)
   const uint64_t* drop_step;
+  // pair mode (A2 != null): a SECOND product of the same shape in the same launch (blockIdx.z >= nb1*nb2): same strides for A and
+  // C, its own B layout — dV = P~^T dO and dK = dS^T Q of an attention layer are one launch
+  const void *A2, *B2;
+  void* C2;
+  int64_t ldb2, sB1_2, sB2_2;
 };
 
 

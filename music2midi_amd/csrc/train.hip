@@ -109,9 +109,14 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BGemmArgs g) {
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
   const bool split = g.ksplit > 1;
-  const int z1 = split ? 0 : blockIdx.z / g.nb2, z2 = split ? 0 : blockIdx.z - z1 * g.nb2;
-  const T* A = reinterpret_cast<const T*>(g.A) + z1 * g.sA1 + z2 * g.sA2;
-  const T* B = reinterpret_cast<const T*>(g.B) + z1 * g.sB1 + z2 * g.sB2;
+  const int nz = g.nb1 * g.nb2;
+  const bool second = !split && g.A2 && (int)blockIdx.z >= nz;            // pair mode: the second product of the launch
+  const int zz = second ? blockIdx.z - nz : blockIdx.z;
+  const int z1 = split ? 0 : zz / g.nb2, z2 = split ? 0 : zz - z1 * g.nb2;
+  const T* A = reinterpret_cast<const T*>(second ? g.A2 : g.A) + z1 * g.sA1 + z2 * g.sA2;
+  const T* B = second ? reinterpret_cast<const T*>(g.B2) + z1 * g.sB1_2 + z2 * g.sB2_2 : reinterpret_cast<const T*>(g.B) + z1 * g.sB1 + z2 * g.sB2;
+  const int64_t ldb = second ? g.ldb2 : g.ldb;
+  void* const Cout = second ? g.C2 : g.C;
   const int64_t coff = z1 * g.sC1 + z2 * g.sC2;
   const int m0 = blockIdx.y * TG_BM, n0 = blockIdx.x * TG_BN;
   const int kbeg = split ? blockIdx.z * g.kchunk : 0, kend = split ? min(g.K, kbeg + g.kchunk) : g.K;
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BGemmArgs g) {
   for (int k0 = kbeg; k0 < kend; k0 += TG_BK) {
     __syncthreads();
     tg_stage<T>(As, A, g.lda, g.a_kmajor, m0, k0, g.M, kend, tid, 0);
-    tg_stage<T>(Bs, B, g.ldb, g.b_kmajor, n0, k0, g.N, kend, tid, 128);
+    tg_stage<T>(Bs, B, ldb, g.b_kmajor, n0, k0, g.N, kend, tid, 128);
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < TG_BK / 16; ++s) {
@@ -143,20 +148,20 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BGemmArgs g) {
     }
     const int64_t at = coff + (int64_t)row * g.ldc + col;
     const float v = g.alpha * acc[i];
-    if constexpr (EPI == TG_STORE_T) reinterpret_cast<T*>(g.C)[at] = from_f32<T>(v);
-    else if constexpr (EPI == TG_STORE_F32) reinterpret_cast<float*>(g.C)[at] = v;
-    else if constexpr (EPI == TG_ACC_F32) reinterpret_cast<float*>(g.C)[at] += v;
+    if constexpr (EPI == TG_STORE_T) reinterpret_cast<T*>(Cout)[at] = from_f32<T>(v);
+    else if constexpr (EPI == TG_STORE_F32) reinterpret_cast<float*>(Cout)[at] = v;
+    else if constexpr (EPI == TG_ACC_F32) reinterpret_cast<float*>(Cout)[at] += v;
     else {                                                                       // TG_RESID_F32: C = R + dropout(acc)
       float u = v;
       if (g.drop_thresh) u = drop_keep(dkey, at, g.drop_thresh) ? v * g.drop_scale : 0.f;
-      reinterpret_cast<float*>(g.C)[at] = g.R[at] + u;
+      reinterpret_cast<float*>(Cout)[at] = g.R[at] + u;
     }
   }
 }
 
 template <typename T>
 static int launch_bgemm_t(int epi, const BGemmArgs& g, hipStream_t st) {
-  dim3 grid((unsigned)ceil_div(g.N, TG_BN), (unsigned)ceil_div(g.M, TG_BM), (unsigned)(g.ksplit > 1 ? g.ksplit : g.nb1 * g.nb2));
+  dim3 grid((unsigned)ceil_div(g.N, TG_BN), (unsigned)ceil_div(g.M, TG_BM), (unsigned)(g.ksplit > 1 ? g.ksplit : g.nb1 * g.nb2 * (g.A2 ? 2 : 1)));
   switch (epi) {
     case TG_STORE_T: hipLaunchKernelGGL((bgemm_kernel<T, TG_STORE_T>), grid, dim3(256), 0, st, g); break;
     case TG_STORE_F32: hipLaunchKernelGGL((bgemm_kernel<T, TG_STORE_F32>), grid, dim3(256), 0, st, g); break;
@@ -461,7 +466,9 @@ int launch_bgemm(int precision, int epi, const BGemmArgs& g, hipStream_t st) {
   M2M_REQUIRE(g.lda % E == 0 && g.ldb % E == 0, "bgemm: operand row strides (%lld, %lld) must be multiples of %d elements (16-byte rows)",
               (long long)g.lda, (long long)g.ldb, E);
   M2M_REQUIRE(g.sA1 % E == 0 && g.sA2 % E == 0 && g.sB1 % E == 0 && g.sB2 % E == 0, "bgemm: batch strides must keep 16-byte alignment");
-  M2M_REQUIRE((int64_t)g.nb1 * g.nb2 <= 65535, "bgemm: too many batch entries");
+  M2M_REQUIRE((int64_t)g.nb1 * g.nb2 * (g.A2 ? 2 : 1) <= 65535, "bgemm: too many batch entries");
+  M2M_REQUIRE(!g.A2 || (g.B2 && g.C2 && g.ksplit <= 1 && g.ldb2 % E == 0 && g.sB1_2 % E == 0 && g.sB2_2 % E == 0 && (!g.b_kmajor || g.ldb2 >= align_up(g.N, E))),
+              "bgemm: bad second product");
   M2M_REQUIRE((!g.a_kmajor || g.lda >= align_up(g.M, E)) && (!g.b_kmajor || g.ldb >= align_up(g.N, E)),
               "bgemm: a k-major operand's row stride must cover its rows padded to %d", E);
   if (g.ksplit > 1) {
@@ -2072,6 +2079,16 @@ struct Ops {
     g.nb1 = nB; g.nb2 = t->g.num_heads; g.sA1 = sA1; g.sA2 = sA2; g.sB1 = sB1; g.sB2 = sB2; g.sC1 = sC1; g.sC2 = sC2; g.alpha = 1.0f;
     return launch_bgemm(t->precision, epi, g, st);
   }
+  // two products of one shape in one launch (BGemmArgs pair mode): (A, B) -> C and (A2, B2) -> C2; A / A2 and C / C2 share strides
+  int mmbh2(int epi, const T* A, const T* A2, int64_t lda, int akm, int64_t sA1, int64_t sA2, const T* B, int64_t ldb, int64_t sB1, int64_t sB2,
+            const T* B2, int64_t ldb2, int64_t sB1_2, int64_t sB2_2, int bkm, void* C, void* C2, int64_t ldc, int64_t sC1, int64_t sC2, int nB, int M, int N,
+            int K) const {
+    BGemmArgs g{};
+    g.A = A; g.B = B; g.C = C; g.R = nullptr; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.a_kmajor = akm; g.b_kmajor = bkm;
+    g.nb1 = nB; g.nb2 = t->g.num_heads; g.sA1 = sA1; g.sA2 = sA2; g.sB1 = sB1; g.sB2 = sB2; g.sC1 = sC1; g.sC2 = sC2; g.alpha = 1.0f;
+    g.A2 = A2; g.B2 = B2; g.C2 = C2; g.ldb2 = ldb2; g.sB1_2 = sB1_2; g.sB2_2 = sB2_2;
+    return launch_bgemm(t->precision, epi, g, st);
+  }
   // dX[M, Kw] (epi) = dY[M, Nw] . W   for a weight stored [Nw][Kw]: an NT product against the transposed copy WT [Kw][Nw]
   int dX(int epi, const void* dY, int64_t ldy, int64_t w_off, int Nw, int Kw, void* C, int64_t ldc, int M) const {
     if (const m2m_trainer::LinW* w = t->fp8_dx ? lin8(w_off) : nullptr) {    // fp8 mode: dY in e5m2 (gradient format), W^T in e4m3
@@ -2188,6 +2205,7 @@ struct Ops {
   // M2M_TRAIN_FUSE_PV: 0 = off, fwd / bwd = only that pass (diagnostics), default both
   static int fuse_mode() { static const int m = [] { const char* v = getenv("M2M_TRAIN_FUSE_PV"); return !v ? 3 : v[0] == '0' ? 0 : v[0] == 'f' ? 1 : v[0] == 'b' ? 2 : 3; }(); return m; }
   static bool fuse_on() { return fuse_mode() != 0; }
+  static bool pair_on() { static const bool on = [] { const char* v = getenv("M2M_TRAIN_PAIR_DVDK"); return !(v && v[0] == '0'); }(); return on; }
   // Xt / O: the fused product of the stripe kernel (StripeArgs), or null
   int attn_probs(const T* K, int64_t ldk, int64_t sK1, int64_t sK2, const T* Q, int64_t ldq, int64_t sQ1, int64_t sQ2, void* Pm, int nB, int Sq, int Sk,
             int ldp, const float* tab, int causal, int site, const T** Puse, const T* Xt = nullptr, void* O = nullptr, int64_t ldo = 0, int64_t sO1 = 0,
@@ -2227,11 +2245,14 @@ struct Ops {
     return M2M_OK;
   }
   // backward: the dropped probabilities again (into t->dS, consumed by the dV product before dS overwrites it)
-  int redrop(const void* Pm, int64_t n, int site, const T** Puse) const {
+  // (into_sc: the dropped copy goes to the fp32 score scratch, unused on the stripe path, so that it survives the dS written later
+  //  and dV can share a launch with dK)
+  int redrop(const void* Pm, int64_t n, int site, const T** Puse, bool into_sc = false) const {
     if (!dropping(site)) { *Puse = (const T*)Pm; return M2M_OK; }
-    hipLaunchKernelGGL(drop_copy_kernel<T>, dim3(grid_1d(n)), dim3(256), 0, st, (const T*)Pm, (T*)t->dS, n, key(site), t->drop_thresh, t->drop_scale);
+    T* dst = into_sc ? (T*)t->sc : (T*)t->dS;
+    hipLaunchKernelGGL(drop_copy_kernel<T>, dim3(grid_1d(n)), dim3(256), 0, st, (const T*)Pm, dst, n, key(site), t->drop_thresh, t->drop_scale);
     M2M_CHECK_HIP(hipGetLastError());
-    *Puse = (const T*)t->dS;
+    *Puse = dst;
     return M2M_OK;
   }
   int softmax_bwd(const void* Pm, const float* dP, void* dS, int rows, int Sk, int ldp, int site) const {
@@ -2348,8 +2369,9 @@ int attn_self_bwd(const Ops<T>& o, const float* x_in, const float* dx_out, float
   T* dq = (T*)t->dqkv;
   const int64_t sP1 = (int64_t)H * S * ldp, sP2 = (int64_t)S * ldp, sQ1 = (int64_t)S * 3 * inner, sO1 = (int64_t)S * inner;
   const T* Pu;
-  RC(o.redrop(Pm, (int64_t)nB * H * S * ldp, site0 + PL_PROBS_SELF, &Pu));
-  RC(o.mmbh(TG_STORE_T, Pu, ldp, 1, sP1, sP2, dO, inner, 1, sO1, DK, dq + 2 * inner, 3 * inner, sQ1, DK, nB, S, DK, S));             // dV = Pd^T dO
+  const bool pair = o.stripe_ok(S) && o.pair_on();            // dV and dK in one launch (after dS exists)
+  RC(o.redrop(Pm, (int64_t)nB * H * S * ldp, site0 + PL_PROBS_SELF, &Pu, pair));
+  if (!pair) RC(o.mmbh(TG_STORE_T, Pu, ldp, 1, sP1, sP2, dO, inner, 1, sO1, DK, dq + 2 * inner, 3 * inner, sQ1, DK, nB, S, DK, S));  // dV = Pd^T dO
   const bool fuse = o.stripe_ok(S) && (o.fuse_mode() & 2) && kt;  // dQ = dS . K inside the stripe kernel, against the transposed K
   if (o.stripe_ok(S)) {
     RC(o.dscores(q + 2 * inner, 3 * inner, sQ1, DK, dO, inner, sO1, DK, Pm, t->dS, nB, S, S, ldp, site0 + PL_PROBS_SELF, buckets != nullptr,   // dS from dPd = dO V^T
@@ -2362,7 +2384,10 @@ int attn_self_bwd(const Ops<T>& o, const float* x_in, const float* dx_out, float
   }
   const T* dS = (const T*)t->dS;
   if (!fuse) RC(o.mmbh(TG_STORE_T, dS, ldp, 0, sP1, sP2, q + inner, 3 * inner, 1, sQ1, DK, dq, 3 * inner, sQ1, DK, nB, S, DK, S));   // dQ = dS K
-  RC(o.mmbh(TG_STORE_T, dS, ldp, 1, sP1, sP2, q, 3 * inner, 1, sQ1, DK, dq + inner, 3 * inner, sQ1, DK, nB, S, DK, S));              // dK = dS^T Q
+  if (pair)                                                                                                                          // dV = Pd^T dO | dK = dS^T Q
+    RC(o.mmbh2(TG_STORE_T, Pu, dS, ldp, 1, sP1, sP2, dO, inner, sO1, DK, q, 3 * inner, sQ1, DK, 1, dq + 2 * inner, dq + inner, 3 * inner, sQ1, DK, nB, S, DK, S));
+  else
+    RC(o.mmbh(TG_STORE_T, dS, ldp, 1, sP1, sP2, q, 3 * inner, 1, sQ1, DK, dq + inner, 3 * inner, sQ1, DK, nB, S, DK, S));            // dK = dS^T Q
   RC(o.dW(dq, 3 * inner, 3 * inner, h, d, d, G + wqkv, M));                                       // dWqkv = dqkv^T . h
   RC(o.dX(TG_STORE_F32, dq, 3 * inner, wqkv, 3 * inner, d, t->dh, d, M));                         // dh = dqkv . Wqkv
   RC(o.norm_bwd(x_in, ln, t->dh, dx_out, dx_in, G, M));
@@ -2519,8 +2544,9 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
     T* dcq = (T*)t->dcq;
     const int64_t sK1 = (int64_t)S * 2 * inner, sQ1 = (int64_t)L * inner;
     const T* Pu;
-    RC(o.redrop(t->Pcd[l], (int64_t)B * H * L * lps, SITE_DEC + 16 * l + PL_PROBS_CROSS, &Pu));
-    RC(o.mmbh(TG_STORE_T, Pu, lps, 1, sPc1, sPc2, dO, inner, 1, sQ1, DK, dckv + inner, 2 * inner, sK1, DK, B, S, DK, L));                   // dV = Pd^T dO
+    const bool pair_c = o.stripe_ok(S) && o.pair_on();
+    RC(o.redrop(t->Pcd[l], (int64_t)B * H * L * lps, SITE_DEC + 16 * l + PL_PROBS_CROSS, &Pu, pair_c));
+    if (!pair_c) RC(o.mmbh(TG_STORE_T, Pu, lps, 1, sPc1, sPc2, dO, inner, 1, sQ1, DK, dckv + inner, 2 * inner, sK1, DK, B, S, DK, L));      // dV = Pd^T dO
     if (o.stripe_ok(S)) {
       RC(o.dscores(ckv + inner, 2 * inner, sK1, DK, dO, inner, sQ1, DK, t->Pcd[l], t->dS, B, L, S, lps, SITE_DEC + 16 * l + PL_PROBS_CROSS, false,
                    fuse_c_dq ? (const T*)t->ktc[l] : nullptr, dcq, inner, sQ1, DK));
@@ -2530,7 +2556,10 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
     }
     const T* dS = (const T*)t->dS;
     if (!fuse_c_dq) RC(o.mmbh(TG_STORE_T, dS, lps, 0, sPc1, sPc2, ckv, 2 * inner, 1, sK1, DK, dcq, inner, sQ1, DK, B, L, DK, S));               // dQ = dS K
-    RC(o.mmbh(TG_STORE_T, dS, lps, 1, sPc1, sPc2, cq, inner, 1, sQ1, DK, dckv, 2 * inner, sK1, DK, B, S, DK, L));                            // dK = dS^T Q
+    if (pair_c)                                                                                                                              // dV | dK
+      RC(o.mmbh2(TG_STORE_T, Pu, dS, lps, 1, sPc1, sPc2, dO, inner, sQ1, DK, cq, inner, sQ1, DK, 1, dckv + inner, dckv, 2 * inner, sK1, DK, B, S, DK, L));
+    else
+      RC(o.mmbh(TG_STORE_T, dS, lps, 1, sPc1, sPc2, cq, inner, 1, sQ1, DK, dckv, 2 * inner, sK1, DK, B, S, DK, L));                          // dK = dS^T Q
     RC(o.dW(dcq, inner, inner, t->h1d[l], d, d, G + e.cq, Md));
     RC(o.dX(TG_STORE_F32, dcq, inner, e.cq, inner, d, t->dh, d, Md));
     o.after_site = SITE_DEC + 16 * l + PL_SELF_OUT;
