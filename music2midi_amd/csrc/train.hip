@@ -589,19 +589,22 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restric
 template <typename T>
 __global__ __launch_bounds__(256) void kv_transpose_kernel(const T* __restrict__ src, int64_t ld, int64_t wstride, T* __restrict__ dst, int S, int Sp, int H,
                                                            int64_t dst_wstride) {
-  __shared__ T tile[64][64 + 2];
-  const int s0 = blockIdx.x * 64, bh = blockIdx.y, which = blockIdx.z, b = bh / H, hh = bh - b * H;
-  const T* sp = src + (int64_t)b * S * ld + which * wstride + hh * 64;
-  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-    const int sl = i >> 6, dd = i & 63;
-    tile[sl][dd] = (s0 + sl < S) ? sp[(int64_t)(s0 + sl) * ld + dd] : from_f32<T>(0.f);
-  }
-  __syncthreads();
-  T* dp = dst + which * dst_wstride + (int64_t)bh * 64 * Sp;
-  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-    const int dd = i >> 6, sl = i & 63;
-    if (s0 + sl < Sp) dp[(int64_t)dd * Sp + s0 + sl] = tile[sl][dd];
-  }
+  // register transposes only (tr_col): a thread takes an E x E block — E rows of s, 16 bytes of d each — and writes E rows of d,
+  // 16 bytes of s each; for a fixed register the lanes of a wave cover whole 128-byte lines on both sides (the LDS form with
+  // 2-byte accesses took 9.3 us per launch)
+  constexpr int E = 16 / sizeof(T), DB = DK / E;              // d blocks per row: 8 (bf16) / 16 (fp32)
+  const int bh = blockIdx.y, which = blockIdx.z, b = bh / H, hh = bh - b * H;
+  const int blk = blockIdx.x * 256 + threadIdx.x;             // block id: d block fastest on the load side
+  const int sb = blk / DB, db = blk - sb * DB;
+  const int s0 = sb * E;
+  if (s0 >= Sp) return;
+  const T* sp = src + (int64_t)b * S * ld + which * wstride + hh * DK + db * E;
+  uint4 rg[E];
+#pragma unroll
+  for (int k = 0; k < E; ++k) rg[k] = (s0 + k < S) ? *reinterpret_cast<const uint4*>(sp + (int64_t)(s0 + k) * ld) : make_uint4(0, 0, 0, 0);
+  T* dp = dst + which * dst_wstride + ((int64_t)bh * DK + db * E) * Sp + s0;
+#pragma unroll
+  for (int jj = 0; jj < E; ++jj) *reinterpret_cast<uint4*>(dp + (int64_t)jj * Sp) = tr_col<T, E>(rg, jj);
 }
 
 // ---- attention stripes: scores -> probabilities (forward) and dP -> dS (backward) WITHOUT the fp32 [Sq, Sk] image ----
@@ -2197,7 +2200,8 @@ struct Ops {
   // K | V of a layer ([rows, ld], K at column 0 and V at column `inner` of `kv`) -> kt [2][nB*H][64][Sp]
   int kv_transpose(const T* kv, int64_t ld, void* kt, int nB, int S) const {
     const int H = t->g.num_heads, Sp = (int)align_up(S, 32);
-    hipLaunchKernelGGL(kv_transpose_kernel<T>, dim3(ceil_div(Sp, 64), nB * H, 2), dim3(256), 0, st, kv, ld, (int64_t)t->inner, (T*)kt, S, Sp, H,
+    constexpr int Et = 16 / sizeof(T);
+    hipLaunchKernelGGL(kv_transpose_kernel<T>, dim3(ceil_div((Sp / Et) * (DK / Et), 256), nB * H, 2), dim3(256), 0, st, kv, ld, (int64_t)t->inner, (T*)kt, S, Sp, H,
                        (int64_t)nB * H * DK * Sp);
     M2M_CHECK_HIP(hipGetLastError());
     return M2M_OK;
