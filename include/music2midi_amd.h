@@ -48,8 +48,9 @@ enum {
 enum {
   M2M_PREC_FP32 = 0,        /* fp32 weights / KV / GEMM inputs (f32 MFMA): parity mode */
   M2M_PREC_BF16 = 1,        /* bf16 weights / KV / GEMM inputs, fp32 accumulate: throughput mode */
-  M2M_PREC_FP8 = 2          /* m2m_trainer_create only: as BF16, but the dense projection products (forward, dX, dW) run on
-                               block-scaled OCP FP8 (MXFP8: e4m3 forward operands, e5m2 gradients) — BASELINE configs[4] */
+  M2M_PREC_FP8 = 2          /* m2m_trainer_create only: as BF16, but the dense projection products run on block-scaled OCP FP8
+                               (MXFP8, e4m3 elements, 32 per E8M0 scale): forward and dX by default, the weight gradients too with
+                               M2M_FP8_PARTS=fwd,dx,dw; M2M_FP8_GRAD=e5m2 for e5m2 gradient operands — BASELINE configs[4] */
 };
 
 int m2m_abi_version(void);
@@ -213,7 +214,9 @@ typedef struct {
 } m2m_tensor_info;
 
 /* n_cond / cond_rows_host: the conditioning embedding tables (ref: music2midi/input.py:45-55), trainable.
- * max_*: largest batch, encoder length (cond rows + frames) and label length of a step. */
+ * max_*: largest batch, encoder length (cond rows + frames) and label length of a step.
+ * A trainer is used from one host thread at a time; it owns its activations (m2m_trainer_workspace_bytes: ~1.5 GB at 16 clips of
+ * 3 s — every sub-layer keeps its operands until the grouped weight-gradient launch), two streams and a captured graph. */
 int  m2m_trainer_create(const m2m_t5_geometry* geom, int n_cond, const int* cond_rows_host, int precision,
                         int max_batch, int max_enc_len, int max_dec_len, m2m_trainer** out);
 void m2m_trainer_destroy(m2m_trainer* t);
