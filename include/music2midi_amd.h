@@ -215,7 +215,7 @@ typedef struct {
 
 /* n_cond / cond_rows_host: the conditioning embedding tables (ref: music2midi/input.py:45-55), trainable.
  * max_*: largest batch, encoder length (cond rows + frames) and label length of a step.
- * A trainer is used from one host thread at a time; it owns its activations (m2m_trainer_workspace_bytes: ~1.5 GB at 16 clips of
+ * A trainer is used from one host thread at a time; it owns its activations (m2m_trainer_workspace_bytes: 2.3 GB at 16 clips of
  * 3 s — every sub-layer keeps its operands until the grouped weight-gradient launch), two streams and a captured graph. */
 int  m2m_trainer_create(const m2m_t5_geometry* geom, int n_cond, const int* cond_rows_host, int precision,
                         int max_batch, int max_enc_len, int max_dec_len, m2m_trainer** out);
