@@ -18,3 +18,15 @@ def test_decode_fuzz_against_oracle(seed):
     print(tail)
     assert r.returncode == 0, tail + r.stderr[-2000:]
     assert "FUZZ OK" in r.stdout
+
+
+@pytest.mark.parametrize("seed", [1, 7])
+def test_training_step_fuzz_against_autograd(seed):
+    """Differential fuzz of the training step (tools/fuzz_train.py): random batch / encoder / label lengths around the tile edges
+    of the fused attention kernels and past their reach, ignored labels, dropout on and off — every gradient tensor within 1e-4 of
+    autograd over the oracle (fp32 mode), graph replay identical to the direct issue."""
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "fuzz_train.py"), "40", str(seed)], capture_output=True, text=True, timeout=1500)
+    tail = "\n".join(r.stdout.splitlines()[-6:])
+    print(tail)
+    assert r.returncode == 0, tail + r.stderr[-2000:]
+    assert "FUZZ OK" in r.stdout

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Differential fuzz of the training step against autograd over the oracle (fp32 mode): random batch sizes, encoder / label
+lengths (odd sizes, single rows, lengths around the tile edges of the fused attention kernels and past their reach), ignored
+labels, dropout on and off.  Every gradient tensor must agree to 1e-4 relative (the fp32 bar of tests/test_train_gpu.py), the
+second call (graph replay) must reproduce the first bit for bit when dropout is off.
+python tools/fuzz_train.py [cases] [seed]"""
+import copy, sys, time
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tests"))
+import numpy as np, torch
+from music2midi_amd import synth
+from music2midi_amd.checkpoint import load_t5_state
+from music2midi_amd.config import DEFAULT_CONFIG, T5Geometry, load_config
+from music2midi_amd.training import NativeTrainer
+from music2midi_amd.transformer import T5Transformer
+from oracle.train import DropoutMasks, T5TrainOracle, leaf_params
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+torch.set_num_threads(16)
+tiny = copy.deepcopy(DEFAULT_CONFIG); tiny["model"]["t5"].update(d_model=64, d_ff=128, num_layers=2, num_decoder_layers=2, num_heads=2)
+geom = T5Geometry(load_config(tiny).model.t5)
+sd = synth.t5_state_dict(geom, seed=3); synth.perturb_layer_norms(sd, 3)
+model = T5Transformer(tiny, precision="fp32"); load_t5_state(model, sd, strict=False); model = model.cuda()
+orc = T5TrainOracle(geom, leaf_params(sd))
+u = synth.uniform01(seed, "fuzz_train", n_cases * 6).reshape(n_cases, 6)
+edges = [1, 2, 7, 8, 9, 31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 128, 129, 255, 257, 319, 321, 511, 513, 530]
+bad = 0; t0 = time.time()
+for i, r in enumerate(u):
+    B = 1 + int(r[0] * 5)
+    F = edges[int(r[1] * len(edges))] if r[4] < 0.6 else 1 + int(r[1] * 300)
+    Ld = edges[int(r[2] * 19)] if r[4] < 0.6 else 1 + int(r[2] * 200)          # labels up to 255 from the edge list
+    drop = r[3] < 0.4
+    tr = NativeTrainer(model, B, F + 2, Ld, precision="fp32")
+    feats = torch.from_numpy(synth.normal(100 + i, "feats", (B, F, geom.d_model), 2.0))
+    cond = torch.from_numpy(synth.cond_index_batch(i, B))
+    labels = torch.from_numpy((synth.uniform01(200 + i, "labels", B * Ld) * 330).astype(np.int64).reshape(B, Ld)) + 3
+    if Ld > 3 and r[5] < 0.5:
+        labels[0, Ld - 2:] = -100
+    x = torch.zeros((B, F + 2, geom.d_model)); x[:, 2:] = feats
+    masks = None
+    if drop:
+        tr.set_dropout(0.1, seed=1000 + i); masks = DropoutMasks(0.1, 1000 + i, 0)
+    loss, _ = tr.forward_backward(x.cuda(), cond.cuda(), labels.cuda())
+    g1 = tr.grads.clone(); l1 = loss.item()
+    loss_o, _, grads_o = orc.loss_and_grads(feats, cond, labels, masks)
+    worst, wname = 0.0, ""
+    for name, (off, shape) in tr.layout.items():
+        g = g1[off:off + int(np.prod(shape))].view(shape).cpu()
+        e = float((g - grads_o[name]).abs().max() / (grads_o[name].abs().max() + 1e-20))
+        if not np.isfinite(e): e = float("inf")
+        if e > worst: worst, wname = e, name
+    ok = abs(l1 - loss_o.item()) < 1e-4 * max(1.0, abs(loss_o.item())) and worst < 1e-4
+    if not drop:                                   # second call: the captured graph must reproduce the direct issue
+        loss2, _ = tr.forward_backward(x.cuda(), cond.cuda(), labels.cuda())
+        ok = ok and torch.equal(g1, tr.grads) and loss2.item() == l1
+    tr.close()
+    print(f"case {i:3d} B={B} F={F} Ld={Ld} dropout={int(drop)}: loss {l1:.5f} / {loss_o.item():.5f}  worst grad {worst:.2e} ({wname.split('.')[-3] if wname.count('.') > 2 else wname})  {'ok' if ok else 'MISMATCH'}", flush=True)
+    bad += 0 if ok else 1
+print(f"{n_cases} cases in {time.time() - t0:.0f} s: {bad} mismatches")
+print("FUZZ OK" if bad == 0 else "FUZZ FAILED")
+sys.exit(0 if bad == 0 else 1)
