@@ -3,7 +3,8 @@
 lengths (odd sizes, single rows, lengths around the tile edges of the fused attention kernels and past their reach), ignored
 labels, dropout on and off.  Every gradient tensor must agree to 1e-4 relative (the fp32 bar of tests/test_train_gpu.py), the
 second call (graph replay) must reproduce the first bit for bit when dropout is off.
-python tools/fuzz_train.py [cases] [seed]"""
+python tools/fuzz_train.py [cases] [seed] [fp32|bf16|fp8]   (bf16 / fp8: every tensor finite and within a relative L2 of 8e-2 /
+0.5 of the fp32 autograd gradient, the loss within 1 % / 3 %: a guard against NaNs and gross errors at odd shapes, not a parity bar)"""
 import copy, sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
@@ -18,12 +19,15 @@ from oracle.train import DropoutMasks, T5TrainOracle, leaf_params
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+prec = sys.argv[3] if len(sys.argv) > 3 else "fp32"
 torch.set_num_threads(16)
 tiny = copy.deepcopy(DEFAULT_CONFIG); tiny["model"]["t5"].update(d_model=64, d_ff=128, num_layers=2, num_decoder_layers=2, num_heads=2)
+if prec == "fp8": tiny["model"]["t5"].update(d_model=128, d_ff=256)          # MX blocks of 32 in 128-byte rows
 geom = T5Geometry(load_config(tiny).model.t5)
 sd = synth.t5_state_dict(geom, seed=3); synth.perturb_layer_norms(sd, 3)
 model = T5Transformer(tiny, precision="fp32"); load_t5_state(model, sd, strict=False); model = model.cuda()
 orc = T5TrainOracle(geom, leaf_params(sd))
+orc.mx8 = prec == "fp8"                        # fp8: against the oracle whose projections quantise the same way (straight-through)
 u = synth.uniform01(seed, "fuzz_train", n_cases * 6).reshape(n_cases, 6)
 edges = [1, 2, 7, 8, 9, 31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 128, 129, 255, 257, 319, 321, 511, 513, 530]
 bad = 0; t0 = time.time()
@@ -32,7 +36,7 @@ for i, r in enumerate(u):
     F = edges[int(r[1] * len(edges))] if r[4] < 0.6 else 1 + int(r[1] * 300)
     Ld = edges[int(r[2] * 19)] if r[4] < 0.6 else 1 + int(r[2] * 200)          # labels up to 255 from the edge list
     drop = r[3] < 0.4
-    tr = NativeTrainer(model, B, F + 2, Ld, precision="fp32")
+    tr = NativeTrainer(model, B, F + 2, Ld, precision=prec)
     feats = torch.from_numpy(synth.normal(100 + i, "feats", (B, F, geom.d_model), 2.0))
     cond = torch.from_numpy(synth.cond_index_batch(i, B))
     labels = torch.from_numpy((synth.uniform01(200 + i, "labels", B * Ld) * 330).astype(np.int64).reshape(B, Ld)) + 3
@@ -48,10 +52,14 @@ for i, r in enumerate(u):
     worst, wname = 0.0, ""
     for name, (off, shape) in tr.layout.items():
         g = g1[off:off + int(np.prod(shape))].view(shape).cpu()
-        e = float((g - grads_o[name]).abs().max() / (grads_o[name].abs().max() + 1e-20))
-        if not np.isfinite(e): e = float("inf")
+        if prec == "fp32":
+            e = float((g - grads_o[name]).abs().max() / (grads_o[name].abs().max() + 1e-20))
+        else:
+            e = float((g - grads_o[name]).norm() / (grads_o[name].norm() + 1e-12)) if float(grads_o[name].norm()) > 1e-6 else 0.0
+        if not np.isfinite(e) or not bool(torch.isfinite(g).all()): e = float("inf")
         if e > worst: worst, wname = e, name
-    ok = abs(l1 - loss_o.item()) < 1e-4 * max(1.0, abs(loss_o.item())) and worst < 1e-4
+    ltol, gtol = {"fp32": (1e-4, 1e-4), "bf16": (1e-2, 8e-2), "fp8": (3e-2, 0.6)}[prec]   # fp8: one or two labels on a d_model=128 random model flip fp8 codes; the bound catches NaNs and wrong terms, test_train_gpu holds the tight cosine
+    ok = abs(l1 - loss_o.item()) < ltol * max(1.0, abs(loss_o.item())) and worst < gtol
     if not drop:                                   # second call: the captured graph must reproduce the direct issue
         loss2, _ = tr.forward_backward(x.cuda(), cond.cuda(), labels.cuda())
         ok = ok and torch.equal(g1, tr.grads) and loss2.item() == l1
