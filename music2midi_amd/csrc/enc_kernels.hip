@@ -151,6 +151,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   const int r = lane & 31, h = lane >> 5;
   const int nk = K / BK;
   M2M_GLOAD(0)
+  // small-tile residual products: the 16 residual values a lane adds to are requested before the k loop (their round trip
+  // would otherwise sit between the last MFMA and the store of a workgroup that lives for three k-steps)
+  float rpre[16];
+  if constexpr (EPI == EPI_RESID && TF == 1) {
+    const float* rsrc = g.resid ? g.resid : reinterpret_cast<const float*>(g.out);
+    const int col = n0 + wn * WT + r;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = m0 + wm * WT + acc_row(e, lane);
+      rpre[e] = (row < g.M && col < g.N) ? rsrc[(int64_t)row * g.ldo + col] : 0.f;
+    }
+  }
   for (int kt = 0; kt < nk; ++kt) {
     __syncthreads();
     M2M_SSTORE()
@@ -308,7 +320,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
             float* p = reinterpret_cast<float*>(g.out) + at;
             float u = v;
             if (g.drop_thresh) u = drop_keep(dkey, at, g.drop_thresh) ? v * g.drop_scale : 0.f;   // training only
-            *p = (g.resid ? g.resid[at] : *p) + u;
+            if constexpr (TF == 1) *p = rpre[e] + u;
+            else *p = (g.resid ? g.resid[at] : *p) + u;
           } else {  // EPI_HEADS
             const int which = col / g.inner, rem = col - which * g.inner;
             const int hh = rem / DK, dd = rem - hh * DK;

@@ -288,6 +288,102 @@ __global__ __launch_bounds__(256) void mxgemm_q_kernel(MxGemmArgs g) {
   }
 }
 
+// Both operands pre-quantised (the activations' fp8 image is written by the kernel that produces them — RMSNorm, gated GELU, the
+// gradient converters), 64 x (64 TN) tile, next k-step's 16-byte chunks prefetched into registers: the operand staging is byte
+// copies only, half the bytes of the bf16 product, and no VALU work in the loop.
+template <int FA, int EPI, int TN>
+__global__ __launch_bounds__(256) void mxgemm_p_kernel(MxGemmArgs g) {
+  constexpr int BN = 64 * TN;
+  __shared__ __align__(16) uint8_t As[64 * MX_PITCH];
+  __shared__ __align__(16) uint8_t Bs[BN * MX_PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * BN;
+  const uint32_t* sA = reinterpret_cast<const uint32_t*>(g.sA) + (int64_t)min(m0 + wm * 32 + r, g.M - 1) * (g.lda / 128);
+  const uint32_t* sB[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) sB[j] = reinterpret_cast<const uint32_t*>(g.sB) + (int64_t)min(n0 + (wn * TN + j) * 32 + r, g.N - 1) * (g.ldb / 128);
+  uint4 ra[2], rb[2 * TN];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + 256 * i, row = m0 + c / 8, kc = (c % 8) * 16;
+      ra[i] = row < g.M ? *reinterpret_cast<const uint4*>(g.A + (int64_t)row * g.lda + k0 + kc) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * TN; ++i) {
+      const int c = tid + 256 * i, row = n0 + c / 8, kc = (c % 8) * 16;
+      rb[i] = row < g.N ? *reinterpret_cast<const uint4*>(g.B + (int64_t)row * g.ldb + k0 + kc) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  f32x16 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) acc[j] = zero_acc();
+  gload(0);
+  for (int k0 = 0; k0 < g.K; k0 += MX_BK) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int c = tid + 256 * i; *reinterpret_cast<uint4*>(As + (c / 8) * MX_PITCH + (c % 8) * 16) = ra[i]; }
+#pragma unroll
+    for (int i = 0; i < 2 * TN; ++i) { const int c = tid + 256 * i; *reinterpret_cast<uint4*>(Bs + (c / 8) * MX_PITCH + (c % 8) * 16) = rb[i]; }
+    const uint32_t sa4 = sA[k0 / 128];
+    uint32_t sb4[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) sb4[j] = sB[j][k0 / 128];
+    __syncthreads();
+    if (k0 + MX_BK < g.K) gload(k0 + MX_BK);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const uint8_t* ap = As + (wm * 32 + r) * MX_PITCH + s * 64 + h * 16;
+      const uint4 a0 = *reinterpret_cast<const uint4*>(ap), a1 = *reinterpret_cast<const uint4*>(ap + 32);
+      const v8i_t av = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
+      const int sa = (int)((sa4 >> (8 * (2 * s + h))) & 0xFF);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const uint8_t* bp = Bs + ((wn * TN + j) * 32 + r) * MX_PITCH + s * 64 + h * 16;
+        const uint4 b0 = *reinterpret_cast<const uint4*>(bp), b1 = *reinterpret_cast<const uint4*>(bp + 32);
+        const v8i_t bv = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
+        const int sb = (int)((sb4[j] >> (8 * (2 * s + h))) & 0xFF);
+        acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc[j], FA, 0, 0, sa, 0, sb);
+      }
+    }
+  }
+  const uint64_t dkey = (EPI == TG_RESID_F32 && g.drop_thresh) ? splitmix64(*g.drop_step + g.drop_key) : 0ull;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + (wn * TN + j) * 32 + r;
+    if (col >= g.N) continue;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = m0 + wm * 32 + acc_row(i, lane);
+      if (row >= g.M) continue;
+      const int64_t at = (int64_t)row * g.ldc + col;
+      const float v = acc[j][i];
+      if constexpr (EPI == TG_STORE_T) reinterpret_cast<bf16_t*>(g.C)[at] = f32_to_bf16(v);
+      else if constexpr (EPI == TG_STORE_F32) reinterpret_cast<float*>(g.C)[at] = v;
+      else if constexpr (EPI == TG_ACC_F32) reinterpret_cast<float*>(g.C)[at] += v;
+      else {
+        float u = v;
+        if (g.drop_thresh) u = drop_keep(dkey, at, g.drop_thresh) ? v * g.drop_scale : 0.f;
+        reinterpret_cast<float*>(g.C)[at] = g.R[at] + u;
+      }
+    }
+  }
+}
+template <int FA, int TN>
+static int launch_mxgemm_p_ft(int epi, const MxGemmArgs& g, hipStream_t st) {
+  dim3 grid((unsigned)ceil_div(g.N, 64 * TN), (unsigned)ceil_div(g.M, 64));
+  switch (epi) {
+    case TG_STORE_T: hipLaunchKernelGGL((mxgemm_p_kernel<FA, TG_STORE_T, TN>), grid, dim3(256), 0, st, g); break;
+    case TG_STORE_F32: hipLaunchKernelGGL((mxgemm_p_kernel<FA, TG_STORE_F32, TN>), grid, dim3(256), 0, st, g); break;
+    case TG_ACC_F32: hipLaunchKernelGGL((mxgemm_p_kernel<FA, TG_ACC_F32, TN>), grid, dim3(256), 0, st, g); break;
+    case TG_RESID_F32: hipLaunchKernelGGL((mxgemm_p_kernel<FA, TG_RESID_F32, TN>), grid, dim3(256), 0, st, g); break;
+    default: set_error("mxgemm_p: bad epilogue %d", epi); return M2M_ERR_INVALID;
+  }
+  M2M_CHECK_HIP(hipGetLastError());
+  return M2M_OK;
+}
+
 template <int FA, int TN>
 static int launch_mxgemm_q_ft(int epi, const MxGemmArgs& g, hipStream_t st) {
   dim3 grid((unsigned)ceil_div(g.N, 64 * TN), (unsigned)ceil_div(g.M, 64));
@@ -347,6 +443,12 @@ int launch_mxgemm(int fmt_a, int fmt_b, int epi, const MxGemmArgs& g, hipStream_
   int rc;
   if (g.ksplit > 1) {
     M2M_REQUIRE(epi == TG_STORE_F32 && g.Cpart && g.kchunk % 128 == 0, "mxgemm: split-K is for plain fp32-store products");
+  }
+  static const bool plain = getenv("M2M_MXGEMM_PLAIN") != nullptr;      // diagnostic: the unprefetched 64x64 kernel
+  static const int wide_from = [] { const char* v = getenv("M2M_MXP_WIDE_FROM"); return v ? atoi(v) : 512; }();
+  if (g.ksplit <= 1 && !plain) {
+    if (g.N >= wide_from) return fmt_a == 0 ? launch_mxgemm_p_ft<0, 2>(epi, g, st) : launch_mxgemm_p_ft<1, 2>(epi, g, st);
+    return fmt_a == 0 ? launch_mxgemm_p_ft<0, 1>(epi, g, st) : launch_mxgemm_p_ft<1, 1>(epi, g, st);
   }
   rc = fmt_a == 0 ? launch_mxgemm_f<0, 0>(epi, g, st) : launch_mxgemm_f<1, 0>(epi, g, st);
   if (rc != M2M_OK) return rc;
