@@ -251,6 +251,17 @@ int m2m_train_forward_backward(m2m_trainer* t, const float* params_dev, const fl
  * backward pass.  p = 0 (the default after create) switches it off. */
 int m2m_trainer_set_dropout(m2m_trainer* t, float p, uint64_t seed);
 
+/* Data-parallel training (ref: train.py:40-41 — pl.Trainer(strategy="ddp"): the gradient all-reduce overlapped with backward).
+ * With a sync stream set, m2m_train_forward_backward issues the backward pass in two parts — decoder side, then encoder side —
+ * and makes `sync_stream` wait (a device-side event, no host synchronisation) for the point where the gradients of the two
+ * "early" ranges are final and will not be written again in this call: the shared embedding + lm_head at the front of the flat
+ * buffer, and the decoder blocks.  The all-reduce of those ranges, enqueued on `sync_stream` right after the call returns, runs
+ * beside the encoder-side backward; the rest of the buffer is final when the caller's own stream continues.  The gradients are
+ * bit-identical to the unsplit pass.  nullptr switches the split off.
+ * m2m_trainer_early_grad_ranges: out[0..3] = {offset, count, offset, count} in floats of the flat gradient buffer. */
+int m2m_trainer_set_sync_stream(m2m_trainer* t, void* sync_stream);
+int m2m_trainer_early_grad_ranges(const m2m_trainer* t, int64_t* out);
+
 /* One transformers.optimization.Adafactor step with the reference's settings (lr=None, eps=(1e-30, 1e-3),
  * clip_threshold=1.0, decay_rate=-0.8, beta1=None, weight_decay=0, scale_parameter, relative_step,
  * warmup_init): params_dev is updated in place from grads_dev.  The step counter and the factored second

@@ -1646,11 +1646,18 @@ struct m2m_trainer {
   std::vector<void*> ring[K_KINDS];
   bool use_group = true;                 // one grouped weight-gradient launch per step (bf16 / fp32 modes)
   void* dw_probs_dev = nullptr;          // DwProb table on the device
-  std::vector<unsigned char> dw_probs_host;   // ... and its host image (re-uploaded only when it changes)
+  std::vector<unsigned char> dw_probs_host[2];   // ... and its host image (re-uploaded only when it changes); [1]: the second half of a split pass
   int dw_tiles = 0;
   int64_t drel_slot_floats = 0;          // one self-attention layer's per-stripe diagonal sums (t->drel holds Le + Ld of them, then the scratch)
   int64_t* norm_offs_dev = nullptr;      // parameter offsets of the RMSNorm weights, in the order the backward pass meets them
-  std::vector<int64_t> norm_offs_host;
+  std::vector<int64_t> norm_offs_host[2];
+  // data-parallel overlap (m2m_trainer_set_sync_stream): the backward pass is issued in two parts — decoder side, then encoder side —
+  // and `sync_stream` is released (ev_mid) as soon as the decoder-side gradients are final, so their all-reduce runs beside the
+  // encoder backward.  The layout keeps them in two flat ranges: [0, o_erb) (shared embedding, lm_head) and the decoder blocks.
+  hipStream_t sync_stream = nullptr;
+  hipEvent_t ev_mid = nullptr;
+  hipGraphExec_t gexec2 = nullptr;       // second half of a split pass
+  int64_t dec_begin = 0, dec_end = 0;
   // streams / graph of the step (trainer-owned: the caller's stream may be the legacy default stream, which cannot capture)
   hipStream_t s_main = nullptr, s_side = nullptr;
   hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_ready = nullptr, ev_free[2] = {nullptr, nullptr};
@@ -1659,8 +1666,10 @@ struct m2m_trainer {
   int64_t* cond_buf = nullptr;
   float* loss_dev = nullptr;
   struct GraphKey {
-    const float* P = nullptr; float* G = nullptr; int B = 0, S = 0, L = 0; uint32_t thresh = 0; uint64_t seed = 0;
-    bool operator==(const GraphKey& o) const { return P == o.P && G == o.G && B == o.B && S == o.S && L == o.L && thresh == o.thresh && seed == o.seed; }
+    const float* P = nullptr; float* G = nullptr; int B = 0, S = 0, L = 0; uint32_t thresh = 0; uint64_t seed = 0; bool split = false;
+    bool operator==(const GraphKey& o) const {
+      return P == o.P && G == o.G && B == o.B && S == o.S && L == o.L && thresh == o.thresh && seed == o.seed && split == o.split;
+    }
   };
   GraphKey last_key, graph_key;          // key of the previous call / of the instantiated graph
   hipGraphExec_t gexec = nullptr;
@@ -1712,6 +1721,7 @@ void build_layout(m2m_trainer* t) {
     e.wo = add_tensor(t, p + "1.DenseReluDense.wo.weight", d, dff, off);
   }
   t->dec.resize(g.num_decoder_layers);
+  t->dec_begin = off;
   for (int l = 0; l < g.num_decoder_layers; ++l) {
     const std::string p = T5 + "decoder.block." + std::to_string(l) + ".layer.";
     DecOff& e = t->dec[l];
@@ -1730,6 +1740,7 @@ void build_layout(m2m_trainer* t) {
     t->tensors.push_back({p + "2.DenseReluDense.wi_1.weight", off, dff, d}); off = align_up(off + (int64_t)dff * d, 64);
     e.wo = add_tensor(t, p + "2.DenseReluDense.wo.weight", d, dff, off);
   }
+  t->dec_end = off;
   t->o_cond.resize(t->n_cond);
   for (int i = 0; i < t->n_cond; ++i)
     t->o_cond[i] = add_tensor(t, "conditioning.embeds." + std::to_string(i) + ".weight", t->cond_rows[i], d, off);
@@ -1986,42 +1997,50 @@ struct Ops {
       if (used[p]) M2M_CHECK_HIP(hipStreamWaitEvent(st, t->ev_free[p], 0));
     return M2M_OK;
   }
+  // A split pass (t->sync_stream) flushes twice: `phase` picks the half of the device tables (and the host image) a flush uses,
+  // so both halves stay constant from step to step and a captured graph never sees a table change.
+  mutable int phase = 0;
   int flush_norms() const {
     if (!group || norm_offs.empty()) return M2M_OK;
-    M2M_REQUIRE(norm_offs.size() <= 64 && (int)norm_offs.size() <= 2 * t->g.num_layers + 3 * t->g.num_decoder_layers + 2, "training: too many norms");
-    if (t->norm_offs_host != norm_offs) {
+    M2M_REQUIRE(norm_offs.size() <= 32 && (int)norm_offs.size() <= 2 * t->g.num_layers + 3 * t->g.num_decoder_layers + 2, "training: too many norms");
+    int64_t* const offs_dev = t->norm_offs_dev + 32 * phase;
+    if (t->norm_offs_host[phase] != norm_offs) {
       hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
       (void)hipStreamIsCapturing(st, &cs);
       M2M_REQUIRE(cs == hipStreamCaptureStatusNone, "training: the norm table changed inside a graph capture");
       M2M_CHECK_HIP(hipStreamSynchronize(st));
-      M2M_CHECK_HIP(hipMemcpy(t->norm_offs_dev, norm_offs.data(), norm_offs.size() * 8, hipMemcpyHostToDevice));
-      t->norm_offs_host = norm_offs;
+      M2M_CHECK_HIP(hipMemcpy(offs_dev, norm_offs.data(), norm_offs.size() * 8, hipMemcpyHostToDevice));
+      t->norm_offs_host[phase] = norm_offs;
     }
     const int d = t->g.d_model;
-    hipLaunchKernelGGL(colsum_group_kernel, dim3(ceil_div(d, 32), (unsigned)norm_offs.size()), dim3(256), 0, st, t->dw_part, t->norm_offs_dev, Gbase,
+    hipLaunchKernelGGL(colsum_group_kernel, dim3(ceil_div(d, 32), (unsigned)norm_offs.size()), dim3(256), 0, st, t->dw_part, offs_dev, Gbase,
                        RN_BLOCKS, d);
     M2M_CHECK_HIP(hipGetLastError());
+    norm_offs.clear();
     return M2M_OK;
   }
   int flush_group() const {
     if (!group || probs.empty()) return M2M_OK;
-    M2M_REQUIRE(probs.size() <= 256, "training: %zu weight-gradient products exceed the table", probs.size());
+    M2M_REQUIRE(probs.size() <= 128, "training: %zu weight-gradient products exceed the table", probs.size());
+    unsigned char* const tab_dev = reinterpret_cast<unsigned char*>(t->dw_probs_dev) + (size_t)phase * 128 * sizeof(DwProb);
+    std::vector<unsigned char>& tab_host = t->dw_probs_host[phase];
     int tiles = 0;
     for (DwProb& p : probs) { p.tn2 = ceil_div(p.g.N2, 128); p.tile0 = tiles; tiles += ceil_div(p.g.N1, 128) * p.tn2; }
     const size_t bytes = probs.size() * sizeof(DwProb);
-    if (t->dw_probs_host.size() != bytes || memcmp(t->dw_probs_host.data(), probs.data(), bytes) != 0) {
+    if (tab_host.size() != bytes || memcmp(tab_host.data(), probs.data(), bytes) != 0) {
       hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
       (void)hipStreamIsCapturing(st, &cs);
       M2M_REQUIRE(cs == hipStreamCaptureStatusNone, "training: the weight-gradient table changed inside a graph capture");
       M2M_CHECK_HIP(hipStreamSynchronize(st));                 // nothing in flight still reads the old table
-      M2M_CHECK_HIP(hipMemcpy(t->dw_probs_dev, probs.data(), bytes, hipMemcpyHostToDevice));
-      t->dw_probs_host.assign(reinterpret_cast<const unsigned char*>(probs.data()), reinterpret_cast<const unsigned char*>(probs.data()) + bytes);
+      M2M_CHECK_HIP(hipMemcpy(tab_dev, probs.data(), bytes, hipMemcpyHostToDevice));
+      tab_host.assign(reinterpret_cast<const unsigned char*>(probs.data()), reinterpret_cast<const unsigned char*>(probs.data()) + bytes);
     }
     if (t->precision == M2M_PREC_BF16)
-      hipLaunchKernelGGL(dw_group_kernel<bf16_t>, dim3(tiles), dim3(256), 0, st, (const DwProb*)t->dw_probs_dev, (int)probs.size());
+      hipLaunchKernelGGL(dw_group_kernel<bf16_t>, dim3(tiles), dim3(256), 0, st, (const DwProb*)tab_dev, (int)probs.size());
     else
-      hipLaunchKernelGGL(dw_group_kernel<float>, dim3(tiles), dim3(256), 0, st, (const DwProb*)t->dw_probs_dev, (int)probs.size());
+      hipLaunchKernelGGL(dw_group_kernel<float>, dim3(tiles), dim3(256), 0, st, (const DwProb*)tab_dev, (int)probs.size());
     M2M_CHECK_HIP(hipGetLastError());
+    probs.clear();
     return M2M_OK;
   }
   int mm(int epi, const void* A, int64_t lda, int akm, const void* B, int64_t ldb, int bkm, void* C, int64_t ldc, int M, int N, int K,
@@ -2437,7 +2456,8 @@ __global__ void step_key_kernel(uint64_t seed, uint64_t* __restrict__ ctr, uint6
 
 template <typename T>
 int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, const int64_t* cond_idx, const int64_t* labels, int B, int S,
-                       int L, float* loss_out, float* G, float* logits_out, hipStream_t st, hipStream_t st_side) {
+                       int L, float* loss_out, float* G, float* logits_out, hipStream_t st, hipStream_t st_side,
+                       const std::function<int()>* at_split = nullptr) {
   const m2m_t5_geometry& g = t->g;
   const int d = g.d_model, inner = t->inner, V = g.vocab_size, H = g.num_heads, Le = g.num_layers, Ld = g.num_decoder_layers;
   const int Me = B * S, Md = B * L, lps = (int)align_up(S, 8), ldv = (int)align_up(V, 8);
@@ -2582,6 +2602,16 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
   RC(o.drop_inplace(dcur, (int64_t)Md * d, SITE_DEC + SITE_EMB));
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(V), dim3(256), 0, st, t->dec_in, Md, 1, 0, dcur, (int64_t)1, (int64_t)0, G + t->o_shared, d,
                      g.pad_token_id, V);
+  // Split pass (data-parallel overlap): everything the decoder side deferred is issued now, so the gradients of the shared embedding,
+  // lm_head and every decoder block are FINAL here — the caller's hook releases whoever waits for them — and the encoder side
+  // flushes again at the end (into the other half of the tables).  Same products, same reductions: bit-identical gradients.
+  if (at_split && o.group) {
+    RC(o.flush_group());
+    RC(o.flush_norms());
+    RC(o.flush_bias());
+    RC((*at_split)());
+    o.phase = 1;
+  }
   // encoder
   RC(o.drop_inplace(t->dhE, (int64_t)Me * d, SITE_ENC + SITE_FIN));
   o.after_site = SITE_ENC + 16 * (Le - 1) + PL_FF_OUT;
@@ -2651,7 +2681,7 @@ extern "C" int m2m_trainer_create(const m2m_t5_geometry* geom, int n_cond, const
   if (t->use_side) {
     hipError_t e = hipStreamCreateWithFlags(&t->s_main, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&t->s_side, hipStreamNonBlocking);
-    hipEvent_t* evs[] = {&t->ev_in, &t->ev_out, &t->ev_ready, &t->ev_free[0], &t->ev_free[1]};
+    hipEvent_t* evs[] = {&t->ev_in, &t->ev_out, &t->ev_ready, &t->ev_free[0], &t->ev_free[1], &t->ev_mid};
     for (hipEvent_t* ev : evs)
       if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
     if (e != hipSuccess) { set_error("m2m_trainer_create: stream / event creation failed: %s", hipGetErrorString(e)); m2m_trainer_destroy(t); return M2M_ERR_HIP; }
@@ -2664,7 +2694,7 @@ extern "C" void m2m_trainer_destroy(m2m_trainer* t) {
   if (!t) return;
   (void)hipDeviceSynchronize();
   drop_graph(t);
-  hipEvent_t evs[] = {t->ev_in, t->ev_out, t->ev_ready, t->ev_free[0], t->ev_free[1]};
+  hipEvent_t evs[] = {t->ev_in, t->ev_out, t->ev_ready, t->ev_free[0], t->ev_free[1], t->ev_mid};
   for (hipEvent_t ev : evs)
     if (ev) (void)hipEventDestroy(ev);
   if (t->s_main) (void)hipStreamDestroy(t->s_main);
@@ -2709,13 +2739,14 @@ int ensure_tables(m2m_trainer* t, int S, int L, hipStream_t st) {
 }
 
 int run_pass(m2m_trainer* t, const float* P, const float* x, const int64_t* cond, const int64_t* labels, int B, int S, int L, float* loss, float* G,
-             float* logits, hipStream_t st, hipStream_t side) {
-  return t->precision == M2M_PREC_BF16 ? forward_backward_t<bf16_t>(t, P, x, cond, labels, B, S, L, loss, G, logits, st, side)
-                                       : forward_backward_t<float>(t, P, x, cond, labels, B, S, L, loss, G, logits, st, side);
+             float* logits, hipStream_t st, hipStream_t side, const std::function<int()>* at_split = nullptr) {
+  return t->precision == M2M_PREC_BF16 ? forward_backward_t<bf16_t>(t, P, x, cond, labels, B, S, L, loss, G, logits, st, side, at_split)
+                                       : forward_backward_t<float>(t, P, x, cond, labels, B, S, L, loss, G, logits, st, side, at_split);
 }
 
 void drop_graph(m2m_trainer* t) {
   if (t->gexec) { (void)hipGraphExecDestroy(t->gexec); t->gexec = nullptr; }
+  if (t->gexec2) { (void)hipGraphExecDestroy(t->gexec2); t->gexec2 = nullptr; }
   t->graph_key = m2m_trainer::GraphKey{};
 }
 
@@ -2739,7 +2770,17 @@ extern "C" int m2m_train_forward_backward(m2m_trainer* t, const float* params_de
   int rc = ensure_tables(t, S, Ld, caller);
   if (rc != M2M_OK) return rc;
   const bool two = grads_dev && t->use_side && t->s_main && t->s_side;
-  if (!two) return run_pass(t, params_dev, enc_inputs_dev, cond_idx_dev, labels_dev, B, S, Ld, loss_out_dev, grads_dev, logits_out_dev, caller, nullptr);
+  // split pass: the stream that carries the decoder-side gradient all-reduce waits for ev_mid, recorded where those gradients are final
+  const bool split = grads_dev && t->sync_stream && t->ev_mid && t->use_group && !(t->fp8 && t->fp8_dw);
+  hipStream_t work = two ? t->s_main : caller;
+  const std::function<int()> release = [t, work]() -> int {
+    M2M_CHECK_HIP(hipEventRecord(t->ev_mid, work));
+    M2M_CHECK_HIP(hipStreamWaitEvent(t->sync_stream, t->ev_mid, 0));
+    return M2M_OK;
+  };
+  if (!two)
+    return run_pass(t, params_dev, enc_inputs_dev, cond_idx_dev, labels_dev, B, S, Ld, loss_out_dev, grads_dev, logits_out_dev, caller, nullptr,
+                    split ? &release : nullptr);
 
   // ---- stage the inputs (stream-ordered behind whatever produced them), then hand over to the trainer's streams ----
   const m2m_t5_geometry& g = t->g;
@@ -2749,29 +2790,60 @@ extern "C" int m2m_train_forward_backward(m2m_trainer* t, const float* params_de
   M2M_CHECK_HIP(hipEventRecord(t->ev_in, caller));
   M2M_CHECK_HIP(hipStreamWaitEvent(t->s_main, t->ev_in, 0));
 
-  const m2m_trainer::GraphKey key{params_dev, grads_dev, B, S, Ld, t->drop_thresh, t->drop_seed};
+  const m2m_trainer::GraphKey key{params_dev, grads_dev, B, S, Ld, t->drop_thresh, t->drop_seed, split};
   const bool seen = key == t->last_key;
   t->last_key = key;
   if (t->use_graph && seen && !(t->gexec && key == t->graph_key)) {         // second call with this key: capture
     drop_graph(t);
-    hipGraph_t graph = nullptr;
+    // a split pass becomes TWO graphs: the capture is closed and reopened where the decoder-side gradients are final, and the
+    // replay records ev_mid between the two launches
+    hipGraphExec_t first = nullptr;
+    const auto close_capture = [t](hipGraphExec_t* out) -> int {
+      hipGraph_t graph = nullptr;
+      const hipError_t ce = hipStreamEndCapture(t->s_main, &graph);
+      if (ce != hipSuccess || !graph) {
+        if (graph) (void)hipGraphDestroy(graph);
+        set_error("m2m_train_forward_backward: graph capture failed: %s", hipGetErrorString(ce));
+        return M2M_ERR_HIP;
+      }
+      const hipError_t ie = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      if (ie != hipSuccess) { *out = nullptr; set_error("m2m_train_forward_backward: hipGraphInstantiate: %s", hipGetErrorString(ie)); return M2M_ERR_HIP; }
+      return M2M_OK;
+    };
+    const std::function<int()> cut = [t, &first, &close_capture]() -> int {
+      const int r = close_capture(&first);
+      if (r != M2M_OK) return r;
+      M2M_CHECK_HIP(hipStreamBeginCapture(t->s_main, hipStreamCaptureModeThreadLocal));
+      return M2M_OK;
+    };
     M2M_CHECK_HIP(hipStreamBeginCapture(t->s_main, hipStreamCaptureModeThreadLocal));
-    rc = run_pass(t, params_dev, t->xe[0], t->cond_buf, t->labels_buf, B, S, Ld, t->loss_dev, grads_dev, nullptr, t->s_main, t->s_side);
-    const hipError_t ce = hipStreamEndCapture(t->s_main, &graph);
-    if (rc != M2M_OK || ce != hipSuccess || !graph) {
-      if (graph) (void)hipGraphDestroy(graph);
-      if (rc == M2M_OK) { set_error("m2m_train_forward_backward: graph capture failed: %s", hipGetErrorString(ce)); rc = M2M_ERR_HIP; }
-      return rc;
+    rc = run_pass(t, params_dev, t->xe[0], t->cond_buf, t->labels_buf, B, S, Ld, t->loss_dev, grads_dev, nullptr, t->s_main, t->s_side,
+                  split ? &cut : nullptr);
+    hipGraphExec_t last = nullptr;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(t->s_main, &cs);
+    int rc2 = M2M_OK;
+    if (cs != hipStreamCaptureStatusNone) rc2 = close_capture(&last);       // (a failed cut leaves no capture open)
+    if (rc != M2M_OK || rc2 != M2M_OK || (split && !first)) {
+      if (first) (void)hipGraphExecDestroy(first);
+      if (last) (void)hipGraphExecDestroy(last);
+      if (rc == M2M_OK && rc2 == M2M_OK) { set_error("m2m_train_forward_backward: the split pass never reached its split point"); rc = M2M_ERR_INVALID; }
+      return rc != M2M_OK ? rc : rc2;
     }
-    const hipError_t ie = hipGraphInstantiate(&t->gexec, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    if (ie != hipSuccess) { t->gexec = nullptr; set_error("m2m_train_forward_backward: hipGraphInstantiate: %s", hipGetErrorString(ie)); return M2M_ERR_HIP; }
+    if (split) { t->gexec = first; t->gexec2 = last; } else { t->gexec = last; }
     t->graph_key = key;
   }
   if (t->gexec && key == t->graph_key) {
     M2M_CHECK_HIP(hipGraphLaunch(t->gexec, t->s_main));
+    if (split) {
+      rc = release();
+      if (rc != M2M_OK) return rc;
+      M2M_CHECK_HIP(hipGraphLaunch(t->gexec2, t->s_main));
+    }
   } else {
-    rc = run_pass(t, params_dev, t->xe[0], t->cond_buf, t->labels_buf, B, S, Ld, t->loss_dev, grads_dev, nullptr, t->s_main, t->s_side);
+    rc = run_pass(t, params_dev, t->xe[0], t->cond_buf, t->labels_buf, B, S, Ld, t->loss_dev, grads_dev, nullptr, t->s_main, t->s_side,
+                  split ? &release : nullptr);
     if (rc != M2M_OK) return rc;
   }
   M2M_CHECK_HIP(hipEventRecord(t->ev_out, t->s_main));
@@ -2790,6 +2862,25 @@ extern "C" int m2m_trainer_set_dropout(m2m_trainer* t, float p, uint64_t seed) {
   t->drop_seed = seed;
   M2M_CHECK_HIP(hipDeviceSynchronize());                               // nothing of an earlier pass still reads the counter
   M2M_CHECK_HIP(hipMemset(t->step_ctr_dev, 0, 8));                     // the mask sequence restarts
+  return M2M_OK;
+}
+
+// Data-parallel overlap.  With a sync stream set, every forward+backward call issues the backward pass in two parts and makes
+// `stream` wait (an event, no host sync) for the point where the gradients in the two "early" ranges are final; work the caller
+// then enqueues on `stream` — the all-reduce of those ranges — runs beside the encoder-side backward.  nullptr switches it off.
+extern "C" int m2m_trainer_set_sync_stream(m2m_trainer* t, void* stream) {
+  M2M_REQUIRE(t, "m2m_trainer_set_sync_stream: null trainer");
+  if (stream && !t->ev_mid) {                                            // (a trainer built without its own streams has no events yet)
+    M2M_CHECK_HIP(hipEventCreateWithFlags(&t->ev_mid, hipEventDisableTiming));
+  }
+  t->sync_stream = (hipStream_t)stream;
+  return M2M_OK;
+}
+// out[0..3] = {offset, count, offset, count} (floats of the flat gradient buffer): shared embedding + lm_head, and the decoder blocks
+extern "C" int m2m_trainer_early_grad_ranges(const m2m_trainer* t, int64_t* out) {
+  M2M_REQUIRE(t && out, "m2m_trainer_early_grad_ranges: null argument");
+  out[0] = 0; out[1] = t->o_erb;
+  out[2] = t->dec_begin; out[3] = t->dec_end - t->dec_begin;
   return M2M_OK;
 }
 

@@ -143,6 +143,47 @@ def all_reduce_gradients(flat_grads: torch.Tensor) -> int:
     return flat_grads.numel() * 4
 
 
+def split_ranges(n: int, early: Sequence[Tuple[int, int]]) -> Tuple[List[Tuple[int, int]], List[Tuple[int, int]]]:
+    """(early, late) as (offset, count) lists that tile [0, n): `late` is the complement of the early ranges."""
+    early = sorted((int(o), int(c)) for o, c in early if c > 0)
+    late, pos = [], 0
+    for o, c in early:
+        if o < pos or o + c > n:
+            raise ValueError(f"early ranges {early} overlap or leave [0, {n})")
+        if o > pos:
+            late.append((pos, o - pos))
+        pos = o + c
+    if pos < n:
+        late.append((pos, n - pos))
+    return early, late
+
+
+def all_reduce_gradients_overlapped(flat_grads: torch.Tensor, early_ranges: Sequence[Tuple[int, int]], sync_stream=None) -> int:
+    """The same averaging as ``all_reduce_gradients`` in pieces, for a trainer with a sync stream
+    (``NativeTrainer.set_sync_stream``): the early ranges — final when the trainer releases `sync_stream`, half-way through the
+    backward pass — are reduced on that stream while the encoder-side backward still runs; the rest follows behind the whole pass
+    on the current stream, which then waits for the early pieces.  Call it right after ``forward_backward`` returns (that call
+    only enqueues).  xGMI is point to point, so the pieces stay large: four collectives per step, the two early ones 2/3 of the
+    bytes.  Returns bytes reduced."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0
+    world = dist.get_world_size()
+    early, late = split_ranges(flat_grads.numel(), early_ranges)
+    pending = []
+    if sync_stream is not None and flat_grads.is_cuda:
+        with torch.cuda.stream(sync_stream):
+            for o, c in early:
+                pending.append(dist.all_reduce(flat_grads[o:o + c], op=dist.ReduceOp.SUM, async_op=True))
+    else:
+        late = early + late
+    for o, c in late:
+        dist.all_reduce(flat_grads[o:o + c], op=dist.ReduceOp.SUM)
+    for w in pending:
+        w.wait()                       # the current stream continues behind the early pieces
+    flat_grads.div_(world)
+    return flat_grads.numel() * 4
+
+
 def barrier() -> None:
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

@@ -69,6 +69,9 @@ class Music2MIDI(nn.Module):
             self._trainer = NativeTrainer(self.model, *limits, precision=getattr(self, "train_precision", None))
             if state is not None:
                 self._trainer.load_optimizer_state(state)
+            if D.dist.is_available() and D.dist.is_initialized() and D.dist.get_world_size() > 1 and self._trainer.device.type == "cuda":
+                # every pass of this trainer releases the decoder-side gradients half-way (distributed.all_reduce_gradients_overlapped)
+                self._trainer.set_sync_stream(torch.cuda.Stream(device=self._trainer.device))
         # dropout as the reference trains: model.train() (ref train.py:33) activates T5Config.dropout_rate (0.1 unless the
         # config says otherwise); .eval() switches it off
         want = float(self.config.model.t5.get("dropout_rate", 0.1)) if self.training else 0.0
@@ -104,7 +107,11 @@ class Music2MIDI(nn.Module):
         losses = []
         for i, batch in enumerate(batches):
             loss = self.training_step(batch, i)
-            D.all_reduce_gradients(self._trainer.grads)
+            tr = self._trainer
+            if tr.sync_stream is not None:       # data-parallel (set when the trainer was built): decoder-side pieces overlap the encoder backward
+                D.all_reduce_gradients_overlapped(tr.grads, tr.early_ranges, tr.sync_stream)
+            else:
+                D.all_reduce_gradients(tr.grads)
             optimizer.step()
             self.global_step += 1
             losses.append(float(loss))

@@ -8,8 +8,9 @@ Forward, backward and the optimizer are HIP kernels behind the C ABI (csrc/train
 ``m2m_train_forward_backward`` / ``m2m_adafactor_step``); there is no autograd graph and no torch
 compute.  The parameters of the ``T5Transformer`` are re-pointed at views of ONE flat fp32 device buffer
 (and their ``.grad`` at views of a second one), so ``state_dict()``, checkpoints and the inference path
-see the trained weights, and data-parallel training is a single RCCL all-reduce of the flat gradient
-(121.6 MB) per step — ``distributed.all_reduce_gradients``.
+see the trained weights, and data-parallel training averages the flat gradient (121.6 MB) over RCCL in four large
+pieces, the decoder-side ones while the encoder-side backward still runs (``set_sync_stream`` +
+``distributed.all_reduce_gradients_overlapped``; ``distributed.all_reduce_gradients`` is the one-call form).
 """
 from __future__ import annotations
 
@@ -62,6 +63,8 @@ class NativeTrainer:
         self._adopt_parameters()
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self.dropout = 0.0
+        self.sync_stream = None
+        self.early_ranges = []
 
     def set_dropout(self, p: float, seed: int = 0):
         """Dropout of the teacher-forced pass (hf T5Config.dropout_rate; 0 = off).  Restarts the mask sequence at `seed`."""
@@ -86,6 +89,20 @@ class NativeTrainer:
                 p.data = view
                 p.grad = self.grads[off:off + n].view(shape)
         self.module._weights_epoch = getattr(self.module, "_weights_epoch", 0) + 1
+
+    # -- data-parallel overlap -----------------------------------------------------
+    def set_sync_stream(self, stream: Optional["torch.cuda.Stream"]):
+        """Issue the backward pass in two parts and release `stream` as soon as the decoder-side gradients (``early_ranges``: shared
+        embedding + lm_head, decoder blocks) are final, so that their all-reduce — enqueued on `stream` right after
+        ``forward_backward`` returns — overlaps the encoder-side backward (``distributed.all_reduce_gradients_overlapped``).
+        ``None`` switches the split off.  The gradients are bit-identical either way."""
+        lib = native.load()
+        native.check(lib.m2m_trainer_set_sync_stream(self.handle, C.c_void_p(stream.cuda_stream) if stream is not None else None),
+                     "m2m_trainer_set_sync_stream")
+        self.sync_stream = stream
+        r = (C.c_int64 * 4)()
+        native.check(lib.m2m_trainer_early_grad_ranges(self.handle, r), "m2m_trainer_early_grad_ranges")
+        self.early_ranges = [(int(r[0]), int(r[1])), (int(r[2]), int(r[3]))]
 
     def fits(self, B: int, S: int, L: int) -> bool:
         return B <= self.limits[0] and S <= self.limits[1] and L <= self.limits[2]

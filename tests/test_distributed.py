@@ -97,6 +97,42 @@ def test_gloo_world2_gradient_all_reduce_averages_the_flat_buffer():
     assert D.all_reduce_gradients(torch.ones(4)) == 0          # single process: no-op
 
 
+def _grad_pieces_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    D.init_process_group("gloo")
+    ref = torch.arange(1000, dtype=torch.float32)
+    flat = ref * (rank + 1)
+    nbytes = D.all_reduce_gradients_overlapped(flat, [(0, 130), (700, 250)])          # early: front + a block near the end
+    assert nbytes == 4000 and torch.equal(flat, ref * 1.5)
+    dist.destroy_process_group()
+    q.put(rank)
+
+
+def test_gloo_world2_gradient_all_reduce_in_pieces():
+    """The overlapped form (early ranges on the trainer's sync stream, the rest behind the pass) averages every element once."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_pieces_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]
+
+
+def test_split_ranges_tile_the_buffer():
+    early, late = D.split_ranges(100, [(60, 30), (0, 10)])
+    assert early == [(0, 10), (60, 30)] and late == [(10, 50), (90, 10)]
+    assert D.split_ranges(10, [(0, 10)]) == ([(0, 10)], [])
+    import pytest
+    with pytest.raises(ValueError):
+        D.split_ranges(10, [(0, 6), (5, 3)])
+    with pytest.raises(ValueError):
+        D.split_ranges(10, [(8, 3)])
+
+
 def _shard_worker(rank, world, port, n_clips, q):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     D.init_process_group("gloo")
