@@ -3,7 +3,8 @@
 lengths (odd sizes, single rows, lengths around the tile edges of the fused attention kernels and past their reach), ignored
 labels, dropout on and off.  Every gradient tensor must agree to 1e-4 relative (the fp32 bar of tests/test_train_gpu.py), the
 second call (graph replay) must reproduce the first bit for bit when dropout is off.
-python tools/fuzz_train.py [cases] [seed] [fp32|bf16|fp8]   (bf16 / fp8: every tensor finite and within a relative L2 of 8e-2 /
+python tools/fuzz_train.py [cases] [seed] [fp32|bf16|fp8] [split]   (split: the two-part backward pass of the data-parallel
+overlap; bf16 / fp8: every tensor finite and within a relative L2 of 8e-2 /
 0.5 of the fp32 autograd gradient, the loss within 1 % / 3 %: a guard against NaNs and gross errors at odd shapes, not a parity bar)"""
 import copy, sys, time
 from pathlib import Path
@@ -20,6 +21,8 @@ from oracle.train import DropoutMasks, T5TrainOracle, leaf_params
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 prec = sys.argv[3] if len(sys.argv) > 3 else "fp32"
+split = len(sys.argv) > 4 and sys.argv[4] == "split"
+sync_stream = torch.cuda.Stream() if split else None
 torch.set_num_threads(16)
 tiny = copy.deepcopy(DEFAULT_CONFIG); tiny["model"]["t5"].update(d_model=64, d_ff=128, num_layers=2, num_decoder_layers=2, num_heads=2)
 if prec == "fp8": tiny["model"]["t5"].update(d_model=128, d_ff=256)          # MX blocks of 32 in 128-byte rows
@@ -37,6 +40,8 @@ for i, r in enumerate(u):
     Ld = edges[int(r[2] * 19)] if r[4] < 0.6 else 1 + int(r[2] * 200)          # labels up to 255 from the edge list
     drop = r[3] < 0.4
     tr = NativeTrainer(model, B, F + 2, Ld, precision=prec)
+    if split:                                      # the two-part backward pass of the data-parallel overlap: same checks
+        tr.set_sync_stream(sync_stream)
     feats = torch.from_numpy(synth.normal(100 + i, "feats", (B, F, geom.d_model), 2.0))
     cond = torch.from_numpy(synth.cond_index_batch(i, B))
     labels = torch.from_numpy((synth.uniform01(200 + i, "labels", B * Ld) * 330).astype(np.int64).reshape(B, Ld)) + 3
