@@ -228,7 +228,7 @@ def train_step_record(model_module, cfg, geom, dev, B: int, precision: str, step
     labels = (torch.from_numpy((synth.uniform01(rank, "train_labels", B * TRAIN_LABELS) * 330).astype(np.int64)
                                .reshape(B, TRAIN_LABELS)) + 3).to(dev)
     tr = NativeTrainer(model_module, B, F + 2, TRAIN_LABELS, precision=precision)
-    overlap = world > 1 and os.environ.get("M2M_DP_OVERLAP", "1") != "0"
+    overlap = (world > 1 and os.environ.get("M2M_DP_OVERLAP", "1") != "0") or os.environ.get("M2M_DP_OVERLAP") == "force"   # force: the split pass on one rank
     if overlap:          # decoder-side gradients are all-reduced on their own stream while the encoder-side backward runs
         tr.set_sync_stream(torch.cuda.Stream(device=dev))
 
@@ -258,7 +258,8 @@ def train_step_record(model_module, cfg, geom, dev, B: int, precision: str, step
            "ms_per_step": dt * 1e3, "clips_per_s": B * world / dt, "label_tokens_per_s": B * world * TRAIN_LABELS / dt,
            "model_TFLOPs_per_gpu": 3 * B * (enc + dec) / dt / 1e12, "loss": float(loss), "grad_allreduce_bytes": nbytes,
            "optimizer": "Adafactor(warmup_init=True), native", "world": world,
-           "grad_allreduce": ("4 pieces, decoder side overlapped with the encoder backward" if overlap else "one call behind the pass") if world > 1 else "none"}
+           "grad_allreduce": ("4 pieces, decoder side overlapped with the encoder backward" if overlap else "one call behind the pass") if world > 1 else
+                             ("none (split pass forced)" if overlap else "none")}
     tr.close()
     return rec
 
