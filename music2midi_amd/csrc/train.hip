@@ -297,6 +297,106 @@ __device__ inline void dw_tile(const DwGemmArgs& g, T* __restrict__ AB, int n1_0
     }
 }
 
+// The same 128 x 128 tile for bf16 WITHOUT the register transposes: the operands' k-major rows are copied to LDS as they lie in
+// memory ([k][n], 320-byte rows: four consecutive k-rows fall into four different 16-bank groups), and an MFMA fragment — 8
+// consecutive k of one column — is two `ds_read_b64_tr_b16` (gfx950's transposing LDS read: per 16 lanes a 4 x 16 block comes back
+// column-major; lane map checked by tools/trprobe.hip).  What this buys is on the LOAD side: with an 8 x 8 register block per
+// thread, neighbouring lanes had to sit in different k-rows (so that the transposed block lands in one LDS row), and every
+// 16-byte request was a cache access of its own — PMC: 2.5e8 L1 accesses per launch for 3.9 GB, 77 % of the kernel's cycles per
+// CU; here 16 neighbouring lanes read one 256-byte row segment.  ~140 VALU instructions per k-step and wave disappear with it.
+constexpr int DWT_PITCH = 160;                       // bf16 elements per staged k-row: 128 + 32 of padding
+typedef short dw_v4s __attribute__((ext_vector_type(4)));
+__device__ inline Frag<bf16_t> dw_tr_frag(const bf16_t* p) {            // p: this lane's address of the first 4 k-rows (see dw_tile_tr)
+  typedef dw_v4s __attribute__((address_space(3))) * lds_v4s;
+  const dw_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(p));
+  const dw_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(p + 4 * DWT_PITCH));
+  Frag<bf16_t> f;
+  f.v = make_uint4(__builtin_bit_cast(uint2, lo).x, __builtin_bit_cast(uint2, lo).y, __builtin_bit_cast(uint2, hi).x, __builtin_bit_cast(uint2, hi).y);
+  return f;
+}
+// FULL: the tile lies inside the matrix on both sides (every tile of the projection weights; not the last tiles of lm_head):
+// no column predicate anywhere.  The k loop runs whole 64-row steps from pointers that advance by a constant — no clamp, no
+// select, no 64-bit multiply per load — and one guarded step takes the ragged end (M = 4 176 rows = 65 steps + 16 rows).
+template <bool FULL>
+__device__ inline void dw_tile_tr(const DwGemmArgs& g, bf16_t* __restrict__ AB, int n1_0, int n2_0, int kbeg, int kend, float* __restrict__ out,
+                                  int64_t ldo) {
+  constexpr int BK = 64, P = DWT_PITCH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // staging: threads 0..127 copy operand A (dY), 128..255 operand B (X); a thread owns 16-byte chunk `ch` of the k-rows
+  // rw, rw + 8, ... rw + 56: 16 neighbouring lanes cover one 256-byte row segment
+  const int op = tid >> 7, c = tid & 127, ch = c & 15, rw = c >> 4;
+  const int n0 = op ? n2_0 : n1_0, nlim = op ? g.N2 : g.N1;
+  const bool ok = FULL || n0 + ch * 8 + 8 <= nlim;
+  const int64_t ld = op ? g.ldb : g.lda;
+  const bf16_t* pk = reinterpret_cast<const bf16_t*>(op ? g.B : g.A) + (ok ? n0 + ch * 8 : 0) + (int64_t)(kbeg + rw) * ld;   // row rw of the current step
+  const int64_t step = (int64_t)BK * ld, ld8 = 8 * ld;
+  bf16_t* dst = AB + op * (BK * P) + rw * P + ch * 8;
+  uint4 r0, r1, r2, r3, r4, r5, r6, r7;               // named: arrays across the k loop end up in scratch (hipcc 7.2)
+#define M2M_DW_LD(u) { const uint4 v = *reinterpret_cast<const uint4*>(pk + (u) * ld8); r##u = ok ? v : make_uint4(0, 0, 0, 0); }
+#define M2M_DW_LD_TAIL(u, k0) { const int k = (k0) + rw + 8 * (u); const uint4 v = *reinterpret_cast<const uint4*>(pk + (int64_t)(min(k, kend - 1) - ((k0) + rw)) * ld); \
+                                r##u = (ok && k < kend) ? v : make_uint4(0, 0, 0, 0); }
+#define M2M_DW_GLOAD() { M2M_DW_LD(0) M2M_DW_LD(1) M2M_DW_LD(2) M2M_DW_LD(3) M2M_DW_LD(4) M2M_DW_LD(5) M2M_DW_LD(6) M2M_DW_LD(7) }
+#define M2M_DW_GLOAD_TAIL(k0) { M2M_DW_LD_TAIL(0, k0) M2M_DW_LD_TAIL(1, k0) M2M_DW_LD_TAIL(2, k0) M2M_DW_LD_TAIL(3, k0) M2M_DW_LD_TAIL(4, k0) \
+                                M2M_DW_LD_TAIL(5, k0) M2M_DW_LD_TAIL(6, k0) M2M_DW_LD_TAIL(7, k0) }
+#define M2M_DW_ST(u) *reinterpret_cast<uint4*>(dst + 8 * (u) * P) = r##u;
+#define M2M_DW_SSTORE() { M2M_DW_ST(0) M2M_DW_ST(1) M2M_DW_ST(2) M2M_DW_ST(3) M2M_DW_ST(4) M2M_DW_ST(5) M2M_DW_ST(6) M2M_DW_ST(7) }
+  // fragment addresses: lane = 16 g + 4 q + p supplies row q of its group's 4 x 16 block, columns 4p .. 4p+3; groups 0 / 1 are the
+  // column halves of k 0..7, groups 2 / 3 those of k 8..15 (h = g >> 1) of a 16-deep substep
+  const int li = lane & 15, q = li >> 2, pp = li & 3, gq = lane >> 4, h = lane >> 5;
+  const bf16_t* fa = AB + (8 * h + q) * P + wm * 64 + 16 * (gq & 1) + 4 * pp;
+  const bf16_t* fb = AB + BK * P + (8 * h + q) * P + wn * 64 + 16 * (gq & 1) + 4 * pp;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = zero_acc();
+  const int nfull = (kend - kbeg) / BK;               // whole steps; a ragged one may follow
+  const bool ragged = kbeg + nfull * BK < kend;
+  const int nsteps = nfull + (ragged ? 1 : 0);
+  if (nfull > 0) M2M_DW_GLOAD() else M2M_DW_GLOAD_TAIL(kbeg)
+  for (int it = 0; it < nsteps; ++it) {
+    __syncthreads();
+    M2M_DW_SSTORE()
+    __syncthreads();
+    pk += step;
+    if (it + 1 < nfull) M2M_DW_GLOAD()
+    else if (it + 1 < nsteps) M2M_DW_GLOAD_TAIL(kbeg + (it + 1) * BK)
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      Frag<bf16_t> a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = dw_tr_frag(fa + 16 * s * P + 32 * i);
+        b[i] = dw_tr_frag(fb + 16 * s * P + 32 * i);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mma16(acc[i][j], a[i], b[j]);
+    }
+  }
+#undef M2M_DW_LD
+#undef M2M_DW_LD_TAIL
+#undef M2M_DW_GLOAD
+#undef M2M_DW_GLOAD_TAIL
+#undef M2M_DW_ST
+#undef M2M_DW_SSTORE
+  const int r = lane & 31;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = n1_0 + wm * 64 + mi * 32 + acc_row(e, lane);
+      if (!FULL && row >= g.N1) continue;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int col = n2_0 + wn * 64 + ni * 32 + r;
+        if (FULL || col < g.N2) out[(int64_t)row * ldo + col] = acc[mi][ni][e];
+      }
+    }
+}
+
 template <typename T, int TF>
 __global__ __launch_bounds__(256) void dw_gemm_kernel(DwGemmArgs g) {
   constexpr int BT = 64 * TF, PITCH = DwCfg<T>::BK + DwCfg<T>::E;
@@ -316,15 +416,26 @@ struct DwProb {
   DwGemmArgs g;
   int tile0, tn2;          // first tile of this problem in the launch; tiles along N2
 };
-template <typename T>
-__global__ __launch_bounds__(256) void dw_group_kernel(const DwProb* __restrict__ probs, int n_probs) {
+template <typename T, bool TR>
+__global__ __launch_bounds__(256) void dw_group_kernel(const DwProb* __restrict__ probs, int n_probs, int n_tiles, int xcd_order) {
   constexpr int PITCH = DwCfg<T>::BK + DwCfg<T>::E;
-  __shared__ __align__(16) T AB[2 * 128 * PITCH];
+  constexpr int LDS_ELEMS = TR ? 2 * 64 * DWT_PITCH : 2 * 128 * PITCH;
+  __shared__ __align__(16) T AB[LDS_ELEMS];
+  // XCD-contiguous tile order (workgroup id % 8 picks the XCD): each XCD walks one eighth of the tile list front to back, so the
+  // tiles that run side by side on an XCD are neighbours in the list — the same product, the same dY column block (tiles of a
+  // product are numbered along X fastest), a handful of X column blocks — and their operand slices meet in that XCD's L2
+  const int per = (n_tiles + 7) >> 3;
+  const int tile = xcd_order ? (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  if (tile >= n_tiles || (xcd_order && (int)(blockIdx.x >> 3) >= per)) return;       // padding workgroups (uniform)
   int p = 0;
-  while (p + 1 < n_probs && (int)blockIdx.x >= probs[p + 1].tile0) ++p;       // uniform scan of <= ~70 entries
+  while (p + 1 < n_probs && tile >= probs[p + 1].tile0) ++p;                          // uniform scan of <= ~70 entries
   const DwProb pr = probs[p];
-  const int tl = blockIdx.x - pr.tile0;
-  dw_tile<T, 2>(pr.g, AB, (tl / pr.tn2) * 128, (tl % pr.tn2) * 128, 0, pr.g.K, pr.g.C, pr.g.ldc);
+  const int tl = tile - pr.tile0;
+  if constexpr (TR) {
+    const int n1_0 = (tl / pr.tn2) * 128, n2_0 = (tl % pr.tn2) * 128;
+    if (n1_0 + 128 <= pr.g.N1 && n2_0 + 128 <= pr.g.N2) dw_tile_tr<true>(pr.g, AB, n1_0, n2_0, 0, pr.g.K, pr.g.C, pr.g.ldc);      // (workgroup-uniform)
+    else dw_tile_tr<false>(pr.g, AB, n1_0, n2_0, 0, pr.g.K, pr.g.C, pr.g.ldc);
+  } else dw_tile<T, 2>(pr.g, AB, (tl / pr.tn2) * 128, (tl % pr.tn2) * 128, 0, pr.g.K, pr.g.C, pr.g.ldc);
 }
 
 // C = A^T . B with the split chosen here: enough workgroups to fill the chip, as few k-slices as that allows (every slice
@@ -2035,10 +2146,15 @@ struct Ops {
       M2M_CHECK_HIP(hipMemcpy(tab_dev, probs.data(), bytes, hipMemcpyHostToDevice));
       tab_host.assign(reinterpret_cast<const unsigned char*>(probs.data()), reinterpret_cast<const unsigned char*>(probs.data()) + bytes);
     }
-    if (t->precision == M2M_PREC_BF16)
-      hipLaunchKernelGGL(dw_group_kernel<bf16_t>, dim3(tiles), dim3(256), 0, st, (const DwProb*)tab_dev, (int)probs.size());
+    static const bool tr_reads = [] { const char* v = getenv("M2M_DW_TR"); return !(v && v[0] == '0'); }();      // 0: the register-transposing tile
+    static const int xcd_order = [] { const char* v = getenv("M2M_DW_XCD"); return v ? atoi(v) : 1; }();
+    const int grid = xcd_order ? 8 * ceil_div(tiles, 8) : tiles;
+    if (t->precision == M2M_PREC_BF16 && tr_reads)
+      hipLaunchKernelGGL((dw_group_kernel<bf16_t, true>), dim3(grid), dim3(256), 0, st, (const DwProb*)tab_dev, (int)probs.size(), tiles, xcd_order);
+    else if (t->precision == M2M_PREC_BF16)
+      hipLaunchKernelGGL((dw_group_kernel<bf16_t, false>), dim3(grid), dim3(256), 0, st, (const DwProb*)tab_dev, (int)probs.size(), tiles, xcd_order);
     else
-      hipLaunchKernelGGL(dw_group_kernel<float>, dim3(tiles), dim3(256), 0, st, (const DwProb*)tab_dev, (int)probs.size());
+      hipLaunchKernelGGL((dw_group_kernel<float, false>), dim3(grid), dim3(256), 0, st, (const DwProb*)tab_dev, (int)probs.size(), tiles, xcd_order);
     M2M_CHECK_HIP(hipGetLastError());
     probs.clear();
     return M2M_OK;
