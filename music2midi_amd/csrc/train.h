@@ -31,6 +31,8 @@ struct BGemmArgs {
   // pair mode (A2 != null): a SECOND product of the same shape in the same launch (blockIdx.z >= nb1*nb2): same strides for A and
   // C, its own B layout — dV = P~^T dO and dK = dS^T Q of an attention layer are one launch
   const void *A2, *B2;
+  // XCD-contiguous workgroup order (set by launch_bgemm): 1-D launch of xcd_total = nx * ny * nz logical workgroups; 0: plain 3-D grid
+  int xcd_total, xcd_nx, xcd_ny;
   void* C2;
   int64_t ldb2, sB1_2, sB2_2;
 };

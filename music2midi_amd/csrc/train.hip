@@ -110,16 +110,25 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BGemmArgs g) {
   const int r = lane & 31, h = lane >> 5;
   const bool split = g.ksplit > 1;
   const int nz = g.nb1 * g.nb2;
-  const bool second = !split && g.A2 && (int)blockIdx.z >= nz;            // pair mode: the second product of the launch
-  const int zz = second ? blockIdx.z - nz : blockIdx.z;
+  // XCD-contiguous workgroup order (g.xcd_total > 0: 1-D launch; workgroup id % 8 picks the XCD): an XCD walks one eighth of the
+  // (x, y, z) list front to back, so the row tiles of one (clip, head) product — which all read the same k-major operand — run
+  // side by side on ONE XCD and meet in its L2 (dV / dK: 124 MB fetched per launch for 33 MB of operands with the launch order)
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (g.xcd_total > 0) {
+    const int per = (g.xcd_total + 7) >> 3, l = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (l >= g.xcd_total || (int)(blockIdx.x >> 3) >= per) return;        // padding workgroups (uniform)
+    bx = l % g.xcd_nx; by = (l / g.xcd_nx) % g.xcd_ny; bz = l / (g.xcd_nx * g.xcd_ny);
+  }
+  const bool second = !split && g.A2 && bz >= nz;            // pair mode: the second product of the launch
+  const int zz = second ? bz - nz : bz;
   const int z1 = split ? 0 : zz / g.nb2, z2 = split ? 0 : zz - z1 * g.nb2;
   const T* A = reinterpret_cast<const T*>(second ? g.A2 : g.A) + z1 * g.sA1 + z2 * g.sA2;
   const T* B = second ? reinterpret_cast<const T*>(g.B2) + z1 * g.sB1_2 + z2 * g.sB2_2 : reinterpret_cast<const T*>(g.B) + z1 * g.sB1 + z2 * g.sB2;
   const int64_t ldb = second ? g.ldb2 : g.ldb;
   void* const Cout = second ? g.C2 : g.C;
   const int64_t coff = z1 * g.sC1 + z2 * g.sC2;
-  const int m0 = blockIdx.y * TG_BM, n0 = blockIdx.x * TG_BN;
-  const int kbeg = split ? blockIdx.z * g.kchunk : 0, kend = split ? min(g.K, kbeg + g.kchunk) : g.K;
+  const int m0 = by * TG_BM, n0 = bx * TG_BN;
+  const int kbeg = split ? bz * g.kchunk : 0, kend = split ? min(g.K, kbeg + g.kchunk) : g.K;
 
   f32x16 acc = zero_acc();
   constexpr int TG_BK = Cfg::BK;
@@ -143,7 +152,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BGemmArgs g) {
     const int row = m0 + wm * 32 + acc_row(i, lane);
     if (row >= g.M) continue;
     if (split) {                                   // partial tile of this k-slice
-      g.Cpart[((int64_t)blockIdx.z * g.M + row) * g.N + col] = acc[i];
+      g.Cpart[((int64_t)bz * g.M + row) * g.N + col] = acc[i];
       continue;
     }
     const int64_t at = coff + (int64_t)row * g.ldc + col;
@@ -160,8 +169,14 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BGemmArgs g) {
 }
 
 template <typename T>
-static int launch_bgemm_t(int epi, const BGemmArgs& g, hipStream_t st) {
+static int launch_bgemm_t(int epi, const BGemmArgs& g_in, hipStream_t st) {
+  BGemmArgs g = g_in;
   dim3 grid((unsigned)ceil_div(g.N, TG_BN), (unsigned)ceil_div(g.M, TG_BM), (unsigned)(g.ksplit > 1 ? g.ksplit : g.nb1 * g.nb2 * (g.A2 ? 2 : 1)));
+  static const bool xcd = [] { const char* v = getenv("M2M_XCD_ORDER"); return !(v && v[0] == '0'); }();
+  if (xcd && (int64_t)grid.x * grid.y * grid.z >= 64 && (int64_t)grid.x * grid.y * grid.z < (1 << 30)) {
+    g.xcd_nx = (int)grid.x; g.xcd_ny = (int)grid.y; g.xcd_total = (int)(grid.x * grid.y * grid.z);
+    grid = dim3((unsigned)(8 * ceil_div(g.xcd_total, 8)));
+  }
   switch (epi) {
     case TG_STORE_T: hipLaunchKernelGGL((bgemm_kernel<T, TG_STORE_T>), grid, dim3(256), 0, st, g); break;
     case TG_STORE_F32: hipLaunchKernelGGL((bgemm_kernel<T, TG_STORE_F32>), grid, dim3(256), 0, st, g); break;
@@ -746,6 +761,7 @@ struct StripeArgs {
   DropKey dk;
   uint32_t thresh;
   float scale;
+  int n_stripes, xcd_total;          // set by launch_attn_stripe: stripes per (clip, head); > 0: 1-D launch in XCD-contiguous order
 };
 constexpr int ST_NT = 16;            // key tiles per stripe: Sk <= 512 (the X operand of a (clip, head) is staged in LDS)
 // softmax exponential: accurate in the fp32 (parity) mode; multiply + v_exp_f32 where the result is rounded to bf16
@@ -777,8 +793,17 @@ __global__ __launch_bounds__(256) void attn_stripe_kernel(StripeArgs a) {
   constexpr int TPW = ST_NT / 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h2 = lane >> 5;
-  const int bh = blockIdx.y, b = bh / a.H, hh = bh - b * a.H;
-  const int q0 = blockIdx.x * 32;
+  // XCD-contiguous order (workgroup id % 8 picks the XCD): the stripes of one (clip, head) — which all read its K, V, K^T / V^T —
+  // run side by side on one XCD instead of on all eight (PMC: 113 MB fetched per backward launch with the launch order)
+  int sx = blockIdx.x, bh = blockIdx.y;
+  const int n_stripes = a.n_stripes;
+  if (a.xcd_total > 0) {
+    const int per = (a.xcd_total + 7) >> 3, l = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (l >= a.xcd_total || (int)(blockIdx.x >> 3) >= per) return;       // padding workgroups (uniform, before any barrier)
+    sx = l % n_stripes; bh = l / n_stripes;
+  }
+  const int b = bh / a.H, hh = bh - b * a.H;
+  const int q0 = sx * 32;
   __shared__ float red_a[4][32], red_b[4][32];       // per-wave partial row statistics
   constexpr bool has_bias = !BWD && BIAS;
   float* st_bias = reinterpret_cast<float*>(st_smem);
@@ -1007,7 +1032,7 @@ __global__ __launch_bounds__(256) void attn_stripe_kernel(StripeArgs a) {
     // dS along the diagonals key - row = i - 31, i in [0, Sk + 31), rows in fixed order; bias_bucket2_kernel adds the stripes
     if (a.diag_part) {
       const int dl = a.Sk + 31, rows = min(32, a.Sq - q0);
-      float* out = a.diag_part + ((int64_t)bh * gridDim.x + blockIdx.x) * dl;
+      float* out = a.diag_part + ((int64_t)bh * n_stripes + sx) * dl;
       for (int i = threadIdx.x; i < dl; i += 256) {
         float acc = 0.f;
         for (int rr = 0; rr < rows; ++rr) {
@@ -1022,8 +1047,15 @@ __global__ __launch_bounds__(256) void attn_stripe_kernel(StripeArgs a) {
 }
 
 template <typename T>
-static int launch_attn_stripe(bool bwd, const StripeArgs& a, int nB, hipStream_t st) {
+static int launch_attn_stripe(bool bwd, const StripeArgs& a_in, int nB, hipStream_t st) {
+  StripeArgs a = a_in;
   dim3 grid((unsigned)ceil_div(a.Sq, 32), (unsigned)(nB * a.H));
+  a.n_stripes = (int)grid.x;
+  static const bool xcd = [] { const char* v = getenv("M2M_XCD_ORDER"); return !(v && v[0] == '0'); }();
+  if (xcd && grid.x * grid.y >= 64) {
+    a.xcd_total = (int)(grid.x * grid.y);
+    grid = dim3((unsigned)(8 * ceil_div(a.xcd_total, 8)));
+  }
   const bool drop = a.thresh != 0, bias = !bwd && a.bias_tab != nullptr;
   const size_t bias_bytes = bias ? ((size_t)(a.tab_stride + 32) * 4 + 15) / 16 * 16 : 0;
   const size_t row_bytes = (size_t)32 * (ceil_div(a.Sk, 32) * 32 + 16 / sizeof(T)) * sizeof(T);
