@@ -741,6 +741,14 @@ __global__ __launch_bounds__(256) void kv_transpose_kernel(const T* __restrict__
 // LDS), causal mask, softmax, P (and its dropped copy) written in T.  Backward: dP = V . dO^T, dS = P o (dP~ - sum P o dP~)
 // with dP~ the dropout-masked dP.  Replaces a batched GEMM that wrote the fp32 image + a row kernel that read it back
 // (35 MB each way per call at 16 clips): 15.6 + 25.7 us -> one launch (forward), 15.6 + 18 us -> one launch (backward).
+#ifdef M2M_ST_STAMP      // diagnostic builds only: phase times of one workgroup of the stripe kernel (100 MHz s_memrealtime)
+__device__ unsigned long long g_st_stamp[4][12];
+#define ST_STAMP(i) do { if (threadIdx.x == 0 && bh == 5 && sx == 4) g_st_stamp[(BWD ? 2 : 0) + (BIAS ? 1 : 0)][i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define ST_WAITLOADS() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define ST_STAMP(i) do {} while (0)
+#define ST_WAITLOADS() do {} while (0)
+#endif
 struct StripeArgs {
   const void *X, *Y;                 // (key, d) at X + b*sX1 + h*sX2 + key*ldx + d;  (query, d) at Y + b*sY1 + h*sY2 + q*ldy + d
   int64_t ldx, sX1, sX2, ldy, sY1, sY2;
@@ -782,8 +790,12 @@ template <> __device__ inline float4 st_load4<bf16_t>(const bf16_t* p) {
 }
 template <> __device__ inline float4 st_load4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-template <typename T, bool BWD, bool DROP, bool BIAS>
-__global__ __launch_bounds__(256) void attn_stripe_kernel(StripeArgs a) {
+// SLIM: the operand fragments are NOT kept across the two passes (reloaded, as the fp32 form always does): ~95 registers, FIVE
+// workgroups per CU.  Chosen by the launch when the grid has more workgroups than the 1 024 that four per CU hold but not more
+// than 1 280: the encoder's 9 stripes x 128 (clip, head) = 1 152 ran as a full round plus a round of 128 — twice one
+// workgroup's time (stamps: 17.6 us of the launch's 38) — and now run as one.
+template <typename T, bool BWD, bool DROP, bool BIAS, bool SLIM = false>
+__global__ __launch_bounds__(256, SLIM ? 5 : 4) void attn_stripe_kernel(StripeArgs a) {
   // A workgroup = 32 queries of one (clip, head); its four waves split the key tiles (wave w: tiles w, w + 4, ...), so the
   // dependent chain of a wave is at most ST_NT / 4 tiles per pass and a 16-clip launch has > 1 000 workgroups.  Operand
   // fragments come straight from memory, all of a wave's loads in flight at once (bf16: kept in registers for both passes);
@@ -819,7 +831,7 @@ __global__ __launch_bounds__(256) void attn_stripe_kernel(StripeArgs a) {
   Frag<T> yf[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) yf[s] = load_frag(Y + (int64_t)qc * a.ldy + 16 * s + 8 * h2);
-  constexpr bool KEEP = sizeof(T) == 2;              // fp32 fragments are twice the registers: reloaded per pass instead
+  constexpr bool KEEP = sizeof(T) == 2 && !SLIM;     // fp32 fragments are twice the registers: reloaded per pass instead
   Frag<T> xf[KEEP ? TPW : 1][4];
   if constexpr (KEEP) {
 #pragma unroll
@@ -829,16 +841,33 @@ __global__ __launch_bounds__(256) void attn_stripe_kernel(StripeArgs a) {
       for (int s = 0; s < 4; ++s) xf[j][s] = load_frag(xr + 16 * s);
     }
   }
+  ST_STAMP(0);
+  ST_WAITLOADS();
+  ST_STAMP(1);
   constexpr int EC = 16 / sizeof(T);
   const int cpr = a.ldp / EC;                        // 16-byte chunks per row (ldp is a multiple of 8)
   const int64_t blk = ((int64_t)bh * a.Sq + q0) * a.ldp;
   if constexpr (BWD) {                               // P rows -> LDS (read twice below), coalesced
     const T* src = reinterpret_cast<const T*>(a.P) + blk;
     const int cpl = nt * 32 / EC;                      // the WHOLE LDS row: a causal stripe never rewrites the tiles above its diagonal,
-    for (int c = threadIdx.x; c < 32 * cpl; c += 256) {          // and the fused product reads them (uninitialised LDS x 0 is not 0)
-      const int row = c / cpl, col = (c - row * cpl) * EC;
-      *reinterpret_cast<uint4*>(pl + row * LP + col) =
-          (q0 + row < a.Sq && col < a.ldp) ? *reinterpret_cast<const uint4*>(src + (int64_t)row * a.ldp + col) : make_uint4(0, 0, 0, 0);
+                                                       // and the fused product reads them (uninitialised LDS x 0 is not 0)
+    // all of a thread's chunks requested before the first is stored: ONE round trip instead of one per loop iteration (stamps: 4.6 us
+    // of the workgroup's 17.6 with the plain loop).  32 rows x at most ST_NT * 32 elements = at most 8 (bf16) / 16 (fp32) chunks per thread.
+    constexpr int PCH = ST_NT * 32 / EC * 32 / 256 / 2;       // in two batches: a single one spills next to the kept operand fragments
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      if (half * PCH * 256 >= 32 * cpl) break;                 // (uniform)
+      uint4 pv[PCH];
+#pragma unroll
+      for (int u = 0; u < PCH; ++u) {
+        const int c = threadIdx.x + 256 * (half * PCH + u), row = c / cpl, col = (c - row * cpl) * EC;
+        pv[u] = (c < 32 * cpl && q0 + row < a.Sq && col < a.ldp) ? *reinterpret_cast<const uint4*>(src + (int64_t)row * a.ldp + col) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < PCH; ++u) {
+        const int c = threadIdx.x + 256 * (half * PCH + u), row = c / cpl, col = (c - row * cpl) * EC;
+        if (c < 32 * cpl) *reinterpret_cast<uint4*>(pl + row * LP + col) = pv[u];
+      }
     }
     __syncthreads();
   }
@@ -846,6 +875,7 @@ __global__ __launch_bounds__(256) void attn_stripe_kernel(StripeArgs a) {
     for (int i = threadIdx.x; i < a.tab_stride + 32; i += 256) st_bias[i] = i < a.tab_stride ? a.bias_tab[(int64_t)hh * a.tab_stride + i] : 0.f;
     __syncthreads();
   }
+  ST_STAMP(2);
   // element i of a tile: key 32 kt + (i & 3) + 8 (i >> 2) + 4 h2, query q (this lane's column); the tile product is
   // RECOMPUTED in the second pass (4 MFMAs) instead of being kept
   auto tile = [&](int j) {
@@ -917,8 +947,10 @@ __global__ __launch_bounds__(256) void attn_stripe_kernel(StripeArgs a) {
       l = l * m2m_exp_t<T>(m - mt) + lo * m2m_exp_t<T>(mo - mt);
       m = mt;
     }
+    ST_STAMP(3);
     if (h2 == 0) { red_a[wave][r] = m; red_b[wave][r] = l; }
     __syncthreads();
+    ST_STAMP(4);
     {                                                // the four waves' (max, sum) of this query, fixed order
       const float m0 = red_a[0][r], m1 = red_a[1][r], m2 = red_a[2][r], m3 = red_a[3][r];
       m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
@@ -960,7 +992,9 @@ __global__ __launch_bounds__(256) void attn_stripe_kernel(StripeArgs a) {
         }
       }
     }
+    ST_STAMP(5);
     __syncthreads();
+    ST_STAMP(6);
     {
       T* dst = reinterpret_cast<T*>(a.P) + blk;
       T* dst2 = DROP ? reinterpret_cast<T*>(a.Pd) + blk : nullptr;
@@ -972,7 +1006,9 @@ __global__ __launch_bounds__(256) void attn_stripe_kernel(StripeArgs a) {
         }
       }
     }
+    ST_STAMP(7);
     rows_times_xt(DROP ? pl2 : pl);                   // O = P~ . V
+    ST_STAMP(9);
   } else {
     T* prd = pl + r * LP;                            // this lane's query row of P, in LDS
     auto masked = [&](float dp, int k) {             // dP arrives for the DROPPED probabilities: through the mask first
@@ -997,8 +1033,10 @@ __global__ __launch_bounds__(256) void attn_stripe_kernel(StripeArgs a) {
       }
     }
     t += lane_xor<32>(t);
+    ST_STAMP(3);
     if (h2 == 0) red_a[wave][r] = t;
     __syncthreads();
+    ST_STAMP(4);
     t = (red_a[0][r] + red_a[1][r]) + (red_a[2][r] + red_a[3][r]);
     // pass 2: dS = P (dP~ - t)
 #pragma unroll
@@ -1020,7 +1058,9 @@ __global__ __launch_bounds__(256) void attn_stripe_kernel(StripeArgs a) {
         st_store4<T>(prd + k0, o[0], o[1], o[2], o[3]);                        // in place: the same lane read these four
       }
     }
+    ST_STAMP(5);
     __syncthreads();
+    ST_STAMP(6);
     {
       T* dst = reinterpret_cast<T*>(a.dS) + blk;
       for (int c = threadIdx.x; c < 32 * cpr; c += 256) {
@@ -1030,19 +1070,28 @@ __global__ __launch_bounds__(256) void attn_stripe_kernel(StripeArgs a) {
     }
     // relative-position-bias gradient, stage 1 (replaces bias_diag_kernel's pass over dS in memory): the sums of this stripe's
     // dS along the diagonals key - row = i - 31, i in [0, Sk + 31), rows in fixed order; bias_bucket2_kernel adds the stripes
+    ST_STAMP(7);
     if (a.diag_part) {
       const int dl = a.Sk + 31, rows = min(32, a.Sq - q0);
       float* out = a.diag_part + ((int64_t)bh * n_stripes + sx) * dl;
       for (int i = threadIdx.x; i < dl; i += 256) {
         float acc = 0.f;
-        for (int rr = 0; rr < rows; ++rr) {
-          const int k = i - 31 + rr;
-          if (k >= 0 && k < a.Sk) acc += to_f32(pl[rr * LP + k]);
+        for (int r8 = 0; r8 < 32; r8 += 8) {          // eight LDS reads in flight, added in row order (the sum is what the plain loop gave)
+          float v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int rr = r8 + u, k = i - 31 + rr;
+            v[u] = (rr < rows && k >= 0 && k < a.Sk) ? to_f32(pl[rr * LP + k]) : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc += v[u];
         }
         out[i] = acc;
       }
     }
+    ST_STAMP(8);
     rows_times_xt(pl);                               // dQ = dS . K
+    ST_STAMP(9);
   }
 }
 
@@ -1060,10 +1109,21 @@ static int launch_attn_stripe(bool bwd, const StripeArgs& a_in, int nB, hipStrea
   const size_t bias_bytes = bias ? ((size_t)(a.tab_stride + 32) * 4 + 15) / 16 * 16 : 0;
   const size_t row_bytes = (size_t)32 * (ceil_div(a.Sk, 32) * 32 + 16 / sizeof(T)) * sizeof(T);
   const size_t smem = bias_bytes + row_bytes * ((!bwd && drop) ? 2 : 1);
+  // five workgroups per CU when that turns two rounds into one (and their LDS fits): see SLIM above
+  static const bool slim_on = [] { const char* v = getenv("M2M_ST_SLIM"); return !(v && v[0] == '0'); }();
+  const int64_t n_wgs = (int64_t)a.n_stripes * nB * a.H;
+  const bool slim = slim_on && sizeof(T) == 2 && n_wgs > 4 * 256 && n_wgs <= 5 * 256 && 5 * (smem + 1024) <= 160 * 1024;
 #define M2M_ST_LAUNCH(B_, D_, I_)                                                                              \
   do {                                                                                                         \
-    M2M_OPT_IN_LDS((attn_stripe_kernel<T, B_, D_, I_>), 158 * 1024);      /* + 1 KB of static LDS */              \
-    hipLaunchKernelGGL((attn_stripe_kernel<T, B_, D_, I_>), grid, dim3(256), smem, st, a);                     \
+    if (slim) {                                                                                                \
+      if constexpr (sizeof(T) == 2) {                                                                          \
+        M2M_OPT_IN_LDS((attn_stripe_kernel<T, B_, D_, I_, true>), 158 * 1024);                                    \
+        hipLaunchKernelGGL((attn_stripe_kernel<T, B_, D_, I_, true>), grid, dim3(256), smem, st, a);           \
+      }                                                                                                        \
+    } else {                                                                                                   \
+      M2M_OPT_IN_LDS((attn_stripe_kernel<T, B_, D_, I_>), 158 * 1024);      /* + 1 KB of static LDS */            \
+      hipLaunchKernelGGL((attn_stripe_kernel<T, B_, D_, I_>), grid, dim3(256), smem, st, a);                   \
+    }                                                                                                          \
   } while (0)
   if (bwd) {
     if (drop) M2M_ST_LAUNCH(true, true, false); else M2M_ST_LAUNCH(true, false, false);
@@ -3052,3 +3112,10 @@ extern "C" int m2m_adafactor_state_import(m2m_trainer* t, const float* state_in_
   t->step = step;
   return M2M_OK;
 }
+
+#ifdef M2M_ST_STAMP
+// diagnostic builds only (not declared in the public header): the stripe kernel's last phase stamps, [variant][phase]
+extern "C" int m2m_debug_stripe_stamps(unsigned long long* out_host) {
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(m2m::g_st_stamp), sizeof(unsigned long long) * 48) == hipSuccess ? 0 : -1;
+}
+#endif
