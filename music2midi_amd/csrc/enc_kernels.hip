@@ -91,6 +91,14 @@ template <typename T, int TF> struct TileCfgT {
   static constexpr int CPR = BK * (int)sizeof(T) / 16;
 };
 
+#ifdef M2M_GEMM_STAMP      // diagnostic builds only (tools/gemm_stamps.py): phase times of one workgroup (100 MHz s_memrealtime), per (EPI, TF)
+__device__ unsigned long long g_gemm_stamp[8][3][8];
+#define GEMM_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 77) g_gemm_stamp[EPI][TF][i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define GEMM_WAITLOADS() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define GEMM_STAMP(i) do {} while (0)
+#define GEMM_WAITLOADS() do {} while (0)
+#endif
 template <typename T, int EPI, int TF = 2>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   using Cfg = TileCfgT<T, TF>;
@@ -163,7 +171,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       rpre[e] = (row < g.M && col < g.N) ? rsrc[(int64_t)row * g.ldo + col] : 0.f;
     }
   }
+  GEMM_STAMP(0);
+  GEMM_WAITLOADS();
+  GEMM_STAMP(1);
   for (int kt = 0; kt < nk; ++kt) {
+    if (kt == 1) GEMM_STAMP(2);
     __syncthreads();
     M2M_SSTORE()
     __syncthreads();
@@ -183,6 +195,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
   }
 
+  GEMM_STAMP(3);
 #undef M2M_GLOAD
 #undef M2M_SSTORE
 #undef M2M_LD
@@ -335,6 +348,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       }
     }
   }
+  GEMM_WAITLOADS();
+  GEMM_STAMP(4);
 }
 
 // Tile choice: the 128x128 kernel unless its grid is smaller than `M2M_GEMM_SMALL_BELOW` tiles (default 512 = two rounds
@@ -692,3 +707,10 @@ int launch_embed_rows(const int64_t* ids, const float* table, float* x, int M, i
 }
 
 }  // namespace m2m
+
+#ifdef M2M_GEMM_STAMP
+// diagnostic builds only (not declared in the public header)
+extern "C" int m2m_debug_gemm_stamps(unsigned long long* out_host) {
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(m2m::g_gemm_stamp), sizeof(unsigned long long) * 8 * 3 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
