@@ -175,7 +175,13 @@ __global__ __launch_bounds__(256) void mxgemm_q_kernel(MxGemmArgs g) {
   __shared__ __align__(4) uint8_t Asc[64 * 4];                 // scale bytes of the A tile: [row][k-block of this step]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * BN;
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (g.xcd_total > 0) {                            // XCD-contiguous order: see MxGemmArgs
+    const int per = (g.xcd_total + 7) >> 3, l = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (l >= g.xcd_total || (int)(blockIdx.x >> 3) >= per) return;        // padding workgroups (uniform, before any barrier)
+    bx = l % g.xcd_nx; by = l / g.xcd_nx;
+  }
+  const int m0 = by * 64, n0 = bx * BN;
   const uint32_t* sB[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) sB[j] = reinterpret_cast<const uint32_t*>(g.sB) + (int64_t)min(n0 + (wn * TN + j) * 32 + r, g.N - 1) * (g.ldb / 128);
@@ -298,7 +304,13 @@ __global__ __launch_bounds__(256) void mxgemm_p_kernel(MxGemmArgs g) {
   __shared__ __align__(16) uint8_t Bs[BN * MX_PITCH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * BN;
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (g.xcd_total > 0) {                            // XCD-contiguous order: see MxGemmArgs
+    const int per = (g.xcd_total + 7) >> 3, l = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (l >= g.xcd_total || (int)(blockIdx.x >> 3) >= per) return;        // padding workgroups (uniform, before any barrier)
+    bx = l % g.xcd_nx; by = l / g.xcd_nx;
+  }
+  const int m0 = by * 64, n0 = bx * BN;
   const uint32_t* sA = reinterpret_cast<const uint32_t*>(g.sA) + (int64_t)min(m0 + wm * 32 + r, g.M - 1) * (g.lda / 128);
   const uint32_t* sB[TN];
 #pragma unroll
@@ -370,9 +382,11 @@ __global__ __launch_bounds__(256) void mxgemm_p_kernel(MxGemmArgs g) {
     }
   }
 }
+static dim3 mx_xcd_grid(MxGemmArgs& g, dim3 grid);
 template <int FA, int TN>
-static int launch_mxgemm_p_ft(int epi, const MxGemmArgs& g, hipStream_t st) {
-  dim3 grid((unsigned)ceil_div(g.N, 64 * TN), (unsigned)ceil_div(g.M, 64));
+static int launch_mxgemm_p_ft(int epi, const MxGemmArgs& g_in, hipStream_t st) {
+  MxGemmArgs g = g_in;
+  const dim3 grid = mx_xcd_grid(g, dim3((unsigned)ceil_div(g.N, 64 * TN), (unsigned)ceil_div(g.M, 64)));
   switch (epi) {
     case TG_STORE_T: hipLaunchKernelGGL((mxgemm_p_kernel<FA, TG_STORE_T, TN>), grid, dim3(256), 0, st, g); break;
     case TG_STORE_F32: hipLaunchKernelGGL((mxgemm_p_kernel<FA, TG_STORE_F32, TN>), grid, dim3(256), 0, st, g); break;
@@ -384,9 +398,16 @@ static int launch_mxgemm_p_ft(int epi, const MxGemmArgs& g, hipStream_t st) {
   return M2M_OK;
 }
 
+static bool mx_xcd_order() { static const bool on = [] { const char* v = getenv("M2M_XCD_ORDER"); return !(v && v[0] == '0'); }(); return on; }
+static dim3 mx_xcd_grid(MxGemmArgs& g, dim3 grid) {
+  if (!mx_xcd_order() || grid.x * grid.y < 64) return grid;
+  g.xcd_nx = (int)grid.x; g.xcd_total = (int)(grid.x * grid.y);
+  return dim3((unsigned)(8 * ceil_div(g.xcd_total, 8)));
+}
 template <int FA, int TN>
-static int launch_mxgemm_q_ft(int epi, const MxGemmArgs& g, hipStream_t st) {
-  dim3 grid((unsigned)ceil_div(g.N, 64 * TN), (unsigned)ceil_div(g.M, 64));
+static int launch_mxgemm_q_ft(int epi, const MxGemmArgs& g_in, hipStream_t st) {
+  MxGemmArgs g = g_in;
+  const dim3 grid = mx_xcd_grid(g, dim3((unsigned)ceil_div(g.N, 64 * TN), (unsigned)ceil_div(g.M, 64)));
   switch (epi) {
     case TG_STORE_T: hipLaunchKernelGGL((mxgemm_q_kernel<FA, TG_STORE_T, TN>), grid, dim3(256), 0, st, g); break;
     case TG_STORE_F32: hipLaunchKernelGGL((mxgemm_q_kernel<FA, TG_STORE_F32, TN>), grid, dim3(256), 0, st, g); break;

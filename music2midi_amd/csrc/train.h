@@ -58,6 +58,9 @@ struct MxGemmArgs {
   const void* Asrc;
   int64_t ld_src;
   int Kvalid;
+  // XCD-contiguous workgroup order (set by the launchers of the _q / _p kernels): 1-D launch of xcd_total = nx * ny logical
+  // workgroups, column tile fastest, so the column tiles of a row block share its rows in ONE XCD's L2; 0: plain 2-D grid
+  int xcd_total, xcd_nx;
 };
 int launch_mxgemm(int fmt_a, int fmt_b, int epi, const MxGemmArgs& g, hipStream_t st);      // fmt: 0 = e4m3, 1 = e5m2
 int launch_mxgemm_q(int fmt_a, int epi, const MxGemmArgs& g, hipStream_t st);               // A quantised in the product's own staging
