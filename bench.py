@@ -215,7 +215,7 @@ TRAIN_SAMPLES = 66150      # ref config.yaml: 3 s segments at dataset.sample_rat
 TRAIN_LABELS = 256         # label tokens per clip (synthetic, none ignored)
 
 
-def train_step_record(model_module, cfg, geom, dev, B: int, precision: str, steps: int, warmup: int, world: int = 1):
+def train_step_record(model_module, cfg, geom, dev, B: int, precision: str, steps: int, warmup: int, world: int = 1, dropout: float = 0.0):
     """forward + backward + (gradient all-reduce) + Adafactor on B clips per GPU; returns a dict for the JSON line."""
     from music2midi_amd import distributed as D
     from music2midi_amd import synth
@@ -228,6 +228,8 @@ def train_step_record(model_module, cfg, geom, dev, B: int, precision: str, step
     labels = (torch.from_numpy((synth.uniform01(rank, "train_labels", B * TRAIN_LABELS) * 330).astype(np.int64)
                                .reshape(B, TRAIN_LABELS)) + 3).to(dev)
     tr = NativeTrainer(model_module, B, F + 2, TRAIN_LABELS, precision=precision)
+    if dropout > 0.0:      # T5Config.dropout_rate as the reference trains (train() mode, ref: train.py:33): masks from the counter-based hash, regenerated in the backward pass
+        tr.set_dropout(dropout, seed=1)
     overlap = (world > 1 and os.environ.get("M2M_DP_OVERLAP", "1") != "0") or os.environ.get("M2M_DP_OVERLAP") == "force"   # force: the split pass on one rank
     if overlap:          # decoder-side gradients are all-reduced on their own stream while the encoder-side backward runs
         tr.set_sync_stream(torch.cuda.Stream(device=dev))
@@ -254,7 +256,7 @@ def train_step_record(model_module, cfg, geom, dev, B: int, precision: str, step
     enc = 6 * (4227072 * S + 2048 * S * S) + 4718592 * S
     dec = TRAIN_LABELS * (6 * (2 * 384 * 512 * 6 + 3 * 2 * 384 * 1152) + 2 * 384 * 400) + 6 * (4 * TRAIN_LABELS * TRAIN_LABELS * 512 + 4 * TRAIN_LABELS * S * 512)
     rec = {"workload": f"BASELINE configs[4]: train step (log-mel + forward + backward + Adafactor), {precision} GEMM inputs, "
-                       f"{B} clips/GPU x {TRAIN_SAMPLES} samples (S={S}), {TRAIN_LABELS} labels/clip, dropout off",
+                       f"{B} clips/GPU x {TRAIN_SAMPLES} samples (S={S}), {TRAIN_LABELS} labels/clip, dropout {'off' if dropout == 0.0 else dropout}",
            "ms_per_step": dt * 1e3, "clips_per_s": B * world / dt, "label_tokens_per_s": B * world * TRAIN_LABELS / dt,
            "model_TFLOPs_per_gpu": 3 * B * (enc + dec) / dt / 1e12, "loss": float(loss), "grad_allreduce_bytes": nbytes,
            "optimizer": "Adafactor(warmup_init=True), native", "world": world,
@@ -280,6 +282,7 @@ def main():
     ap.add_argument("--mode", default="generate", choices=["generate", "train"],
                     help="train: BASELINE configs[4] (forward+backward+Adafactor, 16 clips/GPU, gradient all-reduce over RCCL)")
     ap.add_argument("--no-train", action="store_true", help="skip the configs[4] training-step record of the default line")
+    ap.add_argument("--dropout", type=float, default=0.0, help="--mode train: T5Config.dropout_rate of the step (the reference trains with 0.1)")
     ap.add_argument("--dry-run", action="store_true", help="launcher + collectives on CPU tensors (gloo), no GPU work")
     ap.add_argument("--max-length", type=int, default=MAX_LENGTH,
                     help="decoder max_length (profiling runs only; the headline number uses 1024)")
@@ -331,7 +334,7 @@ def main():
         sys.exit(2)
     if args.mode == "train":
         Bt = 16 if args.batch == 32 else args.batch
-        rec = train_step_record(model, cfg, geom, dev, Bt, args.precision, args.steps, args.warmup, world)
+        rec = train_step_record(model, cfg, geom, dev, Bt, args.precision, args.steps, args.warmup, world, dropout=args.dropout)
         if rank == 0:
             print(json.dumps({"metric": "training clips/sec/node (forward+backward+Adafactor step)", "value": rec["clips_per_s"], "unit": "clips/s",
                               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"],
@@ -497,6 +500,9 @@ def main():
         mt = mt.to(dev)
         out["train_configs4"] = train_step_record(mt, cfg, geom, dev, 16, "bf16", 10, 2)
         fp8 = train_step_record(mt, cfg, geom, dev, 16, "fp8", 10, 2)          # configs[4] names fp8 GEMMs: MXFP8 projections, same step
+        drop = train_step_record(mt, cfg, geom, dev, 16, "bf16", 10, 2, dropout=0.1)   # the reference trains in train() mode: T5Config.dropout_rate 0.1
+        out["train_configs4"]["dropout_0p1_ms_per_step"] = drop["ms_per_step"]
+        out["train_configs4"]["dropout_0p1_clips_per_s"] = drop["clips_per_s"]
         out["train_configs4"]["fp8_mx_ms_per_step"] = fp8["ms_per_step"]
         out["train_configs4"]["fp8_mx_clips_per_s"] = fp8["clips_per_s"]
         out["train_configs4"]["fp8_note"] = ("projection products (forward and dX; the weight gradients take the grouped bf16 launch) on block-scaled OCP FP8 (e4m3, 32 elements per E8M0 scale, "

@@ -866,7 +866,10 @@ __global__ __launch_bounds__(256, SLIM ? 5 : 4) void attn_stripe_kernel(StripeAr
 #pragma unroll
       for (int u = 0; u < PCH; ++u) {
         const int c = threadIdx.x + 256 * (half * PCH + u), row = c / cpl, col = (c - row * cpl) * EC;
-        if (c < 32 * cpl) *reinterpret_cast<uint4*>(pl + row * LP + col) = pv[u];
+        if (c < 32 * cpl) {
+          *reinterpret_cast<uint4*>(pl + row * LP + col) = pv[u];
+          if (DROP && a.Pd) *reinterpret_cast<uint4*>(pl2 + row * LP + col) = make_uint4(0, 0, 0, 0);     // tiles pass 2 skips stay zero
+        }
       }
     }
     __syncthreads();
@@ -985,10 +988,12 @@ __global__ __launch_bounds__(256, SLIM ? 5 : 4) void attn_stripe_kernel(StripeAr
         }
         st_store4<T>(pl + r * LP + k0, pv[0], pv[1], pv[2], pv[3]);          // keys >= kend are zeros
         if constexpr (DROP) {
-          float dv[4];
+          if (a.Pd) {                                   // the dropped copy is wanted in memory: a second row block
+            float dv[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) dv[e] = drop_keep(key, prow + k0 + e, a.thresh) ? pv[e] * a.scale : 0.f;
-          st_store4<T>(pl2 + r * LP + k0, dv[0], dv[1], dv[2], dv[3]);
+            for (int e = 0; e < 4; ++e) dv[e] = drop_keep(key, prow + k0 + e, a.thresh) ? pv[e] * a.scale : 0.f;
+            st_store4<T>(pl2 + r * LP + k0, dv[0], dv[1], dv[2], dv[3]);
+          }
         }
       }
     }
@@ -997,17 +1002,42 @@ __global__ __launch_bounds__(256, SLIM ? 5 : 4) void attn_stripe_kernel(StripeAr
     ST_STAMP(6);
     {
       T* dst = reinterpret_cast<T*>(a.P) + blk;
-      T* dst2 = DROP ? reinterpret_cast<T*>(a.Pd) + blk : nullptr;
+      T* dst2 = (DROP && a.Pd) ? reinterpret_cast<T*>(a.Pd) + blk : nullptr;
       for (int c = threadIdx.x; c < 32 * cpr; c += 256) {
         const int row = c / cpr, col = (c - row * cpr) * EC;
         if (q0 + row < a.Sq) {
           *reinterpret_cast<uint4*>(dst + (int64_t)row * a.ldp + col) = *reinterpret_cast<const uint4*>(pl + row * LP + col);
-          if constexpr (DROP) *reinterpret_cast<uint4*>(dst2 + (int64_t)row * a.ldp + col) = *reinterpret_cast<const uint4*>(pl2 + row * LP + col);
+          if (DROP && dst2) *reinterpret_cast<uint4*>(dst2 + (int64_t)row * a.ldp + col) = *reinterpret_cast<const uint4*>(pl2 + row * LP + col);
         }
       }
     }
+    if constexpr (DROP) {
+      // The dropped probabilities are only the operand of the fused product (the backward pass re-forms them): no second row block —
+      // half the LDS, four (or five) workgroups per CU instead of three — the rows are masked IN PLACE once they have been copied out,
+      // every lane rewriting the elements it wrote
+      if (!a.Pd && a.Xt) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+          const int kt = wave + 4 * j;
+          if (kt >= nt) break;                             // wave-uniform
+          if (a.causal && kt * 32 > q0 + 31) continue;     // zeros stay zeros
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int k0 = kt * 32 + 8 * g + 4 * h2;
+            const float4 pv = st_load4<T>(pl + r * LP + k0);
+            const float pe[4] = {pv.x, pv.y, pv.z, pv.w};
+            float dv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dv[e] = drop_keep(key, prow + k0 + e, a.thresh) ? pe[e] * a.scale : 0.f;
+            st_store4<T>(pl + r * LP + k0, dv[0], dv[1], dv[2], dv[3]);
+          }
+        }
+        __syncthreads();
+      }
+    }
     ST_STAMP(7);
-    rows_times_xt(DROP ? pl2 : pl);                   // O = P~ . V
+    rows_times_xt((DROP && a.Pd) ? pl2 : pl);         // O = P~ . V
     ST_STAMP(9);
   } else {
     T* prd = pl + r * LP;                            // this lane's query row of P, in LDS
@@ -1055,6 +1085,16 @@ __global__ __launch_bounds__(256, SLIM ? 5 : 4) void attn_stripe_kernel(StripeAr
         float o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (k0 + e < a.Sk) ? pe[e] * (masked(acc[4 * g + e], k0 + e) - t) : 0.f;
+        if constexpr (DROP) {
+          // the dropped probabilities again (the dV product's operand; a scratch buffer in the forward pass): what drop_copy_kernel
+          // produced in a launch of its own — 18 launches, 0.28 ms of a step — from the P row this lane holds anyway
+          if (a.Pd) {
+            float pd[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pd[e] = drop_keep(key, prow + k0 + e, a.thresh) ? pe[e] * a.scale : 0.f;
+            st_store4<T>(pl2 + r * LP + k0, pd[0], pd[1], pd[2], pd[3]);
+          }
+        }
         st_store4<T>(prd + k0, o[0], o[1], o[2], o[3]);                        // in place: the same lane read these four
       }
     }
@@ -1063,9 +1103,13 @@ __global__ __launch_bounds__(256, SLIM ? 5 : 4) void attn_stripe_kernel(StripeAr
     ST_STAMP(6);
     {
       T* dst = reinterpret_cast<T*>(a.dS) + blk;
+      T* dst2 = (DROP && a.Pd) ? reinterpret_cast<T*>(a.Pd) + blk : nullptr;
       for (int c = threadIdx.x; c < 32 * cpr; c += 256) {
         const int row = c / cpr, col = (c - row * cpr) * EC;
-        if (q0 + row < a.Sq) *reinterpret_cast<uint4*>(dst + (int64_t)row * a.ldp + col) = *reinterpret_cast<const uint4*>(pl + row * LP + col);
+        if (q0 + row < a.Sq) {
+          *reinterpret_cast<uint4*>(dst + (int64_t)row * a.ldp + col) = *reinterpret_cast<const uint4*>(pl + row * LP + col);
+          if (DROP && dst2) *reinterpret_cast<uint4*>(dst2 + (int64_t)row * a.ldp + col) = *reinterpret_cast<const uint4*>(pl2 + row * LP + col);
+        }
       }
     }
     // relative-position-bias gradient, stage 1 (replaces bias_diag_kernel's pass over dS in memory): the sums of this stripe's
@@ -1108,7 +1152,7 @@ static int launch_attn_stripe(bool bwd, const StripeArgs& a_in, int nB, hipStrea
   const bool drop = a.thresh != 0, bias = !bwd && a.bias_tab != nullptr;
   const size_t bias_bytes = bias ? ((size_t)(a.tab_stride + 32) * 4 + 15) / 16 * 16 : 0;
   const size_t row_bytes = (size_t)32 * (ceil_div(a.Sk, 32) * 32 + 16 / sizeof(T)) * sizeof(T);
-  const size_t smem = bias_bytes + row_bytes * ((!bwd && drop) ? 2 : 1);
+  const size_t smem = bias_bytes + row_bytes * ((drop && a.Pd) ? 2 : 1);      // a dropped copy of P wanted in memory: two row blocks
   // five workgroups per CU when that turns two rounds into one (and their LDS fits): see SLIM above
   static const bool slim_on = [] { const char* v = getenv("M2M_ST_SLIM"); return !(v && v[0] == '0'); }();
   const int64_t n_wgs = (int64_t)a.n_stripes * nB * a.H;
@@ -2444,7 +2488,9 @@ struct Ops {
     const bool dr = dropping(site);
     StripeArgs a{};
     a.X = K; a.ldx = ldk; a.sX1 = sK1; a.sX2 = sK2; a.Y = Q; a.ldy = ldq; a.sY1 = sQ1; a.sY2 = sQ2;
-    a.P = Pm; a.Pd = dr ? t->dS : nullptr; a.bias_tab = tab; a.tab_stride = Sq + Sk - 1; a.tab_center = Sq - 1;
+    static const bool keep_pd = [] { const char* v = getenv("M2M_TRAIN_FWD_PD"); return v && v[0] == '1'; }();      // 1: always write the dropped copy (measurement)
+    a.P = Pm; a.Pd = (dr && (keep_pd || !(Xt && O))) ? t->dS : nullptr;      // fused P.V: the dropped copy never leaves the kernel
+    a.bias_tab = tab; a.tab_stride = Sq + Sk - 1; a.tab_center = Sq - 1;
     a.H = t->g.num_heads; a.Sq = Sq; a.Sk = Sk; a.ldp = ldp; a.causal = causal;
     a.dk = dr ? key(site) : DropKey{nullptr, 0}; a.thresh = dr ? t->drop_thresh : 0u; a.scale = t->drop_scale;
     a.Xt = Xt; a.xt_ld = align_up(Sk, 32); a.O = O; a.ldo = ldo; a.sO1 = sO1; a.sO2 = sO2;
@@ -2454,9 +2500,10 @@ struct Ops {
   // Fused dP + softmax backward: V = (key, d) operand, dO = (query, d) operand; dS out
   int dscores(const T* V, int64_t ldv, int64_t sV1, int64_t sV2, const T* dO, int64_t ldo, int64_t sO1, int64_t sO2, const void* Pm, void* dS, int nB,
               int Sq, int Sk, int ldp, int site, bool want_diag = false, const T* Xt = nullptr, void* Out = nullptr, int64_t ld_out = 0, int64_t s1_out = 0,
-              int64_t s2_out = 0, int causal = 0) const {
+              int64_t s2_out = 0, int causal = 0, void* Pd_out = nullptr) const {
     const bool dr = dropping(site);
     StripeArgs a{};
+    a.Pd = dr ? Pd_out : nullptr;        // the dropped probabilities again, for the dV product (instead of a drop_copy launch)
     a.X = V; a.ldx = ldv; a.sX1 = sV1; a.sX2 = sV2; a.Y = dO; a.ldy = ldo; a.sY1 = sO1; a.sY2 = sO2;
     a.P = const_cast<void*>(Pm); a.dS = dS; a.H = t->g.num_heads; a.Sq = Sq; a.Sk = Sk; a.ldp = ldp;
     a.causal = causal;                   // only lets the kernel skip key tiles above the diagonal (P is zero there anyway)
@@ -2478,6 +2525,7 @@ struct Ops {
   // backward: the dropped probabilities again (into t->dS, consumed by the dV product before dS overwrites it)
   // (into_sc: the dropped copy goes to the fp32 score scratch, unused on the stripe path, so that it survives the dS written later
   //  and dV can share a launch with dK)
+  static bool pd_fuse_on() { static const bool on = [] { const char* v = getenv("M2M_TRAIN_FUSE_PD"); return !(v && v[0] == '0'); }(); return on; }
   int redrop(const void* Pm, int64_t n, int site, const T** Puse, bool into_sc = false) const {
     if (!dropping(site)) { *Puse = (const T*)Pm; return M2M_OK; }
     T* dst = into_sc ? (T*)t->sc : (T*)t->dS;
@@ -2601,12 +2649,14 @@ int attn_self_bwd(const Ops<T>& o, const float* x_in, const float* dx_out, float
   const int64_t sP1 = (int64_t)H * S * ldp, sP2 = (int64_t)S * ldp, sQ1 = (int64_t)S * 3 * inner, sO1 = (int64_t)S * inner;
   const T* Pu;
   const bool pair = o.stripe_ok(S) && o.pair_on();            // dV and dK in one launch (after dS exists)
-  RC(o.redrop(Pm, (int64_t)nB * H * S * ldp, site0 + PL_PROBS_SELF, &Pu, pair));
+  const bool pd_fused = pair && o.dropping(site0 + PL_PROBS_SELF) && o.pd_fuse_on();      // the stripe kernel re-emits the dropped P itself
+  if (pd_fused) Pu = (const T*)t->sc;
+  else RC(o.redrop(Pm, (int64_t)nB * H * S * ldp, site0 + PL_PROBS_SELF, &Pu, pair));
   if (!pair) RC(o.mmbh(TG_STORE_T, Pu, ldp, 1, sP1, sP2, dO, inner, 1, sO1, DK, dq + 2 * inner, 3 * inner, sQ1, DK, nB, S, DK, S));  // dV = Pd^T dO
   const bool fuse = o.stripe_ok(S) && (o.fuse_mode() & 2) && kt;  // dQ = dS . K inside the stripe kernel, against the transposed K
   if (o.stripe_ok(S)) {
     RC(o.dscores(q + 2 * inner, 3 * inner, sQ1, DK, dO, inner, sO1, DK, Pm, t->dS, nB, S, S, ldp, site0 + PL_PROBS_SELF, buckets != nullptr,   // dS from dPd = dO V^T
-                 fuse ? (const T*)kt : nullptr, dq, 3 * inner, sQ1, DK, buckets == t->dbucket ? 1 : 0));
+                 fuse ? (const T*)kt : nullptr, dq, 3 * inner, sQ1, DK, buckets == t->dbucket ? 1 : 0, pd_fused ? t->sc : nullptr));
     if (buckets) RC(o.bias_grad_stripes(buckets, G + bias_off, nB, S, S, bias_accumulate));
   } else {
     RC(o.mmbh(TG_STORE_F32, dO, inner, 0, sO1, DK, q + 2 * inner, 3 * inner, 0, sQ1, DK, t->sc, ldp, sP1, sP2, nB, S, S, DK));      // dPd = dO V^T
@@ -2777,11 +2827,13 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
     const int64_t sK1 = (int64_t)S * 2 * inner, sQ1 = (int64_t)L * inner;
     const T* Pu;
     const bool pair_c = o.stripe_ok(S) && o.pair_on();
-    RC(o.redrop(t->Pcd[l], (int64_t)B * H * L * lps, SITE_DEC + 16 * l + PL_PROBS_CROSS, &Pu, pair_c));
+    const bool pd_fused_c = pair_c && o.dropping(SITE_DEC + 16 * l + PL_PROBS_CROSS) && o.pd_fuse_on();
+    if (pd_fused_c) Pu = (const T*)t->sc;
+    else RC(o.redrop(t->Pcd[l], (int64_t)B * H * L * lps, SITE_DEC + 16 * l + PL_PROBS_CROSS, &Pu, pair_c));
     if (!pair_c) RC(o.mmbh(TG_STORE_T, Pu, lps, 1, sPc1, sPc2, dO, inner, 1, sQ1, DK, dckv + inner, 2 * inner, sK1, DK, B, S, DK, L));      // dV = Pd^T dO
     if (o.stripe_ok(S)) {
       RC(o.dscores(ckv + inner, 2 * inner, sK1, DK, dO, inner, sQ1, DK, t->Pcd[l], t->dS, B, L, S, lps, SITE_DEC + 16 * l + PL_PROBS_CROSS, false,
-                   fuse_c_dq ? (const T*)t->ktc[l] : nullptr, dcq, inner, sQ1, DK));
+                   fuse_c_dq ? (const T*)t->ktc[l] : nullptr, dcq, inner, sQ1, DK, 0, pd_fused_c ? t->sc : nullptr));
     } else {
       RC(o.mmbh(TG_STORE_F32, dO, inner, 0, sQ1, DK, ckv + inner, 2 * inner, 0, sK1, DK, t->sc, lps, sPc1, sPc2, B, L, S, DK));             // dPd = dO V^T
       RC(o.softmax_bwd(t->Pcd[l], t->sc, t->dS, B * H * L, S, lps, SITE_DEC + 16 * l + PL_PROBS_CROSS));

@@ -16,6 +16,8 @@ sd = synth.t5_state_dict(geom, 0)
 model = T5Transformer(cfg.to_dict(), precision="fp32"); load_t5_state(model, sd, strict=False); model = model.cuda()
 for (B, S, Ld) in ((16, 190, 128), (16, 261, 256), (64, 261, 256)):
     tr = NativeTrainer(model, B, S, Ld, precision=prec)
+    if "dropout" in sys.argv[2:]:                          # T5Config.dropout_rate = 0.1, as the reference trains (train() mode)
+        tr.set_dropout(0.1, 1)
     if len(sys.argv) > 2 and sys.argv[2] == "split":       # the two-part backward pass of the data-parallel overlap (one GPU: what the split costs)
         tr.set_sync_stream(torch.cuda.Stream())
     x = torch.from_numpy(synth.normal(1, "x", (B, S, 384), 2.0)).cuda()
