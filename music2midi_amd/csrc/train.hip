@@ -1041,8 +1041,13 @@ __global__ __launch_bounds__(256, SLIM ? 5 : 4) void attn_stripe_kernel(StripeAr
     ST_STAMP(9);
   } else {
     T* prd = pl + r * LP;                            // this lane's query row of P, in LDS
-    auto masked = [&](float dp, int k) {             // dP arrives for the DROPPED probabilities: through the mask first
-      if constexpr (DROP) dp = drop_keep(key, prow + k, a.thresh) ? dp * a.scale : 0.f;
+    // dP arrives for the DROPPED probabilities: through the mask first.  The keep bits of a lane's 16 elements per tile are hashed
+    // ONCE (pass 1) and kept as a bit mask for pass 2 and for the dropped copy (three hashes per element before: 22 -> 36 us per launch)
+    uint32_t kbits[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) kbits[j] = 0u;
+    auto masked = [&](float dp, int k, bool keep) {
+      if constexpr (DROP) dp = keep ? dp * a.scale : 0.f;
       return k < a.Sk ? dp : 0.f;
     };
     // pass 1: t = sum_k P dP~
@@ -1059,7 +1064,11 @@ __global__ __launch_bounds__(256, SLIM ? 5 : 4) void attn_stripe_kernel(StripeAr
         const float4 pv = st_load4<T>(prd + k0);
         const float pe[4] = {pv.x, pv.y, pv.z, pv.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) t += (k0 + e < a.Sk ? pe[e] : 0.f) * masked(acc[4 * g + e], k0 + e);
+        for (int e = 0; e < 4; ++e) {
+          bool keep = true;
+          if constexpr (DROP) { keep = drop_keep(key, prow + k0 + e, a.thresh); kbits[j] |= (keep ? 1u : 0u) << (4 * g + e); }
+          t += (k0 + e < a.Sk ? pe[e] : 0.f) * masked(acc[4 * g + e], k0 + e, keep);
+        }
       }
     }
     t += lane_xor<32>(t);
@@ -1084,14 +1093,14 @@ __global__ __launch_bounds__(256, SLIM ? 5 : 4) void attn_stripe_kernel(StripeAr
         const float pe[4] = {pv.x, pv.y, pv.z, pv.w};
         float o[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (k0 + e < a.Sk) ? pe[e] * (masked(acc[4 * g + e], k0 + e) - t) : 0.f;
+        for (int e = 0; e < 4; ++e) o[e] = (k0 + e < a.Sk) ? pe[e] * (masked(acc[4 * g + e], k0 + e, (kbits[j] >> (4 * g + e)) & 1u) - t) : 0.f;
         if constexpr (DROP) {
           // the dropped probabilities again (the dV product's operand; a scratch buffer in the forward pass): what drop_copy_kernel
           // produced in a launch of its own — 18 launches, 0.28 ms of a step — from the P row this lane holds anyway
           if (a.Pd) {
             float pd[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) pd[e] = drop_keep(key, prow + k0 + e, a.thresh) ? pe[e] * a.scale : 0.f;
+            for (int e = 0; e < 4; ++e) pd[e] = ((kbits[j] >> (4 * g + e)) & 1u) ? pe[e] * a.scale : 0.f;
             st_store4<T>(pl2 + r * LP + k0, pd[0], pd[1], pd[2], pd[3]);
           }
         }
