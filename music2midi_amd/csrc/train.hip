@@ -990,8 +990,9 @@ __global__ __launch_bounds__(256, SLIM ? 5 : 4) void attn_stripe_kernel(StripeAr
         if constexpr (DROP) {
           if (a.Pd) {                                   // the dropped copy is wanted in memory: a second row block
             float dv[4];
+            const uint32_t kb = drop_keep4(key, prow + k0, a.thresh);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dv[e] = drop_keep(key, prow + k0 + e, a.thresh) ? pv[e] * a.scale : 0.f;
+            for (int e = 0; e < 4; ++e) dv[e] = ((kb >> e) & 1u) ? pv[e] * a.scale : 0.f;
             st_store4<T>(pl2 + r * LP + k0, dv[0], dv[1], dv[2], dv[3]);
           }
         }
@@ -1027,9 +1028,10 @@ __global__ __launch_bounds__(256, SLIM ? 5 : 4) void attn_stripe_kernel(StripeAr
             const int k0 = kt * 32 + 8 * g + 4 * h2;
             const float4 pv = st_load4<T>(pl + r * LP + k0);
             const float pe[4] = {pv.x, pv.y, pv.z, pv.w};
+            const uint32_t kb4 = drop_keep4(key, prow + k0, a.thresh);
             float dv[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dv[e] = drop_keep(key, prow + k0 + e, a.thresh) ? pe[e] * a.scale : 0.f;
+            for (int e = 0; e < 4; ++e) dv[e] = ((kb4 >> e) & 1u) ? pe[e] * a.scale : 0.f;
             st_store4<T>(pl + r * LP + k0, dv[0], dv[1], dv[2], dv[3]);
           }
         }
@@ -1063,12 +1065,10 @@ __global__ __launch_bounds__(256, SLIM ? 5 : 4) void attn_stripe_kernel(StripeAr
         const int k0 = kt * 32 + 8 * g + 4 * h2;
         const float4 pv = st_load4<T>(prd + k0);
         const float pe[4] = {pv.x, pv.y, pv.z, pv.w};
+        uint32_t kb = 0xFu;
+        if constexpr (DROP) { kb = drop_keep4(key, prow + k0, a.thresh); kbits[j] |= kb << (4 * g); }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          bool keep = true;
-          if constexpr (DROP) { keep = drop_keep(key, prow + k0 + e, a.thresh); kbits[j] |= (keep ? 1u : 0u) << (4 * g + e); }
-          t += (k0 + e < a.Sk ? pe[e] : 0.f) * masked(acc[4 * g + e], k0 + e, keep);
-        }
+        for (int e = 0; e < 4; ++e) t += (k0 + e < a.Sk ? pe[e] : 0.f) * masked(acc[4 * g + e], k0 + e, (kb >> e) & 1u);
       }
     }
     t += lane_xor<32>(t);
@@ -1317,8 +1317,9 @@ __global__ void gated_fwd_kernel(const T* __restrict__ ab, T* __restrict__ mid, 
     const float4 a = st_load4<T>(ab + row * 2 * dff + c), b = st_load4<T>(ab + row * 2 * dff + dff + c);
     float v[4] = {gelu_new(a.x) * b.x, gelu_new(a.y) * b.y, gelu_new(a.z) * b.z, gelu_new(a.w) * b.w};
     if (thresh) {                                                       // hf: T5DenseGatedActDense dropout before wo
+      const uint32_t kb = drop_keep4(key, row * dff + c, thresh);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = drop_keep(key, row * dff + c + e, thresh) ? v[e] * scale : 0.f;
+      for (int e = 0; e < 4; ++e) v[e] = ((kb >> e) & 1u) ? v[e] * scale : 0.f;
     }
     st_store4<T>(mid + row * dff + c, v[0], v[1], v[2], v[3]);
   }
@@ -1344,9 +1345,10 @@ __global__ void gated_bwd_kernel(const T* __restrict__ ab, const T* __restrict__
     const float4 a4 = st_load4<T>(ab + row * 2 * dff + c), b4 = st_load4<T>(ab + row * 2 * dff + dff + c), d4 = st_load4<T>(dmid + row * dff + c);
     const float a[4] = {a4.x, a4.y, a4.z, a4.w}, b[4] = {b4.x, b4.y, b4.z, b4.w};
     float dm[4] = {d4.x, d4.y, d4.z, d4.w}, da[4], db[4];
+    const uint32_t kb = thresh ? drop_keep4(key, row * dff + c, thresh) : 0xFu;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      if (thresh) dm[e] = drop_keep(key, row * dff + c + e, thresh) ? dm[e] * scale : 0.f;
+      if (thresh) dm[e] = ((kb >> e) & 1u) ? dm[e] * scale : 0.f;
       float g, dg;
       gelu_new_both(a[e], &g, &dg);
       da[e] = dm[e] * b[e] * dg;
@@ -1413,8 +1415,9 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
           const int64_t at = (int64_t)row * d + col;
           float v[4] = {o.x, o.y, o.z, o.w};
           if (thresh) {
+            const uint32_t kb = drop_keep4(key, at, thresh);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = drop_keep(key, at + e, thresh) ? v[e] * scale : 0.f;
+            for (int e = 0; e < 4; ++e) v[e] = ((kb >> e) & 1u) ? v[e] * scale : 0.f;
           }
           st_store4<T>(out_t + at, v[0], v[1], v[2], v[3]);
         }

@@ -41,8 +41,9 @@ def _splitmix64(x: np.ndarray) -> np.ndarray:
 
 
 class DropoutMasks:
-    """The device's counter-based dropout masks, regenerated on the host (csrc/train.h drop_keep): element i of a site is
-    kept iff the high 32 bits of splitmix64(key(site) + i) are >= p * 2^32; kept values are scaled by 1 / (1 - p)."""
+    """The device's counter-based dropout masks, regenerated on the host (csrc/common.h drop_keep): four consecutive elements
+    share one hash — element i of a site is kept iff the 16-bit field (i & 3) of splitmix64(key(site) + (i >> 2)) is
+    >= (p * 2^32) >> 16; kept values are scaled by 1 / (1 - p)."""
 
     def __init__(self, p: float, seed: int, call_index: int = 0):
         self.p = float(p)
@@ -56,8 +57,10 @@ class DropoutMasks:
             return torch.ones(n)
         with np.errstate(over="ignore"):
             key = _splitmix64(np.asarray([self.step_key + _U64((site * _GOLDEN) & 0xFFFFFFFFFFFFFFFF)], dtype=np.uint64))[0]
-            h = _splitmix64(key + np.arange(n, dtype=np.uint64))
-        keep = (h >> _U64(32)) >= _U64(self.thresh)
+            i = np.arange(n, dtype=np.uint64)
+            h = _splitmix64(key + (i >> _U64(2)))
+        field = (h >> (_U64(16) * (i & _U64(3)))) & _U64(0xFFFF)
+        keep = field >= _U64(self.thresh >> 16)
         return torch.from_numpy(keep.astype(np.float32) * np.float32(self.scale))
 
 

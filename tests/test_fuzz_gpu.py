@@ -34,7 +34,7 @@ def test_training_step_fuzz_against_autograd(seed):
 
 @pytest.mark.parametrize("prec,seed", [("bf16", 5), ("fp8", 2)])
 def test_training_step_fuzz_reduced_precision(prec, seed):
-    """The same fuzz in the bf16 and MXFP8 modes: every loss and gradient finite, loss within 1 % / 3 %, every gradient tensor
+    """The same fuzz in the bf16 and MXFP8 modes: every loss and gradient finite, loss within 1 % / 5 %, every gradient tensor
     within a relative L2 of 0.12 (bf16, against fp32 autograd; two-label cases reach 0.106) / 0.6 (fp8, against the oracle that quantises its projections
     the same way) — the bounds catch NaNs, dropped terms and stale buffers at odd shapes, not rounding."""
     r = subprocess.run([sys.executable, str(ROOT / "tools" / "fuzz_train.py"), "40", str(seed), prec], capture_output=True, text=True, timeout=1500)

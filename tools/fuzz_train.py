@@ -5,7 +5,7 @@ labels, dropout on and off.  Every gradient tensor must agree to 1e-4 relative (
 second call (graph replay) must reproduce the first bit for bit when dropout is off.
 python tools/fuzz_train.py [cases] [seed] [fp32|bf16|fp8] [split]   (split: the two-part backward pass of the data-parallel
 overlap; bf16 / fp8: every tensor finite and within a relative L2 of 0.12 /
-0.5 of the fp32 autograd gradient, the loss within 1 % / 3 %: a guard against NaNs and gross errors at odd shapes, not a parity bar)"""
+0.5 of the fp32 autograd gradient, the loss within 1 % / 5 %: a guard against NaNs and gross errors at odd shapes, not a parity bar)"""
 import copy, sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
@@ -63,7 +63,7 @@ for i, r in enumerate(u):
             e = float((g - grads_o[name]).norm() / (grads_o[name].norm() + 1e-12)) if float(grads_o[name].norm()) > 1e-6 else 0.0
         if not np.isfinite(e) or not bool(torch.isfinite(g).all()): e = float("inf")
         if e > worst: worst, wname = e, name
-    ltol, gtol = {"fp32": (1e-4, 1e-4), "bf16": (1e-2, 0.12), "fp8": (3e-2, 0.6)}[prec]   # fp8: one or two labels on a d_model=128 random model flip fp8 codes; the bound catches NaNs and wrong terms, test_train_gpu holds the tight cosine
+    ltol, gtol = {"fp32": (1e-4, 1e-4), "bf16": (1e-2, 0.12), "fp8": (5e-2, 0.6)}[prec]   # fp8: one or two labels on a d_model=128 random model flip fp8 codes; the bound catches NaNs and wrong terms, test_train_gpu holds the tight cosine
     ok = abs(l1 - loss_o.item()) < ltol * max(1.0, abs(loss_o.item())) and worst < gtol
     if not drop:                                   # second call: the captured graph must reproduce the direct issue
         loss2, _ = tr.forward_backward(x.cuda(), cond.cuda(), labels.cuda())
