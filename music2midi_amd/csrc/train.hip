@@ -617,6 +617,18 @@ __global__ void cvt_kernel(const float* __restrict__ src, T* __restrict__ dst, i
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) dst[i] = from_f32<T>(src[i]);
 }
+// four consecutive elements of the storage type <-> four floats (8- / 16-byte accesses)
+template <typename T> __device__ inline void st_store4(T* p, float a, float b, float c, float d);
+template <> __device__ inline void st_store4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(pack2_bf16(a, b), pack2_bf16(c, d));
+}
+template <> __device__ inline void st_store4<float>(float* p, float a, float b, float c, float d) { *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d); }
+template <typename T> __device__ inline float4 st_load4(const T* p);
+template <> __device__ inline float4 st_load4<bf16_t>(const bf16_t* p) {
+  const uint2 v = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xFFFF0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xFFFF0000u));
+}
+template <> __device__ inline float4 st_load4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
 // dst = T(keep(i) * scale * src)  (the gradient entering a dropped branch)
 template <typename T>
 __global__ void cvt_drop_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t n, DropKey dk, uint32_t thresh, float scale) {
@@ -631,7 +643,14 @@ __global__ void drop_inplace_kernel(T* __restrict__ x, int64_t n, DropKey dk, ui
   const uint64_t key = thresh ? drop_site_key(dk) : 0ull;
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) x[i] = from_f32<T>(drop_keep(key, i, thresh) ? to_f32(x[i]) * scale : 0.f);
+  // groups of four (one hash, 16- / 8-byte accesses); the tail, if n is not a multiple of 4, element by element
+  const int64_t n4 = n >> 2;
+  for (; i < n4; i += stride) {
+    const uint32_t kb = drop_keep4(key, 4 * i, thresh);
+    const float4 v = st_load4<T>(x + 4 * i);
+    st_store4<T>(x + 4 * i, (kb & 1u) ? v.x * scale : 0.f, (kb & 2u) ? v.y * scale : 0.f, (kb & 4u) ? v.z * scale : 0.f, (kb & 8u) ? v.w * scale : 0.f);
+  }
+  for (int64_t j = 4 * n4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) x[j] = from_f32<T>(drop_keep(key, j, thresh) ? to_f32(x[j]) * scale : 0.f);
 }
 static inline int grid_1d(int64_t n, int per_block = 256) {
   int64_t g = (n + per_block - 1) / per_block;
@@ -778,17 +797,6 @@ template <typename T> __device__ inline float m2m_exp_t(float x) {
   else return expf(x);
 }
 
-template <typename T> __device__ inline void st_store4(T* p, float a, float b, float c, float d);
-template <> __device__ inline void st_store4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
-  *reinterpret_cast<uint2*>(p) = make_uint2(pack2_bf16(a, b), pack2_bf16(c, d));
-}
-template <> __device__ inline void st_store4<float>(float* p, float a, float b, float c, float d) { *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d); }
-template <typename T> __device__ inline float4 st_load4(const T* p);
-template <> __device__ inline float4 st_load4<bf16_t>(const bf16_t* p) {
-  const uint2 v = *reinterpret_cast<const uint2*>(p);
-  return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xFFFF0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xFFFF0000u));
-}
-template <> __device__ inline float4 st_load4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 // SLIM: the operand fragments are NOT kept across the two passes (reloaded, as the fp32 form always does): ~95 registers, FIVE
 // workgroups per CU.  Chosen by the launch when the grid has more workgroups than the 1 024 that four per CU hold but not more
