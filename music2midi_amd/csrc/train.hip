@@ -855,6 +855,7 @@ __global__ __launch_bounds__(256, SLIM ? 5 : 4) void attn_stripe_kernel(StripeAr
   constexpr int EC = 16 / sizeof(T);
   const int cpr = a.ldp / EC;                        // 16-byte chunks per row (ldp is a multiple of 8)
   const int64_t blk = ((int64_t)bh * a.Sq + q0) * a.ldp;
+  const uint64_t key = DROP ? drop_site_key(a.dk) : 0ull;
   if constexpr (BWD) {                               // P rows -> LDS (read twice below), coalesced
     const T* src = reinterpret_cast<const T*>(a.P) + blk;
     const int cpl = nt * 32 / EC;                      // the WHOLE LDS row: a causal stripe never rewrites the tiles above its diagonal,
@@ -874,13 +875,30 @@ __global__ __launch_bounds__(256, SLIM ? 5 : 4) void attn_stripe_kernel(StripeAr
 #pragma unroll
       for (int u = 0; u < PCH; ++u) {
         const int c = threadIdx.x + 256 * (half * PCH + u), row = c / cpl, col = (c - row * cpl) * EC;
-        if (c < 32 * cpl) {
-          *reinterpret_cast<uint4*>(pl + row * LP + col) = pv[u];
-          if (DROP && a.Pd) *reinterpret_cast<uint4*>(pl2 + row * LP + col) = make_uint4(0, 0, 0, 0);     // tiles pass 2 skips stay zero
-        }
+        if (c < 32 * cpl) *reinterpret_cast<uint4*>(pl + row * LP + col) = pv[u];
       }
     }
     __syncthreads();
+    if constexpr (DROP) {
+      // The dropped probabilities again (the dV product's operand; a scratch buffer in the forward pass) — what drop_copy_kernel
+      // produced in a launch of its own, 18 launches / 0.28 ms of a step: masked straight from the staged P rows into memory, chunk by
+      // chunk, before the passes overwrite them.  No second row block, so the five-per-CU variant stays available with dropout on.
+      if (a.Pd) {
+        T* dst2 = reinterpret_cast<T*>(a.Pd) + blk;
+        for (int c = threadIdx.x; c < 32 * cpr; c += 256) {
+          const int row = c / cpr, col = (c - row * cpr) * EC;
+          if (q0 + row >= a.Sq) continue;
+          const int64_t at = ((int64_t)bh * a.Sq + q0 + row) * a.ldp + col;
+#pragma unroll
+          for (int g4 = 0; g4 < EC / 4; ++g4) {
+            const float4 v = st_load4<T>(pl + row * LP + col + 4 * g4);
+            const uint32_t kb = drop_keep4(key, at + 4 * g4, a.thresh);
+            st_store4<T>(dst2 + (int64_t)row * a.ldp + col + 4 * g4, (kb & 1u) ? v.x * a.scale : 0.f, (kb & 2u) ? v.y * a.scale : 0.f,
+                         (kb & 4u) ? v.z * a.scale : 0.f, (kb & 8u) ? v.w * a.scale : 0.f);
+          }
+        }
+      }
+    }
   }
   if (has_bias) {
     for (int i = threadIdx.x; i < a.tab_stride + 32; i += 256) st_bias[i] = i < a.tab_stride ? a.bias_tab[(int64_t)hh * a.tab_stride + i] : 0.f;
@@ -924,7 +942,6 @@ __global__ __launch_bounds__(256, SLIM ? 5 : 4) void attn_stripe_kernel(StripeAr
   };
   const int kend = BWD ? a.Sk : (a.causal ? min(a.Sk, q + 1) : a.Sk);
   const int64_t prow = ((int64_t)bh * a.Sq + qc) * a.ldp;
-  const uint64_t key = DROP ? drop_site_key(a.dk) : 0ull;
   if constexpr (!BWD) {
     const float* bt = st_bias + a.tab_center - qc;
     // pass 1: running (max, sum) of this lane's half of the keys
@@ -1102,16 +1119,6 @@ __global__ __launch_bounds__(256, SLIM ? 5 : 4) void attn_stripe_kernel(StripeAr
         float o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (k0 + e < a.Sk) ? pe[e] * (masked(acc[4 * g + e], k0 + e, (kbits[j] >> (4 * g + e)) & 1u) - t) : 0.f;
-        if constexpr (DROP) {
-          // the dropped probabilities again (the dV product's operand; a scratch buffer in the forward pass): what drop_copy_kernel
-          // produced in a launch of its own — 18 launches, 0.28 ms of a step — from the P row this lane holds anyway
-          if (a.Pd) {
-            float pd[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) pd[e] = ((kbits[j] >> (4 * g + e)) & 1u) ? pe[e] * a.scale : 0.f;
-            st_store4<T>(pl2 + r * LP + k0, pd[0], pd[1], pd[2], pd[3]);
-          }
-        }
         st_store4<T>(prd + k0, o[0], o[1], o[2], o[3]);                        // in place: the same lane read these four
       }
     }
@@ -1120,13 +1127,9 @@ __global__ __launch_bounds__(256, SLIM ? 5 : 4) void attn_stripe_kernel(StripeAr
     ST_STAMP(6);
     {
       T* dst = reinterpret_cast<T*>(a.dS) + blk;
-      T* dst2 = (DROP && a.Pd) ? reinterpret_cast<T*>(a.Pd) + blk : nullptr;
       for (int c = threadIdx.x; c < 32 * cpr; c += 256) {
         const int row = c / cpr, col = (c - row * cpr) * EC;
-        if (q0 + row < a.Sq) {
-          *reinterpret_cast<uint4*>(dst + (int64_t)row * a.ldp + col) = *reinterpret_cast<const uint4*>(pl + row * LP + col);
-          if (DROP && dst2) *reinterpret_cast<uint4*>(dst2 + (int64_t)row * a.ldp + col) = *reinterpret_cast<const uint4*>(pl2 + row * LP + col);
-        }
+        if (q0 + row < a.Sq) *reinterpret_cast<uint4*>(dst + (int64_t)row * a.ldp + col) = *reinterpret_cast<const uint4*>(pl + row * LP + col);
       }
     }
     // relative-position-bias gradient, stage 1 (replaces bias_diag_kernel's pass over dS in memory): the sums of this stripe's
@@ -1169,7 +1172,7 @@ static int launch_attn_stripe(bool bwd, const StripeArgs& a_in, int nB, hipStrea
   const bool drop = a.thresh != 0, bias = !bwd && a.bias_tab != nullptr;
   const size_t bias_bytes = bias ? ((size_t)(a.tab_stride + 32) * 4 + 15) / 16 * 16 : 0;
   const size_t row_bytes = (size_t)32 * (ceil_div(a.Sk, 32) * 32 + 16 / sizeof(T)) * sizeof(T);
-  const size_t smem = bias_bytes + row_bytes * ((drop && a.Pd) ? 2 : 1);      // a dropped copy of P wanted in memory: two row blocks
+  const size_t smem = bias_bytes + row_bytes * ((!bwd && drop && a.Pd) ? 2 : 1);      // forward with a dropped copy of P wanted in memory: two row blocks
   // five workgroups per CU when that turns two rounds into one (and their LDS fits): see SLIM above
   static const bool slim_on = [] { const char* v = getenv("M2M_ST_SLIM"); return !(v && v[0] == '0'); }();
   const int64_t n_wgs = (int64_t)a.n_stripes * nB * a.H;
