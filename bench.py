@@ -44,6 +44,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured-achievable)
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp8": 5000.0}   # dense peaks (no 2:1 sparsity)
 N_SAMPLES = 220500        # 10 s @ 22.05 kHz
 N_FRAMES = 1 + N_SAMPLES // 256
 MAX_LENGTH = 1024
@@ -57,21 +58,68 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
+def _rank_log_dir() -> Path:
+    """Where the ranks' stderr goes: gpurun_out/ (merged back from the GPU box) or $M2M_BENCH_LOG_DIR; a temp dir as a last resort."""
+    for cand in (os.environ.get("M2M_BENCH_LOG_DIR"), ROOT / "gpurun_out"):
+        if not cand:
+            continue
+        try:
+            Path(cand).mkdir(parents=True, exist_ok=True)
+            probe = Path(cand) / ".bench_write_probe"
+            probe.write_text("")
+            probe.unlink()
+            return Path(cand)
+        except OSError:
+            continue
+    import tempfile
+    return Path(tempfile.mkdtemp(prefix="m2m_bench_"))
+
+
+def _tail(path: Path, n: int = 25) -> str:
+    try:
+        return "\n".join(path.read_text(errors="replace").splitlines()[-n:])
+    except OSError:
+        return ""
+
+
 def spawn_ranks(n: int) -> int:
-    """Start n rank processes of this script (one per GPU) and wait for them.
+    """Start n rank processes of this script (one per GPU) and wait for them — with a deadline.
 
     Runs in a parent that has not touched the GPU (no torch.cuda / HIP call so far): children are
-    fresh interpreters started with subprocess, each pinned to its GPU through LOCAL_RANK.  stdout
-    of rank 0 carries the JSON line and is inherited; a failing rank ends the others (by PID) and
-    makes the exit code non-zero."""
+    fresh interpreters started with subprocess (never an exec of this process), each pinned to its GPU
+    through LOCAL_RANK and to its share of the host cores through OMP_NUM_THREADS.  stdout of rank 0
+    carries the JSON line and is inherited; every rank's stderr goes to a file of its own
+    (bench_rank<r>.err: 8 interleaved RCCL logs are unreadable).  A failing rank ends the others (by
+    PID) and makes the exit code non-zero; so does the watchdog: if the ranks have not all finished
+    after M2M_BENCH_TIMEOUT seconds (default 1500; a rank stuck in RCCL initialisation is the likeliest
+    failure of a first multi-GPU run) the parent says which ranks were still alive, shows the tail of
+    their logs, terminates them (SIGTERM, then SIGKILL) and exits with 124."""
     port = _free_port()
-    procs = []
+    logdir = _rank_log_dir()
+    deadline = time.monotonic() + float(os.environ.get("M2M_BENCH_TIMEOUT", "1500"))
+    threads = max(1, min(16, (os.cpu_count() or n) // n))
+    procs, logs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), M2M_BENCH_CHILD="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
+        env.setdefault("OMP_NUM_THREADS", str(threads))
+        env.setdefault("M2M_BENCH_THREADS", str(threads))
+        logs.append(logdir / f"bench_rank{r}.err")
+        with open(logs[r], "w") as errf:
+            procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env,
+                                          stdout=None if r == 0 else subprocess.DEVNULL, stderr=errf))
+
+    def stop(ranks):
+        for o in ranks:
+            procs[o].terminate()
+        t_end = time.monotonic() + 10.0
+        for o in ranks:
+            try:
+                procs[o].wait(max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                procs[o].kill()
+
     rc = 0
     pending = set(range(n))
     while pending:
@@ -82,11 +130,30 @@ def spawn_ranks(n: int) -> int:
             pending.discard(r)
             if code != 0 and rc == 0:
                 rc = code if code > 0 else 1
-                print(f"[bench] rank {r} exited with {code}: stopping the other ranks", file=sys.stderr)
-                for o in pending:
-                    procs[o].terminate()
+                print(f"[bench] rank {r} exited with {code}: stopping the other ranks (logs: {logdir}/bench_rank*.err)\n"
+                      f"---- rank {r} stderr (tail) ----\n{_tail(logs[r])}", file=sys.stderr)
+                stop(sorted(pending))
+        if pending and rc == 0 and time.monotonic() > deadline:
+            alive = sorted(pending)
+            print(f"[bench] watchdog: ranks {alive} still running after {os.environ.get('M2M_BENCH_TIMEOUT', '1500')} s "
+                  f"(finished: {sorted(set(range(n)) - pending)}); terminating them", file=sys.stderr)
+            for r in alive:
+                print(f"---- rank {r} stderr (tail) ----\n{_tail(logs[r], 12)}", file=sys.stderr)
+            stop(alive)
+            return 124
         time.sleep(0.05)
+    if rc == 0:      # a clean run still shows what rank 0 had to say (warnings), briefly
+        t0 = _tail(logs[0], 6)
+        if t0.strip():
+            print(t0, file=sys.stderr)
     return rc
+
+
+def pin_host_threads(world: int) -> int:
+    """Each rank keeps to its share of the host cores (8 ranks x every core oversubscribes the box; the CPU side of a step is tiny)."""
+    n = int(os.environ.get("M2M_BENCH_THREADS") or max(1, min(16, (os.cpu_count() or world) // max(1, world))))
+    torch.set_num_threads(n)
+    return n
 
 
 # ------------------------------------------------------------------ CPU baselines (oracle; checker code, timed only)
@@ -147,18 +214,24 @@ def cpu_frontend_baseline(cfg, clips: int = 64, threads: int = 16):
             "sample": f"torch.stft + dense [1025x384] mel matmul + clamp/log on {clips} x {N_SAMPLES} samples, fp32"}
 
 
-def pmc_traffic_bytes(kernel_substr: str, batch: int, n_chains: int = 1):
+def pmc_traffic_bytes(kernel_substr: str, batch: int, n_chains: int = 1, profiles_dir=None):
     """HBM bytes of one co-scheduled launch set (all `batch` clips) of a kernel from the newest committed PMC summary
     (profiles/*pmc_traffic_summary.txt, collected by tools/pmc_traffic.sh in separate FETCH_SIZE / WRITE_SIZE passes;
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  The summary lists bytes per KERNEL launch; a launch
-    covers `clips/launch` clips (header of the summary; 32 when absent = round 1), so the figure is scaled to `batch` clips.
-    None when no summary is present."""
+    covers `clips/launch` clips — stated in the summary's header, which tools/pmc_traffic.sh writes — so the figure is scaled to
+    `batch` clips.  A summary WITHOUT that header is refused (None, with a note on stderr): guessing the launch width is how round 2
+    reported half the traffic.  None when no summary is present."""
     import re
     best = None
-    for f in sorted((ROOT / "profiles").glob("*pmc_traffic_summary.txt")):
+    files = sorted(Path(profiles_dir or ROOT / "profiles").glob("*pmc_traffic_summary.txt"), key=lambda f: (_round_of(f.name), f.name))
+    files = [f for f in files if "frontend" not in f.name]
+    for f in files[-1:]:                       # the newest round's summary only: an older one describes older kernels
         text = f.read_text()
         m = re.search(r"clips/launch\s*=\s*(\d+)", text)
-        per_launch = int(m.group(1)) if m else 32
+        if not m:
+            print(f"[bench] {f.name} has no 'clips/launch = N' header: roofline.traffic left null", file=sys.stderr)
+            return None
+        per_launch = int(m.group(1))
         vals = []
         for line in text.splitlines():
             if kernel_substr in line:
@@ -168,6 +241,40 @@ def pmc_traffic_bytes(kernel_substr: str, batch: int, n_chains: int = 1):
         if vals:   # several template variants of the kernel (cache policy): mean per launch
             best = sum(vals) / len(vals)
     return best
+
+
+def _round_of(name: str) -> int:
+    import re
+    m = re.match(r"r(\d+)_", name)
+    return int(m.group(1)) if m else 0
+
+
+BF16_NOISE_MARGIN = 0.5    # top-2 logit margin below which a bf16 decode may legitimately take the other token (tests/test_golden_gpu.py)
+
+
+def golden_divergence(ids_bf16, ids_fp32) -> dict:
+    """Clips 0 and 1 of this workload against the committed oracle ids (tests/golden/t5_bf16.npz, written by
+    tests/golden/make_golden.py t5_bf16 from the bf16-EMULATING oracle and the fp32 oracle on the same waveforms): where the
+    device's bf16 ids first leave the emulation's, and the oracle's own top-2 margin at that step — a divergence at a margin
+    below BF16_NOISE_MARGIN is rounding, one above it would be a bug; the fp32 mode must not diverge at all.  A fixture file
+    (data), read here; the oracle itself is not imported."""
+    f = ROOT / "tests" / "golden" / "t5_bf16.npz"
+    if not f.exists():
+        return {}
+    z = np.load(f)
+
+    def first_div(ids, want, margins):
+        ids = ids[: want.shape[0], : want.shape[1]].cpu().numpy()
+        rows = []
+        for b in range(want.shape[0]):
+            d = np.nonzero(ids[b] != want[b, : ids.shape[1]])[0]
+            rows.append({"step": int(d[0]), "oracle_margin": float(margins[b, d[0] - 1])} if len(d) else {"step": -1, "oracle_margin": None})
+        return rows
+    bf = first_div(ids_bf16, z["bench_clips_bf16/ids"].astype(np.int64), z["bench_clips_bf16/margins"])
+    fp = first_div(ids_fp32, z["bench_clips_fp32/ids"].astype(np.int64), z["bench_clips_fp32/margins"])
+    return {"bf16_vs_bf16_oracle_first_divergence": bf, "bf16_noise_margin": BF16_NOISE_MARGIN,
+            "bf16_divergences_above_noise_margin": int(sum(1 for r in bf if r["step"] >= 0 and r["oracle_margin"] >= BF16_NOISE_MARGIN)),
+            "fp32_vs_fp32_oracle_first_divergence": [r["step"] for r in fp]}
 
 
 def decode_bytes_per_step(B: int, S: int, t_mean: float, esize: int) -> float:
@@ -186,6 +293,12 @@ def dry_run(args):
     rank, local_rank, world = D.init_process_group("gloo")
     if os.environ.get("M2M_BENCH_FAIL_RANK") == str(rank):      # test hook: a rank that dies must fail the whole launch
         sys.exit(3)
+    if os.environ.get("M2M_BENCH_HANG_RANK") == str(rank):      # test hook: a rank that never finishes must trip the watchdog
+        print(f"[bench] rank {rank}: hanging on purpose (test hook)", file=sys.stderr, flush=True)
+        time.sleep(3600)
+    pin_host_threads(world)
+    if args.mode == "train":
+        return dry_run_train(args, rank, world)
     cfg = default_config()
     geom = T5Geometry(cfg.model.t5)
     torch.manual_seed(1234 + rank)                      # ranks start from DIFFERENT weights ...
@@ -210,12 +323,110 @@ def dry_run(args):
     return 0 if ok and pmin == pmax else 1
 
 
+def dry_run_train(args, rank: int, world: int) -> int:
+    """--mode train --dry-run: the data-parallel plumbing of a training step on CPU tensors over gloo — the flat-gradient
+    average in one piece and in the overlapped form's four pieces (real early ranges of the model's layout, derived from the
+    module tree as the trainer lays it out), the sync_dist metric reduction, barrier + max-over-ranks timing — no GPU work."""
+    from music2midi_amd import distributed as D
+    from music2midi_amd.config import default_config
+    from music2midi_amd.transformer import T5Transformer
+    cfg = default_config()
+    model = T5Transformer(cfg.to_dict(), precision="fp32")
+    n = sum(p.numel() for p in model.parameters())
+    # early ranges as the native trainer reports them: [shared + lm_head] in front, the decoder blocks as one block
+    n_front = model.transformer.shared.weight.numel() + model.transformer.lm_head.weight.numel()
+    n_dec = sum(p.numel() for p in model.transformer.decoder.block.parameters())
+    early = [(0, n_front), (n - n_dec - 4096, n_dec)]
+    g = torch.Generator().manual_seed(99)
+    base = torch.randn(n, generator=g)
+    t0 = time.perf_counter()
+    flat = base * (rank + 1)
+    b1 = D.all_reduce_gradients(flat)
+    want = base * (sum(range(1, world + 1)) / world)
+    ok = torch.allclose(flat, want, rtol=1e-6, atol=1e-6)
+    flat = base * (rank + 1)
+    b2 = D.all_reduce_gradients_overlapped(flat, early, None)
+    ok = ok and torch.allclose(flat, want, rtol=1e-6, atol=1e-6) and b1 == b2 == (n * 4 if world > 1 else 0)
+    logged = D.reduce_logged({"train/loss": torch.tensor(1.0 + rank), "train/score": 0.25 * rank, "batch_size": 16})
+    ok = ok and abs(logged["train/loss"] - (1.0 + (world - 1) / 2)) < 1e-12 and logged["batch_size"] == 16 * world
+    D.barrier()
+    dt = D.all_reduce_max(time.perf_counter() - t0, "cpu")
+    if rank == 0:
+        print(json.dumps({"metric": "training clips/sec/node (forward+backward+Adafactor step)", "value": 0.0, "unit": "clips/s", "n_gpus": world,
+                          "dry_run": True, "mode": "train", "backend": torch.distributed.get_backend() if world > 1 else "none",
+                          "world": torch.distributed.get_world_size() if world > 1 else 1, "grad_allreduce_bytes": b1,
+                          "grad_average_ok": bool(ok), "logged": logged, "host_threads": torch.get_num_threads(), "wall_s": dt,
+                          "config": {"global_batch": 16 * world, "parallelism": f"data-parallel x{world}"}}), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    return 0 if ok else 1
+
+
 # ------------------------------------------------------------------ BASELINE configs[4]: training step
 TRAIN_SAMPLES = 66150      # ref config.yaml: 3 s segments at dataset.sample_rate 22 050 Hz -> 259 frames, S = 261
 TRAIN_LABELS = 256         # label tokens per clip (synthetic, none ignored)
 
 
-def train_step_record(model_module, cfg, geom, dev, B: int, precision: str, steps: int, warmup: int, world: int = 1, dropout: float = 0.0):
+def launch_profile(make_trainer, run_step):
+    """Share of a training step's GPU time that is NOT a matrix product, from torch's profiler (kineto over roctracer) around ONE
+    directly issued step (a trainer built with M2M_TRAIN_GRAPH=0, so every kernel is a launch of its own); {} when the profiler
+    sees no device activity.  Product kernels = names containing gemm / dw_group / attn_stripe (projections, batched attention
+    products, weight gradients, the fused attention stripes); everything else is row / element-wise work."""
+    old = os.environ.get("M2M_TRAIN_GRAPH")
+    os.environ["M2M_TRAIN_GRAPH"] = "0"
+    tr = None
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        tr = make_trainer()
+        for _ in range(2):
+            run_step(tr)
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            run_step(tr)
+            torch.cuda.synchronize()
+        evs = [e for e in prof.events() if "cuda" in str(e.device_type).lower() and (getattr(e, "device_time", 0) or 0) > 0]
+        if not evs:
+            return {}
+        tot = sum(e.device_time for e in evs)
+        gemm = sum(e.device_time for e in evs if any(k in e.name for k in ("gemm", "dw_group", "attn_stripe")))
+        return {"direct_issue_launches": len(evs), "kernel_us_per_step": tot, "non_gemm_us": tot - gemm}
+    except Exception as e:          # measurement garnish: never fail the bench for it
+        return {"launch_profile_error": str(e)[:160]}
+    finally:
+        if tr is not None:
+            tr.close()
+        if old is None:
+            os.environ.pop("M2M_TRAIN_GRAPH", None)
+        else:
+            os.environ["M2M_TRAIN_GRAPH"] = old
+
+
+def cpu_train_baseline(cfg, state, B: int, threads: int = 16):
+    """The CPU side of configs[4]: the oracle's training step on the host — autograd forward + backward over oracle/train.py and
+    the restated Adafactor — on the same shape (B clips, S = 261, 256 labels), fp32."""
+    from music2midi_amd import synth
+    from music2midi_amd.config import T5Geometry
+    from oracle.train import AdafactorOracle, T5TrainOracle, leaf_params
+    geom = T5Geometry(cfg.model.t5)
+    threads = min(threads, os.cpu_count() or threads)
+    torch.set_num_threads(threads)
+    F = 1 + TRAIN_SAMPLES // 256
+    params = leaf_params(state)
+    orc, opt = T5TrainOracle(geom, params), AdafactorOracle(params)
+    feats = torch.from_numpy(synth.normal(5, "feats", (B, F, geom.d_model), 2.0))
+    cond = torch.from_numpy(synth.cond_index_batch(0, B))
+    labels = torch.from_numpy((synth.uniform01(0, "train_labels", B * TRAIN_LABELS) * 330).astype(np.int64).reshape(B, TRAIN_LABELS)) + 3
+    t0 = time.perf_counter()
+    loss, _, grads = orc.loss_and_grads(feats, cond, labels)
+    opt.step(grads)
+    dt = time.perf_counter() - t0
+    return {"value": B / dt, "unit": "clips/s", "ms_per_step": dt * 1e3, "cores": threads, "kind": "port",
+            "sample": f"ONE step: {B} clips x S={F + 2} x {TRAIN_LABELS} labels, fp32 torch-CPU autograd over the oracle + restated Adafactor "
+                      f"(log-mel excluded), {dt:.1f} s wall, {threads} threads", "loss": float(loss)}
+
+
+def train_step_record(model_module, cfg, geom, dev, B: int, precision: str, steps: int, warmup: int, world: int = 1, dropout: float = 0.0,
+                      profile_launches: bool = False):
     """forward + backward + (gradient all-reduce) + Adafactor on B clips per GPU; returns a dict for the JSON line."""
     from music2midi_amd import distributed as D
     from music2midi_amd import synth
@@ -255,13 +466,32 @@ def train_step_record(model_module, cfg, geom, dev, B: int, precision: str, step
     S = F + 2
     enc = 6 * (4227072 * S + 2048 * S * S) + 4718592 * S
     dec = TRAIN_LABELS * (6 * (2 * 384 * 512 * 6 + 3 * 2 * 384 * 1152) + 2 * 384 * 400) + 6 * (4 * TRAIN_LABELS * TRAIN_LABELS * 512 + 4 * TRAIN_LABELS * S * 512)
+    flops = 3 * B * (enc + dec)                                    # forward + 2x backward, dense products only (SURVEY 8d formulas)
+    peak = MFMA_PEAK_TFLOPS["fp8" if precision == "fp8" else "bf16"]
     rec = {"workload": f"BASELINE configs[4]: train step (log-mel + forward + backward + Adafactor), {precision} GEMM inputs, "
                        f"{B} clips/GPU x {TRAIN_SAMPLES} samples (S={S}), {TRAIN_LABELS} labels/clip, dropout {'off' if dropout == 0.0 else dropout}",
            "ms_per_step": dt * 1e3, "clips_per_s": B * world / dt, "label_tokens_per_s": B * world * TRAIN_LABELS / dt,
-           "model_TFLOPs_per_gpu": 3 * B * (enc + dec) / dt / 1e12, "loss": float(loss), "grad_allreduce_bytes": nbytes,
+           "model_TFLOPs_per_gpu": flops / dt / 1e12, "loss": float(loss), "grad_allreduce_bytes": nbytes,
+           "roofline": {"bound": "mfma", "flops_per_step": flops, "achieved": flops / dt / 1e12, "peak": peak, "unit": "TFLOP/s",
+                        "frac": flops / dt / 1e12 / peak, "peak_note": f"dense {'MXFP8' if precision == 'fp8' else 'bf16'} MFMA peak (MI355X_MICROARCH.md)",
+                        "graph_nodes_per_step": tr.graph_nodes()},
            "optimizer": "Adafactor(warmup_init=True), native", "world": world,
            "grad_allreduce": ("4 pieces, decoder side overlapped with the encoder backward" if overlap else "one call behind the pass") if world > 1 else
                              ("none (split pass forced)" if overlap else "none")}
+    if world == 1 and profile_launches:
+        def make():
+            t2 = NativeTrainer(model_module, B, F + 2, TRAIN_LABELS, precision=precision)
+            if dropout > 0.0:
+                t2.set_dropout(dropout, seed=1)
+            return t2
+
+        def run(t2):
+            x = model_module.encoder_inputs(ModelInputs(input_waveform=wav, cond_index=cond))
+            t2.forward_backward(x, cond, labels)
+            t2.optimizer_step()
+        tr.close()
+        rec["roofline"].update(launch_profile(make, run))
+        return rec
     tr.close()
     return rec
 
@@ -314,6 +544,7 @@ def main():
     native.require_gpu()
     dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
+    pin_host_threads(world)
 
     cfg = default_config()
     geom = T5Geometry(cfg.model.t5)
@@ -491,6 +722,7 @@ def main():
             "bf16_vs_fp32_first_divergence_step": first_div,
             "bf16_vs_fp32_mean_identical_prefix": float(np.mean(prefix)),
         }
+        out["parity_mode"].update(golden_divergence(ids_bf16, ids_fp32))
         del m32
 
     # ---- BASELINE configs[4] (per-GPU share: 128 clips / 8 GPUs): one training step, timed on this GPU ----
@@ -499,8 +731,9 @@ def main():
         load_t5_state(mt, state, strict=False)
         mt = mt.to(dev)
         # the step as the reference runs it: train() mode (ref: train.py:33), T5Config.dropout_rate 0.1 — the main record; without dropout beside it
-        out["train_configs4"] = train_step_record(mt, cfg, geom, dev, 16, "bf16", 10, 2, dropout=0.1)
+        out["train_configs4"] = train_step_record(mt, cfg, geom, dev, 16, "bf16", 10, 2, dropout=0.1, profile_launches=True)
         fp8 = train_step_record(mt, cfg, geom, dev, 16, "fp8", 10, 2, dropout=0.1)          # configs[4] names fp8 GEMMs: MXFP8 projections, same step
+        out["train_configs4"]["fp8_mx_roofline"] = fp8["roofline"]
         nodrop = train_step_record(mt, cfg, geom, dev, 16, "bf16", 10, 2)
         out["train_configs4"]["dropout_off_ms_per_step"] = nodrop["ms_per_step"]
         out["train_configs4"]["dropout_off_clips_per_s"] = nodrop["clips_per_s"]
@@ -509,6 +742,8 @@ def main():
         out["train_configs4"]["fp8_note"] = ("projection products (forward and dX; the weight gradients take the grouped bf16 launch) on block-scaled OCP FP8 (e4m3, 32 elements per E8M0 scale, "
                                              "v_mfma_scale_f32_32x32x64_f8f6f4); activations quantised inside the product's operand staging; at 16 clips/GPU the products are latency- and "
                                              "VALU-bound, not MFMA-bound, so the faster matrix instruction does not show")
+        if args.cpu_tokens > 0:
+            out["train_configs4"]["cpu_baseline"] = cpu_train_baseline(cfg, state, 16)
         del mt
 
     if rank == 0 and world == 1 and args.cpu_tokens > 0:

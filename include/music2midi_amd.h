@@ -238,7 +238,10 @@ int64_t m2m_trainer_workspace_bytes(const m2m_trainer* t);   /* device bytes the
  * Streams: with gradients the pass runs on the trainer's own streams — stream-ordered behind everything already on `stream`
  * (the inputs are copied into trainer-owned buffers first) and `stream` waits for its end, so for the caller it behaves like
  * work on `stream`.  From the second call with the same (params_dev, grads_dev, B, S, Ld, dropout) on, the pass is replayed as
- * one captured HIP graph (M2M_TRAIN_GRAPH=0 disables that); params_dev / grads_dev must stay valid while the trainer lives.
+ * one captured HIP graph (M2M_TRAIN_GRAPH=0 disables that), one graph PER SHAPE: up to 8 keys are kept, least recently used
+ * first out, so batches whose label length changes and comes back replay their own graph; params_dev / grads_dev must stay
+ * valid while the trainer lives.  A batch without any scored label (all -100) gives loss = NaN and zero gradients, as torch's
+ * CrossEntropyLoss does.
  */
 int m2m_train_forward_backward(m2m_trainer* t, const float* params_dev, const float* enc_inputs_dev,
                                const int64_t* cond_idx_dev, const int64_t* labels_dev, int B, int S, int Ld,
@@ -261,6 +264,9 @@ int m2m_trainer_set_dropout(m2m_trainer* t, float p, uint64_t seed);
  * m2m_trainer_early_grad_ranges: out[0..3] = {offset, count, offset, count} in floats of the flat gradient buffer. */
 int m2m_trainer_set_sync_stream(m2m_trainer* t, void* sync_stream);
 int m2m_trainer_early_grad_ranges(const m2m_trainer* t, int64_t* out);
+/* Measurement hook (bench.py train_configs4.roofline): nodes (kernel launches + copies) of the captured graph(s) of the shape
+ * most recently passed to m2m_train_forward_backward = launches per training step; 0 while that shape has not been captured. */
+int m2m_trainer_graph_nodes(const m2m_trainer* t);
 
 /* One transformers.optimization.Adafactor step with the reference's settings (lr=None, eps=(1e-30, 1e-3),
  * clip_threshold=1.0, decay_rate=-0.8, beta1=None, weight_decay=0, scale_parameter, relative_step,

@@ -1516,7 +1516,9 @@ __global__ void count_valid_kernel(const int64_t* __restrict__ labels, int n, fl
     if (threadIdx.x < s) cnt[threadIdx.x] += cnt[threadIdx.x + s];
     __syncthreads();
   }
-  if (threadIdx.x == 0) { inv_n[0] = cnt[0] > 0 ? 1.0f / (float)cnt[0] : 0.f; inv_n[1] = (float)cnt[0]; }
+  // no label to score: the mean over zero rows is NaN, as torch's CrossEntropyLoss gives (its gradient is zero there too: ce_kernel
+  // multiplies only the scored rows)
+  if (threadIdx.x == 0) { inv_n[0] = cnt[0] > 0 ? 1.0f / (float)cnt[0] : __builtin_nanf(""); inv_n[1] = (float)cnt[0]; }
 }
 // one wave per row: row_loss[row] = logsumexp - logit[label] (0 if ignored); dlogits (T) = (softmax - onehot) / n_valid
 template <typename T>
@@ -1915,18 +1917,15 @@ struct m2m_trainer {
   enum { K_DXT = 0, K_DAB, K_DQKV, K_DCQ, K_DCKV, K_KINDS };
   std::vector<void*> ring[K_KINDS];
   bool use_group = true;                 // one grouped weight-gradient launch per step (bf16 / fp32 modes)
-  void* dw_probs_dev = nullptr;          // DwProb table on the device
-  std::vector<unsigned char> dw_probs_host[2];   // ... and its host image (re-uploaded only when it changes); [1]: the second half of a split pass
+  void* dw_probs_dev = nullptr;          // DwProb tables on the device: [N_SLOTS + 1 table slots][2 phases][128 entries] (see GraphSlot)
   int dw_tiles = 0;
   int64_t drel_slot_floats = 0;          // one self-attention layer's per-stripe diagonal sums (t->drel holds Le + Ld of them, then the scratch)
-  int64_t* norm_offs_dev = nullptr;      // parameter offsets of the RMSNorm weights, in the order the backward pass meets them
-  std::vector<int64_t> norm_offs_host[2];
+  int64_t* norm_offs_dev = nullptr;      // parameter offsets of the RMSNorm weights, in the order the backward pass meets them: [N_SLOTS + 1][2][32]
   // data-parallel overlap (m2m_trainer_set_sync_stream): the backward pass is issued in two parts — decoder side, then encoder side —
   // and `sync_stream` is released (ev_mid) as soon as the decoder-side gradients are final, so their all-reduce runs beside the
   // encoder backward.  The layout keeps them in two flat ranges: [0, o_erb) (shared embedding, lm_head) and the decoder blocks.
   hipStream_t sync_stream = nullptr;
   hipEvent_t ev_mid = nullptr;
-  hipGraphExec_t gexec2 = nullptr;       // second half of a split pass
   int64_t dec_begin = 0, dec_end = 0;
   // streams / graph of the step (trainer-owned: the caller's stream may be the legacy default stream, which cannot capture)
   hipStream_t s_main = nullptr, s_side = nullptr;
@@ -1941,8 +1940,27 @@ struct m2m_trainer {
       return P == o.P && G == o.G && B == o.B && S == o.S && L == o.L && thresh == o.thresh && seed == o.seed && split == o.split;
     }
   };
-  GraphKey last_key, graph_key;          // key of the previous call / of the instantiated graph
-  hipGraphExec_t gexec = nullptr;
+  // One captured graph PER SHAPE.  The grouped weight-gradient launch and the norm column sums read device-resident tables
+  // (operand pointers, reduction lengths, tile counts) that depend on (B, S, L); a graph bakes the table's ADDRESS in, so every
+  // cached shape owns a table slot of its own and a pass with another shape can never rewrite the table a kept graph replays
+  // (training batches are padded to their longest label sequence, ref: music2midi/tokenizer.py:86-96, so L changes from batch
+  // to batch and comes back).  The first call with a key runs directly and uploads the slot's tables, the second captures, later
+  // ones replay; the least recently used slot is recycled (its graphs destroyed first).  Slot N_SLOTS serves the passes issued on
+  // the caller's stream (no graph).
+  static constexpr int N_SLOTS = 8;
+  struct GraphSlot {
+    GraphKey key;
+    bool valid = false;
+    int calls = 0;
+    uint64_t last_use = 0;
+    hipGraphExec_t gexec = nullptr, gexec2 = nullptr;      // gexec2: second half of a split pass
+    int nodes = 0;                                         // nodes of the captured graph(s): launches per step
+    std::vector<unsigned char> dw_probs_host[2];           // host images of the slot's device tables (re-uploaded only when they change);
+    std::vector<int64_t> norm_offs_host[2];                // [1]: the second half of a split pass
+  };
+  GraphSlot slots[N_SLOTS + 1];
+  int cur_slot = N_SLOTS;                // the table slot the pass being issued uses
+  uint64_t tick = 0;
   // optimizer
   AfPlan af;
   unsigned char* af_mem = nullptr;
@@ -2083,7 +2101,7 @@ int build_arena(m2m_trainer* t) {
   for (int l = 0; l < Le; ++l) o_kte.push_back(T(2 * B * H * 64 * Sp32));
   for (int l = 0; l < Ld; ++l) { o_ktd.push_back(T(2 * B * H * 64 * Lp32)); o_ktc.push_back(T(2 * B * H * 64 * Sp32)); }
   const int64_t o_hE = T(Me * d), o_hD = T(Md * d), o_logits = F(Md * V), o_sc = F(B * H * Sm * lpm), o_dxa = F(Mx * d), o_dxb = F(Mx * d),
-                o_dh = F(Mx * d), o_dhE = F(Me * d), o_dwp = F((int64_t)RN_BLOCKS * d * (2 * Le + 3 * Ld + 2)), o_nofs = c.take(64 * 8), o_rl = F(Md), o_inv = F(64), o_drel = F((int64_t)(Le + Ld) * B * H * std::max<int64_t>(2 * Sm, ((Sm + 31) / 32) * (Sm + 32)) + (int64_t)std::max(Le, Ld) * H * 2 * Sm + B * H * 2 * Sm),
+                o_dh = F(Mx * d), o_dhE = F(Me * d), o_dwp = F((int64_t)RN_BLOCKS * d * (2 * Le + 3 * Ld + 2)), o_nofs = c.take((int64_t)(m2m_trainer::N_SLOTS + 1) * 64 * 8), o_rl = F(Md), o_inv = F(64), o_drel = F((int64_t)(Le + Ld) * B * H * std::max<int64_t>(2 * Sm, ((Sm + 31) / 32) * (Sm + 32)) + (int64_t)std::max(Le, Ld) * H * 2 * Sm + B * H * 2 * Sm),
                 o_etab = F(H * (2 * S)), o_dtab = F(H * (2 * L)), o_dlog = T(Md * align_up(V, 8)), o_dxT = T(Mx * d), o_dmid = T(Mx * dff),
                 o_dab = T(Mx * 2 * dff), o_dO = T(Mx * inner), o_dqkv = T(Mx * 3 * inner), o_dS = T(B * H * Sm * lpm), o_dcq = T(Md * inner),
                 o_dckv = T(Me * 2 * inner), o_lab = c.take(Md * 8), o_cnd = c.take(B * 8 * 8), o_skey = c.take(256), o_decin = c.take(Md * 8), o_eb = c.take(2 * S * 4), o_db = c.take(2 * L * 4),
@@ -2093,7 +2111,7 @@ int build_arena(m2m_trainer* t) {
   for (int i = 1; i < 2 * Le + 3 * Ld; ++i) o_ring[m2m_trainer::K_DXT].push_back(T(Mx * d));
   for (int i = 1; i < Le + Ld; ++i) { o_ring[m2m_trainer::K_DAB].push_back(T(Mx * 2 * dff)); o_ring[m2m_trainer::K_DQKV].push_back(T(Mx * 3 * inner)); }
   for (int i = 1; i < Ld; ++i) { o_ring[m2m_trainer::K_DCQ].push_back(T(Md * inner)); o_ring[m2m_trainer::K_DCKV].push_back(T(Me * 2 * inner)); }
-  const int64_t o_dwp_tab = c.take(256 * (int64_t)sizeof(DwProb));
+  const int64_t o_dwp_tab = c.take((int64_t)(m2m_trainer::N_SLOTS + 1) * 256 * (int64_t)sizeof(DwProb));
   const int64_t Mxp = align_up(Mx, 8), fmax = std::max<int64_t>(std::max<int64_t>(3 * inner, 2 * dff), align_up(V, 8));
   const int64_t o_tA = T(fmax * Mxp), o_tB = T(std::max<int64_t>(std::max<int64_t>(dff, inner), d) * Mxp);
   t->kpart_floats = std::max<int64_t>((int64_t)8 << 20, fmax * std::max<int64_t>(dff, d) + 64);
@@ -2273,14 +2291,15 @@ struct Ops {
   int flush_norms() const {
     if (!group || norm_offs.empty()) return M2M_OK;
     M2M_REQUIRE(norm_offs.size() <= 32 && (int)norm_offs.size() <= 2 * t->g.num_layers + 3 * t->g.num_decoder_layers + 2, "training: too many norms");
-    int64_t* const offs_dev = t->norm_offs_dev + 32 * phase;
-    if (t->norm_offs_host[phase] != norm_offs) {
+    int64_t* const offs_dev = t->norm_offs_dev + 64 * t->cur_slot + 32 * phase;
+    std::vector<int64_t>& offs_host = t->slots[t->cur_slot].norm_offs_host[phase];
+    if (offs_host != norm_offs) {
       hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
       (void)hipStreamIsCapturing(st, &cs);
       M2M_REQUIRE(cs == hipStreamCaptureStatusNone, "training: the norm table changed inside a graph capture");
       M2M_CHECK_HIP(hipStreamSynchronize(st));
       M2M_CHECK_HIP(hipMemcpy(offs_dev, norm_offs.data(), norm_offs.size() * 8, hipMemcpyHostToDevice));
-      t->norm_offs_host[phase] = norm_offs;
+      offs_host = norm_offs;
     }
     const int d = t->g.d_model;
     hipLaunchKernelGGL(colsum_group_kernel, dim3(ceil_div(d, 32), (unsigned)norm_offs.size()), dim3(256), 0, st, t->dw_part, offs_dev, Gbase,
@@ -2292,8 +2311,8 @@ struct Ops {
   int flush_group() const {
     if (!group || probs.empty()) return M2M_OK;
     M2M_REQUIRE(probs.size() <= 128, "training: %zu weight-gradient products exceed the table", probs.size());
-    unsigned char* const tab_dev = reinterpret_cast<unsigned char*>(t->dw_probs_dev) + (size_t)phase * 128 * sizeof(DwProb);
-    std::vector<unsigned char>& tab_host = t->dw_probs_host[phase];
+    unsigned char* const tab_dev = reinterpret_cast<unsigned char*>(t->dw_probs_dev) + (size_t)(2 * t->cur_slot + phase) * 128 * sizeof(DwProb);
+    std::vector<unsigned char>& tab_host = t->slots[t->cur_slot].dw_probs_host[phase];
     int tiles = 0;
     for (DwProb& p : probs) { p.tn2 = ceil_div(p.g.N2, 128); p.tile0 = tiles; tiles += ceil_div(p.g.N1, 128) * p.tn2; }
     const size_t bytes = probs.size() * sizeof(DwProb);
@@ -3027,10 +3046,26 @@ int run_pass(m2m_trainer* t, const float* P, const float* x, const int64_t* cond
                                        : forward_backward_t<float>(t, P, x, cond, labels, B, S, L, loss, G, logits, st, side, at_split);
 }
 
+void drop_slot_graphs(m2m_trainer::GraphSlot& s) {
+  if (s.gexec) { (void)hipGraphExecDestroy(s.gexec); s.gexec = nullptr; }
+  if (s.gexec2) { (void)hipGraphExecDestroy(s.gexec2); s.gexec2 = nullptr; }
+}
 void drop_graph(m2m_trainer* t) {
-  if (t->gexec) { (void)hipGraphExecDestroy(t->gexec); t->gexec = nullptr; }
-  if (t->gexec2) { (void)hipGraphExecDestroy(t->gexec2); t->gexec2 = nullptr; }
-  t->graph_key = m2m_trainer::GraphKey{};
+  for (auto& s : t->slots) { drop_slot_graphs(s); s.valid = false; s.calls = 0; }
+}
+// the slot of `key`: its own if the key is cached, else the least recently used one, recycled (tables stay: the next direct pass
+// compares against their host image and uploads what differs — behind a stream sync, so no kept graph of THIS slot is in flight)
+int slot_for(m2m_trainer* t, const m2m_trainer::GraphKey& key) {
+  int lru = 0;
+  for (int i = 0; i < m2m_trainer::N_SLOTS; ++i) {
+    if (t->slots[i].valid && t->slots[i].key == key) return i;
+    if (!t->slots[i].valid) { if (t->slots[lru].valid) lru = i; }
+    else if (t->slots[lru].valid && t->slots[i].last_use < t->slots[lru].last_use) lru = i;
+  }
+  m2m_trainer::GraphSlot& s = t->slots[lru];
+  drop_slot_graphs(s);
+  s.key = key; s.valid = true; s.calls = 0;
+  return lru;
 }
 
 }  // namespace
@@ -3061,9 +3096,17 @@ extern "C" int m2m_train_forward_backward(m2m_trainer* t, const float* params_de
     M2M_CHECK_HIP(hipStreamWaitEvent(t->sync_stream, t->ev_mid, 0));
     return M2M_OK;
   };
-  if (!two)
-    return run_pass(t, params_dev, enc_inputs_dev, cond_idx_dev, labels_dev, B, S, Ld, loss_out_dev, grads_dev, logits_out_dev, caller, nullptr,
-                    split ? &release : nullptr);
+  // A sync stream is set but this pass is NOT split (per-product weight gradients: M2M_TRAIN_DW_GROUP=0, fp8 weight gradients):
+  // whoever enqueues the early all-reduce on the sync stream must still find FINISHED gradients, so the stream is released at
+  // the END of the pass instead of half-way (no overlap, no race)
+  const bool release_at_end = grads_dev && t->sync_stream && t->ev_mid && !split;
+  if (!two) {
+    t->cur_slot = m2m_trainer::N_SLOTS;
+    rc = run_pass(t, params_dev, enc_inputs_dev, cond_idx_dev, labels_dev, B, S, Ld, loss_out_dev, grads_dev, logits_out_dev, caller, nullptr,
+                  split ? &release : nullptr);
+    if (rc == M2M_OK && release_at_end) rc = release();
+    return rc;
+  }
 
   // ---- stage the inputs (stream-ordered behind whatever produced them), then hand over to the trainer's streams ----
   const m2m_t5_geometry& g = t->g;
@@ -3074,14 +3117,17 @@ extern "C" int m2m_train_forward_backward(m2m_trainer* t, const float* params_de
   M2M_CHECK_HIP(hipStreamWaitEvent(t->s_main, t->ev_in, 0));
 
   const m2m_trainer::GraphKey key{params_dev, grads_dev, B, S, Ld, t->drop_thresh, t->drop_seed, split};
-  const bool seen = key == t->last_key;
-  t->last_key = key;
-  if (t->use_graph && seen && !(t->gexec && key == t->graph_key)) {         // second call with this key: capture
-    drop_graph(t);
+  const int si = slot_for(t, key);
+  m2m_trainer::GraphSlot& slot = t->slots[si];
+  slot.calls += 1;
+  slot.last_use = ++t->tick;
+  t->cur_slot = si;
+  if (t->use_graph && slot.calls >= 2 && !slot.gexec) {                    // second call with this key: capture
     // a split pass becomes TWO graphs: the capture is closed and reopened where the decoder-side gradients are final, and the
     // replay records ev_mid between the two launches
     hipGraphExec_t first = nullptr;
-    const auto close_capture = [t](hipGraphExec_t* out) -> int {
+    int n_nodes = 0;
+    const auto close_capture = [t, &n_nodes](hipGraphExec_t* out) -> int {
       hipGraph_t graph = nullptr;
       const hipError_t ce = hipStreamEndCapture(t->s_main, &graph);
       if (ce != hipSuccess || !graph) {
@@ -3089,6 +3135,8 @@ extern "C" int m2m_train_forward_backward(m2m_trainer* t, const float* params_de
         set_error("m2m_train_forward_backward: graph capture failed: %s", hipGetErrorString(ce));
         return M2M_ERR_HIP;
       }
+      size_t nn = 0;
+      if (hipGraphGetNodes(graph, nullptr, &nn) == hipSuccess) n_nodes += (int)nn;
       const hipError_t ie = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
       (void)hipGraphDestroy(graph);
       if (ie != hipSuccess) { *out = nullptr; set_error("m2m_train_forward_backward: hipGraphInstantiate: %s", hipGetErrorString(ie)); return M2M_ERR_HIP; }
@@ -3112,23 +3160,25 @@ extern "C" int m2m_train_forward_backward(m2m_trainer* t, const float* params_de
       if (first) (void)hipGraphExecDestroy(first);
       if (last) (void)hipGraphExecDestroy(last);
       if (rc == M2M_OK && rc2 == M2M_OK) { set_error("m2m_train_forward_backward: the split pass never reached its split point"); rc = M2M_ERR_INVALID; }
+      slot.valid = false;                                                    // the next call starts this key over
       return rc != M2M_OK ? rc : rc2;
     }
-    if (split) { t->gexec = first; t->gexec2 = last; } else { t->gexec = last; }
-    t->graph_key = key;
+    if (split) { slot.gexec = first; slot.gexec2 = last; } else { slot.gexec = last; }
+    slot.nodes = n_nodes;
   }
-  if (t->gexec && key == t->graph_key) {
-    M2M_CHECK_HIP(hipGraphLaunch(t->gexec, t->s_main));
+  if (slot.gexec) {
+    M2M_CHECK_HIP(hipGraphLaunch(slot.gexec, t->s_main));
     if (split) {
       rc = release();
       if (rc != M2M_OK) return rc;
-      M2M_CHECK_HIP(hipGraphLaunch(t->gexec2, t->s_main));
+      M2M_CHECK_HIP(hipGraphLaunch(slot.gexec2, t->s_main));
     }
   } else {
     rc = run_pass(t, params_dev, t->xe[0], t->cond_buf, t->labels_buf, B, S, Ld, t->loss_dev, grads_dev, nullptr, t->s_main, t->s_side,
                   split ? &release : nullptr);
-    if (rc != M2M_OK) return rc;
+    if (rc != M2M_OK) { slot.valid = false; return rc; }
   }
+  if (release_at_end) { rc = release(); if (rc != M2M_OK) return rc; }
   M2M_CHECK_HIP(hipEventRecord(t->ev_out, t->s_main));
   M2M_CHECK_HIP(hipStreamWaitEvent(caller, t->ev_out, 0));
   M2M_CHECK_HIP(hipMemcpyAsync(loss_out_dev, t->loss_dev, 4, hipMemcpyDeviceToDevice, caller));
@@ -3165,6 +3215,12 @@ extern "C" int m2m_trainer_early_grad_ranges(const m2m_trainer* t, int64_t* out)
   out[0] = 0; out[1] = t->o_erb;
   out[2] = t->dec_begin; out[3] = t->dec_end - t->dec_begin;
   return M2M_OK;
+}
+
+extern "C" int m2m_trainer_graph_nodes(const m2m_trainer* t) {
+  if (!t) return M2M_ERR_INVALID;
+  const m2m_trainer::GraphSlot& s = t->slots[t->cur_slot];
+  return (s.valid && s.gexec) ? s.nodes : 0;
 }
 
 extern "C" int m2m_adafactor_step(m2m_trainer* t, float* params_dev, const float* grads_dev, void* stream) {

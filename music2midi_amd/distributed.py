@@ -16,7 +16,7 @@ collectives exist, both outside it:
 from __future__ import annotations
 
 import os
-from typing import List, Optional, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -182,6 +182,30 @@ def all_reduce_gradients_overlapped(flat_grads: torch.Tensor, early_ranges: Sequ
         w.wait()                       # the current stream continues behind the early pieces
     flat_grads.div_(world)
     return flat_grads.numel() * 4
+
+
+def reduce_logged(metrics: Dict[str, object], device=None) -> Dict[str, float]:
+    """What ``self.log(name, value, sync_dist=True)`` does in the reference (ref: music2midi/model.py:37,42,49,52): every
+    logged scalar becomes its MEAN over the ranks (Lightning's default ``reduce_fx="mean"`` with ``sync_dist=True``).  All
+    values travel in ONE all-reduce (a handful of doubles: SURVEY.md C2); values may be Python numbers or 0-dim tensors that
+    are still on the device (this is where they are read — one host sync for the whole set).  ``batch_size`` is a count, not
+    a metric: it is summed.  Without a process group the values are just converted."""
+    names = sorted(metrics)
+    if not names:
+        return {}
+    vals = [metrics[k] for k in names]
+    on_dev = [v for v in vals if torch.is_tensor(v)]
+    dev = device if device is not None else (on_dev[0].device if on_dev else torch.device("cpu"))
+    packed = torch.stack([v.detach().to(dev, torch.float64).reshape(()) if torch.is_tensor(v) else torch.tensor(float(v), dtype=torch.float64, device=dev)
+                          for v in vals])
+    world = 1
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        world = dist.get_world_size()
+        if dist.get_backend() == "nccl" and packed.device.type != "cuda":
+            packed = packed.cuda()
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+    out = packed.cpu().tolist()
+    return {k: (v if k == "batch_size" else v / world) for k, v in zip(names, out)}
 
 
 def barrier() -> None:

@@ -67,6 +67,8 @@ class Music2MIDI(nn.Module):
                 tr.close()
             limits = (max(B, old[0], int(self.config.dataloader.batch_size)), max(S, old[1]), max(L, old[2], 64))
             self._trainer = NativeTrainer(self.model, *limits, precision=getattr(self, "train_precision", None))
+            if state is None and self._resume_optimizer_state is not None:      # a checkpoint read before the first batch
+                state, self._resume_optimizer_state = self._resume_optimizer_state, None
             if state is not None:
                 self._trainer.load_optimizer_state(state)
             if D.dist.is_available() and D.dist.is_initialized() and D.dist.get_world_size() > 1 and self._trainer.device.type == "cuda":
@@ -79,31 +81,107 @@ class Music2MIDI(nn.Module):
             self._trainer.set_dropout(want, seed=int(getattr(self, "seed", 0)) + self.global_step)
         return self._trainer
 
+    _resume_optimizer_state = None
+
     def configure_optimizers(self):
         """ref model.py:27-30: Adafactor(self.parameters(), warmup_init=True) + AdafactorSchedule."""
         from .training import Adafactor, AdafactorSchedule
         optimizer = Adafactor(self)
         return [optimizer], [AdafactorSchedule(optimizer)]
 
+    # Labels are padded to the longest sequence of the batch (ref: music2midi/tokenizer.py:86-96), so the decoder length changes
+    # from batch to batch.  Rounded up to a multiple of LABEL_BUCKET with ignored (-100) positions the loss and every gradient are
+    # unchanged — an ignored position contributes nothing and, being causal, is seen by no scored one — while the trainer meets a
+    # handful of shapes instead of one per batch and replays their captured graphs (csrc/train.hip GraphSlot).
+    LABEL_BUCKET = 16
+
+    def _labels(self, notes_batch) -> torch.Tensor:
+        t5 = self.model
+        labels = t5.tokenizer(notes_batch)
+        labels[labels == t5.geometry.pad_token_id] = -100
+        pad = -labels.shape[1] % self.LABEL_BUCKET
+        if pad:
+            labels = torch.nn.functional.pad(labels, (0, pad), value=-100)
+        return labels
+
     def training_step(self, inputs: ModelInputs, batch_idx):
         """ref model.py:32-43.  Lightning calls backward() on the returned loss; here forward AND backward have
-        already run when this returns: every parameter's ``.grad`` holds d loss / d parameter (views of one flat
-        buffer), ready for ``distributed.all_reduce_gradients`` and ``optimizer.step()``."""
+        already been ENQUEUED when this returns: every parameter's ``.grad`` will hold d loss / d parameter (views of one flat
+        buffer), ready for ``distributed.all_reduce_gradients`` and ``optimizer.step()``.  Nothing here waits for the device: the
+        returned loss and ``self.logged["train/loss"]`` are 0-dim tensors on the GPU (``logged_metrics()`` reads them), so the
+        gradient all-reduce the caller enqueues next overlaps the backward pass that is still running."""
         t5 = self.model
-        labels = t5.tokenizer(inputs.notes_batch)
-        labels[labels == t5.geometry.pad_token_id] = -100
+        labels = self._labels(inputs.notes_batch)
         x = t5.encoder_inputs(inputs)
         tr = self._native_trainer(x.shape[0], x.shape[1], labels.shape[1])
         loss, _ = tr.forward_backward(x, inputs.cond_index, labels)
-        self.logged = {"train/loss": float(loss), "batch_size": int(x.shape[0])}
+        loss = loss[0].clone()                                # the trainer's loss word is rewritten by the next pass
+        self.logged = {"train/loss": loss, "batch_size": int(x.shape[0])}
         if (self.global_step + 1) % int(self.config.trainer.log_every_n_steps) == 0:
             self.logged["train/score"] = float(self.evaluate_batch(inputs)[0])
-        return loss[0]
+        return loss
 
-    def fit_batches(self, batches, optimizer=None, world_size: int = 1):
-        """Minimal stand-in for ``pl.Trainer.fit`` (ref train.py:40-41): step over an iterable of ModelInputs."""
+    def logged_metrics(self) -> dict:
+        """The values of the last step as Lightning would log them: ``self.log(..., sync_dist=True)`` in the reference
+        (ref model.py:37,42,49,52) means the MEAN over the data-parallel ranks — one packed all-reduce
+        (``distributed.reduce_logged``); this is also where device-resident values are read."""
+        return D.reduce_logged(dict(getattr(self, "logged", {}) or {}), device=self.device)
+
+    # -- checkpoints of a training run (ref train.py:41: trainer.fit(..., ckpt_path=args.ckpt)) ------------------------------
+    def save_checkpoint(self, path) -> None:
+        """A Lightning-layout ``.ckpt`` of the run: ``state_dict`` (``model.*`` keys incl. the torchaudio buffers), the optimizer
+        state as ``transformers.optimization.Adafactor.state_dict()`` lays it out (``optimizer_states[0]``), ``global_step``,
+        ``hyper_parameters`` — what ``load_from_checkpoint`` and ``fit_batches(ckpt_path=)`` (and the reference's own
+        ``trainer.fit(ckpt_path=)``) read."""
+        tr = self._trainer
+        opt = tr.optimizer_state_hf() if tr is not None else {"state": {}, "param_groups": []}
+        torch.cuda.synchronize(self.device) if self.device.type == "cuda" else None
+        torch.save({
+            "epoch": int(getattr(self, "current_epoch", 0)), "global_step": int(self.global_step), "pytorch-lightning_version": "2.1.0",
+            "state_dict": {k: v.detach().cpu().clone() for k, v in self.state_dict().items()},
+            "callbacks": {}, "optimizer_states": [opt],
+            "lr_schedulers": [{"base_lrs": [0.0], "last_epoch": int(self.global_step), "_step_count": int(self.global_step) + 1}],
+            "hparams_name": "kwargs", "hyper_parameters": dict(self.hparams),
+        }, path)
+
+    def resume_from_checkpoint(self, path) -> None:
+        """Weights, Adafactor state and step counter of a ``.ckpt`` written by ``save_checkpoint`` or by Lightning."""
+        ckpt = read_checkpoint(path)
+        state = ckpt["state_dict"] if "state_dict" in ckpt else ckpt
+        inner = {k[len("model."):]: v for k, v in state.items() if k.startswith("model.")}
+        tr = self._trainer
+        if tr is not None:                                   # the parameters are views of the trainer's flat buffer: copy in place
+            own = dict(self.model.named_parameters())
+            with torch.no_grad():
+                for k, v in (inner or state).items():
+                    if k in own:
+                        own[k].copy_(torch.as_tensor(v).to(own[k].device, own[k].dtype))
+            self.model._weights_epoch = getattr(self.model, "_weights_epoch", 0) + 1
+        else:
+            load_t5_state(self.model, inner if inner else state, strict=False)
+        self.global_step = int(ckpt.get("global_step", 0))
+        opts = ckpt.get("optimizer_states") or []
+        opt = opts[0] if opts else None
+        if opt is not None and opt.get("state"):
+            if tr is not None:
+                tr.load_optimizer_state(opt)
+            else:
+                self._resume_optimizer_state = opt
+        if tr is not None:
+            tr.dropout = -1.0                                # the mask sequence restarts from the restored step (see _native_trainer)
+
+    def fit_batches(self, batches, optimizer=None, world_size: int = 1, ckpt_path=None, save_path=None, save_every_n_steps: int = 0):
+        """Minimal stand-in for ``pl.Trainer.fit`` (ref train.py:40-41): step over an iterable of ModelInputs.  ``ckpt_path``
+        resumes a run (weights + Adafactor state + step counter) as ``trainer.fit(..., ckpt_path=)`` does; ``save_path`` is
+        (re)written every ``save_every_n_steps`` steps and at the end.  The host never waits for a step: losses stay on the device
+        until the loop is over, metrics are reduced over the ranks and read every ``trainer.log_every_n_steps`` steps
+        (``self.log_history``)."""
+        if ckpt_path is not None:
+            self.resume_from_checkpoint(ckpt_path)
         if optimizer is None:
             optimizer = self.configure_optimizers()[0][0]
+        log_every = max(1, int(self.config.trainer.log_every_n_steps))
+        self.log_history = getattr(self, "log_history", [])
         losses = []
         for i, batch in enumerate(batches):
             loss = self.training_step(batch, i)
@@ -114,16 +192,24 @@ class Music2MIDI(nn.Module):
                 D.all_reduce_gradients(tr.grads)
             optimizer.step()
             self.global_step += 1
-            losses.append(float(loss))
-        return losses
+            losses.append(loss)
+            if self.global_step % log_every == 0:
+                self.log_history.append(dict(self.logged_metrics(), step=self.global_step))
+            if save_path is not None and save_every_n_steps and self.global_step % save_every_n_steps == 0:
+                self.save_checkpoint(save_path)
+        if save_path is not None:
+            self.save_checkpoint(save_path)
+        return [float(v) for v in torch.stack(losses).cpu()] if losses else []
 
     def validation_step(self, inputs: ModelInputs, batch_idx):
         """ref model.py:45-54: teacher-forced loss + chroma score of a greedy decode; returns the LOSS (as the
         reference does).  Lightning's ``self.log`` does not exist here: the two values are kept in
-        ``self.logged`` under the reference's metric names."""
+        ``self.logged`` under the reference's metric names, already reduced over the ranks (``sync_dist=True``)."""
         loss = self.model(inputs).loss
         score = self.evaluate_batch(inputs)[0]
-        self.logged = {"val/loss": float(loss), "val/score": float(score), "batch_size": int(inputs.input_waveform.shape[0])}
+        self.logged = D.reduce_logged({"val/loss": loss, "val/score": float(score), "batch_size": int(inputs.input_waveform.shape[0])},
+                                      device=self.device)
+        self.logged["batch_size"] = int(self.logged["batch_size"])
         return loss
 
     # -- inference -----------------------------------------------------------

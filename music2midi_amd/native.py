@@ -96,6 +96,7 @@ _SIGNATURES = {
     "m2m_trainer_set_dropout": (C.c_int, [C.c_void_p, C.c_float, C.c_uint64]),
     "m2m_trainer_set_sync_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "m2m_trainer_early_grad_ranges": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "m2m_trainer_graph_nodes": (C.c_int, [C.c_void_p]),
     "m2m_adafactor_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "m2m_adafactor_get_step": (C.c_int, [C.c_void_p]),
     "m2m_adafactor_state_floats": (C.c_int64, [C.c_void_p]),

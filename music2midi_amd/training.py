@@ -104,6 +104,10 @@ class NativeTrainer:
         native.check(lib.m2m_trainer_early_grad_ranges(self.handle, r), "m2m_trainer_early_grad_ranges")
         self.early_ranges = [(int(r[0]), int(r[1])), (int(r[2]), int(r[3]))]
 
+    def graph_nodes(self) -> int:
+        """Launches per step: nodes of the captured graph(s) of the most recent shape (0 before its capture)."""
+        return int(native.load().m2m_trainer_graph_nodes(self.handle))
+
     def fits(self, B: int, S: int, L: int) -> bool:
         return B <= self.limits[0] and S <= self.limits[1] and L <= self.limits[2]
 
@@ -157,11 +161,76 @@ class NativeTrainer:
         return {"step": self.step_count, "second_moments": buf.cpu()}
 
     def load_optimizer_state(self, state: dict):
+        if "second_moments" not in state:                  # torch / Lightning layout (``optimizer.state_dict()`` of HF's Adafactor)
+            state = self.optimizer_state_from_hf(state)
         buf = state["second_moments"].to(self.device, torch.float32).contiguous()
+        n = int(native.load().m2m_adafactor_state_floats(self.handle))
+        if buf.numel() != n:
+            raise native.NativeError(f"optimizer state has {buf.numel()} floats, this model's Adafactor state has {n}")
         with torch.cuda.device(self.device):
             native.check(native.load().m2m_adafactor_state_import(self.handle, buf.data_ptr(), int(state["step"]),
                                                                   native.stream_handle(self.device)), "m2m_adafactor_state_import")
             torch.cuda.synchronize(self.device)
+
+    # -- the optimizer state as transformers.optimization.Adafactor keeps it (what a Lightning .ckpt carries) -------------
+    # The native state is one flat buffer in tensor order: a matrix owns R[rows] | C[cols] (HF: exp_avg_sq_row / exp_avg_sq_col), a
+    # vector V[n] (HF: exp_avg_sq) — csrc/train.hip build_optimizer.  torch numbers an optimizer's parameters in the order of
+    # ``module.parameters()``; the module tree registers its parameters in the order of HuggingFace T5's, so index i here is index
+    # i of ``Adafactor(self.parameters())`` in ref: music2midi/model.py:28.
+    _HF_GROUP = {"lr": None, "eps": (1e-30, 1e-3), "clip_threshold": 1.0, "decay_rate": -0.8, "beta1": None, "weight_decay": 0.0,
+                 "scale_parameter": True, "relative_step": True, "warmup_init": True}
+
+    def _state_slices(self):
+        """[(name, shape, offset of R or V, offset of C or None)] in the native tensor order."""
+        out, off = [], 0
+        for name, (_, shape) in self.layout.items():
+            if len(shape) == 2:
+                out.append((name, shape, off, off + shape[0]))
+                off += shape[0] + shape[1]
+            else:
+                out.append((name, shape, off, None))
+                off += shape[0]
+        return out
+
+    def _param_order(self):
+        return [n for n, _ in self.module.named_parameters()]       # (aliases of the shared embedding appear once, as in torch)
+
+    def optimizer_state_hf(self) -> dict:
+        own = self.optimizer_state()
+        flat, step = own["second_moments"], own["step"]
+        index = {n: i for i, n in enumerate(self._param_order())}
+        params = dict(self.module.named_parameters())
+        state = {}
+        for name, shape, o_r, o_c in self._state_slices():
+            if step == 0:
+                continue
+            rms = float(params[name].detach().float().norm() / params[name].numel() ** 0.5)
+            if o_c is not None:
+                state[index[name]] = {"step": step, "exp_avg_sq_row": flat[o_r:o_r + shape[0]].clone(),
+                                      "exp_avg_sq_col": flat[o_c:o_c + shape[1]].clone(), "RMS": rms}
+            else:
+                state[index[name]] = {"step": step, "exp_avg_sq": flat[o_r:o_r + shape[0]].clone(), "RMS": rms}
+        return {"state": dict(sorted(state.items())), "param_groups": [dict(self._HF_GROUP, params=list(range(len(index))))]}
+
+    def optimizer_state_from_hf(self, hf: dict) -> dict:
+        index = {n: i for i, n in enumerate(self._param_order())}
+        n = int(native.load().m2m_adafactor_state_floats(self.handle))
+        flat = torch.zeros(n, dtype=torch.float32)
+        steps = set()
+        st = {int(k): v for k, v in hf.get("state", {}).items()}
+        for name, shape, o_r, o_c in self._state_slices():
+            e = st.get(index[name])
+            if e is None:
+                continue
+            steps.add(int(e["step"]))
+            if o_c is not None:
+                flat[o_r:o_r + shape[0]] = torch.as_tensor(e["exp_avg_sq_row"], dtype=torch.float32).reshape(-1)
+                flat[o_c:o_c + shape[1]] = torch.as_tensor(e["exp_avg_sq_col"], dtype=torch.float32).reshape(-1)
+            else:
+                flat[o_r:o_r + shape[0]] = torch.as_tensor(e["exp_avg_sq"], dtype=torch.float32).reshape(-1)
+        if len(steps) > 1:
+            raise native.NativeError(f"optimizer state with different step counts per parameter {sorted(steps)[:4]}: one step counter is kept")
+        return {"step": steps.pop() if steps else 0, "second_moments": flat}
 
 
 class Adafactor:

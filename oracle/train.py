@@ -64,6 +64,43 @@ class DropoutMasks:
         return torch.from_numpy(keep.astype(np.float32) * np.float32(self.scale))
 
 
+class _MxLinear(torch.autograd.Function):
+    """y = x . W^T as the device's fp8 training mode computes it AND differentiates it (csrc/train.hip Ops::mm / dX / dW,
+    csrc/mx8.hip).  Each of the three products quantises ITS OWN operands along ITS OWN reduction dimension:
+
+    * forward  y  = Qk(bf16(x)) . Qk(W)^T          — blocks of 32 along the input features K; the activation is quantised from
+                                                     its bf16 storage, the weight from the fp32 master copy;
+    * dX       dx = Qn(bf16(dy)) . Qn(W^T)^T       — blocks along the OUTPUT features N: a different quantisation of the same
+                                                     weight (``mxq_weights_kernel`` keeps both images), and dy itself is
+                                                     quantised (format ``grad_fmt``);
+    * dW       dw = bf16(dy)^T . bf16(x)           — the grouped bf16 weight-gradient launch (default), or with ``dw_fp8``
+                                                     Qm(dy^T) . Qm(x^T)^T with blocks along the rows M (zero-padded).
+
+    A straight-through estimator over the forward alone (round 2's emulation) differentiates a different function: it leaves dy
+    and the second weight image unquantised, which is where the 0.93-0.95 gradient cosine of round 2 came from."""
+
+    @staticmethod
+    def forward(ctx, x, w, dw_fp8, grad_fmt):
+        from .mx8 import mx_quant_dequant
+        xb = x.detach().bfloat16().float()
+        ctx.save_for_backward(xb, w.detach())
+        ctx.dw_fp8, ctx.grad_fmt = dw_fp8, grad_fmt
+        return mx_quant_dequant(xb, "e4m3") @ mx_quant_dequant(w.detach(), "e4m3").T
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .mx8 import mx_quant_dequant
+        xb, w = ctx.saved_tensors
+        dyb = dy.bfloat16().float()
+        dx = mx_quant_dequant(dyb, ctx.grad_fmt) @ mx_quant_dequant(w.T.contiguous(), "e4m3").T
+        dy2, x2 = dyb.reshape(-1, dyb.shape[-1]), xb.reshape(-1, xb.shape[-1])
+        if ctx.dw_fp8:
+            dw = mx_quant_dequant(dy2.T.contiguous(), ctx.grad_fmt) @ mx_quant_dequant(x2.T.contiguous(), "e4m3").T
+        else:
+            dw = dy2.T @ x2
+        return dx, dw, None, None
+
+
 def leaf_params(sd: Dict[str, np.ndarray]) -> Dict[str, torch.Tensor]:
     """state dict (numpy, keys ``transformer.*`` / ``conditioning.*``) -> fp32 leaf tensors with requires_grad."""
     return {k: torch.from_numpy(np.asarray(v, dtype=np.float32)).clone().requires_grad_(True)
@@ -77,6 +114,8 @@ class T5TrainOracle:
         self.p = params
         self.masks = None
         self.mx8 = False          # True: emulate the fp8 training mode's projection products (see _lin)
+        self.mx8_dw = False       # ... the weight gradients on MXFP8 too (M2M_FP8_PARTS=fwd,dx,dw)
+        self.mx8_grad_fmt = "e4m3"
 
     def w(self, name: str) -> torch.Tensor:
         return self.p["transformer." + name]
@@ -100,15 +139,12 @@ class T5TrainOracle:
         return x * self.masks.mask(site, x.numel()).view(x.shape)
 
     def _lin(self, x, wname):
-        """x @ W^T.  With ``self.mx8`` the product is the fp8 training mode's: both operands MXFP8-quantised along the
-        reduction dimension (oracle/mx8.py), straight-through in the backward — d/dx sees the quantised W, d/dW the
-        quantised x, exactly the operands the device's dX / dW products use (csrc/train.hip fp8 mode)."""
+        """x @ W^T.  With ``self.mx8`` the product and BOTH of its gradient products are the fp8 training mode's
+        (``_MxLinear``: every product quantises its own operands along its own reduction dimension, as csrc/train.hip does);
+        lm_head is not a ``_lin`` product: it stays in the bf16 mode's arithmetic on the device too."""
         w = self.w(wname)
         if getattr(self, "mx8", False):
-            from .mx8 import mx_quant_dequant
-            # the device quantises the activation from its bf16 storage, the weight from the fp32 master
-            x = x + (mx_quant_dequant(x.detach().bfloat16().float(), "e4m3") - x).detach()
-            w = w + (mx_quant_dequant(w.detach(), "e4m3") - w).detach()
+            return _MxLinear.apply(x, w, bool(self.mx8_dw), self.mx8_grad_fmt)
         return x @ w.T
 
     def _attn(self, hq, hkv, prefix, bias, site_probs=-1):

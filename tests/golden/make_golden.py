@@ -140,6 +140,49 @@ def make_t5(out_path):
     np.savez_compressed(out_path, **flat)
 
 
+# ------------------------------------------------------------------ bf16-mode goldens at the headline size
+def make_t5_bf16(out_path):
+    """The bf16 throughput mode's pin at BASELINE configs[2]'s geometry (S = 864, max_length 1024): greedy ids and top-2 logit
+    margins of ``T5Oracle(emulate="bf16")`` — the oracle that rounds to bfloat16 where the device's bf16 mode stores bfloat16 —
+    (a) on the two embedding clips of the ``full_s864`` case (whose fp32 ids are pinned to HuggingFace in t5.npz), and
+    (b) on clips 0 and 1 of bench.py's own workload (synthetic 10 s waveforms -> log-mel -> conditioning rows, plain seed-0
+    weights), with the fp32 oracle's ids beside them.  The fp32 oracle is the one pinned to HF (make_t5); the bf16 emulation is
+    the same code with its rounding points switched on, so this fixture pins the DEVICE against the emulation, not the emulation
+    against a third party (none exists for this rounding scheme)."""
+    from oracle.logmel import conditioning
+    cfg = ref_config()
+    geom = T5Geometry(dict(cfg["model"]["t5"]))
+    data = {}
+    # (a)
+    sd = synth.t5_state_dict(geom, seed=0)
+    synth.perturb_layer_norms(sd, 0)
+    x = embeds(2, 864, geom.d_model)
+    ids, margins = T5Oracle(geom, sd, emulate="bf16").generate(x, 1024, return_margins=True)
+    ids32 = T5Oracle(geom, sd).generate(x, 1024)
+    z = np.load(HERE / "t5.npz")
+    assert np.array_equal(ids32.numpy(), z["full_s864/ids"].astype(np.int64)), "the fp32 oracle no longer reproduces the HF golden"
+    data["full_s864_bf16/ids"] = ids.numpy().astype(np.int16)
+    data["full_s864_bf16/margins"] = margins.numpy().astype(np.float32)
+    print(f"[t5_bf16] full_s864: ids {tuple(ids.shape)}, min margin {margins.min():.4f}, agreement with fp32 {(ids == ids32).float().mean():.3f}")
+    # (b)
+    sd = synth.t5_state_dict(geom, seed=0)
+    sp = cfg["spectrogram"]
+    T = 220500
+    wav = torch.from_numpy(synth.waveform_batch(0, 2, T))
+    idx = torch.from_numpy(synth.cond_index_batch(0, 2))
+    emb = [torch.from_numpy(sd[f"conditioning.embeds.{i}.weight"]) for i in range(2)]
+    xw = conditioning(LogMelOracle(cfg["model"]["sample_rate"], sp["n_fft"], sp["hop_length"], sp["f_min"], geom.d_model)(wav), idx, emb)
+    assert xw.shape == (2, 864, geom.d_model)
+    ids, margins = T5Oracle(geom, sd, emulate="bf16").generate(xw, 1024, return_margins=True)
+    ids32, margins32 = T5Oracle(geom, sd).generate(xw, 1024, return_margins=True)
+    data["bench_clips_bf16/ids"] = ids.numpy().astype(np.int16)
+    data["bench_clips_bf16/margins"] = margins.numpy().astype(np.float32)
+    data["bench_clips_fp32/ids"] = ids32.numpy().astype(np.int16)
+    data["bench_clips_fp32/margins"] = margins32.numpy().astype(np.float32)
+    print(f"[t5_bf16] bench clips 0-1: min margin bf16 {margins.min():.4f} / fp32 {margins32.min():.4f}, agreement {(ids == ids32).float().mean():.3f}")
+    np.savez_compressed(out_path, **data)
+
+
 # ------------------------------------------------------------------ frontend goldens
 def make_frontend(out_path):
     cfg = ref_config()
@@ -295,6 +338,8 @@ if __name__ == "__main__":
         make_t5(HERE / "t5.npz")
     if not only or "train" in only:
         make_train(HERE / "train.npz")
+    if not only or "t5_bf16" in only:
+        make_t5_bf16(HERE / "t5_bf16.npz")
     for p in sorted(HERE.glob("*.npz")) + sorted(HERE.glob("*.json")):
         print(p.name, p.stat().st_size, "bytes")
     # never leave bytecode in the read-only reference tree

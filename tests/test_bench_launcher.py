@@ -11,10 +11,10 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 
 
-def _run(extra_env=None, gpus=2):
+def _run(extra_env=None, gpus=2, extra_args=()):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     env.update(extra_env or {})
-    return subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", str(gpus), "--dry-run", "--batch", "3"],
+    return subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", str(gpus), "--dry-run", "--batch", "3", *extra_args],
                           env=env, capture_output=True, text=True, timeout=300)
 
 
@@ -43,3 +43,44 @@ def test_bench_honours_the_torchrun_environment():
                        env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+def test_bench_watchdog_ends_a_hung_launch_and_names_the_live_ranks(tmp_path):
+    """A rank stuck in communicator set-up is the likeliest failure of a first 8-GPU run: the launcher must not wait for the
+    driver's timeout.  Rank 1 hangs (test hook); the parent gives up after M2M_BENCH_TIMEOUT, names it, shows its log, ends it."""
+    import time
+    t0 = time.monotonic()
+    r = _run({"M2M_BENCH_HANG_RANK": "1", "M2M_BENCH_TIMEOUT": "20", "M2M_BENCH_LOG_DIR": str(tmp_path)})
+    assert r.returncode == 124, (r.returncode, r.stderr[-1500:])
+    assert time.monotonic() - t0 < 120
+    assert "watchdog: ranks [0, 1] still running" in r.stderr             # rank 0 waits for rank 1 inside the collective: both are named
+    assert "hanging on purpose" in r.stderr                              # the tail of the live rank's own log is shown
+    assert (tmp_path / "bench_rank0.err").exists() and "hanging on purpose" in (tmp_path / "bench_rank1.err").read_text()
+
+
+def test_bench_train_mode_dry_run_averages_gradients_and_metrics_over_the_ranks(tmp_path):
+    """`--mode train --gpus 2 --dry-run`: BASELINE configs[4]'s data-parallel plumbing on gloo — the 121.6 MB flat gradient
+    averaged in one piece and in the overlapped form's pieces, the sync_dist metric mean (ref model.py:37), pinned host threads."""
+    r = _run({"M2M_BENCH_LOG_DIR": str(tmp_path)}, extra_args=("--mode", "train"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["mode"] == "train" and rec["world"] == 2 and rec["backend"] == "gloo" and rec["grad_average_ok"] is True
+    assert rec["grad_allreduce_bytes"] > 30_000_000 * 4
+    assert rec["logged"]["train/loss"] == 1.5 and rec["logged"]["train/score"] == 0.125 and rec["logged"]["batch_size"] == 32
+    assert 1 <= rec["host_threads"] <= max(1, (os.cpu_count() or 2) // 2)
+
+
+def test_pmc_summary_without_the_launch_width_header_is_refused(tmp_path, capsys):
+    sys.path.insert(0, str(ROOT))
+    import bench
+    line = ("m2m::dec_attn_kernel<m2m::bf16_t, false, 1>   launches    288  FETCH_SIZE/launch    14462.0 KiB (x2 corrected    29.62 MB)  "
+            "WRITE_SIZE/launch     430.0 KiB ( 0.440 MB)\n")
+    (tmp_path / "r3_x_pmc_traffic_summary.txt").write_text(line)
+    assert bench.pmc_traffic_bytes("dec_attn_kernel<m2m::bf16_t, false,", 32, profiles_dir=tmp_path) is None
+    assert "clips/launch" in capsys.readouterr().err
+    (tmp_path / "r3_x_pmc_traffic_summary.txt").write_text("# decode kernels: clips/launch = 16\n" + line)
+    got = bench.pmc_traffic_bytes("dec_attn_kernel<m2m::bf16_t, false,", 32, profiles_dir=tmp_path)
+    assert abs(got - 2 * (29.62 + 0.44) * 1e6) < 1.0                       # two 16-clip launches make the 32-clip launch set
+    # the committed summary of the newest round carries the header and gives ~1.06x the algorithmic 56.7 MB
+    real = bench.pmc_traffic_bytes("dec_attn_kernel<m2m::bf16_t, false,", 32)
+    assert real is None or 0.9 * 56.72e6 < real < 1.3 * 56.72e6, real

@@ -172,3 +172,28 @@ def test_gloo_world2_generate_sharded_returns_clip_order(n_clips):
         p.join(120)
         assert p.exitcode == 0
     assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]
+
+
+def _logged_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    D.init_process_group("gloo")
+    out = D.reduce_logged({"train/loss": torch.tensor(2.0 + rank), "train/score": 0.5 * rank, "batch_size": 16})
+    assert out == {"train/loss": 2.5, "train/score": 0.25, "batch_size": 32}, out
+    assert D.reduce_logged({}) == {}
+    dist.destroy_process_group()
+    q.put(rank)
+
+
+def test_gloo_world2_logged_metrics_are_averaged_like_sync_dist():
+    """ref model.py:37,42,49,52: self.log(..., sync_dist=True) = the mean over the ranks, in one packed all-reduce."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_logged_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]
+    assert D.reduce_logged({"val/loss": torch.tensor(3.0), "batch_size": 4}) == {"val/loss": 3.0, "batch_size": 4}      # single process

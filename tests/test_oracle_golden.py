@@ -116,3 +116,21 @@ def test_training_oracle_reproduces_huggingface_golden(golden_dir):
         opt.step(grads)
     for i, k in enumerate(keys):
         assert abs(params[k].detach().double().abs().sum().item() - z["param_abs_sum_after3"][i]) <= 1e-6 * z["param_abs_sum_after3"][i], k
+
+
+def test_bf16_emulating_oracle_reproduces_its_headline_fixture_prefix(golden_dir):
+    """tests/golden/t5_bf16.npz (the bf16 mode's pin at S = 864): the oracle regenerates the first 24 tokens and margins of the
+    committed 1024 (the whole run takes ~40 s; `make_golden.py t5_bf16` regenerates all of it), and the fixture's fp32 twin is the
+    HF-pinned full_s864 case."""
+    z = np.load(golden_dir / "t5_bf16.npz")
+    geom = T5Geometry(DEFAULT_CONFIG["model"]["t5"])
+    sd = synth.t5_state_dict(geom, seed=0)
+    synth.perturb_layer_norms(sd, 0)
+    x = embeds(2, 864, geom.d_model)
+    ids, margins = T5Oracle(geom, sd, emulate="bf16").generate(x, 24, return_margins=True)
+    want = z["full_s864_bf16/ids"].astype(np.int64)
+    assert want.shape == (2, 1024) and z["full_s864_bf16/margins"].shape == (2, 1023)
+    assert np.array_equal(ids.numpy(), want[:, :24])
+    assert np.abs(margins.numpy() - z["full_s864_bf16/margins"][:, :23]).max() < 1e-3
+    assert z["bench_clips_bf16/ids"].shape == z["bench_clips_fp32/ids"].shape == (2, 1024)
+    assert (z["bench_clips_bf16/ids"][:, 0] == 1).all() and z["bench_clips_bf16/margins"].min() > 0

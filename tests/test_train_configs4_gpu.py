@@ -1,0 +1,155 @@
+"""GPU parity of the training step AT BASELINE configs[4]'s own per-GPU shape and dtypes: the full model (ref config.yaml
+model.t5), 16 clips per GPU (batch 128 over 8 GPUs; ref config.yaml:44 trains batches of 16 too), 3 s segments at
+dataset.sample_rate 22 050 Hz -> 66 150 samples -> 259 frames -> S = 261 (ref config.yaml:2,4), 256 label positions per clip with
+ragged ignored tails (-100, ref transformer.py:30).  ref: music2midi/model.py:32-38, transformer.py:28-39.
+
+The oracle (autograd over oracle/train.py, pinned to HuggingFace by tests/golden/train.npz) runs ONCE per module on the host
+(~15 s each for the plain and the MX-emulating pass on 8-16 threads)."""
+import copy
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from music2midi_amd import synth
+from music2midi_amd.checkpoint import load_t5_state
+from music2midi_amd.config import DEFAULT_CONFIG, T5Geometry
+
+pytestmark = pytest.mark.gpu
+
+B, F, LD = 16, 259, 256          # S = F + 2 = 261
+
+
+@pytest.fixture(scope="module")
+def c4():
+    from oracle.train import T5TrainOracle, leaf_params
+    torch.set_num_threads(min(16, os.cpu_count() or 16))
+    geom = T5Geometry(DEFAULT_CONFIG["model"]["t5"])
+    sd = synth.t5_state_dict(geom, seed=0)
+    synth.perturb_layer_norms(sd, 0)
+    feats = torch.from_numpy(synth.normal(5, "feats", (B, F, geom.d_model), 2.0))
+    cond = torch.from_numpy(synth.cond_index_batch(2, B))
+    labels = torch.from_numpy((synth.uniform01(4, "labels", B * LD) * 330).astype(np.int64).reshape(B, LD)) + 3
+    for b in range(B):                       # ragged label lengths as a real batch has them: up to 90 ignored positions at the tail
+        cut = (b * 37) % 91
+        if cut:
+            labels[b, LD - cut:] = -100
+    x = torch.zeros((B, F + 2, geom.d_model))
+    x[:, 2:] = feats
+    orc = T5TrainOracle(geom, leaf_params(sd))
+    t0 = time.perf_counter()
+    loss, logits, grads = orc.loss_and_grads(feats, cond, labels)
+    t_plain = time.perf_counter() - t0
+    print(f"[configs4] oracle forward+backward on the host: {t_plain:.1f} s ({torch.get_num_threads()} threads), loss {loss.item():.5f}")
+    return dict(geom=geom, sd=sd, feats=feats, cond=cond, labels=labels, x=x, orc=orc, loss=loss, logits=logits, grads=grads)
+
+
+def _trainer(c4, precision, **env):
+    from music2midi_amd.training import NativeTrainer
+    from music2midi_amd.transformer import T5Transformer
+    model = T5Transformer(copy.deepcopy(DEFAULT_CONFIG), precision="fp32")
+    load_t5_state(model, c4["sd"], strict=False)
+    model = model.cuda()
+    return model, NativeTrainer(model, B, F + 2, LD, precision=precision)
+
+
+def _agreement(tr, ref):
+    cs, ws, worst_max = [], [], 0.0
+    for name, (off, shape) in tr.layout.items():
+        g = tr.grads[off:off + int(np.prod(shape))].cpu().double()
+        r = ref[name].reshape(-1).double()
+        if r.norm() < 1e-12:
+            continue
+        cs.append((float(torch.dot(g, r) / (g.norm() * r.norm() + 1e-30)), name))
+        ws.append(float((g - r).norm() / r.norm()))
+        worst_max = max(worst_max, float((g - r).abs().max() / (r.abs().max() + 1e-30)))
+    return cs, ws, worst_max
+
+
+def test_fp32_mode_every_gradient_matches_autograd_at_the_config_shape(c4):
+    model, tr = _trainer(c4, "fp32")
+    loss, logits = tr.forward_backward(c4["x"].cuda(), c4["cond"].cuda(), c4["labels"].cuda(), want_logits=True)
+    assert abs(loss.item() - c4["loss"].item()) < 1e-4 * abs(c4["loss"].item()), (loss.item(), c4["loss"].item())
+    assert (logits.cpu() - c4["logits"]).abs().max() < 2e-3
+    worst = {}
+    for name, (off, shape) in tr.layout.items():
+        g = tr.grads[off:off + int(np.prod(shape))].view(shape).cpu()
+        r = c4["grads"][name]
+        worst[name] = float((g - r).abs().max() / (r.abs().max() + 1e-20))
+    bad = {k: v for k, v in worst.items() if v > 1e-4}
+    print(f"configs[4] shape, fp32: loss {loss.item():.6f} (autograd {c4['loss'].item():.6f}); worst gradient rel err {max(worst.values()):.2e} "
+          f"over {len(worst)} tensors")
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:5]
+    g1 = tr.grads.clone()                                   # deterministic
+    tr.forward_backward(c4["x"].cuda(), c4["cond"].cuda(), c4["labels"].cuda())
+    assert torch.equal(g1, tr.grads)
+    tr.close()
+
+
+def test_bf16_mode_tracks_autograd_at_the_config_shape(c4):
+    model, tr = _trainer(c4, "bf16")
+    loss, _ = tr.forward_backward(c4["x"].cuda(), c4["cond"].cuda(), c4["labels"].cuda())
+    cs, ws, _ = _agreement(tr, c4["grads"])
+    cmin = min(cs)
+    print(f"configs[4] shape, bf16: loss {loss.item():.4f} vs fp32 autograd {c4['loss'].item():.4f}; gradient cosine min {cmin[0]:.5f} ({cmin[1]}), "
+          f"median {np.median([c for c, _ in cs]):.5f}, worst rel l2 {max(ws):.3e}")
+    assert abs(loss.item() - c4["loss"].item()) < 2e-2 * abs(c4["loss"].item())
+    assert cmin[0] > 0.995 and max(ws) < 0.1
+    tr.close()
+
+
+@pytest.mark.parametrize("parts", [None, "fwd,dx,dw"])
+def test_fp8_mode_matches_the_mx_emulating_autograd_at_the_config_shape(c4, parts, monkeypatch):
+    """configs[4]'s dtype.  The emulating oracle quantises every product's operands the way that product does on the device
+    (oracle/train.py _MxLinear: forward along K, dX along N with dY quantised too, dW bf16 or along M), so the comparison is
+    device arithmetic against the same function differentiated on the host."""
+    if parts:
+        monkeypatch.setenv("M2M_FP8_PARTS", parts)
+    model, tr = _trainer(c4, "fp8")
+    loss, _ = tr.forward_backward(c4["x"].cuda(), c4["cond"].cuda(), c4["labels"].cuda())
+    g1 = tr.grads.clone()
+    loss_b, _ = tr.forward_backward(c4["x"].cuda(), c4["cond"].cuda(), c4["labels"].cuda())
+    assert torch.equal(g1, tr.grads) and loss.item() == loss_b.item()
+    orc = c4["orc"]
+    orc.mx8, orc.mx8_dw = True, bool(parts)
+    try:
+        t0 = time.perf_counter()
+        loss_o, _, grads_o = orc.loss_and_grads(c4["feats"], c4["cond"], c4["labels"])
+        dt = time.perf_counter() - t0
+    finally:
+        orc.mx8, orc.mx8_dw = False, False
+    cs, ws, _ = _agreement(tr, grads_o)
+    ps, _, _ = _agreement(tr, c4["grads"])
+    cmin = min(cs)
+    print(f"configs[4] shape, fp8 ({parts or 'fwd,dx'}): loss {loss.item():.4f} (MX-emulating autograd {loss_o.item():.4f} in {dt:.0f} s, fp32 autograd "
+          f"{c4['loss'].item():.4f}); gradient cosine vs the emulation min {cmin[0]:.4f} ({cmin[1]}) / median {np.median([c for c, _ in cs]):.4f}, "
+          f"worst rel l2 {max(ws):.3f}; vs unquantised autograd min {min(ps)[0]:.4f} / median {np.median([c for c, _ in ps]):.4f}")
+    assert abs(loss.item() - loss_o.item()) < 5e-3 * abs(loss_o.item())
+    assert cmin[0] > 0.98 and np.median([c for c, _ in cs]) > 0.99
+    tr.close()
+
+
+def test_dropout_step_is_reproducible_and_graph_replay_equals_direct_issue_at_the_config_shape(c4, monkeypatch):
+    from music2midi_amd.training import NativeTrainer
+    model, tr_graph = _trainer(c4, "bf16")
+    monkeypatch.setenv("M2M_TRAIN_GRAPH", "0")
+    tr_direct = NativeTrainer(model, B, F + 2, LD, precision="bf16")
+    x, cond, labels = c4["x"].cuda(), c4["cond"].cuda(), c4["labels"].cuda()
+    for tr in (tr_graph, tr_direct):
+        tr.set_dropout(0.1, seed=21)
+    losses = []
+    for call in range(4):                                    # call 0 direct, call 1 captures, 2.. replay
+        la, _ = tr_graph.forward_backward(x, cond, labels)
+        ga = tr_graph.grads.clone()
+        lb, _ = tr_direct.forward_backward(x, cond, labels)
+        assert la.item() == lb.item() and torch.equal(ga, tr_direct.grads), f"call {call}: graph replay differs from direct issue"
+        losses.append(la.item())
+    assert len(set(losses)) == 4                             # the masks advance from call to call
+    tr_graph.set_dropout(0.1, seed=21)                       # and the sequence restarts reproducibly
+    l0, _ = tr_graph.forward_backward(x, cond, labels)
+    assert l0.item() == losses[0]
+    # the loss with dropout stays near the dropout-free one (a statistical bound, not a parity claim)
+    assert abs(l0.item() - c4["loss"].item()) < 0.1 * abs(c4["loss"].item())
+    tr_graph.close(); tr_direct.close()

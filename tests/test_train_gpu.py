@@ -252,7 +252,7 @@ def test_fp8_mode_matches_the_mx_emulating_oracle(cfg_name, B, F, Ld, parts, mon
     loss2, _ = tr.forward_backward(x.cuda(), cond.cuda(), labels.cuda())
     assert torch.equal(g1, tr.grads) and loss.item() == loss2.item()                  # deterministic
     loss_plain, _, grads_plain = orc.loss_and_grads(feats, cond, labels)
-    orc.mx8 = True
+    orc.mx8, orc.mx8_dw = True, bool(parts)          # every product's operands quantised the way that product does (oracle/train.py _MxLinear)
     loss_o, _, grads_o = orc.loss_and_grads(feats, cond, labels)
 
     def agreement(ref):
@@ -272,7 +272,7 @@ def test_fp8_mode_matches_the_mx_emulating_oracle(cfg_name, B, F, Ld, parts, mon
           f"the emulating oracle min {cmin:.4f} / median {cmed:.4f} (worst rel l2 {worst:.3f}); vs the unquantised oracle min {pmin:.4f} / median {pmed:.4f}")
     assert abs(loss.item() - loss_o.item()) < 1e-2 * abs(loss_o.item())
     assert abs(loss.item() - loss_plain.item()) < 3e-2 * abs(loss_plain.item())
-    assert cmin > (0.97 if cfg_name == "tiny" else 0.93) and cmed > (0.985 if cfg_name == "tiny" else 0.95)
+    assert cmin > 0.98 and cmed > 0.99
     if cfg_name == "tiny":                            # and it trains (Adafactor's warm-up steps are ~1e-6: the first few do not
         loss0 = loss.item()                           # move an FP8-quantised weight at all, so give it a while); NB `loss` is
         for _ in range(150):                          # the trainer's own device scalar, overwritten by every call
@@ -362,3 +362,166 @@ def test_split_backward_releases_final_decoder_gradients_early(precision):
         torch.cuda.synchronize()
         assert loss_s.item() == loss_w.item() and torch.equal(tr_split.grads, tr_whole.grads)
     tr_split.close(); tr_whole.close()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_a_graph_per_shape_survives_other_shapes_in_between(precision, monkeypatch):
+    """Labels are padded to the longest sequence of the batch, so (B, S, L) changes from step to step and comes back.  The grouped
+    weight-gradient launch reads a device-resident table of operand pointers and reduction lengths; every cached shape owns its
+    own table slot, so a captured graph replays ITS table whatever ran in between (round 2 kept one table: A, A, B, A replayed
+    A's graph over B's table).  Three shapes interleaved, A A B A B B A C A C B A — every call bit-identical to a trainer
+    that never captures."""
+    from music2midi_amd.training import NativeTrainer
+    shapes = {"A": (3, 21, 14), "B": (3, 21, 9), "C": (2, 30, 14)}
+    Bm, Fm, Lm = 3, 30, 14
+    model, tr_graph, orc, params, geom, x, feats, cond, labels = _setup(tiny_config(), precision, Bm, Fm, Lm)
+    monkeypatch.setenv("M2M_TRAIN_GRAPH", "0")
+    tr_direct = NativeTrainer(model, Bm, Fm + 2, Lm, precision=precision)
+    for tr in (tr_graph, tr_direct):
+        tr.set_dropout(0.1, seed=3)
+    for call, name in enumerate("AABABBACACBA"):
+        b, f, l = shapes[name]
+        xi = (x[:b, :f + 2] + 0.01 * call).contiguous().cuda()
+        ci, li = cond[:b].cuda(), labels[:b, :l].contiguous().cuda()
+        la, _ = tr_graph.forward_backward(xi, ci, li)
+        ga = tr_graph.grads.clone()
+        lb, _ = tr_direct.forward_backward(xi, ci, li)
+        assert la.item() == lb.item() and torch.equal(ga, tr_direct.grads), f"call {call} (shape {name}): graph path differs from direct issue"
+    tr_graph.close(); tr_direct.close()
+
+
+def test_more_shapes_than_graph_slots_recycles_the_least_recently_used(monkeypatch):
+    from music2midi_amd.training import NativeTrainer
+    model, tr_graph, orc, params, geom, x, feats, cond, labels = _setup(tiny_config(), "fp32", 3, 21, 14)
+    monkeypatch.setenv("M2M_TRAIN_GRAPH", "0")
+    tr_direct = NativeTrainer(model, 3, 23, 14, precision="fp32")
+    order = list(range(3, 14)) * 2 + [3, 3, 13, 13, 3]          # 11 label lengths (> 8 slots), twice round, then revisits
+    for call, l in enumerate(order):
+        li = labels[:, :l].contiguous().cuda()
+        la, _ = tr_graph.forward_backward(x.cuda(), cond.cuda(), li)
+        ga = tr_graph.grads.clone()
+        lb, _ = tr_direct.forward_backward(x.cuda(), cond.cuda(), li)
+        assert la.item() == lb.item() and torch.equal(ga, tr_direct.grads), f"call {call} (L = {l})"
+    tr_graph.close(); tr_direct.close()
+
+
+@pytest.mark.parametrize("env", [{"M2M_TRAIN_DW_GROUP": "0"}, {"M2M_TRAIN_DW_GROUP": "0", "M2M_TRAIN_SIDE": "0"}])
+def test_sync_stream_without_a_split_pass_is_released_behind_the_whole_pass(env, monkeypatch):
+    """A sync stream is set but the pass cannot be split (per-product weight gradients): the stream must be released at the END of
+    the pass, so the early all-reduce a caller enqueues on it reads finished gradients (round 2 never released it: a race)."""
+    from music2midi_amd import distributed as D
+    from music2midi_amd.training import NativeTrainer
+    B, F, Ld = 3, 37, 19
+    model, tr_ref, orc, params, geom, x, feats, cond, labels = _setup(tiny_config(), "bf16", B, F, Ld)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    tr = NativeTrainer(model, B, F + 2, Ld, precision="bf16")
+    sync = torch.cuda.Stream()
+    tr.set_sync_stream(sync)
+    early, _ = D.split_ranges(tr.n_floats, tr.early_ranges)
+    for call in range(3):
+        tr.grads.fill_(float("nan"))
+        tr.forward_backward(x.cuda(), cond.cuda(), labels.cuda())
+        with torch.cuda.stream(sync):
+            snap = [tr.grads[o:o + c].clone() for o, c in early]
+        tr_ref.forward_backward(x.cuda(), cond.cuda(), labels.cuda())
+        torch.cuda.synchronize()
+        assert not torch.isnan(tr.grads).any()
+        for (o, c), sn in zip(early, snap):
+            assert torch.equal(sn, tr.grads[o:o + c]), f"call {call}: the sync stream ran ahead of the pass"
+        # per-product split-K weight gradients vs the grouped launch: same numbers to rounding
+        assert _rel(tr.grads, tr_ref.grads) < 1e-3
+    tr.close(); tr_ref.close()
+
+
+def test_a_batch_without_any_scored_label_gives_nan_loss_and_zero_gradients():
+    """torch / HF CrossEntropyLoss(ignore_index=-100) over zero scored rows is NaN with a zero gradient; so is the device's."""
+    model, tr, orc, params, geom, x, feats, cond, labels = _setup(tiny_config(), "fp32", 2, 9, 6)
+    lab = torch.full_like(labels, -100)
+    loss, _ = tr.forward_backward(x.cuda(), cond.cuda(), lab.cuda())
+    loss_o, _, grads_o = orc.loss_and_grads(feats, cond, lab)
+    assert torch.isnan(loss_o) and all(float(g.abs().max()) == 0.0 for g in grads_o.values())
+    assert torch.isnan(loss).all() and float(tr.grads.abs().max()) == 0.0
+    tr.close()
+
+
+def _notes_batches(n_batches, B=3):
+    out = []
+    for i in range(n_batches):
+        notes = []
+        for b in range(B):
+            n = 2 + (5 * i + 3 * b) % 7
+            u = synth.uniform01(100 + i, f"notes{b}", n * 3).reshape(n, 3)
+            on = np.sort(u[:, 0] * 2.5)
+            notes.append(np.stack([on, on + 0.05 + u[:, 1] * 0.4, np.floor(40 + u[:, 2] * 40), np.full(n, 80.0)], axis=1))
+        wav = torch.from_numpy(synth.waveform_batch(200 + 3 * i, B, 48000, "music")).cuda()
+        idx = torch.from_numpy(synth.cond_index_batch(7 + i, B)).cuda()
+        out.append(ModelInputs(input_waveform=wav, notes_batch=tuple(notes), cond_index=idx))
+    return out
+
+
+def test_fit_batches_resumes_from_a_checkpoint_bit_for_bit(tmp_path):
+    """ref train.py:41 ``trainer.fit(..., ckpt_path=)``: k steps, a Lightning-layout .ckpt (weights + Adafactor state in
+    transformers' own state layout + step counter), a NEW process-worth of objects loading it and continuing m steps ==
+    the uninterrupted k + m steps, bit for bit (dropout on: the mask sequence continues from the restored step)."""
+    from music2midi_amd.checkpoint import read_checkpoint
+    from music2midi_amd.model import Music2MIDI
+    cfg = copy.deepcopy(DEFAULT_CONFIG)
+    cfg["dataloader"]["batch_size"] = 3
+    cfg["trainer"]["log_every_n_steps"] = 1000                  # no greedy decode inside the steps of this test
+    batches = _notes_batches(7)
+    k = 4
+
+    def fresh():
+        torch.manual_seed(5)
+        m = Music2MIDI(copy.deepcopy(cfg)).cuda()
+        m.train_precision = "bf16"
+        return m
+
+    whole = fresh()
+    losses_whole = whole.fit_batches(batches)
+    first = fresh()
+    ck = tmp_path / "step4.ckpt"
+    losses_a = first.fit_batches(batches[:k], save_path=ck)
+    raw = read_checkpoint(ck)
+    assert raw["global_step"] == k and raw["hyper_parameters"]["config_path"] is not None
+    opt = raw["optimizer_states"][0]
+    n_params = len(list(first.parameters()))
+    assert sorted(opt["state"]) == list(range(n_params)) and opt["param_groups"][0]["params"] == list(range(n_params))
+    some = opt["state"][1]                                      # a matrix: factored second moments, HF's names
+    assert set(some) >= {"step", "exp_avg_sq_row", "exp_avg_sq_col", "RMS"} and some["step"] == k
+    second = Music2MIDI(copy.deepcopy(cfg)).cuda()              # different random init: everything must come from the file
+    second.train_precision = "bf16"
+    losses_b = second.fit_batches(batches[k:], ckpt_path=ck)
+    assert second.global_step == len(batches) and second._trainer.step_count == len(batches)
+    assert losses_a + losses_b == losses_whole, (losses_a + losses_b, losses_whole)
+    for (n1, p1), (n2, p2) in zip(whole.named_parameters(), second.named_parameters()):
+        assert n1 == n2 and torch.equal(p1, p2), n1
+    assert torch.equal(whole._trainer.optimizer_state()["second_moments"], second._trainer.optimizer_state()["second_moments"])
+    # load_from_checkpoint reads the same file for inference
+    third = Music2MIDI.load_from_checkpoint(ck, config_path=copy.deepcopy(cfg)).cuda()
+    assert torch.equal(third.model.transformer.lm_head.weight, first.model.transformer.lm_head.weight)
+
+
+def test_training_step_pads_labels_to_a_bucket_without_changing_loss_or_gradients():
+    """Music2MIDI.training_step rounds the label length up to LABEL_BUCKET with ignored positions (so that the trainer meets few
+    shapes): same loss, same gradients as the batch's own length, and nothing in the step waits for the device."""
+    from music2midi_amd.model import Music2MIDI
+    cfg = copy.deepcopy(DEFAULT_CONFIG)
+    cfg["dataloader"]["batch_size"] = 3
+    cfg["trainer"]["log_every_n_steps"] = 1000
+    m = Music2MIDI(cfg).cuda().eval()                           # eval(): dropout off, so the two passes are comparable
+    m.train_precision = "fp32"
+    batch = _notes_batches(1)[0]
+    loss = m.training_step(batch, 0)
+    assert torch.is_tensor(loss) and loss.is_cuda and torch.is_tensor(m.logged["train/loss"])
+    g_bucket = m._trainer.grads.clone()
+    raw = m.model.tokenizer(batch.notes_batch)
+    assert raw.shape[1] % m.LABEL_BUCKET != 0                   # the batch really is padded
+    raw[raw == 0] = -100
+    x = m.model.encoder_inputs(batch)
+    loss_raw, _ = m._trainer.forward_backward(x, batch.cond_index, raw)
+    assert abs(loss.item() - loss_raw.item()) < 1e-6 * abs(loss_raw.item())
+    assert _rel(g_bucket, m._trainer.grads) < 1e-5
+    logged = m.logged_metrics()
+    assert logged["train/loss"] == pytest.approx(loss.item()) and logged["batch_size"] == 3

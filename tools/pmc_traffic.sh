@@ -25,7 +25,13 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         k = r["Kernel_Name"].split("(")[0]
         agg[k][0] += 1; agg[k][1] += float(r["Counter_Value"])
     res[c] = agg
+# clips per decode-kernel launch of the profiled run (bench.py reads this header and refuses a summary without it): the bench
+# decodes 32 clips per GPU as chains of M2M_GROUP_ROWS clips (default: two chains of 16 from 24 clips on)
+batch = int(os.environ.get("PMC_BATCH", "32"))
+rows = int(os.environ.get("M2M_GROUP_ROWS") or (16 if batch >= 24 else batch))
 with open(out + "/summary.txt", "w") as fh:
+    head = f"# decode kernels: clips/launch = {min(rows, batch)}   (batch {batch} per GPU; FETCH_SIZE x2-corrected for gfx950; separate --pmc passes)"
+    print(head); fh.write(head + "\n")
     for k in sorted(set(res.get("FETCH_SIZE", {})) | set(res.get("WRITE_SIZE", {}))):
         if "dec_" not in k and "logmel" not in k and "gemm_kernel" not in k and "attn_kernel" not in k: continue
         n, fs = res.get("FETCH_SIZE", {}).get(k, [0, 0.0]); _, ws = res.get("WRITE_SIZE", {}).get(k, [0, 0.0])
