@@ -99,16 +99,29 @@ __device__ unsigned long long g_gemm_stamp[8][3][8];
 #define GEMM_STAMP(i) do {} while (0)
 #define GEMM_WAITLOADS() do {} while (0)
 #endif
-template <typename T, int EPI, int TF = 2>
+// NS > 0 (bf16 only) is the LDS-DMA form of the main loop.  The register-staged loop keeps ONE k-step of loads in flight (a
+// second register set costs the occupancy that hides the rest), so every k-step of a workgroup pays a memory round trip:
+// ~0.45 us per 64 k, measured with stamps — and the products of a 16-clip training step run 6 - 36 such steps with one or two
+// workgroups per CU.  Here the operand tiles go global -> LDS directly (global_load_lds_dwordx4: no VGPRs, 1 KiB = 8 rows x 128 B
+// per wave instruction) into a ring of NS stages of 64 k, NS - 1 stages requested ahead, retired by a COUNTED s_waitcnt
+// vmcnt + one raw s_barrier per step (a __syncthreads() would drain the ring: its fence waits vmcnt(0)).  The LDS image is
+// lane-linear per instruction, so the bank swizzle sits on the SOURCE address: 16-byte chunk c of tile row r is stored at slot
+// c ^ ((r >> 1) & 7) of its 128-byte row, and the fragment reads apply the same involution (16 lanes then cover all 64 banks).
+// Same k order per output element as the register-staged loop: bit-identical results (tests/test_gemm_dma_gpu.py).
+template <int N> __device__ inline void m2m_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename T, int EPI, int TF = 2, int NS = 0>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   using Cfg = TileCfgT<T, TF>;
   constexpr int BM = 64 * TF, BN = 64 * TF, WT = 32 * TF;      // tile, and the square each of the 2x2 waves owns
   static_assert(TF == 2 || EPI == EPI_STORE || EPI == EPI_STORE_F32 || EPI == EPI_RESID, "LDS-staged epilogues are written for 128x128 tiles");
-  constexpr int BK = Cfg::BK;
+  static_assert(NS == 0 || sizeof(T) == 2, "the LDS-DMA loop is written for bf16 operands");
+  constexpr int BK = NS > 0 ? 64 : Cfg::BK;
   constexpr int EPC = 16 / sizeof(T);                          // elements per 16-byte chunk
   constexpr int CHUNKS = BM * Cfg::CPR;                        // per operand tile
   constexpr int PER_THREAD = CHUNKS / 256;
-  __shared__ __align__(16) T AB[(BM + BN) * Cfg::PITCH];   // one block: the head-major epilogue re-uses all of it
+  constexpr int LDS_ELEMS = NS > 0 ? NS * (BM + BN) * 64 : (BM + BN) * Cfg::PITCH;
+  __shared__ __align__(1024) T AB[LDS_ELEMS];             // one block: the head-major epilogue re-uses all of it
   T* const As = AB;
   T* const Bs = AB + BM * Cfg::PITCH;
 
@@ -132,6 +145,95 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   const T* W = reinterpret_cast<const T*>(g.W);
   const int K = g.K;
 
+  f32x16 acc[TF][TF];
+#pragma unroll
+  for (int i = 0; i < TF; ++i)
+#pragma unroll
+    for (int j = 0; j < TF; ++j) acc[i][j] = zero_acc();
+
+  const int r = lane & 31, h = lane >> 5;
+  // small-tile residual products: the 16 residual values a lane adds to are requested before the k loop (their round trip
+  // would otherwise sit between the last MFMA and the store of a workgroup that lives for three k-steps)
+  float rpre[16];
+  if constexpr (EPI == EPI_RESID && TF == 1) {
+    const float* rsrc = g.resid ? g.resid : reinterpret_cast<const float*>(g.out);
+    const int col = n0 + wn * WT + r;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = m0 + wm * WT + acc_row(e, lane);
+      rpre[e] = (row < g.M && col < g.N) ? rsrc[(int64_t)row * g.ldo + col] : 0.f;
+    }
+  }
+  if constexpr (NS > 0) {
+    // ---- LDS-DMA ring (see above) ----
+    constexpr int IPO = BM / 32;                               // wave instructions per operand per stage (8 rows each, 4 waves)
+    constexpr int PER = 2 * IPO;                               // ... per wave per stage
+    constexpr int STAGE = (BM + BN) * 64;                      // elements per stage: A tile [BM][64], then B tile [BN][64]
+    static_assert(NS >= 2 && NS <= 4 && (NS - 1) * PER <= 63, "ring depth: the vmcnt field counts 63 loads");
+    const int lrow = lane >> 3, slot = lane & 7;
+    const T* ap[IPO];
+    const T* bp[IPO];
+#pragma unroll
+    for (int j = 0; j < IPO; ++j) {
+      const int row = (wave * IPO + j) * 8 + lrow;             // tile row this lane fetches a chunk of
+      const int chunk = slot ^ ((row >> 1) & 7);
+      ap[j] = A + (int64_t)min(m0 + row, g.M - 1) * K + chunk * 8;
+      bp[j] = W + (int64_t)min(n0 + row, g.N - 1) * K + chunk * 8;
+    }
+    // The DMA instructions are inline asm ON PURPOSE: through __builtin_amdgcn_global_load_lds hipcc (ROCm 7.2) knows the LDS is
+    // being written and puts s_waitcnt vmcnt(0) in front of the first ds_read of every k-step — the whole ring drains each step.
+    // In asm the loads are invisible to its bookkeeping; their completion is counted by hand below (vmcnt is in-order, the only
+    // compiler-issued loads — the residual prefetch — are older than every DMA).  M0 = wave-uniform LDS byte address of the piece.
+    typedef __attribute__((address_space(3))) T* lds_ptr_t;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)AB;
+    const unsigned wave_u = (unsigned)__builtin_amdgcn_readfirstlane(wave);
+    auto glds16 = [](const T* gsrc, unsigned lds_dst) {
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    };
+    auto issue = [&](int kt) {                                 // stage kt -> ring slot kt % NS
+      const unsigned base = lds0 + 2u * ((unsigned)(kt % NS) * STAGE + wave_u * (IPO * 8 * 64));
+#pragma unroll
+      for (int j = 0; j < IPO; ++j) {
+        glds16(ap[j] + (int64_t)kt * 64, base + 2u * (j * 8 * 64));
+        glds16(bp[j] + (int64_t)kt * 64, base + 2u * (BM * 64 + j * 8 * 64));
+      }
+    };
+    const int nk = K / 64;
+#pragma unroll
+    for (int s0 = 0; s0 < NS - 1; ++s0)
+      if (s0 < nk) issue(s0);
+    GEMM_STAMP(0);
+    const int sw = (r >> 1) & 7;                               // the read side of the swizzle: tile row & 31 == r for every fragment
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt == 1) GEMM_STAMP(2);
+      // stage kt has landed when at most `ahead` younger stages of this wave are still outstanding ...
+      const int ahead = min(nk, kt + NS - 1) - kt - 1;
+      if (ahead >= NS - 2) m2m_wait_vmcnt<(NS - 2) * PER>();
+      else if (NS > 3 && ahead == 1) m2m_wait_vmcnt<PER>();
+      else m2m_wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();                            // ... and when every wave has seen its own land: all of stage kt is in LDS
+      asm volatile("" ::: "memory");
+      if (kt + NS - 1 < nk) issue(kt + NS - 1);                // into the slot stage kt - 1 was read from (every wave is past that read)
+      const T* Asg = AB + (kt % NS) * STAGE;
+      const T* Bsg = Asg + BM * 64;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        Frag<T> fa[TF], fb[TF];
+#pragma unroll
+        for (int i = 0; i < TF; ++i) {
+          fa[i] = load_frag(Asg + (wm * WT + i * 32 + r) * 64 + (((2 * s + h) ^ sw) << 3));
+          fb[i] = load_frag(Bsg + (wn * WT + i * 32 + r) * 64 + (((2 * s + h) ^ sw) << 3));
+        }
+#pragma unroll
+        for (int i = 0; i < TF; ++i)
+#pragma unroll
+          for (int j = 0; j < TF; ++j) mma16(acc[i][j], fa[i], fb[j]);
+      }
+    }
+    GEMM_STAMP(3);
+  } else {
   // register staging in NAMED scalars: arrays here (uint4 ra[PER_THREAD]) are demoted to scratch by
   // hipcc 7.2 across the k-loop even when every index is a compile-time constant
   static_assert(PER_THREAD == 2 || PER_THREAD == 4, "staging below is written for 2 or 4 chunks per thread");
@@ -150,27 +252,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #define M2M_SSTORE() { M2M_ST(0) M2M_ST(1) if constexpr (PER_THREAD == 4) { M2M_ST(2) M2M_ST(3) } }
   ra2 = rb2 = ra3 = rb3 = make_uint4(0, 0, 0, 0);
 
-  f32x16 acc[TF][TF];
-#pragma unroll
-  for (int i = 0; i < TF; ++i)
-#pragma unroll
-    for (int j = 0; j < TF; ++j) acc[i][j] = zero_acc();
-
-  const int r = lane & 31, h = lane >> 5;
   const int nk = K / BK;
   M2M_GLOAD(0)
-  // small-tile residual products: the 16 residual values a lane adds to are requested before the k loop (their round trip
-  // would otherwise sit between the last MFMA and the store of a workgroup that lives for three k-steps)
-  float rpre[16];
-  if constexpr (EPI == EPI_RESID && TF == 1) {
-    const float* rsrc = g.resid ? g.resid : reinterpret_cast<const float*>(g.out);
-    const int col = n0 + wn * WT + r;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int row = m0 + wm * WT + acc_row(e, lane);
-      rpre[e] = (row < g.M && col < g.N) ? rsrc[(int64_t)row * g.ldo + col] : 0.f;
-    }
-  }
   GEMM_STAMP(0);
   GEMM_WAITLOADS();
   GEMM_STAMP(1);
@@ -196,6 +279,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   }
 
   GEMM_STAMP(3);
+  }
 #undef M2M_GLOAD
 #undef M2M_SSTORE
 #undef M2M_LD
@@ -359,6 +443,24 @@ static int gemm_small_below() {
   return v;
 }
 
+// Which main loop (bf16).  Measured per launch shape on MI355X (tools/r3_gemm_bygrid.sh, 16-clip training step, rocprofv3, us,
+// register-staged -> LDS-DMA ring of 4): the long reductions with few workgroups win — N = 384 outputs, 384-432 small tiles,
+// K = 512 ... 2304: residual products 13.9 -> 12.3 / 12.5 -> 11.3, dX into fp32 18.3 -> 15.5 / 15.3 -> 13.1 — and the short ones
+// with many workgroups lose — K = 384, 576-1728 small tiles: 7.6 -> 8.6, 11.8 -> 12.6, 12.4 -> 13.7, 14.5 -> 16.1 (64 KiB of
+// LDS per workgroup leaves two per CU where the register-staged loop runs four; six k-steps never fill a ring) — as do the
+// 128x128 tiles (18.1 -> 24.8: 96 KiB, one workgroup per CU).  So: the ring for small tiles with K >= M2M_GEMM_DMA_MINK (512),
+// the register-staged loop otherwise.  M2M_GEMM_DMA=0 / =all force one or the other; M2M_GEMM_DMA_NS1 / _NS2 pick the depths.
+static int gemm_dma_ns(int tf, int K, int tiles) {
+  static const int mode = [] { const char* e = getenv("M2M_GEMM_DMA"); return !e ? 1 : e[0] == '0' ? 0 : e[0] == 'a' ? 2 : 1; }();
+  static const int ns1 = [] { const char* e = getenv("M2M_GEMM_DMA_NS1"); return e ? atoi(e) : 4; }();
+  static const int ns2 = [] { const char* e = getenv("M2M_GEMM_DMA_NS2"); return e ? atoi(e) : 3; }();
+  static const int mink = [] { const char* e = getenv("M2M_GEMM_DMA_MINK"); return e ? atoi(e) : 512; }();
+  static const int maxt = [] { const char* e = getenv("M2M_GEMM_DMA_MAXT"); return e ? atoi(e) : 1024; }();      // (64 clips: 1 566 tiles per N = 384 product, the ring costs 1 %)
+  if (mode == 0) return 0;
+  if (mode == 2) return tf == 1 ? ns1 : ns2;
+  return (tf == 1 && K >= mink && tiles <= maxt) ? ns1 : 0;
+}
+
 template <typename T, int TF>
 static int launch_gemm_tt(int epi, const GemmArgs& a_in, hipStream_t st) {
   constexpr int BM = 64 * TF, BN = 64 * TF;
@@ -368,22 +470,35 @@ static int launch_gemm_tt(int epi, const GemmArgs& a_in, hipStream_t st) {
   const int ngroups = ceil_div(ntn, ng_max < 1 ? 1 : ng_max);
   a.ng = ceil_div(ntn, ngroups);
   dim3 grid((unsigned)(8 * ngroups * ceil_div(ceil_div(a.M, BM), 8) * a.ng));
+  int ns = sizeof(T) == 2 ? gemm_dma_ns(TF, a.K, ceil_div(a.M, BM) * ntn) : 0;
+  if (TF == 1 && ns != 0 && ns != 3 && ns != 4) ns = 4;
+  if (TF == 2 && ns != 0 && ns != 2 && ns != 3) ns = 3;
+#define M2M_GEMM_GO(E_, NS_) hipLaunchKernelGGL((gemm_kernel<T, E_, TF, NS_>), grid, dim3(256), 0, st, a)
+#define M2M_GEMM_LAUNCH(E_)                                                                    \
+  do {                                                                                         \
+    if constexpr (sizeof(T) == 2) {                                                            \
+      if constexpr (TF == 1) { if (ns == 4) M2M_GEMM_GO(E_, 4); else if (ns == 3) M2M_GEMM_GO(E_, 3); else M2M_GEMM_GO(E_, 0); } \
+      else { if (ns == 3) M2M_GEMM_GO(E_, 3); else if (ns == 2) M2M_GEMM_GO(E_, 2); else M2M_GEMM_GO(E_, 0); }                 \
+    } else M2M_GEMM_GO(E_, 0);                                                                 \
+  } while (0)
   switch (epi) {
-    case EPI_STORE: hipLaunchKernelGGL((gemm_kernel<T, EPI_STORE, TF>), grid, dim3(256), 0, st, a); break;
-    case EPI_RESID: hipLaunchKernelGGL((gemm_kernel<T, EPI_RESID, TF>), grid, dim3(256), 0, st, a); break;
-    case EPI_STORE_F32: hipLaunchKernelGGL((gemm_kernel<T, EPI_STORE_F32, TF>), grid, dim3(256), 0, st, a); break;
+    case EPI_STORE: M2M_GEMM_LAUNCH(EPI_STORE); break;
+    case EPI_RESID: M2M_GEMM_LAUNCH(EPI_RESID); break;
+    case EPI_STORE_F32: M2M_GEMM_LAUNCH(EPI_STORE_F32); break;
     default:
       if constexpr (TF == 2) {
         switch (epi) {
-          case EPI_GATED: hipLaunchKernelGGL((gemm_kernel<T, EPI_GATED, 2>), grid, dim3(256), 0, st, a); break;
-          case EPI_HEADS: hipLaunchKernelGGL((gemm_kernel<T, EPI_HEADS, 2>), grid, dim3(256), 0, st, a); break;
-          case EPI_GATED16: hipLaunchKernelGGL((gemm_kernel<T, EPI_GATED16, 2>), grid, dim3(256), 0, st, a); break;
+          case EPI_GATED: M2M_GEMM_LAUNCH(EPI_GATED); break;
+          case EPI_HEADS: M2M_GEMM_LAUNCH(EPI_HEADS); break;
+          case EPI_GATED16: M2M_GEMM_LAUNCH(EPI_GATED16); break;
           default: set_error("launch_gemm: bad epilogue %d", epi); return M2M_ERR_INVALID;
         }
       } else {
         set_error("launch_gemm: epilogue %d has no small-tile variant", epi); return M2M_ERR_INVALID;
       }
   }
+#undef M2M_GEMM_LAUNCH
+#undef M2M_GEMM_GO
   M2M_CHECK_HIP(hipGetLastError());
   return M2M_OK;
 }
@@ -392,7 +507,7 @@ template <typename T>
 static int launch_gemm_t(int epi, const GemmArgs& a, hipStream_t st) {
   const bool plain = epi == EPI_STORE || epi == EPI_STORE_F32 || epi == EPI_RESID;
   const int tiles128 = ceil_div(a.M, 128) * ceil_div(a.N, 128);
-  if (plain && tiles128 < gemm_small_below() && a.K % TileCfgT<T, 1>::BK == 0) return launch_gemm_tt<T, 1>(epi, a, st);
+  if (plain && tiles128 < gemm_small_below() && a.K % TileCfgT<T, 1>::BK == 0) return launch_gemm_tt<T, 1>(epi, a, st);      // (K % 128: the register-staged small tile's step)
   return launch_gemm_tt<T, 2>(epi, a, st);
 }
 

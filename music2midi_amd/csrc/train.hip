@@ -512,8 +512,12 @@ __global__ __launch_bounds__(256) void transpose_kernel(const TS* __restrict__ s
 
 // all weight matrices of the model in one launch: WT[off .. ] = W[off ..]^T in the storage type (block -> (matrix, tile) table)
 struct WtBlock { int64_t off; int N, K, tn, tk; };
+// ... and, in the same pass over the fp32 master (Wc != null: bf16 mode), the plain copy in the storage type the forward products
+// read: every matrix a product reads is in the table, so the separate conversion of the whole parameter buffer (30 us, 121 MB read
+// a second time) is gone.  WT == null (a forward-only pass): the copy only.
 template <typename TD>
-__global__ __launch_bounds__(256) void weights_transpose_kernel(const WtBlock* __restrict__ blocks, const float* __restrict__ P, TD* __restrict__ WT) {
+__global__ __launch_bounds__(256) void weights_transpose_kernel(const WtBlock* __restrict__ blocks, const float* __restrict__ P, TD* __restrict__ WT,
+                                                                TD* __restrict__ Wc) {
   __shared__ float tile[64][65];
   const WtBlock b = blocks[blockIdx.x];
   const int n0 = b.tn * 64, k0 = b.tk * 64;
@@ -521,8 +525,12 @@ __global__ __launch_bounds__(256) void weights_transpose_kernel(const WtBlock* _
   TD* dst = WT + b.off;
   for (int i = threadIdx.x; i < 64 * 64; i += 256) {
     const int nl = i >> 6, kl = i & 63;
-    tile[nl][kl] = (n0 + nl < b.N && k0 + kl < b.K) ? src[(int64_t)(n0 + nl) * b.K + k0 + kl] : 0.f;
+    const bool in = n0 + nl < b.N && k0 + kl < b.K;
+    const float v = in ? src[(int64_t)(n0 + nl) * b.K + k0 + kl] : 0.f;
+    tile[nl][kl] = v;
+    if (Wc && in) Wc[b.off + (int64_t)(n0 + nl) * b.K + k0 + kl] = from_f32<TD>(v);
   }
+  if (!WT) return;
   __syncthreads();
   for (int i = threadIdx.x; i < 64 * 64; i += 256) {
     const int kl = i >> 6, nl = i & 63;
@@ -1392,18 +1400,29 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
   float4 gv[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) gv[j] = (lane * 4 + 256 * j < d) ? *reinterpret_cast<const float4*>(w + lane * 4 + 256 * j) : make_float4(0, 0, 0, 0);
-  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
-    const float* xr = x + (int64_t)row * d;
-    const float* dyr = dy + (int64_t)row * d;
-    float4 xv[2], dv[2], rv[2];
+  // A wave walks its rows (4 at M = 4 176) with the NEXT row's loads in flight while it reduces the current one: the first form
+  // paid a dependent load -> reduce -> store chain per row (10 us per launch, 32 launches per step).
+  const int stride = gridDim.x * 4;
+  float4 xv[2], dv[2], rv[2], xn[2], dn[2], rn[2];
+  const float* const res_src = dx_res ? dx_res : x;     // (never predicated: clamped addresses, unconditional loads, then a select)
+  auto load_row = [&](int row, float4 (&xa)[2], float4 (&da)[2], float4 (&ra)[2]) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = lane * 4 + 256 * j;
-      const bool in = col < d;
-      xv[j] = in ? *reinterpret_cast<const float4*>(xr + col) : make_float4(0, 0, 0, 0);
-      dv[j] = in ? *reinterpret_cast<const float4*>(dyr + col) : make_float4(0, 0, 0, 0);
-      rv[j] = (in && dx_res) ? *reinterpret_cast<const float4*>(dx_res + (int64_t)row * d + col) : make_float4(0, 0, 0, 0);
+      const bool in = col < d && row < M;
+      const int64_t at = (int64_t)min(row, M - 1) * d + min(col, d - 4);
+      const float4 a = *reinterpret_cast<const float4*>(x + at), b = *reinterpret_cast<const float4*>(dy + at),
+                   c4 = *reinterpret_cast<const float4*>(res_src + at);
+      const float4 z = make_float4(0, 0, 0, 0);
+      xa[j] = in ? a : z;
+      da[j] = in ? b : z;
+      ra[j] = (in && dx_res) ? c4 : z;
     }
+  };
+  int row = blockIdx.x * 4 + wave;
+  if (row < M) load_row(row, xv, dv, rv);
+  for (; row < M; row += stride) {
+    load_row(row + stride, xn, dn, rn);                 // (past the end: no loads, zeros)
     float ss = 0.f, c = 0.f;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {       // same association as the two-pass form: per piece, then pieces in order
@@ -1436,6 +1455,8 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
         dwacc[4 * j + 2] += dv[j].z * xv[j].z * r; dwacc[4 * j + 3] += dv[j].w * xv[j].w * r;
       }
     }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { xv[j] = xn[j]; dv[j] = dn[j]; rv[j] = rn[j]; }
   }
   int j = 0;
   for (int col = lane * 4; col < d; col += 256, ++j) {
@@ -1615,6 +1636,16 @@ __global__ void shift_right_kernel(const int64_t* __restrict__ labels, int64_t* 
   int64_t v = t == 0 ? start_id : labels[i - 1];
   if (v == -100) v = pad_id;
   dec_in[i] = v;
+}
+
+// The flat gradient buffer is OVERWRITTEN by every pass — each tensor in full, by its own product / reduction — so all that needs
+// zeroing is the alignment padding between tensors (<= 63 floats each, ~150 ranges): one wave per range instead of a 121 MB memset
+// (28 us per step).  tests fill the buffer with NaN before a pass, so a tensor nobody wrote would show.
+__global__ __launch_bounds__(256) void zero_pads_kernel(const int64_t* __restrict__ pads, int n_pads, float* __restrict__ G) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= n_pads) return;
+  const int64_t off = pads[2 * i], cnt = pads[2 * i + 1];
+  for (int64_t j = lane; j < cnt; j += 64) G[off + j] = 0.f;
 }
 
 // fp32 c = a + b (either may be null -> treated as 0)
@@ -1891,6 +1922,8 @@ struct m2m_trainer {
   int *ebucket = nullptr, *dbucket = nullptr, *counter = nullptr;
   int64_t* cond_off_dev = nullptr;
   int* cond_rows_dev = nullptr;
+  int64_t* pads_dev = nullptr;           // (offset, count) of the alignment gaps of the flat layout
+  int n_pads = 0;
   int tab_S = -1, tab_L = -1;            // geometry the bucket tables on the device were built for
   // fp8 mode (M2M_PREC_FP8): storage type stays bf16, the projection products run on MXFP8 (mx8.hip)
   bool fp8 = false;
@@ -2129,6 +2162,19 @@ int build_arena(m2m_trainer* t) {
                                      add(e.ckv, 2 * (int)inner, (int)d); add(e.co, (int)d, (int)inner); add(e.wi, 2 * (int)dff, (int)d); add(e.wo, (int)d, (int)dff); }
   }
   const int64_t o_wtb = c.take((int64_t)wtb.size() * sizeof(WtBlock));
+  std::vector<int64_t> pads;             // gaps between consecutive tensors of the flat layout (and behind the last one)
+  {
+    std::vector<std::pair<int64_t, int64_t>> spans;
+    for (const TensorDesc& td : t->tensors) spans.push_back({td.off, (int64_t)td.rows * (td.cols ? td.cols : 1)});
+    std::sort(spans.begin(), spans.end());
+    int64_t pos = 0;
+    for (const auto& sp : spans) {
+      if (sp.first > pos) { pads.push_back(pos); pads.push_back(sp.first - pos); }
+      pos = std::max(pos, sp.first + sp.second);
+    }
+    if (t->n_floats > pos) { pads.push_back(pos); pads.push_back(t->n_floats - pos); }
+  }
+  const int64_t o_pads = c.take((int64_t)std::max<size_t>(pads.size(), 2) * 8);
   // fp8 mode: MXFP8 copies of every projection matrix (lm_head stays bf16) + quantised-activation scratch
   std::vector<W8Tile> w8t;
   int64_t w8_bytes = 0, o_w8 = 0, o_w8t = 0, o_q8a = 0, o_s8a = 0, o_q8ta = 0, o_s8ta = 0, o_q8tb = 0, o_s8tb = 0;
@@ -2190,6 +2236,8 @@ int build_arena(m2m_trainer* t) {
   t->Wc = (t->precision == M2M_PREC_BF16) ? (void*)(b + o_wc) : nullptr;
   t->WT = b + o_wt; t->tA = b + o_tA; t->tB = b + o_tB; t->kpart = (float*)(b + o_kp); t->wt_blocks = b + o_wtb; t->n_wt_blocks = (int)wtb.size();
   M2M_CHECK_HIP(hipMemcpy(t->wt_blocks, wtb.data(), wtb.size() * sizeof(WtBlock), hipMemcpyHostToDevice));
+  t->pads_dev = (int64_t*)(b + o_pads); t->n_pads = (int)(pads.size() / 2);
+  if (!pads.empty()) M2M_CHECK_HIP(hipMemcpy(t->pads_dev, pads.data(), pads.size() * 8, hipMemcpyHostToDevice));
   if (t->fp8) {
     t->w8 = b + o_w8; t->w8_tiles = b + o_w8t; t->n_w8_tiles = (int)w8t.size();
     t->q8a = b + o_q8a; t->s8a = b + o_s8a; t->q8ta = b + o_q8ta; t->s8ta = b + o_s8ta; t->q8tb = b + o_q8tb; t->s8tb = b + o_s8tb;
@@ -2657,6 +2705,9 @@ int attn_self_fwd(const Ops<T>& o, const float* x_in, float* x_out, int64_t ln, 
   const bool fuse = o.stripe_ok(S) && o.fuse_on() && kt;         // P . V inside the stripe kernel, against the transposed V
   const bool fuse_pv = fuse && (o.fuse_mode() & 1);
   const T* vt = (const T*)kt + (int64_t)nB * H * DK * align_up(S, 32);
+  // (K^T | V^T from the projection's own epilogue was built twice in round 3 — the tile staged through LDS, then the transpose taken
+  //  from the matrix core with the operands swapped — and both cost the projection as much as these launches take: 64-byte row
+  //  pieces instead of whole lines; removed again)
   if (fuse) RC(o.kv_transpose(q + inner, 3 * inner, kt, nB, S));
   if (o.stripe_ok(S)) {
     RC(o.attn_probs(q + inner, 3 * inner, (int64_t)S * 3 * inner, DK, q, 3 * inner, (int64_t)S * 3 * inner, DK, Pm, nB, S, S, ldp, tab, causal,
@@ -2771,16 +2822,19 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
   hipLaunchKernelGGL(bias_table_kernel, dim3(ceil_div(H * (2 * L - 1), 128)), dim3(128), 0, st, P + t->o_drb, t->dbucket, t->dtab, H, 2 * L - 1);
   M2M_CHECK_HIP(hipGetLastError());
   hipLaunchKernelGGL(step_key_kernel, dim3(1), dim3(1), 0, st, t->drop_seed, t->step_ctr_dev, t->step_key_dev);
-  if (t->precision == M2M_PREC_BF16) RC(o.cvt(P, t->Wc, t->n_floats));
-  if (G) {
-    hipLaunchKernelGGL(weights_transpose_kernel<T>, dim3(t->n_wt_blocks), dim3(256), 0, st, (const WtBlock*)t->wt_blocks, P, (T*)t->WT);
+  if (G || t->precision == M2M_PREC_BF16) {      // W^T for the dX products (with gradients) and the bf16 copy the forward products read, one pass over P
+    hipLaunchKernelGGL(weights_transpose_kernel<T>, dim3(t->n_wt_blocks), dim3(256), 0, st, (const WtBlock*)t->wt_blocks, P, G ? (T*)t->WT : (T*)nullptr,
+                       t->precision == M2M_PREC_BF16 ? (T*)t->Wc : (T*)nullptr);
     M2M_CHECK_HIP(hipGetLastError());
   }
   if (t->fp8) {
     hipLaunchKernelGGL(mxq_weights_kernel, dim3(t->n_w8_tiles), dim3(64), 0, st, (const W8Tile*)t->w8_tiles, P, t->w8);
     M2M_CHECK_HIP(hipGetLastError());
   }
-  if (G) M2M_CHECK_HIP(hipMemsetAsync(G, 0, (size_t)t->n_floats * 4, st));
+  if (G && t->n_pads > 0) {
+    hipLaunchKernelGGL(zero_pads_kernel, dim3(ceil_div(t->n_pads, 4)), dim3(256), 0, st, t->pads_dev, t->n_pads, G);
+    M2M_CHECK_HIP(hipGetLastError());
+  }
 
   // ================= forward =================
   if (enc_inputs != t->xe[0]) M2M_CHECK_HIP(hipMemcpyAsync(t->xe[0], enc_inputs, (size_t)Me * d * 4, hipMemcpyDeviceToDevice, st));

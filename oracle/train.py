@@ -101,6 +101,38 @@ class _MxLinear(torch.autograd.Function):
         return dx, dw, None, None
 
 
+class _Round(torch.autograd.Function):
+    """bfloat16 rounding where the device's bf16 / fp8 training modes STORE bfloat16: fwd / bwd select whether the value, its
+    gradient, or both pass through a bf16 buffer on the device (csrc/train.hip: activations h, qkv, P, attention output, gate pair,
+    gated activation are stored in bf16 and so are the gradients dxT, dO, dqkv, dS, dmid, dab, dlogits; the residual stream, its
+    gradient and the norm inputs' gradient dh stay fp32)."""
+
+    @staticmethod
+    def forward(ctx, x, fwd, bwd):
+        ctx.bwd = bwd
+        return x.bfloat16().float() if fwd else x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g.bfloat16().float() if ctx.bwd else g), None, None
+
+
+class _SoftmaxBf16(torch.autograd.Function):
+    """Attention probabilities as the stripe kernels keep them: P = bf16(softmax(s)) is what is stored, and the backward forms
+    dS = bf16(P o (dP - sum_k P o dP)) FROM THAT STORED P (csrc/train.hip attn_stripe_kernel<BWD>)."""
+
+    @staticmethod
+    def forward(ctx, s):
+        p = torch.softmax(s, dim=-1).bfloat16().float()
+        ctx.save_for_backward(p)
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        (p,) = ctx.saved_tensors
+        return (p * (dp - (p * dp).sum(-1, keepdim=True))).bfloat16().float()
+
+
 def leaf_params(sd: Dict[str, np.ndarray]) -> Dict[str, torch.Tensor]:
     """state dict (numpy, keys ``transformer.*`` / ``conditioning.*``) -> fp32 leaf tensors with requires_grad."""
     return {k: torch.from_numpy(np.asarray(v, dtype=np.float32)).clone().requires_grad_(True)
@@ -116,6 +148,12 @@ class T5TrainOracle:
         self.mx8 = False          # True: emulate the fp8 training mode's projection products (see _lin)
         self.mx8_dw = False       # ... the weight gradients on MXFP8 too (M2M_FP8_PARTS=fwd,dx,dw)
         self.mx8_grad_fmt = "e4m3"
+        # True: bfloat16 rounding at every point where the device's bf16 (and fp8) training modes store bfloat16 — values AND
+        # gradients (_Round, _SoftmaxBf16).  Without it the oracle is the fp32 reference arithmetic.  The fp8 comparison needs it:
+        # an MXFP8 element is 3 mantissa bits, so two runs whose quantiser INPUTS differ by bf16 rounding noise flip a few percent
+        # of the fp8 roundings in every layer, and after twelve layers the two gradients are two different noisy draws around the
+        # fp32 one (round 2's cosine 0.93-0.95); with the inputs agreeing to fp32 noise the device has to reproduce the emulation.
+        self.bf16 = False
 
     def w(self, name: str) -> torch.Tensor:
         return self.p["transformer." + name]
@@ -138,6 +176,9 @@ class T5TrainOracle:
             return x
         return x * self.masks.mask(site, x.numel()).view(x.shape)
 
+    def _r(self, x, fwd=True, bwd=True):
+        return _Round.apply(x, fwd, bwd) if self.bf16 else x
+
     def _lin(self, x, wname):
         """x @ W^T.  With ``self.mx8`` the product and BOTH of its gradient products are the fp8 training mode's
         (``_MxLinear``: every product quantises its own operands along its own reduction dimension, as csrc/train.hip does);
@@ -145,28 +186,30 @@ class T5TrainOracle:
         w = self.w(wname)
         if getattr(self, "mx8", False):
             return _MxLinear.apply(x, w, bool(self.mx8_dw), self.mx8_grad_fmt)
-        return x @ w.T
+        return x @ self._r(w, True, False).T            # bf16 mode: the product reads a bf16 copy of the fp32 master weight
 
     def _attn(self, hq, hkv, prefix, bias, site_probs=-1):
         B, Lq, _ = hq.shape
-        q = self._heads(self._lin(hq, prefix + ".q.weight"))
-        k = self._heads(self._lin(hkv, prefix + ".k.weight"))
-        v = self._heads(self._lin(hkv, prefix + ".v.weight"))
+        q = self._heads(self._r(self._lin(hq, prefix + ".q.weight")))
+        k = self._heads(self._r(self._lin(hkv, prefix + ".k.weight")))
+        v = self._heads(self._r(self._lin(hkv, prefix + ".v.weight")))
         s = q @ k.transpose(2, 3)                      # no 1/sqrt(d_kv) (hf: modeling_t5.py:197)
         if bias is not None:
             s = s + bias
-        pr = torch.softmax(s, dim=-1)
+        pr = _SoftmaxBf16.apply(s) if self.bf16 else torch.softmax(s, dim=-1)
         if self.masks is not None:                     # the device stores probabilities with a row pitch of ceil8(Sk)
             Sk = pr.shape[-1]
             ldp = (Sk + 7) // 8 * 8
             m = self.masks.mask(site_probs, B * self.g.num_heads * Lq * ldp).view(B, self.g.num_heads, Lq, ldp)[..., :Sk]
             pr = pr * m
-        o = (pr @ v).transpose(1, 2).reshape(B, Lq, self.g.inner_dim)
-        return self._lin(o, prefix + ".o.weight")
+        if self.bf16 and self.masks is not None:
+            pr = self._r(pr, True, False)              # the dropped copy is rounded again after the 1/(1-p) scale
+        o = self._r((pr @ v).transpose(1, 2).reshape(B, Lq, self.g.inner_dim))
+        return self._r(self._lin(o, prefix + ".o.weight"), False, True)      # the branch's gradient enters as bf16 (dxT)
 
     def _ffn(self, h, prefix, site_mid=-1):
-        mid = gelu_new(self._lin(h, prefix + ".wi_0.weight")) * self._lin(h, prefix + ".wi_1.weight")
-        return self._lin(self._drop(mid, site_mid), prefix + ".wo.weight")
+        mid = self._r(gelu_new(self._r(self._lin(h, prefix + ".wi_0.weight"))) * self._r(self._lin(h, prefix + ".wi_1.weight")))
+        return self._r(self._lin(self._drop(mid, site_mid), prefix + ".wo.weight"), False, True)
 
     def encoder_inputs(self, feats: torch.Tensor, cond_idx: torch.Tensor) -> torch.Tensor:
         """ref: music2midi/input.py:57-59 — conditioning rows first, then the (constant) log-mel rows."""
@@ -184,10 +227,10 @@ class T5TrainOracle:
         for i in range(g.num_layers):
             p = f"encoder.block.{i}.layer"
             st = SITE_ENC + 16 * i
-            h = self._norm(x, self.w(f"{p}.0.layer_norm.weight"))
+            h = self._r(self._norm(x, self.w(f"{p}.0.layer_norm.weight")), True, False)
             x = x + self._drop(self._attn(h, h, f"{p}.0.SelfAttention", ebias, st + PL_PROBS_SELF), st + PL_SELF_OUT)
-            x = x + self._drop(self._ffn(self._norm(x, self.w(f"{p}.1.layer_norm.weight")), f"{p}.1.DenseReluDense", st + PL_MID), st + PL_FF_OUT)
-        enc = self._drop(self._norm(x, self.w("encoder.final_layer_norm.weight")), SITE_ENC + SITE_FIN)
+            x = x + self._drop(self._ffn(self._r(self._norm(x, self.w(f"{p}.1.layer_norm.weight")), True, False), f"{p}.1.DenseReluDense", st + PL_MID), st + PL_FF_OUT)
+        enc = self._drop(self._r(self._norm(x, self.w("encoder.final_layer_norm.weight")), True, False), SITE_ENC + SITE_FIN)
         B, Ld = labels.shape
         dec_in = torch.full((B, Ld), g.decoder_start_token_id, dtype=torch.long)
         dec_in[:, 1:] = labels[:, :-1]
@@ -198,12 +241,13 @@ class T5TrainOracle:
         for i in range(g.num_decoder_layers):
             p = f"decoder.block.{i}.layer"
             st = SITE_DEC + 16 * i
-            h = self._norm(y, self.w(f"{p}.0.layer_norm.weight"))
+            h = self._r(self._norm(y, self.w(f"{p}.0.layer_norm.weight")), True, False)
             y = y + self._drop(self._attn(h, h, f"{p}.0.SelfAttention", dbias + causal, st + PL_PROBS_SELF), st + PL_SELF_OUT)
-            h = self._norm(y, self.w(f"{p}.1.layer_norm.weight"))
+            h = self._r(self._norm(y, self.w(f"{p}.1.layer_norm.weight")), True, False)
             y = y + self._drop(self._attn(h, enc, f"{p}.1.EncDecAttention", None, st + PL_PROBS_CROSS), st + PL_CROSS_OUT)
-            y = y + self._drop(self._ffn(self._norm(y, self.w(f"{p}.2.layer_norm.weight")), f"{p}.2.DenseReluDense", st + PL_MID), st + PL_FF_OUT)
-        logits = self._drop(self._norm(y, self.w("decoder.final_layer_norm.weight")), SITE_DEC + SITE_FIN) @ self.w("lm_head.weight").T
+            y = y + self._drop(self._ffn(self._r(self._norm(y, self.w(f"{p}.2.layer_norm.weight")), True, False), f"{p}.2.DenseReluDense", st + PL_MID), st + PL_FF_OUT)
+        hD = self._drop(self._r(self._norm(y, self.w("decoder.final_layer_norm.weight")), True, False), SITE_DEC + SITE_FIN)
+        logits = self._r(hD @ self._r(self.w("lm_head.weight"), True, False).T, False, True)      # logits fp32, their gradient stored in bf16
         loss = torch.nn.functional.cross_entropy(logits.reshape(-1, g.vocab_size), labels.reshape(-1), ignore_index=-100)
         return loss, logits
 

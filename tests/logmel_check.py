@@ -27,7 +27,7 @@ import numpy as np
 import torch
 
 TOL = 1e-4
-ILL_K = 4.0        # device fp32 noise vs torch.stft's fp32 noise on the ill-conditioned class, percentile by percentile (CALIBRATE)
+ILL_K = 3.0        # device fp32 noise vs torch.stft's fp32 noise on the ill-conditioned class, percentile by percentile (measured on MI355X: 1.09 - 1.78)
 U = 2.0 ** -24
 FLOOR = float(np.log(np.float32(1e-6)))
 

@@ -232,18 +232,59 @@ def test_dropout_bf16_full_model_statistics():
     assert abs(a - ref.item()) < 3e-2 * abs(ref.item())
 
 
+def fp8_agreement(tr, ref):
+    cs, ws = [], []
+    for name, (off, shape) in tr.layout.items():
+        g = tr.grads[off:off + int(np.prod(shape))].cpu().double()
+        r = ref[name].reshape(-1).double()
+        if r.norm() < 1e-9:
+            continue
+        cs.append(float(torch.dot(g, r) / (g.norm() * r.norm() + 1e-30)))
+        ws.append(float((g - r).norm() / r.norm()))
+    return min(cs), float(np.median(cs)), max(ws)
+
+
+def fp8_self_consistency(orc, feats, cond, labels, grads_emul):
+    """How far the emulating oracle agrees WITH ITSELF when its input moves by 1e-4 (relative, seeded noise; a fortieth of a bf16
+    ulp): an MXFP8 element has 3 mantissa bits, so a difference far below bf16 rounding flips a few quantiser decisions per layer,
+    each flip moves its element by 6 %, and the flips compound with depth — measured on the host (full width, 4 clips, 1e-6 noise):
+    per-tensor gradient cosine min / median 0.995 / 0.997 with 1 + 1 layers, 0.979 / 0.989 with 2 + 2, 0.953 / 0.964 with 6 + 6
+    (1e-4 and 1e-3 noise give the same 0.945-0.951 / 0.956-0.960: the floor is reached by ANY difference), while the fp32 network
+    under 1e-3 noise stays at 0.999995 and the bf16-emulating one at 0.9996 (rel l2 2.7e-2 — exactly what the device's bf16 mode
+    shows against it).  Two evaluations of the fp8 step that are not BIT-identical in every quantiser input (device vs emulation:
+    different fp32 summation orders, the hardware exp2) therefore cannot agree better than this floor; that, not a device /
+    emulation mismatch, is where round 2's 0.93-0.95 came from."""
+    noise = torch.from_numpy(synth.normal(77, "fp8_floor", tuple(feats.shape), 1.0))
+    _, _, g2 = orc.loss_and_grads(feats * (1.0 + 1e-4 * noise), cond, labels)
+    cs = []
+    for k, r in grads_emul.items():
+        if r.norm() < 1e-9:
+            continue
+        a, b = g2[k].reshape(-1).double(), r.reshape(-1).double()
+        cs.append(float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)))
+    return min(cs), float(np.median(cs))
+
+
+def one_layer_config():
+    cfg = copy.deepcopy(DEFAULT_CONFIG)
+    cfg["model"]["t5"].update(num_layers=1, num_decoder_layers=1)
+    return cfg
+
+
 @pytest.mark.parametrize("parts", [None, "fwd,dx,dw"])
-@pytest.mark.parametrize("cfg_name,B,F,Ld", [("tiny", 3, 21, 14), ("full", 4, 188, 48)])
+@pytest.mark.parametrize("cfg_name,B,F,Ld", [("tiny", 3, 21, 14), ("full_1layer", 4, 188, 48), ("full", 4, 188, 48)])
 def test_fp8_mode_matches_the_mx_emulating_oracle(cfg_name, B, F, Ld, parts, monkeypatch):
     """fp8 mode (BASELINE configs[4]'s dtype): the projection products — forward and dX by default, dW with M2M_FP8_PARTS=fwd,dx,dw
-    (second parametrisation) — on block-scaled OCP FP8
-    (MXFP8 e4m3, 32 elements per power-of-two scale; csrc/mx8.hip), everything else as the bf16 mode.  The product itself
-    is pinned by tests/test_mx8_gpu.py.  The step is compared with autograd over an oracle whose projections quantise
-    their operands the same way (oracle/train.py mx8 + straight-through): that is the function the device differentiates.
-    Against the UNQUANTISED fp32 oracle the loss moves by 0.2 % but the gradient of this random-init, loss-58 network
-    turns by cos ~0.93 — a property of the perturbed forward, which the ablation (forward-only fp8: 0.937; dX-only 0.995;
-    dW-only 0.9988) and the emulating oracle both show."""
-    cfg = tiny_config() if cfg_name == "tiny" else copy.deepcopy(DEFAULT_CONFIG)
+    (second parametrisation) — on block-scaled OCP FP8 (MXFP8 e4m3, 32 elements per power-of-two scale; csrc/mx8.hip), everything
+    else as the bf16 mode.  The product itself is pinned by tests/test_mx8_gpu.py (element quantisation bit-identical).  The STEP is
+    compared with autograd over an oracle whose three products per projection (forward, dX, dW) each quantise their own operands
+    along their own reduction dimension, from values rounded to bfloat16 where the device stores bfloat16 (oracle/train.py _MxLinear,
+    _Round): the arithmetic the device runs.  Two bars:
+      * full width, ONE encoder + ONE decoder layer — where quantiser flips cannot compound — min cosine > 0.98 (the per-layer
+        arithmetic is right: this is the localisation round 2's review asked for);
+      * any depth: the device agrees with the emulation at least as well as the emulation agrees with itself under a 1e-4 input
+        perturbation (fp8_self_consistency; - 0.015): at 6 + 6 layers that floor is ~0.95 / 0.96 and no implementation can beat it."""
+    cfg = tiny_config() if cfg_name == "tiny" else one_layer_config() if cfg_name == "full_1layer" else copy.deepcopy(DEFAULT_CONFIG)
     if parts:
         monkeypatch.setenv("M2M_FP8_PARTS", parts)
     model, tr, orc, params, geom, x, feats, cond, labels = _setup(cfg, "fp8", B, F, Ld)
@@ -252,27 +293,19 @@ def test_fp8_mode_matches_the_mx_emulating_oracle(cfg_name, B, F, Ld, parts, mon
     loss2, _ = tr.forward_backward(x.cuda(), cond.cuda(), labels.cuda())
     assert torch.equal(g1, tr.grads) and loss.item() == loss2.item()                  # deterministic
     loss_plain, _, grads_plain = orc.loss_and_grads(feats, cond, labels)
-    orc.mx8, orc.mx8_dw = True, bool(parts)          # every product's operands quantised the way that product does (oracle/train.py _MxLinear)
+    orc.mx8, orc.mx8_dw, orc.bf16 = True, bool(parts), True
     loss_o, _, grads_o = orc.loss_and_grads(feats, cond, labels)
-
-    def agreement(ref):
-        cs, ws = [], []
-        for name, (off, shape) in tr.layout.items():
-            g = tr.grads[off:off + int(np.prod(shape))].cpu().double()
-            r = ref[name].reshape(-1).double()
-            if r.norm() < 1e-9:
-                continue
-            cs.append(float(torch.dot(g, r) / (g.norm() * r.norm() + 1e-30)))
-            ws.append(float((g - r).norm() / r.norm()))
-        return min(cs), float(np.median(cs)), max(ws)
-
-    cmin, cmed, worst = agreement(grads_o)
-    pmin, pmed, _ = agreement(grads_plain)
+    fmin, fmed = fp8_self_consistency(orc, feats, cond, labels, grads_o)
+    cmin, cmed, worst = fp8_agreement(tr, grads_o)
+    pmin, pmed, _ = fp8_agreement(tr, grads_plain)
     print(f"fp8 {cfg_name}: loss {loss.item():.4f} (MX-emulating oracle {loss_o.item():.4f}, fp32 oracle {loss_plain.item():.4f}); gradient cosine vs "
-          f"the emulating oracle min {cmin:.4f} / median {cmed:.4f} (worst rel l2 {worst:.3f}); vs the unquantised oracle min {pmin:.4f} / median {pmed:.4f}")
+          f"the emulating oracle min {cmin:.4f} / median {cmed:.4f} (worst rel l2 {worst:.3f}); the emulation vs itself under 1e-4 input noise "
+          f"min {fmin:.4f} / median {fmed:.4f}; vs the unquantised oracle min {pmin:.4f} / median {pmed:.4f}")
     assert abs(loss.item() - loss_o.item()) < 1e-2 * abs(loss_o.item())
     assert abs(loss.item() - loss_plain.item()) < 3e-2 * abs(loss_plain.item())
-    assert cmin > 0.98 and cmed > 0.99
+    assert cmin > fmin - 0.015 and cmed > fmed - 0.015
+    if cfg_name == "full_1layer":
+        assert cmin > 0.98 and cmed > 0.99
     if cfg_name == "tiny":                            # and it trains (Adafactor's warm-up steps are ~1e-6: the first few do not
         loss0 = loss.item()                           # move an FP8-quantised weight at all, so give it a while); NB `loss` is
         for _ in range(150):                          # the trainer's own device scalar, overwritten by every call
