@@ -367,38 +367,25 @@ TRAIN_SAMPLES = 66150      # ref config.yaml: 3 s segments at dataset.sample_rat
 TRAIN_LABELS = 256         # label tokens per clip (synthetic, none ignored)
 
 
-def launch_profile(make_trainer, run_step):
-    """Share of a training step's GPU time that is NOT a matrix product, from torch's profiler (kineto over roctracer) around ONE
-    directly issued step (a trainer built with M2M_TRAIN_GRAPH=0, so every kernel is a launch of its own); {} when the profiler
-    sees no device activity.  Product kernels = names containing gemm / dw_group / attn_stripe (projections, batched attention
-    products, weight gradients, the fused attention stripes); everything else is row / element-wise work."""
-    old = os.environ.get("M2M_TRAIN_GRAPH")
-    os.environ["M2M_TRAIN_GRAPH"] = "0"
-    tr = None
-    try:
-        from torch.profiler import ProfilerActivity, profile
-        tr = make_trainer()
-        for _ in range(2):
-            run_step(tr)
-        torch.cuda.synchronize()
-        with profile(activities=[ProfilerActivity.CUDA]) as prof:
-            run_step(tr)
-            torch.cuda.synchronize()
-        evs = [e for e in prof.events() if "cuda" in str(e.device_type).lower() and (getattr(e, "device_time", 0) or 0) > 0]
-        if not evs:
-            return {}
-        tot = sum(e.device_time for e in evs)
-        gemm = sum(e.device_time for e in evs if any(k in e.name for k in ("gemm", "dw_group", "attn_stripe")))
-        return {"direct_issue_launches": len(evs), "kernel_us_per_step": tot, "non_gemm_us": tot - gemm}
-    except Exception as e:          # measurement garnish: never fail the bench for it
-        return {"launch_profile_error": str(e)[:160]}
-    finally:
-        if tr is not None:
-            tr.close()
-        if old is None:
-            os.environ.pop("M2M_TRAIN_GRAPH", None)
-        else:
-            os.environ["M2M_TRAIN_GRAPH"] = old
+def train_profile_summary(profiles_dir=None):
+    """Launches per step and the share of a step's GPU time that is NOT a matrix product, from the newest committed rocprofv3
+    kernel-stats summary of the training step (profiles/r*_train_dropout_kernel_stats.csv: `tools/train_gap.py` — the same
+    16-clip / S = 261 / 256-label / dropout 0.1 step, directly issued so that every kernel is a launch of its own — under
+    `rocprofv3 --kernel-trace --stats`).  Product kernels = names containing gemm / dw_group / attn_stripe (projections, batched
+    attention products, weight gradients, the fused attention stripes); everything else is row / element-wise work.  {} when no
+    summary is committed."""
+    import csv
+    files = sorted(Path(profiles_dir or ROOT / "profiles").glob("*train_dropout_kernel_stats.csv"), key=lambda f: (_round_of(f.name), f.name))
+    if not files:
+        return {}
+    rows = list(csv.DictReader(open(files[-1])))
+    steps = next((int(r["Calls"]) for r in rows if "step_key_kernel" in r["Name"]), 0)
+    if not steps:
+        return {}
+    tot = sum(float(r["TotalDurationNs"]) for r in rows) / steps / 1e3
+    gemm = sum(float(r["TotalDurationNs"]) for r in rows if any(k in r["Name"] for k in ("gemm", "dw_group", "attn_stripe"))) / steps / 1e3
+    return {"launches_per_step": round(sum(int(r["Calls"]) for r in rows) / steps, 1), "kernel_us_per_step": round(tot, 1),
+            "non_gemm_us": round(tot - gemm, 1), "profile": files[-1].name}
 
 
 def cpu_train_baseline(cfg, state, B: int, threads: int = 16):
@@ -479,19 +466,7 @@ def train_step_record(model_module, cfg, geom, dev, B: int, precision: str, step
            "grad_allreduce": ("4 pieces, decoder side overlapped with the encoder backward" if overlap else "one call behind the pass") if world > 1 else
                              ("none (split pass forced)" if overlap else "none")}
     if world == 1 and profile_launches:
-        def make():
-            t2 = NativeTrainer(model_module, B, F + 2, TRAIN_LABELS, precision=precision)
-            if dropout > 0.0:
-                t2.set_dropout(dropout, seed=1)
-            return t2
-
-        def run(t2):
-            x = model_module.encoder_inputs(ModelInputs(input_waveform=wav, cond_index=cond))
-            t2.forward_backward(x, cond, labels)
-            t2.optimizer_step()
-        tr.close()
-        rec["roofline"].update(launch_profile(make, run))
-        return rec
+        rec["roofline"].update(train_profile_summary())
     tr.close()
     return rec
 

@@ -1388,8 +1388,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ dy, const float* __restrict__ dx_res,
                                                           float* __restrict__ dx_out, float* __restrict__ dw_part, int M, int d, float eps,
-                                                          T* __restrict__ out_t, DropKey dk, uint32_t thresh, float scale) {
+                                                          T* __restrict__ out_t, DropKey dk, uint32_t thresh, float scale,
+                                                          DropKey dk_in, uint32_t thresh_in) {
+  // thresh_in != 0: dy arrives through the dropout that follows THIS norm in the forward pass (the final norm of a stack): masked
+  // as it is loaded — a drop_inplace launch over the whole buffer before
   const uint64_t key = (out_t && thresh) ? drop_site_key(dk) : 0ull;
+  const uint64_t key_in = thresh_in ? drop_site_key(dk_in) : 0ull;
   extern __shared__ float red[];          // [4][d]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float dwacc[8];
@@ -1415,7 +1419,12 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
                    c4 = *reinterpret_cast<const float4*>(res_src + at);
       const float4 z = make_float4(0, 0, 0, 0);
       xa[j] = in ? a : z;
-      da[j] = in ? b : z;
+      float4 bm = b;
+      if (thresh_in) {
+        const uint32_t kb = drop_keep4(key_in, at, thresh_in);
+        bm = make_float4((kb & 1u) ? b.x * scale : 0.f, (kb & 2u) ? b.y * scale : 0.f, (kb & 4u) ? b.z * scale : 0.f, (kb & 8u) ? b.w * scale : 0.f);
+      }
+      da[j] = in ? bm : z;
       ra[j] = (in && dx_res) ? c4 : z;
     }
   };
@@ -1595,9 +1604,13 @@ __global__ void cond_gather_kernel(const float* __restrict__ params, const int64
 // gradient of an embedding table: one block per table row v.  The ids are scanned 256 at a time; a wave ballot marks the
 // activation rows whose id is v and every thread (= column) adds those rows in order: G[v] = sum of dx[row] with id[row] == v,
 // fixed order.  ids[i * id_stride + id_off] is the id of activation row (i * x_row_stride + x_row_off).
+// thresh != 0: dx arrives through the dropout on the embeddings (hf: T5Stack dropout(inputs_embeds)); only the rows that are READ
+// here are masked, as they are read — a drop_inplace launch over the whole gradient buffer before.
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, int n_ids, int id_stride, int id_off,
                                                         const float* __restrict__ dx, int64_t x_row_stride, int64_t x_row_off,
-                                                        float* __restrict__ gtab, int d, int pad_to_zero_id, int V) {
+                                                        float* __restrict__ gtab, int d, int pad_to_zero_id, int V, DropKey dk, uint32_t thresh,
+                                                        float scale) {
+  const uint64_t dkey = thresh ? drop_site_key(dk) : 0ull;
   __shared__ unsigned long long masks[4];
   const int v = blockIdx.x, wave = threadIdx.x >> 6;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};          // columns tid, tid + 256, ... (d <= 1024)
@@ -1618,9 +1631,13 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
       while (mm) {                                    // uniform: every thread walks the same set bits in the same order
         const int j = __ffsll((long long)mm) - 1;
         mm &= mm - 1;
-        const float* row = dx + ((int64_t)(i0 + 64 * w + j) * x_row_stride + x_row_off) * d;
+        const int64_t roff = ((int64_t)(i0 + 64 * w + j) * x_row_stride + x_row_off) * d;
+        const float* row = dx + roff;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int c = threadIdx.x + 256 * u; if (c < d) acc[u] += row[c]; }
+        for (int u = 0; u < 4; ++u) {
+          const int c = threadIdx.x + 256 * u;
+          if (c < d) acc[u] += thresh ? (drop_keep(dkey, roff + c, thresh) ? row[c] * scale : 0.f) : row[c];
+        }
       }
     }
     __syncthreads();
@@ -1628,6 +1645,78 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
 #pragma unroll
   for (int u = 0; u < 4; ++u) { const int c = threadIdx.x + 256 * u; if (c < d) gtab[(int64_t)v * d + c] = acc[u]; }
 }
+// Final norm of a stack with the dropout that follows it (hf: T5Stack dropout(final_layer_norm(x))): y = T(x * rstd * w), then the
+// mask on the ROUNDED value, as the separate in-place pass did — one wave per row, one launch instead of two.
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_drop_kernel(const float* __restrict__ x, const float* __restrict__ w, T* __restrict__ out, int M, int d,
+                                                           float eps, DropKey dk, uint32_t thresh, float scale) {
+  const uint64_t key = thresh ? drop_site_key(dk) : 0ull;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (int64_t)row * d;
+  float ss = 0.f;
+  for (int c = lane * 4; c < d; c += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(xr + c);
+    ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  ss = wave_sum(ss);
+  const float rstd = rsqrtf(ss / (float)d + eps);
+  for (int c = lane * 4; c < d; c += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(xr + c);
+    const float4 gw = *reinterpret_cast<const float4*>(w + c);
+    float y[4] = {to_f32(from_f32<T>(gw.x * (v.x * rstd))), to_f32(from_f32<T>(gw.y * (v.y * rstd))), to_f32(from_f32<T>(gw.z * (v.z * rstd))),
+                  to_f32(from_f32<T>(gw.w * (v.w * rstd)))};
+    const int64_t at = (int64_t)row * d + c;
+    const uint32_t kb = drop_keep4(key, at, thresh);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[e] = ((kb >> e) & 1u) ? y[e] * scale : 0.f;
+    st_store4<T>(out + at, y[0], y[1], y[2], y[3]);
+  }
+}
+// Encoder input of a pass in place: rows [0, n_tab) of every clip from the conditioning tables (ref: music2midi/input.py:57-59), then
+// the dropout on the embeddings over ALL rows (cond_gather_kernel + drop_inplace_kernel before).
+__global__ __launch_bounds__(256) void enc_input_kernel(const float* __restrict__ params, const int64_t* __restrict__ tab_off, const int* __restrict__ tab_rows,
+                                                        int n_tab, const int64_t* __restrict__ idx, float* __restrict__ x, int B, int S, int d, DropKey dk,
+                                                        uint32_t thresh, float scale) {
+  const uint64_t key = thresh ? drop_site_key(dk) : 0ull;
+  const int q = d >> 2;
+  const int64_t n4 = (int64_t)B * S * q, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i4 < n4; i4 += stride) {
+    const int64_t row = i4 / q;
+    const int c = (int)(i4 - row * q) * 4, b = (int)(row / S), s = (int)(row - (int64_t)b * S);
+    float4 v;
+    if (s < n_tab) {
+      int64_t id = idx[(int64_t)b * n_tab + s];
+      if (id < 0 || id >= tab_rows[s]) id = 0;
+      v = *reinterpret_cast<const float4*>(params + tab_off[s] + id * d + c);
+    } else {
+      if (!thresh) continue;                                 // nothing to do for a feature row
+      v = *reinterpret_cast<const float4*>(x + row * d + c);
+    }
+    if (thresh) {
+      const uint32_t kb = drop_keep4(key, row * d + c, thresh);
+      v = make_float4((kb & 1u) ? v.x * scale : 0.f, (kb & 2u) ? v.y * scale : 0.f, (kb & 4u) ? v.z * scale : 0.f, (kb & 8u) ? v.w * scale : 0.f);
+    }
+    *reinterpret_cast<float4*>(x + row * d + c) = v;
+  }
+}
+// Decoder input embedding of the teacher-forced pass with its dropout: x[row] = dropout(table[ids[row]])
+__global__ __launch_bounds__(256) void embed_rows_drop_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table, float* __restrict__ x, int M,
+                                                              int d, int V, int pad_id, DropKey dk, uint32_t thresh, float scale) {
+  const uint64_t key = thresh ? drop_site_key(dk) : 0ull;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  int tok = (int)ids[row];
+  if (tok < 0 || tok >= V) tok = pad_id;
+  for (int c = lane * 4; c < d; c += 256) {
+    float4 v = *reinterpret_cast<const float4*>(table + (int64_t)tok * d + c);
+    const uint32_t kb = drop_keep4(key, (int64_t)row * d + c, thresh);
+    v = make_float4((kb & 1u) ? v.x * scale : 0.f, (kb & 2u) ? v.y * scale : 0.f, (kb & 4u) ? v.z * scale : 0.f, (kb & 8u) ? v.w * scale : 0.f);
+    *reinterpret_cast<float4*>(x + (int64_t)row * d + c) = v;
+  }
+}
+
 // decoder input ids = shift_right(labels): start token, then labels[:-1] with -100 -> pad (hf: modeling_t5.py:618-637)
 __global__ void shift_right_kernel(const int64_t* __restrict__ labels, int64_t* __restrict__ dec_in, int B, int Ld, int start_id, int pad_id) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2530,7 +2619,15 @@ struct Ops {
   }
   int cvt(const float* src, void* dst, int64_t n) const { return launch_cvt(t->precision, src, dst, n, st); }
   int norm(const float* x, int64_t w_off, void* out, int M) const { return launch_rmsnorm(t->precision, x, P + w_off, out, M, t->g.d_model, t->g.layer_norm_eps, st); }
-  int norm_bwd(const float* x, int64_t w_off, const float* dy, const float* dx_res, float* dx_out, float* G, int M) const {
+  // final norm of a stack + the dropout behind it
+  int norm_drop(const float* x, int64_t w_off, void* out, int M, int site) const {
+    if (!dropping(site)) return norm(x, w_off, out, M);
+    hipLaunchKernelGGL(rmsnorm_drop_kernel<T>, dim3(ceil_div(M, 4)), dim3(256), 0, st, x, P + w_off, (T*)out, M, t->g.d_model, t->g.layer_norm_eps, key(site),
+                       t->drop_thresh, t->drop_scale);
+    M2M_CHECK_HIP(hipGetLastError());
+    return M2M_OK;
+  }
+  int norm_bwd(const float* x, int64_t w_off, const float* dy, const float* dx_res, float* dx_out, float* G, int M, int dy_site = -1) const {
     const int d = t->g.d_model;
     // (summing the partials in the last block to finish, behind a __threadfence() + counter, was measured: the agent-scope
     //  fence of 256 blocks costs ~100 us per launch on this machine — 8.7 -> 12.3 ms per step; the second launch stays)
@@ -2546,8 +2643,9 @@ struct Ops {
       if (dropping(after_site)) { dk = key(after_site); thr = t->drop_thresh; }
       pre.src = dx_out; pre.dst = out_t; pre.site = after_site;
     }
+    const bool din = dropping(dy_site);
     hipLaunchKernelGGL(rmsnorm_bwd_kernel<T>, dim3(RN_BLOCKS), dim3(256), (size_t)4 * d * sizeof(float), st, x, P + w_off, dy, dx_res, dx_out,
-                       part, M, d, t->g.layer_norm_eps, out_t, dk, thr, t->drop_scale);
+                       part, M, d, t->g.layer_norm_eps, out_t, dk, thr, t->drop_scale, din ? key(dy_site) : DropKey{nullptr, 0}, din ? t->drop_thresh : 0u);
     if (group) norm_offs.push_back(w_off);
     else hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(d, 32)), dim3(256), 0, st, part, G + w_off, RN_BLOCKS, d, 0);
     M2M_CHECK_HIP(hipGetLastError());
@@ -2805,6 +2903,77 @@ __global__ void step_key_kernel(uint64_t seed, uint64_t* __restrict__ ctr, uint6
   *ctr = c + 1;
 }
 
+// Everything a pass needs before its first product and that depends on nothing but the inputs, in ONE launch (they were six:
+// two bias-table gathers, the dropout key, the pad zeroing, the valid-label count, the decoder inputs — ~5 us of launch each for
+// microseconds of work).  Block roles by index: [0, nb_e) encoder bias table, [nb_e, nb_e + nb_d) decoder bias table, then the pad
+// ranges (one wave each), then shift_right; block 0 also advances the dropout key (thread 0) and, the LAST block counts
+// the scored labels (a single-block reduction, as count_valid_kernel).
+struct PrologueArgs {
+  const float *w_e, *w_d;              // relative-position-bias weights [buckets][H]
+  const int *bucket_e, *bucket_d;
+  float *tab_e, *tab_d;
+  int H, nrel_e, nrel_d, nb_e, nb_d;
+  uint64_t seed;
+  uint64_t *ctr, *key;
+  const int64_t* pads;
+  int n_pads, nb_p;
+  float* G;                            // null: forward only (no pads)
+  const int64_t* labels;
+  int64_t* dec_in;
+  int B, L, start_id, pad_id, nb_s;
+  float* inv_n;
+};
+__global__ __launch_bounds__(256) void train_prologue_kernel(PrologueArgs a) {
+  int blk = blockIdx.x;
+  if (blk == 0 && threadIdx.x == 0) {                      // key of this pass (step_key_kernel)
+    const uint64_t c = *a.ctr;
+    *a.key = splitmix64(a.seed + c);
+    *a.ctr = c + 1;
+  }
+  if (blk < a.nb_e + a.nb_d) {                             // bias tables from the CURRENT (trainable) bucket weights
+    const bool dec = blk >= a.nb_e;
+    const int idx = (dec ? blk - a.nb_e : blk) * 256 + threadIdx.x, nrel = dec ? a.nrel_d : a.nrel_e;
+    if (idx < a.H * nrel) {
+      const int hh = idx / nrel, i = idx - hh * nrel;
+      (dec ? a.tab_d : a.tab_e)[idx] = (dec ? a.w_d : a.w_e)[(int64_t)(dec ? a.bucket_d : a.bucket_e)[i] * a.H + hh];
+    }
+    return;
+  }
+  blk -= a.nb_e + a.nb_d;
+  if (blk < a.nb_p) {                                      // alignment padding of the flat gradient buffer
+    const int i = blk * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i < a.n_pads) {
+      const int64_t off = a.pads[2 * i], cnt = a.pads[2 * i + 1];
+      for (int64_t j = lane; j < cnt; j += 64) a.G[off + j] = 0.f;
+    }
+    return;
+  }
+  blk -= a.nb_p;
+  if (blk < a.nb_s) {                                      // decoder inputs = shift_right(labels)
+    const int i = blk * 256 + threadIdx.x;
+    if (i < a.B * a.L) {
+      const int tpos = i % a.L;
+      int64_t v = tpos == 0 ? a.start_id : a.labels[i - 1];
+      if (v == -100) v = a.pad_id;
+      a.dec_in[i] = v;
+    }
+    return;
+  }
+  // last block: number of scored labels
+  __shared__ int cnt[256];
+  int c = 0;
+  const int n = a.B * a.L;
+  for (int i = threadIdx.x; i < n; i += 256) c += a.labels[i] != -100;
+  cnt[threadIdx.x] = c;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st) cnt[threadIdx.x] += cnt[threadIdx.x + st];
+    __syncthreads();
+  }
+  // no label to score: the mean over zero rows is NaN, as torch's CrossEntropyLoss gives (its gradient is zero there too)
+  if (threadIdx.x == 0) { a.inv_n[0] = cnt[0] > 0 ? 1.0f / (float)cnt[0] : __builtin_nanf(""); a.inv_n[1] = (float)cnt[0]; }
+}
+
 template <typename T>
 int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, const int64_t* cond_idx, const int64_t* labels, int B, int S,
                        int L, float* loss_out, float* G, float* logits_out, hipStream_t st, hipStream_t st_side,
@@ -2818,10 +2987,17 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
   o.st2 = (G && !o.group) ? st_side : nullptr;
   int rc;
   // (the bucket tables of this geometry are on the device already: ensure_tables())
-  hipLaunchKernelGGL(bias_table_kernel, dim3(ceil_div(H * (2 * S - 1), 128)), dim3(128), 0, st, P + t->o_erb, t->ebucket, t->etab, H, 2 * S - 1);
-  hipLaunchKernelGGL(bias_table_kernel, dim3(ceil_div(H * (2 * L - 1), 128)), dim3(128), 0, st, P + t->o_drb, t->dbucket, t->dtab, H, 2 * L - 1);
-  M2M_CHECK_HIP(hipGetLastError());
-  hipLaunchKernelGGL(step_key_kernel, dim3(1), dim3(1), 0, st, t->drop_seed, t->step_ctr_dev, t->step_key_dev);
+  {
+    PrologueArgs a{};
+    a.w_e = P + t->o_erb; a.w_d = P + t->o_drb; a.bucket_e = t->ebucket; a.bucket_d = t->dbucket; a.tab_e = t->etab; a.tab_d = t->dtab;
+    a.H = H; a.nrel_e = 2 * S - 1; a.nrel_d = 2 * L - 1; a.nb_e = ceil_div(H * a.nrel_e, 256); a.nb_d = ceil_div(H * a.nrel_d, 256);
+    a.seed = t->drop_seed; a.ctr = t->step_ctr_dev; a.key = t->step_key_dev;
+    a.pads = t->pads_dev; a.n_pads = G ? t->n_pads : 0; a.nb_p = ceil_div(a.n_pads, 4); a.G = G;
+    a.labels = labels; a.dec_in = t->dec_in; a.B = B; a.L = L; a.start_id = g.decoder_start_token_id; a.pad_id = g.pad_token_id;
+    a.nb_s = ceil_div(Md, 256); a.inv_n = t->inv_n;
+    hipLaunchKernelGGL(train_prologue_kernel, dim3(a.nb_e + a.nb_d + a.nb_p + a.nb_s + 1), dim3(256), 0, st, a);
+    M2M_CHECK_HIP(hipGetLastError());
+  }
   if (G || t->precision == M2M_PREC_BF16) {      // W^T for the dX products (with gradients) and the bf16 copy the forward products read, one pass over P
     hipLaunchKernelGGL(weights_transpose_kernel<T>, dim3(t->n_wt_blocks), dim3(256), 0, st, (const WtBlock*)t->wt_blocks, P, G ? (T*)t->WT : (T*)nullptr,
                        t->precision == M2M_PREC_BF16 ? (T*)t->Wc : (T*)nullptr);
@@ -2831,29 +3007,31 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
     hipLaunchKernelGGL(mxq_weights_kernel, dim3(t->n_w8_tiles), dim3(64), 0, st, (const W8Tile*)t->w8_tiles, P, t->w8);
     M2M_CHECK_HIP(hipGetLastError());
   }
-  if (G && t->n_pads > 0) {
-    hipLaunchKernelGGL(zero_pads_kernel, dim3(ceil_div(t->n_pads, 4)), dim3(256), 0, st, t->pads_dev, t->n_pads, G);
-    M2M_CHECK_HIP(hipGetLastError());
-  }
 
   // ================= forward =================
   if (enc_inputs != t->xe[0]) M2M_CHECK_HIP(hipMemcpyAsync(t->xe[0], enc_inputs, (size_t)Me * d * 4, hipMemcpyDeviceToDevice, st));
-  if (t->n_cond > 0)
+  if (o.dropping(SITE_ENC + SITE_EMB)) {     // conditioning rows + the dropout on the embeddings, one launch
+    hipLaunchKernelGGL(enc_input_kernel, dim3(grid_1d((int64_t)Me * d / 4)), dim3(256), 0, st, P, t->cond_off_dev, t->cond_rows_dev, t->n_cond, cond_idx,
+                       t->xe[0], B, S, d, o.key(SITE_ENC + SITE_EMB), t->drop_thresh, t->drop_scale);
+  } else if (t->n_cond > 0) {
     hipLaunchKernelGGL(cond_gather_kernel, dim3(B * t->n_cond), dim3(128), 0, st, P, t->cond_off_dev, t->cond_rows_dev, t->n_cond, cond_idx,
                        t->xe[0], S, d);
-  RC(o.drop_inplace(t->xe[0], (int64_t)Me * d, SITE_ENC + SITE_EMB));
+  }
   for (int l = 0; l < Le; ++l) {
     const EncOff& e = t->enc[l];
     RC(attn_self_fwd<T>(o, t->xe[2 * l], t->xe[2 * l + 1], e.ln0, e.qkv, e.o, t->h0e[l], t->qkve[l], t->Pe[l], t->aoe[l], B, S, t->etab, 0,
                         SITE_ENC + 16 * l, t->kte[l]));
     RC(ff_fwd<T>(o, t->xe[2 * l + 1], t->xe[2 * l + 2], e.ln1, e.wi, e.wo, t->h1e[l], t->abe[l], t->mide[l], Me, SITE_ENC + 16 * l));
   }
-  RC(o.norm(t->xe[2 * Le], t->o_eln, t->hE, Me));
-  RC(o.drop_inplace((T*)t->hE, (int64_t)Me * d, SITE_ENC + SITE_FIN));
+  RC(o.norm_drop(t->xe[2 * Le], t->o_eln, t->hE, Me, SITE_ENC + SITE_FIN));
   // decoder
-  hipLaunchKernelGGL(shift_right_kernel, dim3(ceil_div(Md, 256)), dim3(256), 0, st, labels, t->dec_in, B, L, g.decoder_start_token_id, g.pad_token_id);
-  RC(launch_embed_rows(t->dec_in, P + t->o_shared, t->xd[0], Md, d, V, g.pad_token_id, st));
-  RC(o.drop_inplace(t->xd[0], (int64_t)Md * d, SITE_DEC + SITE_EMB));
+  if (o.dropping(SITE_DEC + SITE_EMB)) {
+    hipLaunchKernelGGL(embed_rows_drop_kernel, dim3(ceil_div(Md, 4)), dim3(256), 0, st, t->dec_in, P + t->o_shared, t->xd[0], Md, d, V, g.pad_token_id,
+                       o.key(SITE_DEC + SITE_EMB), t->drop_thresh, t->drop_scale);
+    M2M_CHECK_HIP(hipGetLastError());
+  } else {
+    RC(launch_embed_rows(t->dec_in, P + t->o_shared, t->xd[0], Md, d, V, g.pad_token_id, st));
+  }
   const int64_t sPc1 = (int64_t)H * L * lps, sPc2 = (int64_t)L * lps;
   const bool fuse_c = o.stripe_ok(S) && o.fuse_on();       // cross-attention: P . V and dQ = dS . K inside the stripe kernels
   const bool fuse_c_pv = fuse_c && (o.fuse_mode() & 1), fuse_c_dq = fuse_c && (o.fuse_mode() & 2);
@@ -2884,12 +3062,10 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
             SITE_DEC + 16 * l + PL_CROSS_OUT));
     RC(ff_fwd<T>(o, t->xd[3 * l + 2], t->xd[3 * l + 3], e.ln2, e.wi, e.wo, t->h2d[l], t->abd[l], t->midd[l], Md, SITE_DEC + 16 * l));
   }
-  RC(o.norm(t->xd[3 * Ld], t->o_dln, t->hD, Md));
-  RC(o.drop_inplace((T*)t->hD, (int64_t)Md * d, SITE_DEC + SITE_FIN));
+  RC(o.norm_drop(t->xd[3 * Ld], t->o_dln, t->hD, Md, SITE_DEC + SITE_FIN));
   RC(o.mm(TG_STORE_F32, t->hD, d, 0, o.W(t->o_lm), d, 0, t->logits, V, Md, V, d));
   if (logits_out) M2M_CHECK_HIP(hipMemcpyAsync(logits_out, t->logits, (size_t)Md * V * 4, hipMemcpyDeviceToDevice, st));
   // loss + gradient of the logits
-  hipLaunchKernelGGL(count_valid_kernel, dim3(1), dim3(256), 0, st, labels, Md, t->inv_n);
   hipLaunchKernelGGL(ce_kernel<T>, dim3(ceil_div(Md, 4)), dim3(256), 0, st, t->logits, labels, t->inv_n, t->row_loss, (T*)t->dlog, Md, V, ldv);
   hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, t->row_loss, Md, t->inv_n, loss_out);
   M2M_CHECK_HIP(hipGetLastError());
@@ -2900,11 +3076,10 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
   RC(o.dW(t->dlog, ldv, V, t->hD, d, d, G + t->o_lm, Md));                                        // dW_lm = dlogits^T . hD
   RC(o.end_sub());
   RC(o.dX(TG_STORE_F32, t->dlog, ldv, t->o_lm, V, d, t->dh, d, Md));                              // dhD = dlogits . W_lm
-  RC(o.drop_inplace(t->dh, (int64_t)Md * d, SITE_DEC + SITE_FIN));
   float* dcur = t->dxa;
   float* dnext = t->dxb;
   o.after_site = SITE_DEC + 16 * (Ld - 1) + PL_FF_OUT;
-  RC(o.norm_bwd(t->xd[3 * Ld], t->o_dln, t->dh, nullptr, dcur, G, Md));
+  RC(o.norm_bwd(t->xd[3 * Ld], t->o_dln, t->dh, nullptr, dcur, G, Md, SITE_DEC + SITE_FIN));
   for (int l = Ld - 1; l >= 0; --l) {
     const DecOff& e = t->dec[l];
     o.after_site = SITE_DEC + 16 * l + PL_CROSS_OUT;
@@ -2955,9 +3130,11 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
     std::swap(dcur, dnext);
   }
   // token embedding (decoder inputs; the encoder is fed inputs_embeds) — hf: modeling_t5.py embed_tokens = shared
-  RC(o.drop_inplace(dcur, (int64_t)Md * d, SITE_DEC + SITE_EMB));
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(V), dim3(256), 0, st, t->dec_in, Md, 1, 0, dcur, (int64_t)1, (int64_t)0, G + t->o_shared, d,
-                     g.pad_token_id, V);
+  {
+    const bool dr = o.dropping(SITE_DEC + SITE_EMB);
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(V), dim3(256), 0, st, t->dec_in, Md, 1, 0, dcur, (int64_t)1, (int64_t)0, G + t->o_shared, d,
+                       g.pad_token_id, V, dr ? o.key(SITE_DEC + SITE_EMB) : DropKey{nullptr, 0}, dr ? t->drop_thresh : 0u, t->drop_scale);
+  }
   // Split pass (data-parallel overlap): everything the decoder side deferred is issued now, so the gradients of the shared embedding,
   // lm_head and every decoder block are FINAL here — the caller's hook releases whoever waits for them — and the encoder side
   // flushes again at the end (into the other half of the tables).  Same products, same reductions: bit-identical gradients.
@@ -2969,9 +3146,8 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
     o.phase = 1;
   }
   // encoder
-  RC(o.drop_inplace(t->dhE, (int64_t)Me * d, SITE_ENC + SITE_FIN));
   o.after_site = SITE_ENC + 16 * (Le - 1) + PL_FF_OUT;
-  RC(o.norm_bwd(t->xe[2 * Le], t->o_eln, t->dhE, nullptr, dcur, G, Me));
+  RC(o.norm_bwd(t->xe[2 * Le], t->o_eln, t->dhE, nullptr, dcur, G, Me, SITE_ENC + SITE_FIN));
   for (int l = Le - 1; l >= 0; --l) {
     const EncOff& e = t->enc[l];
     o.after_site = SITE_ENC + 16 * l + PL_SELF_OUT;
@@ -2982,16 +3158,33 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
                         l == Le - 1 ? 0 : 1, SITE_ENC + 16 * l, t->kte[l]));
     std::swap(dcur, dnext);
   }
-  RC(o.drop_inplace(dcur, (int64_t)Me * d, SITE_ENC + SITE_EMB));
+  // The tail of the pass is a set of reductions that do not depend on one another: the grouped weight-gradient launch (0.35 ms,
+  // seven rounds of workgroups) and a handful of small ones — conditioning-embedding rows, the norm-weight column sums, the
+  // relative-position-bias reductions (~90 us as a chain).  The small ones go to the side stream and run beside the big launch.
+  static const bool tail_side = [] { const char* v = getenv("M2M_TRAIN_TAIL_SIDE"); return !(v && v[0] == '0'); }();
+  const bool fork = o.group && st_side && tail_side;
+  hipStream_t small = fork ? st_side : st;
+  if (fork) {
+    M2M_CHECK_HIP(hipEventRecord(t->ev_ready, st));
+    M2M_CHECK_HIP(hipStreamWaitEvent(st_side, t->ev_ready, 0));
+  }
   // conditioning embeddings: rows 0 .. n_cond-1 of every clip's encoder input (ref: music2midi/input.py:57-59)
-  for (int i = 0; i < t->n_cond; ++i)
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(t->cond_rows[i]), dim3(256), 0, st, cond_idx, B, t->n_cond, i, dcur, (int64_t)S, (int64_t)i,
-                       G + t->o_cond[i], d, 0, t->cond_rows[i]);
+  for (int i = 0; i < t->n_cond; ++i) {
+    const bool dr = o.dropping(SITE_ENC + SITE_EMB);
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(t->cond_rows[i]), dim3(256), 0, small, cond_idx, B, t->n_cond, i, dcur, (int64_t)S, (int64_t)i,
+                       G + t->o_cond[i], d, 0, t->cond_rows[i], dr ? o.key(SITE_ENC + SITE_EMB) : DropKey{nullptr, 0}, dr ? t->drop_thresh : 0u,
+                       t->drop_scale);
+  }
   M2M_CHECK_HIP(hipGetLastError());
   RC(o.join_side());
+  o.st = small;
+  rc = o.flush_norms();
+  if (rc == M2M_OK) rc = o.flush_bias();
+  o.st = st;
+  if (rc != M2M_OK) return rc;
+  if (fork) M2M_CHECK_HIP(hipEventRecord(t->ev_free[0], st_side));
   RC(o.flush_group());
-  RC(o.flush_norms());
-  RC(o.flush_bias());
+  if (fork) M2M_CHECK_HIP(hipStreamWaitEvent(st, t->ev_free[0], 0));
   return M2M_OK;
 }
 
