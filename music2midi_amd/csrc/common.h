@@ -150,6 +150,17 @@ __device__ inline float gelu_new_fast(float x) {
   const float th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
   return 0.5f * x * (1.0f + th);
 }
+// gelu_new(x) and its derivative from ONE tanh: accurate (tanhf) in the fp32 parity mode, through the hardware exp2 / rcp where the
+// results are rounded to bf16 (the training step's gate gradient)
+template <typename T> __device__ inline void gelu_new_both_t(float x, float* g, float* dg) {
+  const float k = 0.7978845608028654f;
+  const float u = k * (x + 0.044715f * x * x * x);
+  float th;
+  if constexpr (sizeof(T) == 2) th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(2.0f * 1.4426950408889634f * u) + 1.0f);
+  else th = tanhf(u);
+  *g = 0.5f * x * (1.0f + th);
+  *dg = 0.5f * (1.0f + th) + 0.5f * x * (1.0f - th * th) * k * (1.0f + 3.0f * 0.044715f * x * x);
+}
 // accurate in the fp32 (parity) mode, fast where the result is stored as bf16
 template <typename T> __device__ inline float gelu_new_t(float x) {
   if constexpr (sizeof(T) == 2) return gelu_new_fast(x);

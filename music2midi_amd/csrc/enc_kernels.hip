@@ -114,7 +114,9 @@ template <typename T, int EPI, int TF = 2, int NS = 0>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   using Cfg = TileCfgT<T, TF>;
   constexpr int BM = 64 * TF, BN = 64 * TF, WT = 32 * TF;      // tile, and the square each of the 2x2 waves owns
-  static_assert(TF == 2 || EPI == EPI_STORE || EPI == EPI_STORE_F32 || EPI == EPI_RESID, "LDS-staged epilogues are written for 128x128 tiles");
+  static_assert(TF == 2 || EPI == EPI_STORE || EPI == EPI_STORE_F32 || EPI == EPI_RESID || EPI == EPI_GATED_BWD, "LDS-staged epilogues are written for 128x128 tiles");
+  static_assert(EPI != EPI_GATED_BWD || (sizeof(T) == 2 && TF == 1), "the gate-gradient epilogue is a bf16 small-tile path");
+  static_assert(EPI != EPI_GATED_TRAIN || sizeof(T) == 2, "the training gate epilogue is a bf16 path");
   static_assert(NS == 0 || sizeof(T) == 2, "the LDS-DMA loop is written for bf16 operands");
   constexpr int BK = NS > 0 ? 64 : Cfg::BK;
   constexpr int EPC = 16 / sizeof(T);                          // elements per 16-byte chunk
@@ -162,6 +164,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     for (int e = 0; e < 16; ++e) {
       const int row = m0 + wm * WT + acc_row(e, lane);
       rpre[e] = (row < g.M && col < g.N) ? rsrc[(int64_t)row * g.ldo + col] : 0.f;
+    }
+  }
+  // gate-gradient epilogue: the tile's a | b chunks (two 16-byte chunks of a, two of b per thread) are requested before the k loop too
+  uint4 ga0 = make_uint4(0, 0, 0, 0), ga1 = ga0, gb0 = ga0, gb1 = ga0;
+  if constexpr (EPI == EPI_GATED_BWD) {
+    const T* abp = reinterpret_cast<const T*>(g.ab_out);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = tid + 256 * u, rl = idx >> 3, ch = idx & 7;
+      const int64_t at = (int64_t)min(m0 + rl, g.M - 1) * (2 * g.N) + min(n0 + ch * 8, g.N - 8);
+      const uint4 va = *reinterpret_cast<const uint4*>(abp + at), vb = *reinterpret_cast<const uint4*>(abp + at + g.N);
+      if (u == 0) { ga0 = va; gb0 = vb; } else { ga1 = va; gb1 = vb; }
     }
   }
   if constexpr (NS > 0) {
@@ -344,6 +358,116 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       return;
     }
   }
+  if constexpr (EPI == EPI_GATED_BWD) {
+    // Training backward of the gated feed-forward: the tile of dmid goes to LDS in bf16 (the rounding the stored dmid had), then every
+    // thread turns two 8-column chunks into da | db — 16-byte reads of a | b (requested before the k loop), 16-byte stores of both
+    // halves of dab, the dropout mask of the forward hashed once per four columns.  What gated_bwd_kernel did in a launch of its own
+    // (12 per step, 12 us each, 38 MB read + 19 MB written per launch) minus the dmid round trip through memory.
+    constexpr int CP = 64 + 8;
+    __syncthreads();
+    T* Cs = AB;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Cs[(wm * 32 + acc_row(e, lane)) * CP + wn * 32 + r] = from_f32<T>(acc[0][0][e]);
+    __syncthreads();
+    const uint64_t dkey = g.drop_thresh ? splitmix64(*g.drop_step + g.drop_key) : 0ull;
+    T* dab = reinterpret_cast<T*>(g.out);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = tid + 256 * u, rl = idx >> 3, ch = idx & 7;
+      const int row = m0 + rl, col = n0 + ch * 8;
+      if (row >= g.M || col >= g.N) continue;
+      const uint4 vd = *reinterpret_cast<const uint4*>(Cs + rl * CP + ch * 8);
+      const uint4 va = u == 0 ? ga0 : ga1, vb = u == 0 ? gb0 : gb1;
+      const uint32_t wd[4] = {vd.x, vd.y, vd.z, vd.w}, wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w};
+      uint32_t oa[4], ob[4];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const uint32_t kb = g.drop_thresh ? drop_keep4(dkey, (int64_t)row * g.N + col + 4 * q, g.drop_thresh) : 0xFu;
+#pragma unroll
+        for (int p2 = 0; p2 < 2; ++p2) {
+          const int w = 2 * q + p2;
+          float da[2], db[2];
+#pragma unroll
+          for (int hl = 0; hl < 2; ++hl) {
+            const float dm0 = __uint_as_float(hl ? (wd[w] & 0xFFFF0000u) : (wd[w] << 16));
+            const float av = __uint_as_float(hl ? (wa[w] & 0xFFFF0000u) : (wa[w] << 16)), bv = __uint_as_float(hl ? (wb[w] & 0xFFFF0000u) : (wb[w] << 16));
+            float dm = dm0;
+            if (g.drop_thresh) dm = ((kb >> (2 * p2 + hl)) & 1u) ? dm0 * g.drop_scale : 0.f;
+            float gg, dg;
+            gelu_new_both_t<T>(av, &gg, &dg);
+            da[hl] = dm * bv * dg;
+            db[hl] = dm * gg;
+          }
+          oa[w] = pack2_bf16(da[0], da[1]);
+          ob[w] = pack2_bf16(db[0], db[1]);
+        }
+      }
+      *reinterpret_cast<uint4*>(dab + (int64_t)row * g.ldo + col) = make_uint4(oa[0], oa[1], oa[2], oa[3]);
+      *reinterpret_cast<uint4*>(dab + (int64_t)row * g.ldo + g.N + col) = make_uint4(ob[0], ob[1], ob[2], ob[3]);
+    }
+    return;
+  }
+  if constexpr (EPI == EPI_GATED_TRAIN) {
+    // Training forward of the gated feed-forward: the gate pair a | b (needed again by the backward pass) and
+    // mid = dropout(gelu_new(a) * b), both from the bf16-ROUNDED a and b — exactly what the separate gated_fwd_kernel computed
+    // from the stored pair — in two LDS-staged rounds so that memory sees whole 128-byte lines.
+    constexpr int GP = BN / 2 + 8, AP = BN + 8;
+    static_assert(BM * AP <= LDS_ELEMS, "the staged gate pair must fit the operand buffers");
+    const int half = g.N / 2;
+    const float dscale = g.drop_thresh ? g.drop_scale : 1.0f;
+    __syncthreads();
+    T* Cs = AB;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int rl = wm * 64 + mi * 32 + acc_row(e, lane);
+        const float av = to_f32(from_f32<T>(acc[mi][0][e])), bv = to_f32(from_f32<T>(acc[mi][1][e]));
+        Cs[rl * GP + wn * 32 + r] = from_f32<T>(gelu_new_t<T>(av) * bv * dscale);      // (one rounding, after the dropout scale)
+      }
+    __syncthreads();
+    {
+      const uint64_t dkey = g.drop_thresh ? splitmix64(*g.drop_step + g.drop_key) : 0ull;
+      for (int idx = tid; idx < BM * (BN / 16); idx += 256) {
+        const int rl = idx / (BN / 16), ch = idx % (BN / 16);
+        const int row = m0 + rl, oc = n0 / 2 + ch * 8;
+        if (row < g.M && oc < half) {
+          uint4 v = *reinterpret_cast<const uint4*>(Cs + rl * GP + ch * 8);
+          if (g.drop_thresh) {
+            uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              const uint32_t kb = drop_keep4(dkey, (int64_t)row * half + oc + 4 * q, g.drop_thresh);
+#pragma unroll
+              for (int p2 = 0; p2 < 2; ++p2)                  // dropped elements to zero (the scale is in the staged value already)
+                w[2 * q + p2] &= (((kb >> (2 * p2)) & 1u) ? 0x0000FFFFu : 0u) | (((kb >> (2 * p2 + 1)) & 1u) ? 0xFFFF0000u : 0u);
+            }
+            v = make_uint4(w[0], w[1], w[2], w[3]);
+          }
+          *reinterpret_cast<uint4*>(reinterpret_cast<T*>(g.out) + (int64_t)row * g.ldo + oc) = v;
+        }
+      }
+    }
+    __syncthreads();
+    // the pair: staged as [row][a of chunk wn=0 | a of chunk wn=1 | b of chunk wn=0 | b of chunk wn=1] — two 128-byte lines per row
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int rl = wm * 64 + mi * 32 + acc_row(e, lane);
+        Cs[rl * AP + wn * 32 + r] = from_f32<T>(acc[mi][0][e]);
+        Cs[rl * AP + 64 + wn * 32 + r] = from_f32<T>(acc[mi][1][e]);
+      }
+    __syncthreads();
+    for (int idx = tid; idx < BM * (BN / 8); idx += 256) {
+      const int rl = idx / (BN / 8), ch = idx % (BN / 8);       // ch 0..7: a, 8..15: b
+      const int row = m0 + rl, oc = n0 / 2 + (ch & 7) * 8;
+      if (row < g.M && oc < half)
+        *reinterpret_cast<uint4*>(reinterpret_cast<T*>(g.ab_out) + (int64_t)row * g.N + (ch >= 8 ? half : 0) + oc) =
+            *reinterpret_cast<const uint4*>(Cs + rl * AP + ch * 8);
+    }
+    return;
+  }
   if constexpr ((EPI == EPI_GATED || EPI == EPI_GATED16) && sizeof(T) == 2) {
     // gated up projection, bf16: the 128-column tile yields 64 outputs per row = one 128-byte line; staged in
     // LDS so that 8 lanes write a whole line with 16-byte stores (straight from the accumulators it is 64-byte
@@ -419,6 +543,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
             if (g.drop_thresh) u = drop_keep(dkey, at, g.drop_thresh) ? v * g.drop_scale : 0.f;   // training only
             if constexpr (TF == 1) *p = rpre[e] + u;
             else *p = (g.resid ? g.resid[at] : *p) + u;
+          } else if constexpr (EPI == EPI_GATED_TRAIN || EPI == EPI_GATED_BWD) {
+            (void)v;                          // (returned above)
           } else {  // EPI_HEADS
             const int which = col / g.inner, rem = col - which * g.inner;
             const int hh = rem / DK, dd = rem - hh * DK;
@@ -485,12 +611,18 @@ static int launch_gemm_tt(int epi, const GemmArgs& a_in, hipStream_t st) {
     case EPI_STORE: M2M_GEMM_LAUNCH(EPI_STORE); break;
     case EPI_RESID: M2M_GEMM_LAUNCH(EPI_RESID); break;
     case EPI_STORE_F32: M2M_GEMM_LAUNCH(EPI_STORE_F32); break;
+    case EPI_GATED_BWD:
+      if constexpr (sizeof(T) == 2 && TF == 1) { M2M_GEMM_LAUNCH(EPI_GATED_BWD); break; }
+      set_error("launch_gemm: the gate-gradient epilogue is a bf16 small-tile path"); return M2M_ERR_INVALID;
     default:
       if constexpr (TF == 2) {
         switch (epi) {
           case EPI_GATED: M2M_GEMM_LAUNCH(EPI_GATED); break;
           case EPI_HEADS: M2M_GEMM_LAUNCH(EPI_HEADS); break;
           case EPI_GATED16: M2M_GEMM_LAUNCH(EPI_GATED16); break;
+          case EPI_GATED_TRAIN:
+            if constexpr (sizeof(T) == 2) { M2M_GEMM_LAUNCH(EPI_GATED_TRAIN); break; }
+            set_error("launch_gemm: the training gate epilogue is a bf16 path"); return M2M_ERR_INVALID;
           default: set_error("launch_gemm: bad epilogue %d", epi); return M2M_ERR_INVALID;
         }
       } else {
@@ -507,11 +639,20 @@ template <typename T>
 static int launch_gemm_t(int epi, const GemmArgs& a, hipStream_t st) {
   const bool plain = epi == EPI_STORE || epi == EPI_STORE_F32 || epi == EPI_RESID;
   const int tiles128 = ceil_div(a.M, 128) * ceil_div(a.N, 128);
+  if (epi == EPI_GATED_BWD) return launch_gemm_tt<T, 1>(epi, a, st);           // (always the small tile: launch_gemm checked the shape)
   if (plain && tiles128 < gemm_small_below() && a.K % TileCfgT<T, 1>::BK == 0) return launch_gemm_tt<T, 1>(epi, a, st);      // (K % 128: the register-staged small tile's step)
   return launch_gemm_tt<T, 2>(epi, a, st);
 }
 
+bool gemm_takes_gated_train(int precision, int M, int N, int K) {     // bf16, and a grid the 128x128 tile is chosen for anyway
+  return precision == M2M_PREC_BF16 && N % 128 == 0 && K % 64 == 0 && ceil_div(M, 128) * ceil_div(N, 128) >= gemm_small_below();
+}
+
+bool gemm_takes_gated_bwd(int precision, int M, int N, int K) { return precision == M2M_PREC_BF16 && N % 64 == 0 && K % 128 == 0 && M >= 1; }
+
 int launch_gemm(int precision, int epi, const GemmArgs& a, hipStream_t st) {
+  if (epi == EPI_GATED_BWD) M2M_REQUIRE(gemm_takes_gated_bwd(precision, a.M, a.N, a.K) && a.ab_out && a.ldo == 2 * a.N, "gemm: shape / arguments outside the gate-gradient epilogue");
+  if (epi == EPI_GATED_TRAIN) M2M_REQUIRE(gemm_takes_gated_train(precision, a.M, a.N, a.K) && a.ab_out && a.ldo == a.N / 2, "gemm: shape / arguments outside the training gate epilogue");
   M2M_REQUIRE(a.K % 64 == 0, "gemm: K=%d must be a multiple of 64", a.K);
   M2M_REQUIRE(a.M >= 1 && a.N >= 1, "gemm: empty problem");
   if (epi == EPI_GATED) M2M_REQUIRE(a.N % 64 == 0, "gemm: gated epilogue needs N %% 64 == 0 (d_ff %% 32 == 0)");

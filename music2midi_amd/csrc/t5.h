@@ -127,7 +127,7 @@ namespace m2m {
 
 // -------------------------------------------------------- launch helpers ---
 // encoder-side (enc_kernels.hip)
-enum { EPI_STORE = 0, EPI_RESID = 1, EPI_GATED = 2, EPI_HEADS = 3, EPI_STORE_F32 = 4, EPI_GATED16 = 5 };
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_GATED = 2, EPI_HEADS = 3, EPI_STORE_F32 = 4, EPI_GATED16 = 5, EPI_GATED_TRAIN = 6, EPI_GATED_BWD = 7 };
 
 struct GemmArgs {
   const void* A;     // [M, K] T row-major
@@ -149,9 +149,20 @@ struct GemmArgs {
   float drop_scale;
   uint64_t drop_key;       // the site's salt: key = splitmix64(*drop_step + drop_key) (common.h DropKey)
   const uint64_t* drop_step;
+  // EPI_GATED_TRAIN (training forward of the gated feed-forward, bf16, weights row-interleaved in 32-row chunks like EPI_GATED): out
+  // = mid [M][N/2] = dropout(gelu_new(a) * b) as EPI_GATED writes it, AND the gate pair itself for the backward pass,
+  // ab_out [M][N] = [a | b] in the MASTER column order (column c of wi_0 at c, of wi_1 at N/2 + c); dropout via the drop_* fields
+  // with element index row * (N/2) + c.  gemm_takes_gated_train() says whether a shape takes this path.
+  void* ab_out;
+  // EPI_GATED_BWD (training backward of the gated feed-forward, bf16, small tiles): the product is dmid = dy . Wo [M][N = d_ff]; the
+  // epilogue turns each tile straight into the gate pair's gradient, out = dab [M][2N] = [dmid~ * b * gelu'(a) | dmid~ * gelu(a)]
+  // (ldo = 2N) with dmid~ = dropout mask of the forward applied to bf16(dmid) and a | b read from ab_out [M][2N]; dmid itself is
+  // never stored.
 };
 
 int launch_gemm(int precision, int epi, const GemmArgs& a, hipStream_t st);
+bool gemm_takes_gated_train(int precision, int M, int N, int K);
+bool gemm_takes_gated_bwd(int precision, int M, int N, int K);
 int launch_rmsnorm(int precision, const float* x, const float* w, void* out, int M, int d, float eps, hipStream_t st);
 // flash attention of the encoder and of the batched (teacher-forced) decoder pass
 struct AttnArgs {

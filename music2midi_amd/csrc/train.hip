@@ -511,13 +511,16 @@ __global__ __launch_bounds__(256) void transpose_kernel(const TS* __restrict__ s
 }
 
 // all weight matrices of the model in one launch: WT[off .. ] = W[off ..]^T in the storage type (block -> (matrix, tile) table)
-struct WtBlock { int64_t off; int N, K, tn, tk; };
+struct WtBlock { int64_t off; int N, K, tn, tk; int il_half; };     // il_half > 0: a gate pair [wi_0 | wi_1], il_half = d_ff rows each
 // ... and, in the same pass over the fp32 master (Wc != null: bf16 mode), the plain copy in the storage type the forward products
 // read: every matrix a product reads is in the table, so the separate conversion of the whole parameter buffer (30 us, 121 MB read
 // a second time) is gone.  WT == null (a forward-only pass): the copy only.
+// Wil (bf16 mode): the gate-pair matrices once more with their rows interleaved in 32-row chunks (wi_0 rows [32c, 32c + 32), then the
+// matching wi_1 rows), the B operand of the fused gated-GELU product (EPI_GATED_TRAIN): a wave's 64 output columns are then a | b of
+// the same 32 hidden units.
 template <typename TD>
 __global__ __launch_bounds__(256) void weights_transpose_kernel(const WtBlock* __restrict__ blocks, const float* __restrict__ P, TD* __restrict__ WT,
-                                                                TD* __restrict__ Wc) {
+                                                                TD* __restrict__ Wc, TD* __restrict__ Wil) {
   __shared__ float tile[64][65];
   const WtBlock b = blocks[blockIdx.x];
   const int n0 = b.tn * 64, k0 = b.tk * 64;
@@ -529,6 +532,10 @@ __global__ __launch_bounds__(256) void weights_transpose_kernel(const WtBlock* _
     const float v = in ? src[(int64_t)(n0 + nl) * b.K + k0 + kl] : 0.f;
     tile[nl][kl] = v;
     if (Wc && in) Wc[b.off + (int64_t)(n0 + nl) * b.K + k0 + kl] = from_f32<TD>(v);
+    if (Wil && in && b.il_half) {
+      const int n = n0 + nl, m = n < b.il_half ? n : n - b.il_half;
+      Wil[b.off + (int64_t)((m >> 5) * 64 + (n < b.il_half ? 0 : 32) + (m & 31)) * b.K + k0 + kl] = from_f32<TD>(v);
+    }
   }
   if (!WT) return;
   __syncthreads();
@@ -644,21 +651,6 @@ __global__ void cvt_drop_kernel(const float* __restrict__ src, T* __restrict__ d
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) dst[i] = from_f32<T>(drop_keep(key, i, thresh) ? src[i] * scale : 0.f);
-}
-// in-place dropout of an fp32 / T buffer
-template <typename T>
-__global__ void drop_inplace_kernel(T* __restrict__ x, int64_t n, DropKey dk, uint32_t thresh, float scale) {
-  const uint64_t key = thresh ? drop_site_key(dk) : 0ull;
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  // groups of four (one hash, 16- / 8-byte accesses); the tail, if n is not a multiple of 4, element by element
-  const int64_t n4 = n >> 2;
-  for (; i < n4; i += stride) {
-    const uint32_t kb = drop_keep4(key, 4 * i, thresh);
-    const float4 v = st_load4<T>(x + 4 * i);
-    st_store4<T>(x + 4 * i, (kb & 1u) ? v.x * scale : 0.f, (kb & 2u) ? v.y * scale : 0.f, (kb & 4u) ? v.z * scale : 0.f, (kb & 8u) ? v.w * scale : 0.f);
-  }
-  for (int64_t j = 4 * n4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) x[j] = from_f32<T>(drop_keep(key, j, thresh) ? to_f32(x[j]) * scale : 0.f);
 }
 static inline int grid_1d(int64_t n, int per_block = 256) {
   int64_t g = (n + per_block - 1) / per_block;
@@ -1334,7 +1326,7 @@ __global__ void gated_fwd_kernel(const T* __restrict__ ab, T* __restrict__ mid, 
     const int64_t row = i4 / q;
     const int c = (int)(i4 - row * q) * 4;
     const float4 a = st_load4<T>(ab + row * 2 * dff + c), b = st_load4<T>(ab + row * 2 * dff + dff + c);
-    float v[4] = {gelu_new(a.x) * b.x, gelu_new(a.y) * b.y, gelu_new(a.z) * b.z, gelu_new(a.w) * b.w};
+    float v[4] = {gelu_new_t<T>(a.x) * b.x, gelu_new_t<T>(a.y) * b.y, gelu_new_t<T>(a.z) * b.z, gelu_new_t<T>(a.w) * b.w};      // (as the fused epilogue)
     if (thresh) {                                                       // hf: T5DenseGatedActDense dropout before wo
       const uint32_t kb = drop_keep4(key, row * dff + c, thresh);
 #pragma unroll
@@ -1342,14 +1334,6 @@ __global__ void gated_fwd_kernel(const T* __restrict__ ab, T* __restrict__ mid, 
     }
     st_store4<T>(mid + row * dff + c, v[0], v[1], v[2], v[3]);
   }
-}
-// gelu_new(x) and its derivative from one tanh
-__device__ inline void gelu_new_both(float x, float* g, float* dg) {
-  const float k = 0.7978845608028654f;
-  const float u = k * (x + 0.044715f * x * x * x);
-  const float th = tanhf(u);
-  *g = 0.5f * x * (1.0f + th);
-  *dg = 0.5f * (1.0f + th) + 0.5f * x * (1.0f - th * th) * k * (1.0f + 3.0f * 0.044715f * x * x);
 }
 template <typename T>
 __global__ void gated_bwd_kernel(const T* __restrict__ ab, const T* __restrict__ dmid, T* __restrict__ dab, int64_t M, int dff, DropKey dk,
@@ -1369,7 +1353,7 @@ __global__ void gated_bwd_kernel(const T* __restrict__ ab, const T* __restrict__
     for (int e = 0; e < 4; ++e) {
       if (thresh) dm[e] = ((kb >> e) & 1u) ? dm[e] * scale : 0.f;
       float g, dg;
-      gelu_new_both(a[e], &g, &dg);
+      gelu_new_both_t<T>(a[e], &g, &dg);                    // (as the fused epilogue: bit-identical either way)
       da[e] = dm[e] * b[e] * dg;
       db[e] = dm[e] * g;
     }
@@ -1536,20 +1520,6 @@ __global__ __launch_bounds__(256) void colsum_group_kernel(const float* __restri
 }
 
 // ---- cross entropy (mean over labels != -100, hf: modeling_t5.py:1049-1054) + gradient of the logits ----
-__global__ void count_valid_kernel(const int64_t* __restrict__ labels, int n, float* __restrict__ inv_n) {
-  __shared__ int cnt[256];
-  int c = 0;
-  for (int i = threadIdx.x; i < n; i += 256) c += labels[i] != -100;
-  cnt[threadIdx.x] = c;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (threadIdx.x < s) cnt[threadIdx.x] += cnt[threadIdx.x + s];
-    __syncthreads();
-  }
-  // no label to score: the mean over zero rows is NaN, as torch's CrossEntropyLoss gives (its gradient is zero there too: ce_kernel
-  // multiplies only the scored rows)
-  if (threadIdx.x == 0) { inv_n[0] = cnt[0] > 0 ? 1.0f / (float)cnt[0] : __builtin_nanf(""); inv_n[1] = (float)cnt[0]; }
-}
 // one wave per row: row_loss[row] = logsumexp - logit[label] (0 if ignored); dlogits (T) = (softmax - onehot) / n_valid
 template <typename T>
 __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
@@ -1715,26 +1685,6 @@ __global__ __launch_bounds__(256) void embed_rows_drop_kernel(const int64_t* __r
     v = make_float4((kb & 1u) ? v.x * scale : 0.f, (kb & 2u) ? v.y * scale : 0.f, (kb & 4u) ? v.z * scale : 0.f, (kb & 8u) ? v.w * scale : 0.f);
     *reinterpret_cast<float4*>(x + (int64_t)row * d + c) = v;
   }
-}
-
-// decoder input ids = shift_right(labels): start token, then labels[:-1] with -100 -> pad (hf: modeling_t5.py:618-637)
-__global__ void shift_right_kernel(const int64_t* __restrict__ labels, int64_t* __restrict__ dec_in, int B, int Ld, int start_id, int pad_id) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * Ld) return;
-  const int t = i % Ld;
-  int64_t v = t == 0 ? start_id : labels[i - 1];
-  if (v == -100) v = pad_id;
-  dec_in[i] = v;
-}
-
-// The flat gradient buffer is OVERWRITTEN by every pass — each tensor in full, by its own product / reduction — so all that needs
-// zeroing is the alignment padding between tensors (<= 63 floats each, ~150 ranges): one wave per range instead of a 121 MB memset
-// (28 us per step).  tests fill the buffer with NaN before a pass, so a tensor nobody wrote would show.
-__global__ __launch_bounds__(256) void zero_pads_kernel(const int64_t* __restrict__ pads, int n_pads, float* __restrict__ G) {
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (i >= n_pads) return;
-  const int64_t off = pads[2 * i], cnt = pads[2 * i + 1];
-  for (int64_t j = lane; j < cnt; j += 64) G[off + j] = 0.f;
 }
 
 // fp32 c = a + b (either may be null -> treated as 0)
@@ -1991,6 +1941,7 @@ struct m2m_trainer {
   unsigned char* arena = nullptr;
   int64_t arena_bytes = 0;
   void* Wc = nullptr;                    // T copy of the parameters (bf16 mode; fp32 mode reads the master buffer)
+  void* Wil = nullptr;                   // bf16 mode: the gate-pair matrices again, rows interleaved (same offsets; see weights_transpose_kernel)
   void* WT = nullptr;                    // every weight matrix TRANSPOSED, in T, at the same offsets (dX = dY . W as an NT product)
   void *tA = nullptr, *tB = nullptr;     // transposed activations of the current dW product: [features][Mp]
   float* kpart = nullptr;                // split-K partial tiles
@@ -2032,7 +1983,7 @@ struct m2m_trainer {
   uint32_t drop_thresh = 0;
   uint64_t drop_seed = 0;
   uint64_t *step_key_dev = nullptr, *step_ctr_dev = nullptr;   // key of the current pass / passes since set_dropout (device words:
-                                                               // a captured graph advances them itself, see step_key_kernel)
+                                                               // a captured graph advances them itself, see train_prologue_kernel)
   // The operands the weight-gradient products read (dxT, dab, dqkv, dcq, dckv) live in per-sub-layer buffers (rings, one
   // entry per use in a pass): the products of a whole step are issued as ONE grouped launch after the backward pass
   // (or, in fp8 mode, on the side stream while the main stream moves on), so nothing may be overwritten before.
@@ -2227,7 +2178,7 @@ int build_arena(m2m_trainer* t) {
                 o_etab = F(H * (2 * S)), o_dtab = F(H * (2 * L)), o_dlog = T(Md * align_up(V, 8)), o_dxT = T(Mx * d), o_dmid = T(Mx * dff),
                 o_dab = T(Mx * 2 * dff), o_dO = T(Mx * inner), o_dqkv = T(Mx * 3 * inner), o_dS = T(B * H * Sm * lpm), o_dcq = T(Md * inner),
                 o_dckv = T(Me * 2 * inner), o_lab = c.take(Md * 8), o_cnd = c.take(B * 8 * 8), o_skey = c.take(256), o_decin = c.take(Md * 8), o_eb = c.take(2 * S * 4), o_db = c.take(2 * L * 4),
-                o_co = c.take(64 * 8), o_cr = c.take(64 * 4), o_cnt = c.take(256), o_wc = (t->precision == M2M_PREC_BF16) ? T(t->n_floats) : 0,
+                o_co = c.take(64 * 8), o_cr = c.take(64 * 4), o_cnt = c.take(256), o_wc = (t->precision == M2M_PREC_BF16) ? T(t->n_floats) : 0, o_wil = (t->precision == M2M_PREC_BF16) ? T(t->n_floats) : 0,
                 o_wt = T(t->n_floats);
   std::vector<int64_t> o_ring[m2m_trainer::K_KINDS];
   for (int i = 1; i < 2 * Le + 3 * Ld; ++i) o_ring[m2m_trainer::K_DXT].push_back(T(Mx * d));
@@ -2242,8 +2193,9 @@ int build_arena(m2m_trainer* t) {
   std::vector<WtBlock> wtb;
   {
     auto add = [&](int64_t off, int N, int K) {
+      const int il = (N == 2 * (int)dff && K == (int)d && dff % 32 == 0) ? (int)dff : 0;      // the gate pairs
       for (int tn = 0; tn < ceil_div(N, 64); ++tn)
-        for (int tk = 0; tk < ceil_div(K, 64); ++tk) wtb.push_back({off, N, K, tn, tk});
+        for (int tk = 0; tk < ceil_div(K, 64); ++tk) wtb.push_back({off, N, K, tn, tk, il});
     };
     add(t->o_lm, (int)V, (int)d);
     for (const EncOff& e : t->enc) { add(e.qkv, 3 * (int)inner, (int)d); add(e.o, (int)d, (int)inner); add(e.wi, 2 * (int)dff, (int)d); add(e.wo, (int)d, (int)dff); }
@@ -2323,6 +2275,7 @@ int build_arena(m2m_trainer* t) {
   t->step_key_dev = (uint64_t*)(b + o_skey); t->step_ctr_dev = t->step_key_dev + 1; t->loss_dev = (float*)(t->step_key_dev + 4);
   t->ebucket = (int*)(b + o_eb); t->dbucket = (int*)(b + o_db); t->counter = (int*)(b + o_cnt); t->cond_off_dev = (int64_t*)(b + o_co); t->cond_rows_dev = (int*)(b + o_cr);
   t->Wc = (t->precision == M2M_PREC_BF16) ? (void*)(b + o_wc) : nullptr;
+  t->Wil = (t->precision == M2M_PREC_BF16) ? (void*)(b + o_wil) : nullptr;
   t->WT = b + o_wt; t->tA = b + o_tA; t->tB = b + o_tB; t->kpart = (float*)(b + o_kp); t->wt_blocks = b + o_wtb; t->n_wt_blocks = (int)wtb.size();
   M2M_CHECK_HIP(hipMemcpy(t->wt_blocks, wtb.data(), wtb.size() * sizeof(WtBlock), hipMemcpyHostToDevice));
   t->pads_dev = (int64_t*)(b + o_pads); t->n_pads = (int)(pads.size() / 2);
@@ -2335,14 +2288,6 @@ int build_arena(m2m_trainer* t) {
   M2M_CHECK_HIP(hipMemcpy(t->cond_off_dev, t->o_cond.data(), t->o_cond.size() * 8, hipMemcpyHostToDevice));
   M2M_CHECK_HIP(hipMemcpy(t->cond_rows_dev, t->cond_rows.data(), t->cond_rows.size() * 4, hipMemcpyHostToDevice));
   return M2M_OK;
-}
-
-// bias table on the device from the CURRENT (trainable) bucket weights: tab[h][i] = weight[bucket_of_rel[i]][h]
-__global__ void bias_table_kernel(const float* __restrict__ weight, const int* __restrict__ bucket_of_rel, float* __restrict__ tab, int H, int nrel) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= H * nrel) return;
-  const int hh = idx / nrel, i = idx - hh * nrel;
-  tab[idx] = weight[(int64_t)bucket_of_rel[i] * H + hh];
 }
 
 // ------------------------------------------------------------ typed helpers
@@ -2514,13 +2459,6 @@ struct Ops {
     pre = PreCvt{};
     if (!dropping(site)) return launch_cvt(t->precision, src, dst, n, st);
     hipLaunchKernelGGL(cvt_drop_kernel<T>, dim3(grid_1d(n)), dim3(256), 0, st, src, (T*)dst, n, key(site), t->drop_thresh, t->drop_scale);
-    M2M_CHECK_HIP(hipGetLastError());
-    return M2M_OK;
-  }
-  template <typename X>
-  int drop_inplace(X* x, int64_t n, int site) const {
-    if (!dropping(site)) return M2M_OK;
-    hipLaunchKernelGGL(drop_inplace_kernel<X>, dim3(grid_1d(n)), dim3(256), 0, st, x, n, key(site), t->drop_thresh, t->drop_scale);
     M2M_CHECK_HIP(hipGetLastError());
     return M2M_OK;
   }
@@ -2873,8 +2811,18 @@ int ff_fwd(const Ops<T>& o, const float* x_in, float* x_out, int64_t ln, int64_t
   const int d = t->g.d_model, dff = t->g.d_ff;
   int rc;
   RC(o.norm(x_in, ln, h, M));
-  RC(o.mm(TG_STORE_T, h, d, 0, o.W(wi), d, 0, ab, 2 * dff, M, 2 * dff, d));
-  RC(o.gated(ab, mid, M, site0 + PL_MID));
+  // the gate product with the activation in its epilogue (bf16, grids the 128x128 tile takes anyway): a | b and
+  // mid = dropout(gelu_new(a) * b) leave the product together — the gated_fwd_kernel launch and its read of the pair are gone
+  static const bool gate_epi = [] { const char* v = getenv("M2M_TRAIN_GATE_EPI"); return !(v && v[0] == '0'); }();
+  if (gate_epi && !t->fp8 && o.use_tuned && t->Wil && gemm_takes_gated_train(t->precision, M, 2 * dff, d)) {
+    GemmArgs a{};
+    a.A = h; a.W = reinterpret_cast<const T*>(t->Wil) + wi; a.M = M; a.N = 2 * dff; a.K = d; a.out = mid; a.ldo = dff; a.ab_out = ab; a.vt_which = -1;
+    if (o.dropping(site0 + PL_MID)) { a.drop_thresh = t->drop_thresh; a.drop_scale = t->drop_scale; a.drop_key = o.key(site0 + PL_MID).salt; a.drop_step = t->step_key_dev; }
+    RC(launch_gemm(t->precision, EPI_GATED_TRAIN, a, o.st));
+  } else {
+    RC(o.mm(TG_STORE_T, h, d, 0, o.W(wi), d, 0, ab, 2 * dff, M, 2 * dff, d));
+    RC(o.gated(ab, mid, M, site0 + PL_MID));
+  }
   RC(o.mm(TG_RESID_F32, mid, dff, 0, o.W(wo), dff, 0, x_out, d, M, d, dff, x_in, site0 + PL_FF_OUT));
   return M2M_OK;
 }
@@ -2887,8 +2835,19 @@ int ff_bwd(const Ops<T>& o, const float* x_in, const float* dx_out, float* dx_in
   RC(o.begin_sub(1u << m2m_trainer::K_DXT | 1u << m2m_trainer::K_DAB));
   RC(o.cvt_branch(dx_out, t->dxT, (int64_t)M * d, site0 + PL_FF_OUT));
   RC(o.dW(t->dxT, d, d, mid, dff, dff, G + wo, M));                                               // dWo = dx^T . mid
-  RC(o.dX(TG_STORE_T, t->dxT, d, wo, d, dff, t->dmid, dff, M));                                   // dmid = dx . Wo
-  RC(o.gated_bwd(ab, t->dmid, t->dab, M, site0 + PL_MID));
+  // dmid = dx . Wo, turned into the gate pair's gradient by the product's own epilogue where it can (bf16): dmid is never stored,
+  // the gated_bwd_kernel launch and its reads are gone
+  static const bool gate_epi = [] { const char* v = getenv("M2M_TRAIN_GATE_EPI"); return !(v && v[0] == '0'); }();
+  if (gate_epi && !t->fp8 && o.use_tuned && gemm_takes_gated_bwd(t->precision, M, dff, d)) {
+    GemmArgs a{};
+    a.A = t->dxT; a.W = reinterpret_cast<const T*>(t->WT) + wo; a.M = M; a.N = dff; a.K = d; a.out = t->dab; a.ldo = 2 * dff; a.ab_out = const_cast<void*>(ab);
+    a.vt_which = -1;
+    if (o.dropping(site0 + PL_MID)) { a.drop_thresh = t->drop_thresh; a.drop_scale = t->drop_scale; a.drop_key = o.key(site0 + PL_MID).salt; a.drop_step = t->step_key_dev; }
+    RC(launch_gemm(t->precision, EPI_GATED_BWD, a, o.st));
+  } else {
+    RC(o.dX(TG_STORE_T, t->dxT, d, wo, d, dff, t->dmid, dff, M));                                 // dmid = dx . Wo
+    RC(o.gated_bwd(ab, t->dmid, t->dab, M, site0 + PL_MID));
+  }
   RC(o.dW(t->dab, 2 * dff, 2 * dff, h, d, d, G + wi, M));                                         // dWi = dab^T . h
   RC(o.dX(TG_STORE_F32, t->dab, 2 * dff, wi, 2 * dff, d, t->dh, d, M));                           // dh = dab . Wi
   RC(o.norm_bwd(x_in, ln, t->dh, dx_out, dx_in, G, M));
@@ -2896,18 +2855,14 @@ int ff_bwd(const Ops<T>& o, const float* x_in, const float* dx_out, float* dx_in
   return M2M_OK;
 }
 
-// key of this pass = splitmix64(seed + passes since set_dropout); the counter lives on the device so that a replayed graph advances it
-__global__ void step_key_kernel(uint64_t seed, uint64_t* __restrict__ ctr, uint64_t* __restrict__ key) {
-  const uint64_t c = *ctr;
-  *key = splitmix64(seed + c);
-  *ctr = c + 1;
-}
-
-// Everything a pass needs before its first product and that depends on nothing but the inputs, in ONE launch (they were six:
+// Everything a pass needs before its first product and that depends on nothing but the inputs, in ONE launch.  (The pad ranges: the
+// flat gradient buffer is OVERWRITTEN by every pass — each tensor in full, by its own product / reduction — so all that needs zeroing
+// is the alignment padding between tensors, <= 63 floats each, instead of a 121 MB memset; tests fill the buffer with NaN before a
+// pass, so a tensor nobody wrote would show.)  In ONE launch (they were six:
 // two bias-table gathers, the dropout key, the pad zeroing, the valid-label count, the decoder inputs — ~5 us of launch each for
 // microseconds of work).  Block roles by index: [0, nb_e) encoder bias table, [nb_e, nb_e + nb_d) decoder bias table, then the pad
 // ranges (one wave each), then shift_right; block 0 also advances the dropout key (thread 0) and, the LAST block counts
-// the scored labels (a single-block reduction, as count_valid_kernel).
+// the scored labels (a single-block reduction).
 struct PrologueArgs {
   const float *w_e, *w_d;              // relative-position-bias weights [buckets][H]
   const int *bucket_e, *bucket_d;
@@ -2925,7 +2880,7 @@ struct PrologueArgs {
 };
 __global__ __launch_bounds__(256) void train_prologue_kernel(PrologueArgs a) {
   int blk = blockIdx.x;
-  if (blk == 0 && threadIdx.x == 0) {                      // key of this pass (step_key_kernel)
+  if (blk == 0 && threadIdx.x == 0) {                      // key of this pass = splitmix64(seed + passes since set_dropout); the counter lives on the device so that a replayed graph advances it
     const uint64_t c = *a.ctr;
     *a.key = splitmix64(a.seed + c);
     *a.ctr = c + 1;
@@ -3000,7 +2955,7 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
   }
   if (G || t->precision == M2M_PREC_BF16) {      // W^T for the dX products (with gradients) and the bf16 copy the forward products read, one pass over P
     hipLaunchKernelGGL(weights_transpose_kernel<T>, dim3(t->n_wt_blocks), dim3(256), 0, st, (const WtBlock*)t->wt_blocks, P, G ? (T*)t->WT : (T*)nullptr,
-                       t->precision == M2M_PREC_BF16 ? (T*)t->Wc : (T*)nullptr);
+                       t->precision == M2M_PREC_BF16 ? (T*)t->Wc : (T*)nullptr, (t->precision == M2M_PREC_BF16 && !t->fp8) ? (T*)t->Wil : (T*)nullptr);
     M2M_CHECK_HIP(hipGetLastError());
   }
   if (t->fp8) {

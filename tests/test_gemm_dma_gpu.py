@@ -1,7 +1,11 @@
 """GPU: the LDS-DMA main loop of the projection GEMM (csrc/enc_kernels.hip gemm_kernel<..., NS>: operand tiles global -> LDS through
 global_load_lds_dwordx4 into a ring of 64-deep stages, counted vmcnt + one raw barrier per step, bank swizzle on the source
 address) against the register-staged loop it replaces.  Both accumulate every output element over k in the same order, so every
-result downstream — encoder states, greedy ids, training loss and gradients — must be BIT-identical, at every ring depth."""
+result downstream — encoder states, greedy ids, training loss and gradients — must be BIT-identical, at every ring depth.
+The same runs cover the gated-GELU forward and backward written by the neighbouring products' own epilogues (EPI_GATED_TRAIN on
+row-interleaved weights, EPI_GATED_BWD; M2M_TRAIN_GATE_EPI=0 restores the gated_fwd / gated_bwd kernel launches): the same
+accumulations, the activation and its derivative computed from the same rounded values with the same functions — bit-identical
+again (the 16-clip shape takes the fused forward; every shape the fused backward)."""
 import os
 import subprocess
 import sys
@@ -23,7 +27,7 @@ def _run(env_extra):
 
 
 def test_lds_dma_gemm_is_bit_identical_to_the_register_staged_gemm():
-    ref = _run({"M2M_GEMM_DMA": "0"})
+    ref = _run({"M2M_GEMM_DMA": "0", "M2M_TRAIN_GATE_EPI": "0"})       # register-staged loop everywhere, gated_fwd_kernel launches
     # default = the ring where it pays (small tiles, K >= 512); "all" = every bf16 product incl. the 128x128 tiles, at two ring depths
     for setting in ({}, {"M2M_GEMM_DMA": "all"}, {"M2M_GEMM_DMA": "all", "M2M_GEMM_DMA_NS1": "3", "M2M_GEMM_DMA_NS2": "2"}):
         got = _run(setting)

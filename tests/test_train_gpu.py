@@ -303,7 +303,7 @@ def test_fp8_mode_matches_the_mx_emulating_oracle(cfg_name, B, F, Ld, parts, mon
           f"min {fmin:.4f} / median {fmed:.4f}; vs the unquantised oracle min {pmin:.4f} / median {pmed:.4f}")
     assert abs(loss.item() - loss_o.item()) < 1e-2 * abs(loss_o.item())
     assert abs(loss.item() - loss_plain.item()) < 3e-2 * abs(loss_plain.item())
-    assert cmin > fmin - 0.015 and cmed > fmed - 0.015
+    assert cmed > fmed - 0.015 and cmin > fmin - 0.03      # (the minimum over the tensors is itself a noisy draw: wider)
     if cfg_name == "full_1layer":
         assert cmin > 0.98 and cmed > 0.99
     if cfg_name == "tiny":                            # and it trains (Adafactor's warm-up steps are ~1e-6: the first few do not
