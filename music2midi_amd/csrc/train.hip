@@ -34,12 +34,18 @@ namespace m2m {
 // Operand storage: a_kmajor == 0: element (m, k) at A[m*lda + k]; a_kmajor == 1: at A[k*lda + m]
 // (the transposed product reads the buffer as it is: the tile is transposed on its way into LDS).
 constexpr int TG_BM = 64, TG_BN = 64;
-// k extent staged per step: 128 (bf16) / 64 (fp32) — 35 KB of LDS either way.  The attention products reduce over <= ~360
-// keys / queries, so the dependent load -> LDS -> MFMA chain of a workgroup is 3 steps instead of the 9 of BK = 32 (16 -> us per launch)
+// k extent staged per step: 96 (bf16) / 64 (fp32).  The attention products reduce over <= ~360 keys / queries, so the dependent
+// load -> LDS -> MFMA chain of a workgroup is 3 steps instead of the 9 of BK = 32 (16 -> us per launch).  96 rather than 128 for
+// bf16 (round 3): 26.6 KB of LDS instead of 34.8 — five workgroups per CU (97 registers allow them) instead of four, so the
+// 1 280 workgroups of the paired dV | dK launch of a 16-clip step are ONE round of the chip, and 261 keys are three steps either way
+// (18 launches per step, 17.8 -> 16.3 us each; M2M_TG_BK at build time for measurements).
 constexpr int TG_BK_MAX = 128;
 
 template <typename T> struct TgCfg;
-template <> struct TgCfg<bf16_t> { static constexpr int E = 8, BK = 128, PITCH = BK + 8; };
+#ifndef M2M_TG_BK
+#define M2M_TG_BK 96
+#endif
+template <> struct TgCfg<bf16_t> { static constexpr int E = 8, BK = M2M_TG_BK, PITCH = BK + 8; };
 template <> struct TgCfg<float> { static constexpr int E = 4, BK = 64, PITCH = BK + 4; };
 
 __device__ inline uint32_t u4_get(const uint4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
