@@ -84,3 +84,15 @@ def test_pmc_summary_without_the_launch_width_header_is_refused(tmp_path, capsys
     # the committed summary of the newest round carries the header and gives ~1.06x the algorithmic 56.7 MB
     real = bench.pmc_traffic_bytes("dec_attn_kernel<m2m::bf16_t, false,", 32)
     assert real is None or 0.9 * 56.72e6 < real < 1.3 * 56.72e6, real
+
+
+def test_train_profile_summary_reads_the_committed_rocprof_stats():
+    """train_configs4.roofline takes launches per step and the non-product share of a step from the newest committed
+    profiles/r*_train_dropout_kernel_stats.csv (rocprofv3 --kernel-trace --stats of tools/train_gap.py, 23 directly issued steps)."""
+    sys.path.insert(0, str(ROOT))
+    import bench
+    rec = bench.train_profile_summary()
+    assert rec and rec["profile"].startswith("r") and rec["profile"].endswith("train_dropout_kernel_stats.csv")
+    assert 150 < rec["launches_per_step"] < 400 and 3000 < rec["kernel_us_per_step"] < 6000
+    assert 0.15 * rec["kernel_us_per_step"] < rec["non_gemm_us"] < 0.5 * rec["kernel_us_per_step"]
+    assert bench.train_profile_summary(profiles_dir=ROOT / "tests") == {}
