@@ -290,6 +290,19 @@ int m2m_mx8_matmul_f32(const float* a_dev, const float* b_dev, int M, int N, int
 int m2m_mx8_matmul_bf16a(const uint16_t* a_bf16_dev, const float* b_dev, int M, int N, int K, int a_is_e5m2, int fused, float* c_dev,
                          void* stream);
 
+/* The training step's whole-head attention kernels on their own (csrc/attn_train.hip; hf: modeling_t5.py:159-170 T5Attention and its
+ * autograd backward): q [B, Sq, H*64], k / v [B, Sk, H*64] bf16, row-major; bias_tab [H][Sq + Sk - 1] fp32 by (key - query + Sq - 1)
+ * or NULL; no 1/sqrt(d) scaling; dropout on the probabilities with the step's counter-based hash (element index
+ * ((b*H + h)*Sq + query) * round_up_8(Sk) + key, key = splitmix64(step_key + site_salt)).  Forward: out [B, Sq, H*64] bf16 and the
+ * row log-sum-exp lse [B*H][Sq] fp32.  Backward: from q, k, v, out, lse and d_out the gradients dq / dk / dv (layouts of q / k / v) and,
+ * with a bias, diag_part [B*H][ceil(Sq/32)][Sk + 31] = per-query-block sums of dS along the diagonals key - local row = x - 31.
+ * Test utilities like m2m_mx8_matmul_f32 (they own one device word for the step key and synchronise `stream` to set it). */
+int m2m_attn_head_fwd_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, const float* bias_tab, int B, int H, int Sq, int Sk,
+                           int causal, float drop_p, uint64_t step_key, uint64_t site_salt, uint16_t* out, float* lse, void* stream);
+int m2m_attn_head_bwd_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, const uint16_t* out, const float* lse, const uint16_t* d_out,
+                           const float* bias_tab, int B, int H, int Sq, int Sk, int causal, float drop_p, uint64_t step_key, uint64_t site_salt,
+                           uint16_t* dq, uint16_t* dk, uint16_t* dv, float* diag_part, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Measurement hooks (bench.py): time one kernel of the decode step in isolation
  * with hipEvents on `stream`, cycling through all decoder layers so the working
