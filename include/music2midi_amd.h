@@ -298,10 +298,11 @@ int m2m_mx8_matmul_bf16a(const uint16_t* a_bf16_dev, const float* b_dev, int M, 
  * with a bias, diag_part [B*H][ceil(Sq/32)][Sk + 31] = per-query-block sums of dS along the diagonals key - local row = x - 31.
  * Test utilities like m2m_mx8_matmul_f32 (they own one device word for the step key and synchronise `stream` to set it). */
 int m2m_attn_head_fwd_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, const float* bias_tab, int B, int H, int Sq, int Sk,
-                           int causal, float drop_p, uint64_t step_key, uint64_t site_salt, uint16_t* out, float* lse, void* stream);
+                           int causal, float drop_p, uint64_t step_key, uint64_t site_salt, uint16_t* out, float* lse, uint32_t* keep_bits,
+                           void* stream);
 int m2m_attn_head_bwd_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, const uint16_t* out, const float* lse, const uint16_t* d_out,
                            const float* bias_tab, int B, int H, int Sq, int Sk, int causal, float drop_p, uint64_t step_key, uint64_t site_salt,
-                           uint16_t* dq, uint16_t* dk, uint16_t* dv, float* diag_part, void* stream);
+                           const uint32_t* keep_bits, uint16_t* dq, uint16_t* dk, uint16_t* dv, float* diag_part, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Measurement hooks (bench.py): time one kernel of the decode step in isolation

@@ -24,10 +24,11 @@
 #include "train.h"
 
 #include <algorithm>
+#include <cstdlib>
+#include <type_traits>
 
 namespace m2m {
 
-constexpr int AH_MAX_S = 288;                // rows an LDS image holds (9 blocks of 32): 36 KB per [S, 64] bf16 operand, two images + tables per workgroup, two workgroups per CU
 
 // LDS image of a [rows, 64] bf16 operand: 128-byte rows, no padding; 16-byte chunk c of row r sits at slot c ^ ah_g(r).  The
 // natural fragment reads (lane = row, 16 lanes cover (r & 1, slot) = all 16 bank groups) and the transposing reads (four consecutive
@@ -72,25 +73,9 @@ __device__ inline void ah_stage(bf16_t* X, const bf16_t* G, int64_t ld, int n_va
   }
 }
 
-struct HeadAttnArgs {
-  // (position, d) of clip b, head h at ptr + b * sXb + h * 64 + position * ldx
-  const bf16_t *Q, *K, *V;
-  int64_t ldq, ldk, ldv, sQb, sKb, sVb;
-  bf16_t* O;                   // forward out, backward in
-  int64_t ldo, sOb;
-  float* lse;                  // [B*H][Sq]: forward out, backward in
-  const bf16_t* dO;            // backward in (layout of O)
-  bf16_t *dQ, *dK, *dV;        // backward out
-  int64_t lddq, lddk, lddv, sdQb, sdKb, sdVb;
-  const float* bias_tab;       // [H][tab_stride] by (key - query + tab_center), or null
-  int tab_stride, tab_center;
-  float* diag_part;            // backward, self-attention with bias: [B*H][ceil(Sq/32)][Sk + 31] diagonal sums of dS, or null
-  int H, Sq, Sk, causal, ldp;  // ldp: row pitch of the dropout element index (round-up-8 of Sk, as the stored P had)
-  DropKey dk;
-  uint32_t thresh;
-  float scale;
-};
 
+// all ones when bit `bit` of w is set, else zero (v_bfe_i32): a dropout keep bit as an AND mask on the value's bits
+__device__ inline uint32_t ah_bit_mask(uint32_t w, int bit) { return (uint32_t)((int32_t)(w << (31 - bit)) >> 31); }
 __device__ inline float ah_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 
 // ------------------------------------------------------------------------------------------------------------ forward
@@ -99,18 +84,19 @@ __global__ __launch_bounds__(256, 2) void attn_head_fwd_kernel(HeadAttnArgs a) {
   extern __shared__ __align__(1024) unsigned char ah_smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int bh = blockIdx.y, b = bh / a.H, hh = bh - b * a.H;
-  const int nk = (a.Sk + 31) >> 5, Skp = nk * 32;
+  const int nk = (a.Sk + 31) >> 5, Skp = nk * 32, Sqp = ((a.Sq + 31) >> 5) * 32;
   bf16_t* Ks = reinterpret_cast<bf16_t*>(ah_smem);
   bf16_t* Vs = Ks + Skp * 64;
   float* bias_s = reinterpret_cast<float*>(Vs + Skp * 64);
   const bf16_t* Kg = a.K + b * a.sKb + hh * 64;
   const bf16_t* Vg = a.V + b * a.sVb + hh * 64;
-  ah_stage(Ks, Kg, a.ldk, a.Sk, Skp, wave, lane, 4);
-  ah_stage(Vs, Vg, a.ldv, a.Sk, Skp, wave, lane, 4);
+  const int nw = blockDim.x >> 6;                              // waves per workgroup: 3 or 4, whichever wastes fewer on this block count
+  ah_stage(Ks, Kg, a.ldk, a.Sk, Skp, wave, lane, nw);
+  ah_stage(Vs, Vg, a.ldv, a.Sk, Skp, wave, lane, nw);
   if (BIAS)
-    for (int i = threadIdx.x; i < a.tab_stride + 32; i += 256) bias_s[i] = i < a.tab_stride ? a.bias_tab[(int64_t)hh * a.tab_stride + i] : 0.f;
+    for (int i = threadIdx.x; i < a.tab_stride + 32; i += blockDim.x) bias_s[i] = i < a.tab_stride ? a.bias_tab[(int64_t)hh * a.tab_stride + i] : 0.f;
   // this wave's query block
-  const int qi = 4 * blockIdx.x + wave;
+  const int qi = nw * blockIdx.x + wave;
   const bool active = qi * 32 < a.Sq;
   const int q = qi * 32 + r, qc = min(q, a.Sq - 1);
   Frag<bf16_t> qf[4];
@@ -154,12 +140,17 @@ __global__ __launch_bounds__(256, 2) void attn_head_fwd_kernel(HeadAttnArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) { oacc[0][e] *= alpha; oacc[1][e] *= alpha; }
       if (DROP) {
+        uint32_t w = 0;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const uint32_t kb = drop_keep4(key, prow + 32 * j + 8 * g + 4 * h, a.thresh);
+          w |= kb << (8 * g);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[4 * g + e] = ((kb >> e) & 1u) ? acc[4 * g + e] * a.scale : 0.f;
+          for (int e = 0; e < 4; ++e) acc[4 * g + e] = __uint_as_float(__float_as_uint(acc[4 * g + e] * a.scale) & ah_bit_mask(kb, e));
         }
+        w <<= 4 * h;                                           // bit k of the word = key 32 j + k of this lane's query
+        w |= __float_as_uint(lane_xor<32>(__uint_as_float(w)));
+        if (h == 0) a.keep_bits[((int64_t)bh * nk + j) * Sqp + qi * 32 + r] = w;
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -194,6 +185,15 @@ __global__ __launch_bounds__(256, 2) void attn_head_fwd_kernel(HeadAttnArgs a) {
   }
 }
 
+// waves per workgroup for `blocks` 32-row blocks: every workgroup stages the whole head, so idle waves in the last one are pure cost
+// (9 blocks: 3 x 3 waves instead of 4 + 4 + 1)
+static int ah_waves(int blocks) {
+  static const int forced = [] { const char* v = getenv("M2M_AH_WAVES"); return v ? atoi(v) : 0; }();
+  if (forced >= 1 && forced <= 4) return forced;
+  if (blocks <= 4) return blocks;
+  return (ceil_div(blocks, 3) * 3 - blocks) < (ceil_div(blocks, 4) * 4 - blocks) ? 3 : 4;
+}
+
 size_t attn_head_fwd_smem(int Sk, bool bias, int tab_stride) {
   const size_t skp = (size_t)((Sk + 31) / 32) * 32;
   const size_t kv = 2 * skp * 64 * sizeof(bf16_t), bias_b = bias ? ((size_t)(tab_stride + 32) * 4 + 15) / 16 * 16 : 0;
@@ -206,13 +206,15 @@ int launch_attn_head_fwd(const HeadAttnArgs& a, int nB, hipStream_t st) {
   M2M_REQUIRE(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0 && a.ldo % 8 == 0 && a.sQb % 8 == 0 && a.sKb % 8 == 0 && a.sVb % 8 == 0 && a.sOb % 8 == 0,
               "attn_head: operand strides must keep 16-byte alignment");
   const bool bias = a.bias_tab != nullptr, drop = a.thresh != 0;
+  M2M_REQUIRE(!drop || a.keep_bits, "attn_head: dropout needs the keep-bit buffer");
   const size_t smem = attn_head_fwd_smem(a.Sk, bias, a.tab_stride);
   M2M_REQUIRE(smem <= 78 * 1024, "attn_head: %zu bytes of LDS", smem);
-  dim3 grid((unsigned)ceil_div(ceil_div(a.Sq, 32), 4), (unsigned)(nB * a.H));
+  const int nw = ah_waves(ceil_div(a.Sq, 32));
+  dim3 grid((unsigned)ceil_div(ceil_div(a.Sq, 32), nw), (unsigned)(nB * a.H));
 #define M2M_AH_FWD(C_, B_, D_)                                                                   \
   do {                                                                                           \
     M2M_OPT_IN_LDS((attn_head_fwd_kernel<C_, B_, D_>), 158 * 1024);                              \
-    hipLaunchKernelGGL((attn_head_fwd_kernel<C_, B_, D_>), grid, dim3(256), smem, st, a);        \
+    hipLaunchKernelGGL((attn_head_fwd_kernel<C_, B_, D_>), grid, dim3(64 * nw), smem, st, a);    \
   } while (0)
   if (a.causal) {
     if (bias) { if (drop) M2M_AH_FWD(true, true, true); else M2M_AH_FWD(true, true, false); }
@@ -250,6 +252,9 @@ template <int X> __device__ inline uint32_t ah_quad_bcast(uint32_t v) {      // 
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, X * 0x55, 0xF, 0xF, true);
 }
 
+constexpr float AH_LOG2E = 1.4426950408889634f;
+constexpr int AH_SKEW_P = 40;      // pitch (elements) of the skewed dS tile of the bias gradient: 80-byte rows keep its 16-byte column reads conflict-free
+
 template <bool CAUSAL, bool BIAS, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_head_bwd_kernel(HeadAttnArgs a) {
   extern __shared__ __align__(1024) unsigned char ah_smem[];
@@ -259,21 +264,25 @@ __global__ __launch_bounds__(256, 2) void attn_head_bwd_kernel(HeadAttnArgs a) {
   const int Sp = max(max(Sqp, Skp), 288);                       // (the output staging needs 36 KB of the second image whatever the lengths)
   bf16_t* Xa = reinterpret_cast<bf16_t*>(ah_smem);             // pass A: Q image; pass B: K image
   bf16_t* Xb = Xa + Sp * 64;                                   // pass A: dO image; then per-wave staging / scratch
-  float* lse_s = reinterpret_cast<float*>(Xb + Sp * 64);       // [Sqp]: +1e30 beyond Sq (=> P = 0 there)
-  float* delta_s = lse_s + Sqp;                                // [Sqp]
-  float* bias_s = delta_s + Sqp;                               // [tab_stride + 32]
+  // Row statistics and bias rows are staged in the units the element loop wants, so that a probability costs a subtract, a
+  // multiply-add and an exp2:  P~ = P / (1 - p) = exp2(S log2e + bias log2e - (lse log2e - log2 scale)),  dS = P~ (keep . dP - delta / scale)
+  float* lse_s = reinterpret_cast<float*>(Xb + Sp * 64);       // [Sqp]: lse log2e - log2 scale; +1e30 beyond Sq (=> P = 0 there)
+  float* delta_s = lse_s + Sqp;                                // [Sqp]: rowsum(dO o O) / scale
+  float* bias_s = delta_s + Sqp;                               // [tab_stride + 32]: bias log2e by (key - query + tab_center), zeros behind
+  float* biasr_s = bias_s + a.tab_stride + 32;                 // the same row reversed (pass A walks queries upwards for a fixed key), zeros behind
   const bf16_t* Qg = a.Q + b * a.sQb + hh * 64;
   const bf16_t* Kg = a.K + b * a.sKb + hh * 64;
   const bf16_t* Vg = a.V + b * a.sVb + hh * 64;
   const bf16_t* Og = a.O + b * a.sOb + hh * 64;
   const bf16_t* dOg = a.dO + b * a.sOb + hh * 64;
-  const int blk = 4 * blockIdx.x + wave;                       // this wave's key block (pass A) and query block (pass B)
-  const uint64_t key = DROP ? drop_site_key(a.dk) : 0ull;
+  const int nw = blockDim.x >> 6;
+  const int blk = nw * blockIdx.x + wave;                      // this wave's key block (pass A) and query block (pass B)
+  const float inv_scale = DROP ? 1.0f / a.scale : 1.0f, lg_scale = DROP ? __log2f(a.scale) : 0.f;
 
-  // ---- phase 0: Q, dO -> LDS; delta = rowsum(dO o O), lse, bias row; this wave's K / V block -> registers
-  ah_stage(Xa, Qg, a.ldq, a.Sq, Sqp, wave, lane, 4);
-  ah_stage(Xb, dOg, a.ldo, a.Sq, Sqp, wave, lane, 4);
-  for (int q = threadIdx.x; q < Sqp; q += 256) {
+  // ---- phase 0: Q, dO -> LDS; delta = rowsum(dO o O), lse, bias rows; this wave's K / V block -> registers
+  ah_stage(Xa, Qg, a.ldq, a.Sq, Sqp, wave, lane, nw);
+  ah_stage(Xb, dOg, a.ldo, a.Sq, Sqp, wave, lane, nw);
+  for (int q = threadIdx.x; q < Sqp; q += blockDim.x) {
     float dsum = 0.f, lv = 1e30f;
     if (q < a.Sq) {
       const uint4* pd = reinterpret_cast<const uint4*>(dOg + (int64_t)q * a.ldo);
@@ -288,13 +297,16 @@ __global__ __launch_bounds__(256, 2) void attn_head_bwd_kernel(HeadAttnArgs a) {
         for (int w = 0; w < 4; ++w)
           dsum += __uint_as_float(wd[w] << 16) * __uint_as_float(wo[w] << 16) + __uint_as_float(wd[w] & 0xFFFF0000u) * __uint_as_float(wo[w] & 0xFFFF0000u);
       }
-      lv = a.lse[(int64_t)bh * a.Sq + q];
+      lv = a.lse[(int64_t)bh * a.Sq + q] * AH_LOG2E - lg_scale;
     }
-    delta_s[q] = dsum;
+    delta_s[q] = dsum * inv_scale;
     lse_s[q] = lv;
   }
   if (BIAS)
-    for (int i = threadIdx.x; i < a.tab_stride + 32; i += 256) bias_s[i] = i < a.tab_stride ? a.bias_tab[(int64_t)hh * a.tab_stride + i] : 0.f;
+    for (int i = threadIdx.x; i < a.tab_stride + 32; i += blockDim.x) {
+      bias_s[i] = i < a.tab_stride ? a.bias_tab[(int64_t)hh * a.tab_stride + i] * AH_LOG2E : 0.f;
+      biasr_s[i] = i < a.tab_stride ? a.bias_tab[(int64_t)hh * a.tab_stride + (a.tab_stride - 1 - i)] * AH_LOG2E : 0.f;
+    }
   const bool actA = blk * 32 < a.Sk;
   Frag<bf16_t> kf[4], vf[4];
   {
@@ -309,47 +321,55 @@ __global__ __launch_bounds__(256, 2) void attn_head_bwd_kernel(HeadAttnArgs a) {
   __syncthreads();
 
   // ---- pass A: this wave's 32 keys against every query block.  S = Q_i K_j^T: accumulator rows = queries, a lane owns ONE key.
+  // Keys beyond Sk (clamped copies of the last row) need no masking here: they only reach columns of dV^T / dK^T that are never stored.
   f32x16 dvT[2] = {zero_acc(), zero_acc()}, dkT[2] = {zero_acc(), zero_acc()};
   if (actA) {
     const int kcol = blk * 32 + r;                              // this lane's key
-    const bool kvalid = kcol < a.Sk;
-    const int t4 = lane & 3;
-    for (int i = CAUSAL ? blk : 0; i < nq; ++i) {
+    const uint32_t* kbits = DROP ? a.keep_bits + ((int64_t)bh * nk + blk) * Sqp + 4 * h : nullptr;
+    const float* brow = biasr_s + (a.tab_stride - 1 - a.tab_center - kcol) + 4 * h;      // brow[q - 4 h] = bias log2e of (kcol - q)
+    const float* lrow = lse_s + 4 * h;
+    const float* drow = delta_s + 4 * h;
+    const int i0 = CAUSAL ? blk : 0;
+    uint4 kw[4];
+    if (DROP) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) kw[g] = *reinterpret_cast<const uint4*>(kbits + 32 * i0 + 8 * g);
+    }
+    auto tile = [&](int i, auto on_diag) {
+      constexpr bool DIAG = decltype(on_diag)::value;           // the causal diagonal tile: keys past the query are masked
       f32x16 sacc = zero_acc(), pacc = zero_acc();
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         mma16(sacc, ah_nat_frag(Xa, 32 * i + r, s, h), kf[s]);
         mma16(pacc, ah_nat_frag(Xb, 32 * i + r, s, h), vf[s]);
       }
-      // dropout keep bits: the four keys 4c .. 4c+3 of a query share one hash, i.e. the four lanes of a quad; lane t of the quad hashes
-      // for the accumulator rows e = 4 g + t and the quad reads each other's 4-bit masks through DPP
-      uint32_t kown[4] = {0xFu, 0xFu, 0xFu, 0xFu};
-      if (DROP) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int qe = min(32 * i + t4 + 8 * g + 4 * h, a.Sq - 1);
-          kown[g] = drop_keep4(key, ((int64_t)bh * a.Sq + qe) * a.ldp + (kcol & ~3), a.thresh);
-        }
-      }
       float ptv[16], dsv[16];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float4 l4 = *reinterpret_cast<const float4*>(lse_s + 32 * i + 8 * g + 4 * h);
-        const float4 d4 = *reinterpret_cast<const float4*>(delta_s + 32 * i + 8 * g + 4 * h);
+        const float4 l4 = *reinterpret_cast<const float4*>(lrow + 32 * i + 8 * g);
+        const float4 d4 = *reinterpret_cast<const float4*>(drow + 32 * i + 8 * g);
         const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq[4] = {d4.x, d4.y, d4.z, d4.w};
-        const uint32_t kq[4] = {ah_quad_bcast<0>(kown[g]), ah_quad_bcast<1>(kown[g]), ah_quad_bcast<2>(kown[g]), ah_quad_bcast<3>(kown[g])};
+        const uint32_t kq[4] = {kw[g].x, kw[g].y, kw[g].z, kw[g].w};      // the keep words of queries 32 i + 8 g + 4 h + (0..3) against this key block
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int e = 4 * g + u, q = 32 * i + u + 8 * g + 4 * h;
-          float v = sacc[e];
-          if (BIAS) v += bias_s[kcol - q + a.tab_center];        // (index stays inside the padded row: |kcol - q| < tab_stride for the rows that count)
-          const bool valid = kvalid && (!CAUSAL || kcol <= q);
-          const float p = valid ? ah_exp(v - lq[u]) : 0.f;
-          const bool keep = !DROP || ((kq[u] >> t4) & 1u);
-          ptv[e] = keep ? p * a.scale : 0.f;
-          const float dpt = keep ? pacc[e] * a.scale : 0.f;
-          dsv[e] = p * (dpt - dq[u]);
+          const int e = 4 * g + u;
+          const float t = BIAS ? brow[32 * i + 8 * g + u] - lq[u] : -lq[u];
+          float arg = fmaf(sacc[e], AH_LOG2E, t);
+          if (DIAG) arg = (r <= u + 8 * g + 4 * h) ? arg : -1e30f;
+          const float ps = __builtin_amdgcn_exp2f(arg);         // P / (1 - p)
+          if (DROP) {
+            const uint32_t mk = (uint32_t)__builtin_amdgcn_sbfe((int)kq[u], (unsigned)r, 1u);
+            ptv[e] = __uint_as_float(__float_as_uint(ps) & mk);
+            dsv[e] = ps * (__uint_as_float(__float_as_uint(pacc[e]) & mk) - dq[u]);
+          } else {
+            ptv[e] = ps;
+            dsv[e] = ps * (pacc[e] - dq[u]);
+          }
         }
+      }
+      if (DROP && i + 1 < nq) {                                 // the next tile's keep words: in flight behind the eight products below
+#pragma unroll
+        for (int g = 0; g < 4; ++g) kw[g] = *reinterpret_cast<const uint4*>(kbits + 32 * (i + 1) + 8 * g);
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -362,12 +382,15 @@ __global__ __launch_bounds__(256, 2) void attn_head_bwd_kernel(HeadAttnArgs a) {
           mma16(dkT[db], ah_tr_frag(Xa, 32 * i + 16 * s, db, lane), df);      // dK^T += Q^T dS
         }
       }
-    }
+    };
+    int i = i0;
+    if (CAUSAL) { tile(i, std::true_type{}); ++i; }
+    for (; i < nq; ++i) tile(i, std::false_type{});
   }
   __syncthreads();                                               // every wave is done with the Q / dO images
 
   // ---- between the passes: K -> LDS (pass B reads it both ways); dV / dK tiles out through the second image; Q_i, dO_i -> registers
-  ah_stage(Xa, Kg, a.ldk, a.Sk, Skp, wave, lane, 4);
+  ah_stage(Xa, Kg, a.ldk, a.Sk, Skp, wave, lane, nw);
   bf16_t* Tw = Xb + wave * (2 * 32 * AH_TP);                     // this wave's 9 KB of the second image
   if (actA) {
     ah_tile_to_lds(Tw, dvT, r, h, 1.0f);
@@ -391,43 +414,65 @@ __global__ __launch_bounds__(256, 2) void attn_head_bwd_kernel(HeadAttnArgs a) {
   // ---- pass B: this wave's 32 queries against every key block.  S^T = K_j Q_i^T: a lane owns ONE query.
   if (!actB) return;
   f32x16 dqT[2] = {zero_acc(), zero_acc()};
-  const float lse_q = q < a.Sq ? lse_s[q] : 1e30f, delta_q = delta_s[min(q, Sqp - 1)];
-  float* tile_s = reinterpret_cast<float*>(Tw);                  // [32][33] fp32: the dS tile for the diagonal sums (bias gradient)
-  float* diag_s = tile_s + 32 * 33;                              // [Sk + 31 (+ padding)]
-  const int dl = a.Sk + 31;
+  const float lse_q = lse_s[blk * 32 + r], delta_q = delta_s[blk * 32 + r];      // (rows beyond Sq: lse = 1e30 => P = 0)
+  // Relative-position-bias gradient, stage 1: sums of this query block's dS along the diagonals key - local row = x - 31 (the layout
+  // bias_stripes_sum_kernel reads).  The tile is written SKEWED — dS[row][key] at [x = key - row + 31][row], bf16 as the product used it
+  // — so a diagonal becomes a row of 32, and its sum a product with a vector of ones on the otherwise idle matrix core; the upper
+  // half of a tile's 63 diagonals continues in the next tile's lower half and rides there as the accumulator input.
   const bool want_diag = a.diag_part != nullptr;
+  bf16_t* skew = Tw;                                            // [64][AH_SKEW_P]; entries outside a row's 32-wide band stay zero
+  const int dl = a.Sk + 31;
+  float* dout = want_diag ? a.diag_part + ((int64_t)bh * nq + blk) * dl : nullptr;
   if (want_diag) {
-    for (int x = lane; x < dl + 33; x += 64) diag_s[x] = 0.f;
+    for (int x = lane; x < 64 * AH_SKEW_P / 8; x += 64) reinterpret_cast<uint4*>(skew)[x] = make_uint4(0u, 0u, 0u, 0u);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
-  const int64_t prow = ((int64_t)bh * a.Sq + qc) * a.ldp;
+  uint16_t* skew_w = reinterpret_cast<uint16_t*>(skew) + (31 + 4 * h - r) * AH_SKEW_P + r;       // + key-in-tile * AH_SKEW_P
+  const bf16_t* skew_r = skew + r * AH_SKEW_P + 8 * h;                                              // + 32 AH_SKEW_P nb + 16 s
+  Frag<bf16_t> ones;
+  ones.v = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
+  f32x16 carry = zero_acc();
   const float* bt = bias_s + a.tab_center - qc;
   const int jend = CAUSAL ? min(nk, blk + 1) : nk;
-  for (int j = 0; j < jend; ++j) {
-    f32x16 sacc = zero_acc(), pacc = zero_acc();
-    {
-      const int vrow = min(32 * j + r, a.Sk - 1);
+  const uint32_t* kbq = DROP ? a.keep_bits + (int64_t)bh * nk * Sqp + blk * 32 + r : nullptr;
+  uint32_t kw_next = DROP ? kbq[0] : 0u;
+  Frag<bf16_t> vfr[4];
+  {
+    const int vrow = min(r, a.Sk - 1);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        mma16(sacc, ah_nat_frag(Xa, 32 * j + r, s, h), qf[s]);
-        mma16(pacc, load_frag(Vg + (int64_t)vrow * a.ldv + 16 * s + 8 * h), dof[s]);
-      }
+    for (int s = 0; s < 4; ++s) vfr[s] = load_frag(Vg + (int64_t)vrow * a.ldv + 16 * s + 8 * h);
+  }
+  auto tileB = [&](int j, auto masked) {
+    constexpr bool MASK = decltype(masked)::value;              // the last key block (keys beyond Sk) and the causal diagonal
+    f32x16 sacc = zero_acc(), pacc = zero_acc();
+    const uint32_t kwq = kw_next >> (4 * h);                    // this query's keep bits against key block j
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      mma16(sacc, ah_nat_frag(Xa, 32 * j + r, s, h), qf[s]);
+      mma16(pacc, vfr[s], dof[s]);
+    }
+    if (j + 1 < jend) {                                         // the next tile's V rows and keep word: in flight behind this tile's element work
+      const int vrow = min(32 * (j + 1) + r, a.Sk - 1);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) vfr[s] = load_frag(Vg + (int64_t)vrow * a.ldv + 16 * s + 8 * h);
+      if (DROP) kw_next = kbq[(int64_t)(j + 1) * Sqp];
     }
     float dsv[16];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int k0 = 32 * j + 8 * g + 4 * h;
-      const uint32_t kb = DROP ? drop_keep4(key, prow + k0, a.thresh) : 0xFu;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int e = 4 * g + u, k = k0 + u;
-        float v = sacc[e];
-        if (BIAS) v += bt[k];
-        const bool valid = k < a.Sk && (!CAUSAL || k <= qc);
-        const float p = valid ? ah_exp(v - lse_q) : 0.f;
-        const float dpt = (!DROP || ((kb >> u) & 1u)) ? pacc[e] * a.scale : 0.f;
-        dsv[e] = p * (dpt - delta_q);
+        const int e = 4 * g + u, kk = 8 * g + u;               // key 32 j + kk + 4 h
+        const float t = BIAS ? bt[32 * j + 4 * h + kk] - lse_q : -lse_q;
+        float arg = fmaf(sacc[e], AH_LOG2E, t);
+        if (MASK) {
+          const int k = 32 * j + 4 * h + kk;
+          arg = (k < a.Sk && (!CAUSAL || k <= qc)) ? arg : -1e30f;
+        }
+        const float ps = __builtin_amdgcn_exp2f(arg);
+        const float dpt = DROP ? __uint_as_float(__float_as_uint(pacc[e]) & (uint32_t)__builtin_amdgcn_sbfe((int)kwq, (unsigned)kk, 1u)) : pacc[e];
+        dsv[e] = ps * (dpt - delta_q);
       }
     }
     Frag<bf16_t> df[2];
@@ -439,28 +484,41 @@ __global__ __launch_bounds__(256, 2) void attn_head_bwd_kernel(HeadAttnArgs a) {
       for (int db = 0; db < 2; ++db) mma16(dqT[db], ah_tr_frag(Xa, 32 * j + 16 * s, db, lane), df[s]);      // dQ^T += K^T dS^T
     }
     if (want_diag) {
-      // relative-position-bias gradient, stage 1: sums of this query block's dS along the diagonals key - local row = x - 31 (the layout
-      // the stripe kernel left for bias_stripes_sum_kernel).  The tile goes to LDS as [row][key] in the bf16 values the product used, lane
-      // x' sums diagonal x' - 31 of the tile in row order and adds it to entry 32 j + x' of the wave's running row.
 #pragma unroll
-      for (int e = 0; e < 16; ++e) tile_s[r * 33 + (e & 3) + 8 * (e >> 2) + 4 * h] = to_f32(from_f32<bf16_t>(dsv[e]));
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      if (lane < 63) {
-        const int dd = lane - 31;
-        float acc = 0.f;
-        for (int rr = max(0, -dd); rr <= min(31, 31 - dd); ++rr) acc += tile_s[rr * 33 + rr + dd];
-        diag_s[32 * j + lane] += acc;
+      for (int s = 0; s < 2; ++s) {
+        const uint32_t w[4] = {df[s].v.x, df[s].v.y, df[s].v.z, df[s].v.w};
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {                          // elements e = 8 s + 2 m, + 1: keys kk = 8 (2 s + (m >> 1)) + 2 (m & 1), + 1
+          const int kk = 8 * (2 * s + (m >> 1)) + 2 * (m & 1);
+          skew_w[kk * AH_SKEW_P] = (uint16_t)(w[m] & 0xFFFFu);
+          skew_w[(kk + 1) * AH_SKEW_P] = (uint16_t)(w[m] >> 16);
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
+      f32x16 c0 = carry, c1 = zero_acc();
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        mma16(c0, ones, load_frag(skew_r + 16 * s));
+        mma16(c1, ones, load_frag(skew_r + 32 * AH_SKEW_P + 16 * s));
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (h == 0) dout[32 * j + r] = c0[0];                    // (32 j + 31 <= Sk + 30: always inside the row)
+      carry = c1;
     }
+  };
+  const bool ragged = (a.Sk & 31) != 0;
+  for (int j = 0; j < jend; ++j) {
+    if ((CAUSAL && j == blk) || (ragged && j == nk - 1)) tileB(j, std::true_type{});
+    else tileB(j, std::false_type{});
   }
   if (want_diag) {
-    float* out = a.diag_part + ((int64_t)bh * nq + blk) * dl;
-    for (int x = lane; x < dl; x += 64) out[x] = diag_s[x];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    // the upper diagonals of the last tile visited, then zeros for what a causal block never reaches
+    if (h == 0) {
+      if (32 * jend + r < dl) dout[32 * jend + r] = r < 31 ? carry[0] : 0.f;
+      for (int x = 32 * (jend + 1) + r; x < dl; x += 32) dout[x] = 0.f;
+    }
   }
   ah_tile_to_lds(Tw, dqT, r, h, 1.0f);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -471,7 +529,7 @@ __global__ __launch_bounds__(256, 2) void attn_head_bwd_kernel(HeadAttnArgs a) {
 size_t attn_head_bwd_smem(int Sq, int Sk, bool bias, int tab_stride) {
   const size_t sqp = (size_t)((Sq + 31) / 32) * 32, skp = (size_t)((Sk + 31) / 32) * 32;
   const size_t sp = std::max<size_t>(std::max(sqp, skp), 288);
-  return 2 * sp * 64 * sizeof(bf16_t) + 2 * sqp * 4 + (bias ? ((size_t)(tab_stride + 32) * 4 + 15) / 16 * 16 : 0);
+  return 2 * sp * 64 * sizeof(bf16_t) + 2 * sqp * 4 + (bias ? ((size_t)2 * (tab_stride + 32) * 4 + 15) / 16 * 16 : 0);
 }
 
 int launch_attn_head_bwd(const HeadAttnArgs& a, int nB, hipStream_t st) {
@@ -480,14 +538,16 @@ int launch_attn_head_bwd(const HeadAttnArgs& a, int nB, hipStream_t st) {
                   a.sQb % 8 == 0 && a.sKb % 8 == 0 && a.sVb % 8 == 0 && a.sOb % 8 == 0 && a.sdQb % 8 == 0 && a.sdKb % 8 == 0 && a.sdVb % 8 == 0,
               "attn_head: operand strides must keep 16-byte alignment");
   const bool bias = a.bias_tab != nullptr, drop = a.thresh != 0;
+  M2M_REQUIRE(!drop || a.keep_bits, "attn_head: dropout needs the keep-bit buffer");
   const size_t smem = attn_head_bwd_smem(a.Sq, a.Sk, bias, a.tab_stride);
   M2M_REQUIRE(smem <= 80 * 1024, "attn_head: %zu bytes of LDS", smem);
   const int nq = ceil_div(a.Sq, 32), nk = ceil_div(a.Sk, 32);
-  dim3 grid((unsigned)ceil_div(std::max(nq, nk), 4), (unsigned)(nB * a.H));
+  const int nw = ah_waves(std::max(nq, nk));
+  dim3 grid((unsigned)ceil_div(std::max(nq, nk), nw), (unsigned)(nB * a.H));
 #define M2M_AH_BWD(C_, B_, D_)                                                                   \
   do {                                                                                           \
     M2M_OPT_IN_LDS((attn_head_bwd_kernel<C_, B_, D_>), 158 * 1024);                              \
-    hipLaunchKernelGGL((attn_head_bwd_kernel<C_, B_, D_>), grid, dim3(256), smem, st, a);        \
+    hipLaunchKernelGGL((attn_head_bwd_kernel<C_, B_, D_>), grid, dim3(64 * nw), smem, st, a);    \
   } while (0)
   if (a.causal) {
     if (bias) { if (drop) M2M_AH_BWD(true, true, true); else M2M_AH_BWD(true, true, false); }
@@ -520,8 +580,9 @@ struct StepWord {
 }  // namespace
 
 extern "C" int m2m_attn_head_fwd_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, const float* bias_tab, int B, int H, int Sq, int Sk,
-                                      int causal, float drop_p, uint64_t step_key, uint64_t site_salt, uint16_t* out, float* lse, void* stream) {
-  M2M_REQUIRE(q && k && v && out && lse && B >= 1 && H >= 1, "m2m_attn_head_fwd_bf16: bad argument");
+                                      int causal, float drop_p, uint64_t step_key, uint64_t site_salt, uint16_t* out, float* lse, uint32_t* keep_bits,
+                                      void* stream) {
+  M2M_REQUIRE(q && k && v && out && lse && B >= 1 && H >= 1 && (keep_bits || drop_p <= 0.f), "m2m_attn_head_fwd_bf16: bad argument");
   static StepWord word;
   hipStream_t st = (hipStream_t)stream;
   int rc = word.set(step_key, st);
@@ -532,14 +593,14 @@ extern "C" int m2m_attn_head_fwd_bf16(const uint16_t* q, const uint16_t* k, cons
   a.ldq = a.ldk = a.ldv = a.ldo = inner; a.sQb = (int64_t)Sq * inner; a.sKb = a.sVb = (int64_t)Sk * inner; a.sOb = (int64_t)Sq * inner;
   a.bias_tab = bias_tab; a.tab_stride = Sq + Sk - 1; a.tab_center = Sq - 1;
   a.H = H; a.Sq = Sq; a.Sk = Sk; a.causal = causal; a.ldp = (Sk + 7) / 8 * 8;
-  a.dk = DropKey{word.dev, site_salt}; a.thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u; a.scale = 1.0f / (1.0f - drop_p);
+  a.dk = DropKey{word.dev, site_salt}; a.thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u; a.scale = 1.0f / (1.0f - drop_p); a.keep_bits = keep_bits;
   return launch_attn_head_fwd(a, B, st);
 }
 
 extern "C" int m2m_attn_head_bwd_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, const uint16_t* out, const float* lse, const uint16_t* d_out,
                                       const float* bias_tab, int B, int H, int Sq, int Sk, int causal, float drop_p, uint64_t step_key, uint64_t site_salt,
-                                      uint16_t* dq, uint16_t* dk, uint16_t* dv, float* diag_part, void* stream) {
-  M2M_REQUIRE(q && k && v && out && lse && d_out && dq && dk && dv && B >= 1 && H >= 1, "m2m_attn_head_bwd_bf16: bad argument");
+                                      const uint32_t* keep_bits, uint16_t* dq, uint16_t* dk, uint16_t* dv, float* diag_part, void* stream) {
+  M2M_REQUIRE(q && k && v && out && lse && d_out && dq && dk && dv && B >= 1 && H >= 1 && (keep_bits || drop_p <= 0.f), "m2m_attn_head_bwd_bf16: bad argument");
   static StepWord word;
   hipStream_t st = (hipStream_t)stream;
   int rc = word.set(step_key, st);
@@ -552,6 +613,6 @@ extern "C" int m2m_attn_head_bwd_bf16(const uint16_t* q, const uint16_t* k, cons
   a.sQb = a.sOb = a.sdQb = (int64_t)Sq * inner; a.sKb = a.sVb = a.sdKb = a.sdVb = (int64_t)Sk * inner;
   a.bias_tab = bias_tab; a.tab_stride = Sq + Sk - 1; a.tab_center = Sq - 1; a.diag_part = diag_part;
   a.H = H; a.Sq = Sq; a.Sk = Sk; a.causal = causal; a.ldp = (Sk + 7) / 8 * 8;
-  a.dk = DropKey{word.dev, site_salt}; a.thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u; a.scale = 1.0f / (1.0f - drop_p);
+  a.dk = DropKey{word.dev, site_salt}; a.thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u; a.scale = 1.0f / (1.0f - drop_p); a.keep_bits = const_cast<uint32_t*>(keep_bits);
   return launch_attn_head_bwd(a, B, st);
 }

@@ -59,8 +59,12 @@ template <> __device__ inline Frag<float> pack_frag<float>(const float (&x)[8]) 
   f.hi = make_float4(x[4], x[5], x[6], x[7]);
   return f;
 }
+// two fp32 -> packed bf16 (a in the low half), round-to-nearest-even: ONE v_cvt_pk_bf16_f32 (element-wise casts + a merge cost three)
 __device__ inline uint32_t pack2_bf16(float a, float b) {
-  return (uint32_t)f32_to_bf16(a).bits | ((uint32_t)f32_to_bf16(b).bits << 16);
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t x = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf16x2_t));
 }
 template <> __device__ inline Frag<bf16_t> pack_frag<bf16_t>(const float (&x)[8]) {
   Frag<bf16_t> f;

@@ -67,6 +67,31 @@ int launch_mxgemm_q(int fmt_a, int epi, const MxGemmArgs& g, hipStream_t st);   
 int launch_mxq_rows(int src_kind, const void* src, int64_t ld_s, uint8_t* q, uint8_t* sc, int R, int C, int Cp, int fmt, hipStream_t st);
 int launch_mxq_cols(int src_kind, const void* src, int64_t ld_s, uint8_t* qt, uint8_t* sc, int R, int C, int Rp, int fmt, hipStream_t st);
 
+// Whole-head attention of the training step (attn_train.hip): forward with the row log-sum-exp, two-pass backward
+struct HeadAttnArgs {
+  // (position, d) of clip b, head h at ptr + b * sXb + h * 64 + position * ldx   (bf16 storage)
+  const bf16_t *Q, *K, *V;
+  int64_t ldq, ldk, ldv, sQb, sKb, sVb;
+  bf16_t* O;                   // forward out, backward in
+  int64_t ldo, sOb;
+  float* lse;                  // [B*H][Sq]: forward out, backward in
+  const bf16_t* dO;            // backward in (layout of O)
+  bf16_t *dQ, *dK, *dV;        // backward out
+  int64_t lddq, lddk, lddv, sdQb, sdKb, sdVb;
+  const float* bias_tab;       // [H][tab_stride] by (key - query + tab_center), or null
+  int tab_stride, tab_center;
+  float* diag_part;            // backward, self-attention with bias: [B*H][ceil(Sq/32)][Sk + 31] diagonal sums of dS, or null
+  int H, Sq, Sk, causal, ldp;  // ldp: row pitch of the dropout element index (round-up-8 of Sk, as the stored P had)
+  DropKey dk;
+  uint32_t thresh;
+  float scale;
+  uint32_t* keep_bits;         // with dropout: [B*H][ceil(Sk/32)][round_up_32(Sq)] words, bit k of word (key block j, query q) = probability (q, 32 j + k)
+                               // is kept.  The forward pass hashes once and writes them; both backward orientations read them instead of hashing again.
+};
+constexpr int AH_MAX_S = 288;  // rows an LDS image holds (9 blocks of 32): 36 KB per [S, 64] bf16 operand, two images + tables per workgroup, two workgroups per CU
+int launch_attn_head_fwd(const HeadAttnArgs& a, int nB, hipStream_t st);
+int launch_attn_head_bwd(const HeadAttnArgs& a, int nB, hipStream_t st);
+
 // Adafactor plan (device tables built once per trainer)
 struct AfTensor {
   int64_t offset;          // into the flat parameter / gradient buffers

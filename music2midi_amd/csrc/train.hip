@@ -1958,6 +1958,7 @@ struct m2m_trainer {
   std::vector<float*> xe, xd;            // residual streams: 2*Le + 1 and 3*Ld + 1 buffers
   std::vector<void*> h0e, h1e, qkve, Pe, aoe, abe, mide;
   std::vector<void*> h0d, h1d, h2d, qkvd, Pd, aod, cqd, ckvd, Pcd, aocd, abd, midd;
+  std::vector<float*> lse_e, lse_d, lse_c;   // per attention layer: row log-sum-exp [B*H][queries] of the whole-head attention kernels (attn_train.hip)
   std::vector<void*> kte, ktd, ktc;      // per layer: K and V transposed, [2][B*H][64][Sp] (kv_transpose_kernel), for the fused stripe products
   void *hE = nullptr, *hD = nullptr;
   float *logits = nullptr, *sc = nullptr, *dxa = nullptr, *dxb = nullptr, *dh = nullptr, *dhE = nullptr, *dw_part = nullptr,
@@ -2167,16 +2168,20 @@ int build_arena(m2m_trainer* t) {
   std::vector<int64_t> o;
   auto T = [&](int64_t elems) { return c.take(elems * es); };
   auto F = [&](int64_t elems) { return c.take(elems * 4); };
+  // a layer's probability buffer [B*H][Sq][ldp]; the whole-head attention path keeps only its dropout keep words there ([B*H][ceil(Sk/32)][round_up_32(Sq)] x 4 bytes)
+  auto PB = [&](int64_t Sq, int64_t Sk, int64_t ldp) { return std::max<int64_t>(B * H * Sq * ldp, B * H * ((Sk + 31) / 32) * align_up(Sq, 32) * 2); };
   // order of `o` must match the assignment below
   for (int i = 0; i < 2 * Le + 1; ++i) o.push_back(F(Me * d));
   for (int i = 0; i < 3 * Ld + 1; ++i) o.push_back(F(Md * d));
-  for (int l = 0; l < Le; ++l) { o.push_back(T(Me * d)); o.push_back(T(Me * d)); o.push_back(T(Me * 3 * inner)); o.push_back(T(B * H * S * lps));
+  for (int l = 0; l < Le; ++l) { o.push_back(T(Me * d)); o.push_back(T(Me * d)); o.push_back(T(Me * 3 * inner)); o.push_back(T(PB(S, S, lps)));
                                   o.push_back(T(Me * inner)); o.push_back(T(Me * 2 * dff)); o.push_back(T(Me * dff)); }
   for (int l = 0; l < Ld; ++l) { o.push_back(T(Md * d)); o.push_back(T(Md * d)); o.push_back(T(Md * d)); o.push_back(T(Md * 3 * inner));
-                                  o.push_back(T(B * H * L * lpl)); o.push_back(T(Md * inner)); o.push_back(T(Md * inner)); o.push_back(T(Me * 2 * inner));
-                                  o.push_back(T(B * H * L * lps)); o.push_back(T(Md * inner)); o.push_back(T(Md * 2 * dff)); o.push_back(T(Md * dff)); }
+                                  o.push_back(T(PB(L, L, lpl))); o.push_back(T(Md * inner)); o.push_back(T(Md * inner)); o.push_back(T(Me * 2 * inner));
+                                  o.push_back(T(PB(L, S, lps))); o.push_back(T(Md * inner)); o.push_back(T(Md * 2 * dff)); o.push_back(T(Md * dff)); }
   const int64_t Sp32 = align_up(S, 32), Lp32 = align_up(L, 32);
   std::vector<int64_t> o_kte, o_ktd, o_ktc;
+  std::vector<int64_t> o_lse;
+  for (int l = 0; l < Le + 2 * Ld; ++l) o_lse.push_back(F(B * H * Sm));
   for (int l = 0; l < Le; ++l) o_kte.push_back(T(2 * B * H * 64 * Sp32));
   for (int l = 0; l < Ld; ++l) { o_ktd.push_back(T(2 * B * H * 64 * Lp32)); o_ktc.push_back(T(2 * B * H * 64 * Sp32)); }
   const int64_t o_hE = T(Me * d), o_hD = T(Md * d), o_logits = F(Md * V), o_sc = F(B * H * Sm * lpm), o_dxa = F(Mx * d), o_dxb = F(Mx * d),
@@ -2261,6 +2266,8 @@ int build_arena(m2m_trainer* t) {
   for (int l = 0; l < Ld; ++l) { t->h0d.push_back(nextT()); t->h1d.push_back(nextT()); t->h2d.push_back(nextT()); t->qkvd.push_back(nextT());
                                   t->Pd.push_back(nextT()); t->aod.push_back(nextT()); t->cqd.push_back(nextT()); t->ckvd.push_back(nextT());
                                   t->Pcd.push_back(nextT()); t->aocd.push_back(nextT()); t->abd.push_back(nextT()); t->midd.push_back(nextT()); }
+  for (int l = 0; l < Le; ++l) t->lse_e.push_back((float*)(b + o_lse[l]));
+  for (int l = 0; l < Ld; ++l) { t->lse_d.push_back((float*)(b + o_lse[Le + 2 * l])); t->lse_c.push_back((float*)(b + o_lse[Le + 2 * l + 1])); }
   for (int64_t off : o_kte) t->kte.push_back(b + off);
   for (int64_t off : o_ktd) t->ktd.push_back(b + off);
   for (int64_t off : o_ktc) t->ktc.push_back(b + off);
@@ -2595,6 +2602,22 @@ struct Ops {
     M2M_CHECK_HIP(hipGetLastError());
     return M2M_OK;
   }
+  // Whole-head attention kernels (attn_train.hip): bf16 storage, both lengths within an LDS image.  M2M_TRAIN_ATTN=stripes keeps round 2's path.
+  static bool head_on() { const char* v = getenv("M2M_TRAIN_ATTN"); return !(v && v[0] == 's'); }      // (read per pass: tests run both paths in one process)
+  bool head_ok(int Sq, int Sk) const { return sizeof(T) == 2 && head_on() && use_tuned && Sq <= AH_MAX_S && Sk <= AH_MAX_S; }
+  HeadAttnArgs head_args(const void* Q, int64_t ldq, int64_t sQb, const void* K, int64_t ldk, const void* V, int64_t ldv, int64_t sKb, void* O, float* lse,
+                         int Sq, int Sk, const float* tab, int causal, int site, void* keep_bits) const {
+    HeadAttnArgs a{};
+    const int inner = t->inner;
+    a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.sQb = sQb; a.sKb = sKb; a.sVb = sKb;
+    a.O = (bf16_t*)O; a.ldo = inner; a.sOb = (int64_t)Sq * inner; a.lse = lse;
+    a.bias_tab = tab; a.tab_stride = Sq + Sk - 1; a.tab_center = Sq - 1;
+    a.H = t->g.num_heads; a.Sq = Sq; a.Sk = Sk; a.causal = causal; a.ldp = (int)align_up(Sk, 8);
+    const bool dr = dropping(site);
+    a.dk = dr ? key(site) : DropKey{nullptr, 0}; a.thresh = dr ? t->drop_thresh : 0u; a.scale = t->drop_scale;
+    a.keep_bits = (uint32_t*)keep_bits;      // (the layer's probability buffer, unused on this path: B*H*Sq*Sk/8 bytes of its B*H*Sq*ldp*2)
+    return a;
+  }
   // Fused scores + softmax (attn_stripe_kernel) when a wave can hold all keys; K = (key, d) operand, Q = (query, d) operand.
   static bool stripes_on() { static const bool on = [] { const char* v = getenv("M2M_TRAIN_STRIPES"); return !(v && v[0] == '0'); }(); return on; }
   bool stripe_ok(int Sk) const {      // the bias row + (two, with dropout) 32-row blocks of P must fit the LDS
@@ -2736,13 +2759,20 @@ enum { SITE_ENC = 0, SITE_DEC = 1000, SITE_EMB = 900, SITE_FIN = 901,
 // self-attention block, forward: x_in -> x_out = x_in + Attn(norm(x_in)).  Buffers of this layer are passed in.
 template <typename T>
 int attn_self_fwd(const Ops<T>& o, const float* x_in, float* x_out, int64_t ln, int64_t wqkv, int64_t wo, void* h, void* qkv, void* Pm, void* ao,
-                  int nB, int S, const float* tab, int causal, int site0, void* kt) {
+                  int nB, int S, const float* tab, int causal, int site0, void* kt, float* lse) {
   m2m_trainer* t = o.t;
   const int d = t->g.d_model, inner = t->inner, M = nB * S, ldp = (int)align_up(S, 8), H = t->g.num_heads;
   int rc;
   RC(o.norm(x_in, ln, h, M));
   RC(o.mm(TG_STORE_T, h, d, 0, o.W(wqkv), d, 0, qkv, 3 * inner, M, 3 * inner, d));
   const T* q = (const T*)qkv;
+  if (lse && o.head_ok(S, S)) {                                  // whole-head kernel: no P, no K^T | V^T, only O and the row log-sum-exp
+    const HeadAttnArgs a = o.head_args(q, 3 * inner, (int64_t)S * 3 * inner, q + inner, 3 * inner, q + 2 * inner, 3 * inner, (int64_t)S * 3 * inner, ao, lse, S, S,
+                                       tab, causal, site0 + PL_PROBS_SELF, Pm);
+    RC(launch_attn_head_fwd(a, nB, o.st));
+    RC(o.mm(TG_RESID_F32, ao, inner, 0, o.W(wo), inner, 0, x_out, d, M, d, inner, x_in, site0 + PL_SELF_OUT));
+    return M2M_OK;
+  }
   const T* Pu;
   const bool fuse = o.stripe_ok(S) && o.fuse_on() && kt;         // P . V inside the stripe kernel, against the transposed V
   const bool fuse_pv = fuse && (o.fuse_mode() & 1);
@@ -2770,7 +2800,7 @@ int attn_self_fwd(const Ops<T>& o, const float* x_in, float* x_out, int64_t ln, 
 template <typename T>
 int attn_self_bwd(const Ops<T>& o, const float* x_in, const float* dx_out, float* dx_in, float* G, int64_t ln, int64_t wqkv, int64_t wo,
                   const void* h, const void* qkv, const void* Pm, const void* ao, int nB, int S, const int* buckets, int64_t bias_off,
-                  int bias_accumulate, int site0, const void* kt) {
+                  int bias_accumulate, int site0, const void* kt, float* lse, const float* tab) {
   m2m_trainer* t = o.t;
   const int d = t->g.d_model, inner = t->inner, M = nB * S, ldp = (int)align_up(S, 8), H = t->g.num_heads;
   int rc;
@@ -2782,6 +2812,21 @@ int attn_self_bwd(const Ops<T>& o, const float* x_in, const float* dx_out, float
   const T* dO = (const T*)t->dO;
   T* dq = (T*)t->dqkv;
   const int64_t sP1 = (int64_t)H * S * ldp, sP2 = (int64_t)S * ldp, sQ1 = (int64_t)S * 3 * inner, sO1 = (int64_t)S * inner;
+  if (lse && o.head_ok(S, S)) {                                  // whole-head kernel: dQ | dK | dV (and the bias gradient's diagonal sums) in one launch
+    HeadAttnArgs a = o.head_args(q, 3 * inner, sQ1, q + inner, 3 * inner, q + 2 * inner, 3 * inner, sQ1, const_cast<void*>(ao), lse, S, S, tab,
+                                 buckets == t->dbucket ? 1 : 0, site0 + PL_PROBS_SELF, const_cast<void*>((const void*)Pm));
+    a.dO = (const bf16_t*)dO;
+    a.dQ = (bf16_t*)dq; a.dK = (bf16_t*)(dq + inner); a.dV = (bf16_t*)(dq + 2 * inner);
+    a.lddq = a.lddk = a.lddv = 3 * inner; a.sdQb = a.sdKb = a.sdVb = sQ1;
+    a.diag_part = buckets ? o.drel_slot() : nullptr;
+    RC(launch_attn_head_bwd(a, nB, o.st));
+    if (buckets) RC(o.bias_grad_stripes(buckets, G + bias_off, nB, S, S, bias_accumulate));
+    RC(o.dW(dq, 3 * inner, 3 * inner, h, d, d, G + wqkv, M));                                     // dWqkv = dqkv^T . h
+    RC(o.dX(TG_STORE_F32, dq, 3 * inner, wqkv, 3 * inner, d, t->dh, d, M));                       // dh = dqkv . Wqkv
+    RC(o.norm_bwd(x_in, ln, t->dh, dx_out, dx_in, G, M));
+    RC(o.end_sub());
+    return M2M_OK;
+  }
   const T* Pu;
   const bool pair = o.stripe_ok(S) && o.pair_on();            // dV and dK in one launch (after dS exists)
   const bool pd_fused = pair && o.dropping(site0 + PL_PROBS_SELF) && o.pd_fuse_on();      // the stripe kernel re-emits the dropped P itself
@@ -2981,7 +3026,7 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
   for (int l = 0; l < Le; ++l) {
     const EncOff& e = t->enc[l];
     RC(attn_self_fwd<T>(o, t->xe[2 * l], t->xe[2 * l + 1], e.ln0, e.qkv, e.o, t->h0e[l], t->qkve[l], t->Pe[l], t->aoe[l], B, S, t->etab, 0,
-                        SITE_ENC + 16 * l, t->kte[l]));
+                        SITE_ENC + 16 * l, t->kte[l], t->lse_e[l]));
     RC(ff_fwd<T>(o, t->xe[2 * l + 1], t->xe[2 * l + 2], e.ln1, e.wi, e.wo, t->h1e[l], t->abe[l], t->mide[l], Me, SITE_ENC + 16 * l));
   }
   RC(o.norm_drop(t->xe[2 * Le], t->o_eln, t->hE, Me, SITE_ENC + SITE_FIN));
@@ -2999,7 +3044,7 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
   for (int l = 0; l < Ld; ++l) {
     const DecOff& e = t->dec[l];
     RC(attn_self_fwd<T>(o, t->xd[3 * l], t->xd[3 * l + 1], e.ln0, e.qkv, e.o, t->h0d[l], t->qkvd[l], t->Pd[l], t->aod[l], B, L, t->dtab, 1,
-                        SITE_DEC + 16 * l, t->ktd[l]));
+                        SITE_DEC + 16 * l, t->ktd[l], t->lse_d[l]));
     // cross-attention (hf: modeling_t5.py:319-342: K/V from the encoder output, zero bias, no mask)
     RC(o.norm(t->xd[3 * l + 1], e.ln1, t->h1d[l], Md));
     RC(o.mm(TG_STORE_T, t->h1d[l], d, 0, o.W(e.cq), d, 0, t->cqd[l], inner, Md, inner, d));
@@ -3007,7 +3052,12 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
     const T* cq = (const T*)t->cqd[l];
     const T* ckv = (const T*)t->ckvd[l];
     const T* Pu;
-    if (o.stripe_ok(S)) {
+    const bool head_c = o.head_ok(L, S);
+    if (head_c) {
+      const HeadAttnArgs a = o.head_args(cq, inner, (int64_t)L * inner, ckv, 2 * inner, ckv + inner, 2 * inner, (int64_t)S * 2 * inner, t->aocd[l], t->lse_c[l], L, S,
+                                         nullptr, 0, SITE_DEC + 16 * l + PL_PROBS_CROSS, t->Pcd[l]);
+      RC(launch_attn_head_fwd(a, B, o.st));
+    } else if (o.stripe_ok(S)) {
       if (fuse_c) RC(o.kv_transpose(ckv, 2 * inner, t->ktc[l], B, S));          // serves P . V here and dQ = dS . K in the backward pass
       RC(o.attn_probs(ckv, 2 * inner, (int64_t)S * 2 * inner, DK, cq, inner, (int64_t)L * inner, DK, t->Pcd[l], B, L, S, lps, nullptr, 0,
                  SITE_DEC + 16 * l + PL_PROBS_CROSS, &Pu, fuse_c_pv ? (const T*)t->ktc[l] + (int64_t)B * H * DK * align_up(S, 32) : nullptr, t->aocd[l], inner,
@@ -3016,7 +3066,7 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
       RC(o.mmbh(TG_STORE_F32, cq, inner, 0, (int64_t)L * inner, DK, ckv, 2 * inner, 0, (int64_t)S * 2 * inner, DK, t->sc, lps, sPc1, sPc2, B, L, S, DK));
       RC(o.softmax(t->sc, t->Pcd[l], B, L, S, lps, nullptr, 0, SITE_DEC + 16 * l + PL_PROBS_CROSS, &Pu));
     }
-    if (!fuse_c_pv)
+    if (!head_c && !fuse_c_pv)
       RC(o.mmbh(TG_STORE_T, Pu, lps, 0, sPc1, sPc2, ckv + inner, 2 * inner, 1, (int64_t)S * 2 * inner, DK, t->aocd[l], inner,
                 (int64_t)L * inner, DK, B, L, DK, S));
     RC(o.mm(TG_RESID_F32, t->aocd[l], inner, 0, o.W(e.co), inner, 0, t->xd[3 * l + 2], d, Md, d, inner, t->xd[3 * l + 1],
@@ -3058,24 +3108,35 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
     T* dcq = (T*)t->dcq;
     const int64_t sK1 = (int64_t)S * 2 * inner, sQ1 = (int64_t)L * inner;
     const T* Pu;
-    const bool pair_c = o.stripe_ok(S) && o.pair_on();
-    const bool pd_fused_c = pair_c && o.dropping(SITE_DEC + 16 * l + PL_PROBS_CROSS) && o.pd_fuse_on();
-    if (pd_fused_c) Pu = (const T*)t->sc;
-    else RC(o.redrop(t->Pcd[l], (int64_t)B * H * L * lps, SITE_DEC + 16 * l + PL_PROBS_CROSS, &Pu, pair_c));
-    if (!pair_c) RC(o.mmbh(TG_STORE_T, Pu, lps, 1, sPc1, sPc2, dO, inner, 1, sQ1, DK, dckv + inner, 2 * inner, sK1, DK, B, S, DK, L));      // dV = Pd^T dO
-    if (o.stripe_ok(S)) {
-      RC(o.dscores(ckv + inner, 2 * inner, sK1, DK, dO, inner, sQ1, DK, t->Pcd[l], t->dS, B, L, S, lps, SITE_DEC + 16 * l + PL_PROBS_CROSS, false,
-                   fuse_c_dq ? (const T*)t->ktc[l] : nullptr, dcq, inner, sQ1, DK, 0, pd_fused_c ? t->sc : nullptr));
-    } else {
-      RC(o.mmbh(TG_STORE_F32, dO, inner, 0, sQ1, DK, ckv + inner, 2 * inner, 0, sK1, DK, t->sc, lps, sPc1, sPc2, B, L, S, DK));             // dPd = dO V^T
-      RC(o.softmax_bwd(t->Pcd[l], t->sc, t->dS, B * H * L, S, lps, SITE_DEC + 16 * l + PL_PROBS_CROSS));
+    const bool head_cb = o.head_ok(L, S);
+    if (head_cb) {
+      HeadAttnArgs a = o.head_args(cq, inner, sQ1, ckv, 2 * inner, ckv + inner, 2 * inner, sK1, t->aocd[l], t->lse_c[l], L, S, nullptr, 0,
+                                   SITE_DEC + 16 * l + PL_PROBS_CROSS, t->Pcd[l]);
+      a.dO = (const bf16_t*)dO;
+      a.dQ = (bf16_t*)dcq; a.lddq = inner; a.sdQb = sQ1;
+      a.dK = (bf16_t*)dckv; a.dV = (bf16_t*)(dckv + inner); a.lddk = a.lddv = 2 * inner; a.sdKb = a.sdVb = sK1;
+      RC(launch_attn_head_bwd(a, B, o.st));
     }
-    const T* dS = (const T*)t->dS;
-    if (!fuse_c_dq) RC(o.mmbh(TG_STORE_T, dS, lps, 0, sPc1, sPc2, ckv, 2 * inner, 1, sK1, DK, dcq, inner, sQ1, DK, B, L, DK, S));               // dQ = dS K
-    if (pair_c)                                                                                                                              // dV | dK
-      RC(o.mmbh2(TG_STORE_T, Pu, dS, lps, 1, sPc1, sPc2, dO, inner, sQ1, DK, cq, inner, sQ1, DK, 1, dckv + inner, dckv, 2 * inner, sK1, DK, B, S, DK, L));
-    else
-      RC(o.mmbh(TG_STORE_T, dS, lps, 1, sPc1, sPc2, cq, inner, 1, sQ1, DK, dckv, 2 * inner, sK1, DK, B, S, DK, L));                          // dK = dS^T Q
+    if (!head_cb) {
+      const bool pair_c = o.stripe_ok(S) && o.pair_on();
+      const bool pd_fused_c = pair_c && o.dropping(SITE_DEC + 16 * l + PL_PROBS_CROSS) && o.pd_fuse_on();
+      if (pd_fused_c) Pu = (const T*)t->sc;
+      else RC(o.redrop(t->Pcd[l], (int64_t)B * H * L * lps, SITE_DEC + 16 * l + PL_PROBS_CROSS, &Pu, pair_c));
+      if (!pair_c) RC(o.mmbh(TG_STORE_T, Pu, lps, 1, sPc1, sPc2, dO, inner, 1, sQ1, DK, dckv + inner, 2 * inner, sK1, DK, B, S, DK, L));      // dV = Pd^T dO
+      if (o.stripe_ok(S)) {
+        RC(o.dscores(ckv + inner, 2 * inner, sK1, DK, dO, inner, sQ1, DK, t->Pcd[l], t->dS, B, L, S, lps, SITE_DEC + 16 * l + PL_PROBS_CROSS, false,
+                     fuse_c_dq ? (const T*)t->ktc[l] : nullptr, dcq, inner, sQ1, DK, 0, pd_fused_c ? t->sc : nullptr));
+      } else {
+        RC(o.mmbh(TG_STORE_F32, dO, inner, 0, sQ1, DK, ckv + inner, 2 * inner, 0, sK1, DK, t->sc, lps, sPc1, sPc2, B, L, S, DK));             // dPd = dO V^T
+        RC(o.softmax_bwd(t->Pcd[l], t->sc, t->dS, B * H * L, S, lps, SITE_DEC + 16 * l + PL_PROBS_CROSS));
+      }
+      const T* dS = (const T*)t->dS;
+      if (!fuse_c_dq) RC(o.mmbh(TG_STORE_T, dS, lps, 0, sPc1, sPc2, ckv, 2 * inner, 1, sK1, DK, dcq, inner, sQ1, DK, B, L, DK, S));               // dQ = dS K
+      if (pair_c)                                                                                                                              // dV | dK
+        RC(o.mmbh2(TG_STORE_T, Pu, dS, lps, 1, sPc1, sPc2, dO, inner, sQ1, DK, cq, inner, sQ1, DK, 1, dckv + inner, dckv, 2 * inner, sK1, DK, B, S, DK, L));
+      else
+        RC(o.mmbh(TG_STORE_T, dS, lps, 1, sPc1, sPc2, cq, inner, 1, sQ1, DK, dckv, 2 * inner, sK1, DK, B, S, DK, L));                          // dK = dS^T Q
+    }
     RC(o.dW(dcq, inner, inner, t->h1d[l], d, d, G + e.cq, Md));
     RC(o.dX(TG_STORE_F32, dcq, inner, e.cq, inner, d, t->dh, d, Md));
     o.after_site = SITE_DEC + 16 * l + PL_SELF_OUT;
@@ -3087,7 +3148,7 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
     // ---- causal self-attention backward ----
     o.after_site = l > 0 ? SITE_DEC + 16 * (l - 1) + PL_FF_OUT : -2;
     RC(attn_self_bwd<T>(o, t->xd[3 * l], dcur, dnext, G, e.ln0, e.qkv, e.o, t->h0d[l], t->qkvd[l], t->Pd[l], t->aod[l], B, L, t->dbucket, t->o_drb,
-                        l == Ld - 1 ? 0 : 1, SITE_DEC + 16 * l, t->ktd[l]));
+                        l == Ld - 1 ? 0 : 1, SITE_DEC + 16 * l, t->ktd[l], t->lse_d[l], t->dtab));
     std::swap(dcur, dnext);
   }
   // token embedding (decoder inputs; the encoder is fed inputs_embeds) — hf: modeling_t5.py embed_tokens = shared
@@ -3116,7 +3177,7 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
     std::swap(dcur, dnext);
     o.after_site = l > 0 ? SITE_ENC + 16 * (l - 1) + PL_FF_OUT : -2;
     RC(attn_self_bwd<T>(o, t->xe[2 * l], dcur, dnext, G, e.ln0, e.qkv, e.o, t->h0e[l], t->qkve[l], t->Pe[l], t->aoe[l], B, S, t->ebucket, t->o_erb,
-                        l == Le - 1 ? 0 : 1, SITE_ENC + 16 * l, t->kte[l]));
+                        l == Le - 1 ? 0 : 1, SITE_ENC + 16 * l, t->kte[l], t->lse_e[l], t->etab));
     std::swap(dcur, dnext);
   }
   // The tail of the pass is a set of reductions that do not depend on one another: the grouped weight-gradient launch (0.35 ms,

@@ -34,6 +34,10 @@ def _masks(p, seed, site, B, H, Sq, Sk):
     return m, int(dm.step_key), (site * GOLDEN) & 0xFFFFFFFFFFFFFFFF
 
 
+def _keep_words(B, H, Sq, Sk):
+    return torch.zeros((B * H, (Sk + 31) // 32, (Sq + 31) // 32 * 32), dtype=torch.int32, device="cuda")
+
+
 def _reference(q, k, v, bias, causal, mask):
     B, Sq, HD = q.shape
     H, Sk = HD // 64, k.shape[1]
@@ -78,10 +82,22 @@ def test_whole_head_attention_forward_matches_torch(B, H, Sq, Sk, causal, use_bi
     bd = bias.cuda() if use_bias else None
     out = torch.full((B, Sq, H * 64), float("nan"), dtype=torch.bfloat16, device="cuda")
     lse = torch.full((B * H, Sq), float("nan"), dtype=torch.float32, device="cuda")
+    bits = _keep_words(B, H, Sq, Sk)
     native.check(lib.m2m_attn_head_fwd_bf16(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), bd.data_ptr() if use_bias else None, B, H, Sq, Sk,
                                             int(causal), float(p), C.c_uint64(step_key), C.c_uint64(salt), out.data_ptr(), lse.data_ptr(),
-                                            native.stream_handle()), "m2m_attn_head_fwd_bf16")
+                                            bits.data_ptr(), native.stream_handle()), "m2m_attn_head_fwd_bf16")
     torch.cuda.synchronize()
+    if p > 0:
+        # the keep words the backward pass will read: bit k of word (key block j, query q) = mask[q, 32 j + k] != 0
+        w = bits.cpu().view(B * H, (Sk + 31) // 32, (Sq + 31) // 32 * 32)[:, :, :Sq].to(torch.int64) & 0xFFFFFFFF
+        keep = (mask.reshape(B * H, Sq, Sk) != 0)
+        for j in range((Sk + 31) // 32):
+            if causal and 32 * j > Sq - 1:
+                continue
+            for kk in range(min(32, Sk - 32 * j)):
+                got = ((w[:, j, :] >> kk) & 1).bool()
+                rows = torch.arange(Sq) // 32 >= j if causal else torch.ones(Sq, dtype=torch.bool)      # (causal: tiles past the diagonal are never visited)
+                assert torch.equal(got[:, rows], keep[:, rows, 32 * j + kk]), (j, kk)
     o_dev, lse_dev = out.float().cpu(), lse.cpu().view(B, H, Sq)
     assert torch.isfinite(o_dev).all() and torch.isfinite(lse_dev).all()
     e_lse = float((lse_dev - lse_ref).abs().max())
@@ -127,14 +143,15 @@ def test_whole_head_attention_backward_matches_autograd(B, H, Sq, Sk, causal, us
     bptr = bd.data_ptr() if use_bias else None
     out = torch.empty((B, Sq, H * 64), dtype=torch.bfloat16, device="cuda")
     lse = torch.empty((B * H, Sq), dtype=torch.float32, device="cuda")
+    bits = _keep_words(B, H, Sq, Sk)
     native.check(lib.m2m_attn_head_fwd_bf16(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), bptr, B, H, Sq, Sk, int(causal), float(p), C.c_uint64(step_key),
-                                            C.c_uint64(salt), out.data_ptr(), lse.data_ptr(), native.stream_handle()), "m2m_attn_head_fwd_bf16")
+                                            C.c_uint64(salt), out.data_ptr(), lse.data_ptr(), bits.data_ptr(), native.stream_handle()), "m2m_attn_head_fwd_bf16")
     nan = float("nan")
     dq = torch.full_like(qd, nan); dk = torch.full_like(kd, nan); dv = torch.full_like(vd, nan)
     nq, dl = (Sq + 31) // 32, Sk + 31
     diag = torch.full((B * H, nq, dl), nan, dtype=torch.float32, device="cuda") if use_bias else None
     native.check(lib.m2m_attn_head_bwd_bf16(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), out.data_ptr(), lse.data_ptr(), dod.data_ptr(), bptr, B, H, Sq, Sk,
-                                            int(causal), float(p), C.c_uint64(step_key), C.c_uint64(salt), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+                                            int(causal), float(p), C.c_uint64(step_key), C.c_uint64(salt), bits.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
                                             diag.data_ptr() if use_bias else None, native.stream_handle()), "m2m_attn_head_bwd_bf16")
     torch.cuda.synchronize()
     errs = {}
