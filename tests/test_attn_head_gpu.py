@@ -66,6 +66,10 @@ CASES = [  # B, H, Sq, Sk, causal, bias, dropout
     (2, 8, 256, 261, False, False, 0.1),
     (1, 2, 280, 288, False, True, 0.0),
     (1, 1, 5, 3, False, False, 0.1),
+    (2, 2, 2, 2, True, True, 0.1),
+    (1, 2, 1, 1, True, True, 0.0),
+    (3, 2, 9, 9, False, True, 0.1),
+    (2, 2, 1, 11, False, False, 0.0),
 ]
 
 
