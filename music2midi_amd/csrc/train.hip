@@ -1295,29 +1295,36 @@ __global__ __launch_bounds__(256) void bias_bucket_kernel(const float* __restric
 
 // stage 1b for the per-stripe diagonal sums of attn_stripe_kernel: part2 [B*H][stripes][Sk + 31] -> tmp [H][nrel], summed over
 // clips and stripes in a fixed order; the diagonal with global index rel (= key - query + Sq - 1) is entry
-// rel + 31 + 32 s - (Sq - 1) of stripe s.  Block = (head, 64 consecutive rels) x 4 clip groups; bias_bucket_kernel (B = 1) follows.
-__global__ __launch_bounds__(256) void bias_stripes_sum_kernel(const float* __restrict__ part2_all, float* __restrict__ tmp_all, int B, int H, int stripes,
-                                                               int Sq, int Sk, int64_t layer_stride) {
+// rel + 31 + 32 s - (Sq - 1) of stripe s.  Block = (head, 64 consecutive rels) x 16 clip groups; bias_bucket_kernel (B = 1) follows.
+__global__ __launch_bounds__(1024) void bias_stripes_sum_kernel(const float* __restrict__ part2_all, float* __restrict__ tmp_all, int B, int H, int stripes,
+                                                                int Sq, int Sk, int64_t layer_stride) {
   const float* part2 = part2_all + (int64_t)blockIdx.z * layer_stride;        // blockIdx.z: layer (grouped mode: all layers of a stack in one launch)
   float* tmp = tmp_all + (int64_t)blockIdx.z * H * (Sq + Sk - 1);
-  __shared__ float sred[4][64];
+  __shared__ float sred[16][64];
   const int nrel = Sq + Sk - 1, dl = Sk + 31;
-  const int hh = blockIdx.x, rl = threadIdx.x & 63, bg = threadIdx.x >> 6;
-  const int rel = blockIdx.y * 64 + rl;
+  const int hh = blockIdx.x, rl = threadIdx.x & 63, bg = threadIdx.x >> 6;     // sixteen clip groups: at 16 clips one clip x all stripes per thread,
+  const int rel = blockIdx.y * 64 + rl;                                        // loads unconditional (clamped) so that they are all in flight at once
   float acc = 0.f;
   if (rel < nrel) {
-    const int per = (B + 3) / 4;
+    const int per = (B + 15) / 16;
     for (int b = bg * per; b < min(B, (bg + 1) * per); ++b) {
       const float* pb = part2 + ((int64_t)b * H + hh) * stripes * dl;
+#pragma unroll 3
       for (int sidx = 0; sidx < stripes; ++sidx) {
         const int loc = rel + 31 + 32 * sidx - (Sq - 1);
-        if (loc >= 0 && loc < dl) acc += pb[(int64_t)sidx * dl + loc];
+        const float v = pb[(int64_t)sidx * dl + min(max(loc, 0), dl - 1)];
+        acc += (loc >= 0 && loc < dl) ? v : 0.f;
       }
     }
   }
   sred[bg][rl] = acc;
   __syncthreads();
-  if (bg == 0 && rel < nrel) tmp[(int64_t)hh * nrel + rel] = (sred[0][rl] + sred[1][rl]) + (sred[2][rl] + sred[3][rl]);
+  if (bg == 0 && rel < nrel) {
+    float sum = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) sum += sred[g][rl];
+    tmp[(int64_t)hh * nrel + rel] = sum;
+  }
 }
 
 // ---- gated GELU (hf: modeling_t5.py T5DenseGatedActDense: gelu_new(wi_0 x) * (wi_1 x)); ab = [a | b], [M, 2*dff] ----
@@ -1371,7 +1378,7 @@ __global__ void gated_bwd_kernel(const T* __restrict__ ab, const T* __restrict__
 // ---- RMSNorm backward (forward: y = w * x * r, r = rsqrt(mean(x^2) + eps), hf: modeling_t5.py:59-72) ----
 // dx_out[row] = dx_res[row] (gradient arriving over the residual connection, may be null)
 //             + r * (w o dy) - x * r^3 * mean(w o dy o x);   dw partial per block (fixed order), reduced by colsum_kernel.
-constexpr int RN_BLOCKS = 256;
+constexpr int RN_BLOCKS = 512;      // (256 until round 3: four rows per wave at 16 clips, one memory round trip each — two now, both in flight from the start)
 // out_t (optional): the gradient again in the GEMM-input type, through the dropout mask of the branch that consumes it next
 // (what cvt_kernel / cvt_drop_kernel would produce in a launch of its own)
 template <typename T>
@@ -1498,30 +1505,32 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ p
 // every RMSNorm weight gradient of a step in one launch: partial image j ([parts][d]) -> out_base + off[j]
 __global__ __launch_bounds__(256) void colsum_group_kernel(const float* __restrict__ part_all, const int64_t* __restrict__ offs, float* __restrict__ out_base,
                                                            int parts, int d) {
-  __shared__ float sred[8][32];
+  // block = 64 columns (16 lanes x 16 bytes: 256-byte row pieces) x 16 row groups, eight rows in flight per thread; the first form read
+  // 128-byte pieces one 4-byte element per lane (54 us for the step's 17 MB of partial rows)
+  __shared__ float4 sred[16][16];
   const int j = blockIdx.y;
   const float* part = part_all + (int64_t)j * parts * d;
-  const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;
-  const int col = blockIdx.x * 32 + cx;
-  float acc = 0.f;
+  const int cx = threadIdx.x & 15, py = threadIdx.x >> 4;
+  const int col = blockIdx.x * 64 + 4 * cx;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (col < d) {
-    int p = py;
-    for (; p + 56 < parts; p += 64) {
-      float v[8];
+    for (int p = py; p < parts; p += 128) {
+      float4 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(p + 8 * u) * d + col];
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(part + (int64_t)min(p + 16 * u, parts - 1) * d + col);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) acc += v[u];
+      for (int u = 0; u < 8; ++u)
+        if (p + 16 * u < parts) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
     }
-    for (; p < parts; p += 8) acc += part[(int64_t)p * d + col];
   }
   sred[py][cx] = acc;
   __syncthreads();
   if (py == 0 && col < d) {
-    float v = sred[0][cx];
+    float4 v = sred[0][cx];
 #pragma unroll
-    for (int u = 1; u < 8; ++u) v += sred[u][cx];
-    out_base[offs[j] + col] = v;
+    for (int u = 1; u < 16; ++u) { const float4 o = sred[u][cx]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+    float* out = out_base + offs[j] + col;
+    out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
   }
 }
 
@@ -1577,19 +1586,26 @@ __global__ void cond_gather_kernel(const float* __restrict__ params, const int64
   float* dst = x + ((int64_t)b * S + i) * d;
   for (int c = threadIdx.x; c < d; c += blockDim.x) dst[c] = src[c];
 }
-// gradient of an embedding table: one block per table row v.  The ids are scanned 256 at a time; a wave ballot marks the
-// activation rows whose id is v and every thread (= column) adds those rows in order: G[v] = sum of dx[row] with id[row] == v,
-// fixed order.  ids[i * id_stride + id_off] is the id of activation row (i * x_row_stride + x_row_off).
+// gradient of an embedding table: one block per table row v, G[v] = sum of dx[row] over the activation rows whose id is v, in a fixed
+// order.  Pass 1 scans the ids 256 at a time and lists the matching rows in LDS (ballot + prefix counts keep them in order); pass 2
+// gives every fourth listed row to one wave, eight rows in flight per wave (a lane reads 16 bytes of each), and the four waves' partial
+// rows meet in LDS in wave order.  (Round 2 walked the matches one after another inside the scan: a hot row — the pad / start token of
+// every clip's ragged tail, ~700 activation rows at 16 clips — paid one memory latency per match, 140 us of the step.)
+// ids[i * id_stride + id_off] is the id of activation row (i * x_row_stride + x_row_off).
 // thresh != 0: dx arrives through the dropout on the embeddings (hf: T5Stack dropout(inputs_embeds)); only the rows that are READ
-// here are masked, as they are read — a drop_inplace launch over the whole gradient buffer before.
+// here are masked, as they are read.
+constexpr int EMB_ROWS_IN_FLIGHT = 8;
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, int n_ids, int id_stride, int id_off,
                                                         const float* __restrict__ dx, int64_t x_row_stride, int64_t x_row_off,
                                                         float* __restrict__ gtab, int d, int pad_to_zero_id, int V, DropKey dk, uint32_t thresh,
                                                         float scale) {
+  extern __shared__ __align__(16) int emb_smem[];
+  int* list = emb_smem;                                          // [round_up_4(n_ids)]
+  float* part = reinterpret_cast<float*>(list + ((n_ids + 3) & ~3));      // [4][256 * 4]: one column block of the four waves' sums
+  __shared__ int wave_cnt[4];
   const uint64_t dkey = thresh ? drop_site_key(dk) : 0ull;
-  __shared__ unsigned long long masks[4];
-  const int v = blockIdx.x, wave = threadIdx.x >> 6;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};          // columns tid, tid + 256, ... (d <= 1024)
+  const int v = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int cnt = 0;
   for (int i0 = 0; i0 < n_ids; i0 += 256) {
     const int i = i0 + threadIdx.x;
     bool match = false;
@@ -1599,28 +1615,51 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
       match = id == v;
     }
     const unsigned long long m = __ballot(match);
-    if ((threadIdx.x & 63) == 0) masks[wave] = m;
+    if (lane == 0) wave_cnt[wave] = __popcll(m);
     __syncthreads();
+    int base = cnt, all = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      unsigned long long mm = masks[w];
-      while (mm) {                                    // uniform: every thread walks the same set bits in the same order
-        const int j = __ffsll((long long)mm) - 1;
-        mm &= mm - 1;
-        const int64_t roff = ((int64_t)(i0 + 64 * w + j) * x_row_stride + x_row_off) * d;
-        const float* row = dx + roff;
+    for (int w = 0; w < 4; ++w) { const int c = wave_cnt[w]; if (w < wave) base += c; all += c; }
+    if (match) list[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+    cnt += all;
+    __syncthreads();
+  }
+  for (int c0 = 0; c0 < d; c0 += 256) {                          // column blocks of 256: lane -> columns c0 + 4 lane .. + 3
+    const int c = c0 + 4 * lane;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < d) {
+      for (int k0 = wave; k0 < cnt; k0 += 4 * EMB_ROWS_IN_FLIGHT) {
+        float4 rows[EMB_ROWS_IN_FLIGHT];
+        uint32_t keep[EMB_ROWS_IN_FLIGHT];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int c = threadIdx.x + 256 * u;
-          if (c < d) acc[u] += thresh ? (drop_keep(dkey, roff + c, thresh) ? row[c] * scale : 0.f) : row[c];
+        for (int rr = 0; rr < EMB_ROWS_IN_FLIGHT; ++rr) {
+          const int k = k0 + 4 * rr;
+          rows[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
+          keep[rr] = 0xFu;
+          if (k < cnt) {
+            const int64_t roff = ((int64_t)list[k] * x_row_stride + x_row_off) * d + c;
+            rows[rr] = *reinterpret_cast<const float4*>(dx + roff);
+            if (thresh) keep[rr] = drop_keep4(dkey, roff, thresh);
+          }
+        }
+#pragma unroll
+        for (int rr = 0; rr < EMB_ROWS_IN_FLIGHT; ++rr) {
+          const float sc = thresh ? scale : 1.0f;
+          acc.x += (keep[rr] & 1u) ? rows[rr].x * sc : 0.f;
+          acc.y += (keep[rr] & 2u) ? rows[rr].y * sc : 0.f;
+          acc.z += (keep[rr] & 4u) ? rows[rr].z * sc : 0.f;
+          acc.w += (keep[rr] & 8u) ? rows[rr].w * sc : 0.f;
         }
       }
     }
+    *reinterpret_cast<float4*>(part + wave * 256 + 4 * lane) = acc;
+    __syncthreads();
+    const int cc = c0 + threadIdx.x;
+    if (cc < d) gtab[(int64_t)v * d + cc] = ((part[threadIdx.x] + part[256 + threadIdx.x]) + part[512 + threadIdx.x]) + part[768 + threadIdx.x];
     __syncthreads();
   }
-#pragma unroll
-  for (int u = 0; u < 4; ++u) { const int c = threadIdx.x + 256 * u; if (c < d) gtab[(int64_t)v * d + c] = acc[u]; }
 }
+static size_t embed_bwd_smem(int n_ids) { return (size_t)((n_ids + 3) & ~3) * 4 + 4 * 256 * 4; }
 // Final norm of a stack with the dropout that follows it (hf: T5Stack dropout(final_layer_norm(x))): y = T(x * rstd * w), then the
 // mask on the ROUNDED value, as the separate in-place pass did — one wave per row, one launch instead of two.
 template <typename T>
@@ -2383,6 +2422,7 @@ struct Ops {
   // A split pass (t->sync_stream) flushes twice: `phase` picks the half of the device tables (and the host image) a flush uses,
   // so both halves stay constant from step to step and a captured graph never sees a table change.
   mutable int phase = 0;
+  mutable int norm_slot_base = 0;          // partial images already handed to an earlier flush of this pass keep their slices
   int flush_norms() const {
     if (!group || norm_offs.empty()) return M2M_OK;
     M2M_REQUIRE(norm_offs.size() <= 32 && (int)norm_offs.size() <= 2 * t->g.num_layers + 3 * t->g.num_decoder_layers + 2, "training: too many norms");
@@ -2397,9 +2437,10 @@ struct Ops {
       offs_host = norm_offs;
     }
     const int d = t->g.d_model;
-    hipLaunchKernelGGL(colsum_group_kernel, dim3(ceil_div(d, 32), (unsigned)norm_offs.size()), dim3(256), 0, st, t->dw_part, offs_dev, Gbase,
-                       RN_BLOCKS, d);
+    hipLaunchKernelGGL(colsum_group_kernel, dim3(ceil_div(d, 64), (unsigned)norm_offs.size()), dim3(256), 0, st,
+                       t->dw_part + (int64_t)norm_slot_base * RN_BLOCKS * d, offs_dev, Gbase, RN_BLOCKS, d);
     M2M_CHECK_HIP(hipGetLastError());
+    norm_slot_base += (int)norm_offs.size();
     norm_offs.clear();
     return M2M_OK;
   }
@@ -2584,7 +2625,7 @@ struct Ops {
     //  fence of 256 blocks costs ~100 us per launch on this machine — 8.7 -> 12.3 ms per step; the second launch stays)
     // grouped mode: the partial image of every norm goes to a slice of its own and ONE launch sums them all after the backward
     // pass (flush_norms); otherwise the column sum follows right away
-    const int slot = group ? (int)norm_offs.size() : 0;
+    const int slot = group ? norm_slot_base + (int)norm_offs.size() : 0;
     float* part = t->dw_part + (int64_t)slot * RN_BLOCKS * d;
     T* out_t = nullptr;
     DropKey dk{nullptr, 0};
@@ -2715,7 +2756,7 @@ struct Ops {
   int bias_reduce(const BiasJob& j, int accumulate) const {
     const int H = t->g.num_heads, nrel = j.Sq + j.Sk - 1, stripes = ceil_div(j.Sq, 32);
     float* tmp = t->drel + (int64_t)(t->g.num_layers + t->g.num_decoder_layers) * t->drel_slot_floats;
-    hipLaunchKernelGGL(bias_stripes_sum_kernel, dim3(H, ceil_div(nrel, 64), j.layers), dim3(256), 0, st, t->drel + (int64_t)j.first_slot * t->drel_slot_floats,
+    hipLaunchKernelGGL(bias_stripes_sum_kernel, dim3(H, ceil_div(nrel, 64), j.layers), dim3(1024), 0, st, t->drel + (int64_t)j.first_slot * t->drel_slot_floats,
                        tmp, j.nB, H, stripes, j.Sq, j.Sk, t->drel_slot_floats);
     hipLaunchKernelGGL(bias_bucket_kernel, dim3(t->g.num_buckets * H), dim3(256), 0, st, tmp, j.buckets, j.Gtab, j.layers, H, nrel, accumulate);
     M2M_CHECK_HIP(hipGetLastError());
@@ -3154,7 +3195,8 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
   // token embedding (decoder inputs; the encoder is fed inputs_embeds) — hf: modeling_t5.py embed_tokens = shared
   {
     const bool dr = o.dropping(SITE_DEC + SITE_EMB);
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(V), dim3(256), 0, st, t->dec_in, Md, 1, 0, dcur, (int64_t)1, (int64_t)0, G + t->o_shared, d,
+    M2M_OPT_IN_LDS(embed_bwd_kernel, 158 * 1024);
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(V), dim3(256), embed_bwd_smem(Md), st, t->dec_in, Md, 1, 0, dcur, (int64_t)1, (int64_t)0, G + t->o_shared, d,
                        g.pad_token_id, V, dr ? o.key(SITE_DEC + SITE_EMB) : DropKey{nullptr, 0}, dr ? t->drop_thresh : 0u, t->drop_scale);
   }
   // Split pass (data-parallel overlap): everything the decoder side deferred is issued now, so the gradients of the shared embedding,
@@ -3167,6 +3209,11 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
     RC((*at_split)());
     o.phase = 1;
   }
+  // (Single-GPU passes flush ONCE, at the end.  Round 3 measured the alternative — the decoder half of the grouped launch and the
+  //  decoder's small reductions issued here on the side stream, beside the encoder's backward chain: 3.73 -> 3.86 ms per pass at
+  //  16 clips x S = 261, unchanged at 64 clips and at S = 190.  The chain's launches are latency-bound, one or two workgroups per CU,
+  //  and every one of them ends when its slowest workgroup does; sharing CUs with a matrix-core-bound launch stretches all of them by
+  //  more than the 0.18 ms it hides.  Stream priorities (main highest, side lowest) did not change that and cost 0.18 ms on their own.)
   // encoder
   o.after_site = SITE_ENC + 16 * (Le - 1) + PL_FF_OUT;
   RC(o.norm_bwd(t->xe[2 * Le], t->o_eln, t->dhE, nullptr, dcur, G, Me, SITE_ENC + SITE_FIN));
@@ -3193,7 +3240,7 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
   // conditioning embeddings: rows 0 .. n_cond-1 of every clip's encoder input (ref: music2midi/input.py:57-59)
   for (int i = 0; i < t->n_cond; ++i) {
     const bool dr = o.dropping(SITE_ENC + SITE_EMB);
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(t->cond_rows[i]), dim3(256), 0, small, cond_idx, B, t->n_cond, i, dcur, (int64_t)S, (int64_t)i,
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(t->cond_rows[i]), dim3(256), embed_bwd_smem(B), small, cond_idx, B, t->n_cond, i, dcur, (int64_t)S, (int64_t)i,
                        G + t->o_cond[i], d, 0, t->cond_rows[i], dr ? o.key(SITE_ENC + SITE_EMB) : DropKey{nullptr, 0}, dr ? t->drop_thresh : 0u,
                        t->drop_scale);
   }

@@ -12,8 +12,8 @@ from music2midi_amd.transformer import T5Transformer
 cfg = default_config(); geom = T5Geometry(cfg.model.t5)
 model = T5Transformer(cfg.to_dict(), precision="fp32"); load_t5_state(model, synth.t5_state_dict(geom, 0), strict=False); model = model.cuda()
 B, S, Ld = 16, 261, 256
-tr = NativeTrainer(model, B, S, Ld, precision="bf16")
 import os
+tr = NativeTrainer(model, B, S, Ld, precision=os.environ.get("M2M_GAP_PREC", "bf16"))
 if os.environ.get("M2M_GAP_DROPOUT"): tr.set_dropout(float(os.environ["M2M_GAP_DROPOUT"]), 1)      # e.g. 0.1: the reference's training mode
 x = torch.from_numpy(synth.normal(1, "x", (B, S, 384), 2.0)).cuda(); cond = torch.from_numpy(synth.cond_index_batch(0, B)).cuda()
 labels = (torch.from_numpy((synth.uniform01(4, "l", B * Ld) * 330).astype(np.int64).reshape(B, Ld)) + 3).cuda()
