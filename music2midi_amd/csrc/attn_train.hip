@@ -54,6 +54,36 @@ __device__ inline Frag<bf16_t> ah_tr_frag(const bf16_t* X, int p0, int db, int l
 }
 // natural fragment: row `row` of the image, k = d in [16 s + 8 h, +8)
 __device__ inline Frag<bf16_t> ah_nat_frag(const bf16_t* X, int row, int s, int h) { return load_frag(X + ah_off(row, 2 * s + h)); }
+// The swizzle of a row depends on its low five bits only, so inside a 32-row tile every fragment address is (tile base) + (a lane
+// constant): the loops below keep these constants in registers and add the tile base — the index arithmetic of ah_off / ah_tr_frag per
+// fragment and tile was a quarter of the VALU instructions of a tile.
+struct AhLaneOffs {
+  int nat[4];        // natural fragment s of tile row (lane & 31)
+  int tr[2][2];      // transposing fragment: [db][first / second group of four rows], + 16 s * 64 for substep s
+};
+__device__ inline AhLaneOffs ah_lane_offs(int lane) {
+  AhLaneOffs o;
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) o.nat[s] = ah_off(r, 2 * s + h);
+  const int li = lane & 15, q = li >> 2, pp = li & 3, gq = lane >> 4;
+#pragma unroll
+  for (int db = 0; db < 2; ++db) {
+    const int c = 4 * db + 2 * (gq & 1) + (pp >> 1), sub = (pp & 1) * 4;
+    o.tr[db][0] = ah_off(4 * h + q, c) + sub;
+    o.tr[db][1] = ah_off(4 * h + q + 8, c) + sub;
+  }
+  return o;
+}
+__device__ inline Frag<bf16_t> ah_tr_frag_at(const bf16_t* T, const AhLaneOffs& o, int s, int db) {      // T: the tile's first row in its image
+  typedef ah_v4s __attribute__((address_space(3))) * lds_v4s;
+  const ah_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(T + 16 * 64 * s + o.tr[db][0]));
+  const ah_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(T + 16 * 64 * s + o.tr[db][1]));
+  Frag<bf16_t> f;
+  f.v = make_uint4(__builtin_bit_cast(uint2, lo).x, __builtin_bit_cast(uint2, lo).y, __builtin_bit_cast(uint2, hi).x, __builtin_bit_cast(uint2, hi).y);
+  return f;
+}
+constexpr int AH_IMG = 288 * 64;      // elements of one LDS image (AH_MAX_S rows): images sit at compile-time distances from one another
 
 // one 16-byte global -> LDS copy per lane (LDS address = wave-uniform base + 16 * lane); inline asm: see gemm_kernel's note on why
 __device__ inline void ah_glds16(const bf16_t* gsrc, unsigned lds_dst) {
@@ -88,8 +118,8 @@ __global__ __launch_bounds__(256, 2) void attn_head_fwd_kernel(HeadAttnArgs a) {
   const int bh = blockIdx.y, b = bh / a.H, hh = bh - b * a.H;
   const int nk = (a.Sk + 31) >> 5, Skp = nk * 32, Sqp = ((a.Sq + 31) >> 5) * 32;
   bf16_t* Ks = reinterpret_cast<bf16_t*>(ah_smem);
-  bf16_t* Vs = Ks + Skp * 64;
-  float* bias_s = reinterpret_cast<float*>(Vs + Skp * 64);
+  bf16_t* Vs = Ks + AH_IMG;
+  float* bias_s = reinterpret_cast<float*>(Vs + AH_IMG);
   const bf16_t* Kg = a.K + b * a.sKb + hh * 64;
   const bf16_t* Vg = a.V + b * a.sVb + hh * 64;
   const int nw = blockDim.x >> 6;                              // waves per workgroup: 3 or 4, whichever wastes fewer on this block count
@@ -121,11 +151,13 @@ __global__ __launch_bounds__(256, 2) void attn_head_fwd_kernel(HeadAttnArgs a) {
     const float* bt = bias_s + a.tab_center - qc + 4 * h;
     const int jend = CAUSAL ? min(nk, qi + 1) : nk;          // causal: tiles past the query block's diagonal hold no key <= q
     const bool ragged = (a.Sk & 31) != 0;
+    const AhLaneOffs lo = ah_lane_offs(lane);
     auto tile = [&](int j, auto masked) {
       constexpr bool MASK = decltype(masked)::value;          // the last key block (keys beyond Sk) and the causal diagonal
       f32x16 acc = zero_acc();
+      const bf16_t* Kt = Ks + 32 * 64 * j;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) mma16(acc, ah_nat_frag(Ks, 32 * j + r, s, h), qf[s]);      // S^T: rows = keys, cols = queries
+      for (int s = 0; s < 4; ++s) mma16(acc, load_frag(Kt + lo.nat[s]), qf[s]);      // S^T: rows = keys, cols = queries
       float tm = -1e30f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
@@ -169,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void attn_head_fwd_kernel(HeadAttnArgs a) {
         const float pv[8] = {acc[8 * s], acc[8 * s + 1], acc[8 * s + 2], acc[8 * s + 3], acc[8 * s + 4], acc[8 * s + 5], acc[8 * s + 6], acc[8 * s + 7]};
         const Frag<bf16_t> pf = pack_frag<bf16_t>(pv);
 #pragma unroll
-        for (int db = 0; db < 2; ++db) mma16(oacc[db], ah_tr_frag(Vs, 32 * j + 16 * s, db, lane), pf);      // O^T += V^T P^T
+        for (int db = 0; db < 2; ++db) mma16(oacc[db], ah_tr_frag_at(Kt + AH_IMG, lo, s, db), pf);      // O^T += V^T P^T
       }
     };
     for (int j = 0; j < jend; ++j) {
@@ -212,8 +244,8 @@ static int ah_waves(int blocks) {
 }
 
 size_t attn_head_fwd_smem(int Sk, bool bias, int tab_stride) {
-  const size_t skp = (size_t)((Sk + 31) / 32) * 32;
-  const size_t kv = 2 * skp * 64 * sizeof(bf16_t), bias_b = bias ? ((size_t)(tab_stride + 32) * 4 + 15) / 16 * 16 : 0;
+  (void)Sk;
+  const size_t kv = 2 * (size_t)AH_IMG * sizeof(bf16_t), bias_b = bias ? ((size_t)(tab_stride + 32) * 4 + 15) / 16 * 16 : 0;
   const size_t out_stage = (size_t)4 * 32 * 72 * sizeof(bf16_t);          // the four waves' output tiles re-use the K / V (/ bias) bytes
   return kv + bias_b > out_stage ? kv + bias_b : out_stage;
 }
@@ -277,12 +309,11 @@ __global__ __launch_bounds__(256, 2) void attn_head_bwd_kernel(HeadAttnArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int bh = blockIdx.y, b = bh / a.H, hh = bh - b * a.H;
   const int nq = (a.Sq + 31) >> 5, nk = (a.Sk + 31) >> 5, Sqp = nq * 32, Skp = nk * 32;
-  const int Sp = max(max(Sqp, Skp), 288);                       // (the output staging needs 36 KB of the second image whatever the lengths)
   bf16_t* Xa = reinterpret_cast<bf16_t*>(ah_smem);             // pass A: Q image; pass B: K image
-  bf16_t* Xb = Xa + Sp * 64;                                   // pass A: dO image; then per-wave staging / scratch
+  bf16_t* Xb = Xa + AH_IMG;                                    // pass A: dO image; then per-wave staging / scratch
   // Row statistics and bias rows are staged in the units the element loop wants, so that a probability costs a subtract, a
   // multiply-add and an exp2:  P~ = P / (1 - p) = exp2(S log2e + bias log2e - (lse log2e - log2 scale)),  dS = P~ (keep . dP - delta / scale)
-  float* lse_s = reinterpret_cast<float*>(Xb + Sp * 64);       // [Sqp]: lse log2e - log2 scale; +1e30 beyond Sq (=> P = 0 there)
+  float* lse_s = reinterpret_cast<float*>(Xb + AH_IMG);        // [Sqp]: lse log2e - log2 scale; +1e30 beyond Sq (=> P = 0 there)
   float* delta_s = lse_s + Sqp;                                // [Sqp]: rowsum(dO o O) / scale
   float* bias_s = delta_s + Sqp;                               // [tab_stride + 32]: bias log2e by (key - query + tab_center), zeros behind
   float* biasr_s = bias_s + a.tab_stride + 32;                 // the same row reversed (pass A walks queries upwards for a fixed key), zeros behind
@@ -339,6 +370,7 @@ __global__ __launch_bounds__(256, 2) void attn_head_bwd_kernel(HeadAttnArgs a) {
   // ---- pass A: this wave's 32 keys against every query block.  S = Q_i K_j^T: accumulator rows = queries, a lane owns ONE key.
   // Keys beyond Sk (clamped copies of the last row) need no masking here: they only reach columns of dV^T / dK^T that are never stored.
   f32x16 dvT[2] = {zero_acc(), zero_acc()}, dkT[2] = {zero_acc(), zero_acc()};
+  const AhLaneOffs lo = ah_lane_offs(lane);
   if (actA) {
     const int kcol = blk * 32 + r;                              // this lane's key
     const uint32_t* kbits = DROP ? a.keep_bits + ((int64_t)bh * nk + blk) * Sqp + 4 * h : nullptr;
@@ -354,10 +386,11 @@ __global__ __launch_bounds__(256, 2) void attn_head_bwd_kernel(HeadAttnArgs a) {
     auto tile = [&](int i, auto on_diag) {
       constexpr bool DIAG = decltype(on_diag)::value;           // the causal diagonal tile: keys past the query are masked
       f32x16 sacc = zero_acc(), pacc = zero_acc();
+      const bf16_t* Qt = Xa + 32 * 64 * i;                      // (the dO tile sits AH_IMG behind it)
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        mma16(sacc, ah_nat_frag(Xa, 32 * i + r, s, h), kf[s]);
-        mma16(pacc, ah_nat_frag(Xb, 32 * i + r, s, h), vf[s]);
+        mma16(sacc, load_frag(Qt + lo.nat[s]), kf[s]);
+        mma16(pacc, load_frag(Qt + AH_IMG + lo.nat[s]), vf[s]);
       }
       float ptv[16], dsv[16];
 #pragma unroll
@@ -394,8 +427,8 @@ __global__ __launch_bounds__(256, 2) void attn_head_bwd_kernel(HeadAttnArgs a) {
         const Frag<bf16_t> pf = pack_frag<bf16_t>(pv), df = pack_frag<bf16_t>(dv);
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
-          mma16(dvT[db], ah_tr_frag(Xb, 32 * i + 16 * s, db, lane), pf);      // dV^T += dO^T P~
-          mma16(dkT[db], ah_tr_frag(Xa, 32 * i + 16 * s, db, lane), df);      // dK^T += Q^T dS
+          mma16(dvT[db], ah_tr_frag_at(Qt + AH_IMG, lo, s, db), pf);      // dV^T += dO^T P~
+          mma16(dkT[db], ah_tr_frag_at(Qt, lo, s, db), df);               // dK^T += Q^T dS
         }
       }
     };
@@ -463,9 +496,10 @@ __global__ __launch_bounds__(256, 2) void attn_head_bwd_kernel(HeadAttnArgs a) {
     constexpr bool MASK = decltype(masked)::value;              // the last key block (keys beyond Sk) and the causal diagonal
     f32x16 sacc = zero_acc(), pacc = zero_acc();
     const uint32_t kwq = kw_next >> (4 * h);                    // this query's keep bits against key block j
+    const bf16_t* Kt = Xa + 32 * 64 * j;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      mma16(sacc, ah_nat_frag(Xa, 32 * j + r, s, h), qf[s]);
+      mma16(sacc, load_frag(Kt + lo.nat[s]), qf[s]);
       mma16(pacc, vfr[s], dof[s]);
     }
     if (j + 1 < jend) {                                         // the next tile's V rows and keep word: in flight behind this tile's element work
@@ -497,7 +531,7 @@ __global__ __launch_bounds__(256, 2) void attn_head_bwd_kernel(HeadAttnArgs a) {
       const float dv[8] = {dsv[8 * s], dsv[8 * s + 1], dsv[8 * s + 2], dsv[8 * s + 3], dsv[8 * s + 4], dsv[8 * s + 5], dsv[8 * s + 6], dsv[8 * s + 7]};
       df[s] = pack_frag<bf16_t>(dv);
 #pragma unroll
-      for (int db = 0; db < 2; ++db) mma16(dqT[db], ah_tr_frag(Xa, 32 * j + 16 * s, db, lane), df[s]);      // dQ^T += K^T dS^T
+      for (int db = 0; db < 2; ++db) mma16(dqT[db], ah_tr_frag_at(Kt, lo, s, db), df[s]);      // dQ^T += K^T dS^T
     }
     if (want_diag) {
 #pragma unroll
@@ -543,9 +577,9 @@ __global__ __launch_bounds__(256, 2) void attn_head_bwd_kernel(HeadAttnArgs a) {
 }
 
 size_t attn_head_bwd_smem(int Sq, int Sk, bool bias, int tab_stride) {
-  const size_t sqp = (size_t)((Sq + 31) / 32) * 32, skp = (size_t)((Sk + 31) / 32) * 32;
-  const size_t sp = std::max<size_t>(std::max(sqp, skp), 288);
-  return 2 * sp * 64 * sizeof(bf16_t) + 2 * sqp * 4 + (bias ? ((size_t)2 * (tab_stride + 32) * 4 + 15) / 16 * 16 : 0);
+  const size_t sqp = (size_t)((Sq + 31) / 32) * 32;
+  (void)Sk;
+  return 2 * (size_t)AH_IMG * sizeof(bf16_t) + 2 * sqp * 4 + (bias ? ((size_t)2 * (tab_stride + 32) * 4 + 15) / 16 * 16 : 0);
 }
 
 int launch_attn_head_bwd(const HeadAttnArgs& a, int nB, hipStream_t st) {
