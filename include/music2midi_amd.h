@@ -297,12 +297,6 @@ int m2m_mx8_matmul_bf16a(const uint16_t* a_bf16_dev, const float* b_dev, int M, 
  * row log-sum-exp lse [B*H][Sq] fp32.  Backward: from q, k, v, out, lse and d_out the gradients dq / dk / dv (layouts of q / k / v) and,
  * with a bias, diag_part [B*H][ceil(Sq/32)][Sk + 31] = per-query-block sums of dS along the diagonals key - local row = x - 31.
  * Test utilities like m2m_mx8_matmul_f32 (they own one device word for the step key and synchronise `stream` to set it). */
-/* Test utility: the row-complete residual product of the training step with the next sub-layer's RMSNorm in its epilogue
- * (csrc/rowgemm_train.hip; ref music2midi/model.py:32-38 -> hf modeling_t5.py: hidden + dropout(branch), then T5LayerNorm):
- * x_out [M][N] = resid + dropout(A [M][K] . W [N][K]^T), h_out [M][N] (bf16, may be null) = rmsnorm(x_out) * norm_w.  N in {128, 256, 384, 512},
- * K a multiple of 32; step_key_dev: the dropout step word on the device (ignored when drop_p = 0). */
-int m2m_rowgemm_norm_bf16(const uint16_t* A, const uint16_t* W, const float* resid, const float* norm_w, int M, int N, int K, float eps,
-                          float drop_p, const uint64_t* step_key_dev, uint64_t site_salt, float* x_out, uint16_t* h_out, int dbg, void* stream);
 int m2m_attn_head_fwd_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, const float* bias_tab, int B, int H, int Sq, int Sk,
                            int causal, float drop_p, uint64_t step_key, uint64_t site_salt, uint16_t* out, float* lse, uint32_t* keep_bits,
                            void* stream);

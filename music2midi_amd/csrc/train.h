@@ -92,25 +92,6 @@ constexpr int AH_MAX_S = 288;  // rows an LDS image holds (9 blocks of 32): 36 K
 int launch_attn_head_fwd(const HeadAttnArgs& a, int nB, hipStream_t st);
 int launch_attn_head_bwd(const HeadAttnArgs& a, int nB, hipStream_t st);
 
-// Row-complete residual product with the next sub-layer's RMSNorm in its epilogue (rowgemm_train.hip, bf16):
-//   x_out = resid + dropout(A [M][K] . W [N][K]^T),  h_out = bf16(rmsnorm(x_out) * norm_w)   (h_out may be null)
-struct RowGemmArgs {
-  const bf16_t* A;
-  const bf16_t* W;
-  int M, N, K;                 // N in {128, 256, 384, 512}, K a multiple of 64, lda = ldb = K, ldc = N
-  const float* resid;
-  float* x_out;
-  const float* norm_w;
-  bf16_t* h_out;
-  float eps;
-  DropKey dk;                  // dropout on the branch output (element index row * N + col), thresh 0: none
-  uint32_t thresh;
-  float scale;
-  int dbg;                     // measurement only (tools/rowgemm_bench.py): 1 no matrix work, 2 no operand traffic, 4 no epilogue
-};
-bool rowgemm_norm_ok(int M, int N, int K);
-int launch_rowgemm_norm(const RowGemmArgs& a, hipStream_t st);
-
 // Adafactor plan (device tables built once per trainer)
 struct AfTensor {
   int64_t offset;          // into the flat parameter / gradient buffers

@@ -2610,36 +2610,15 @@ struct Ops {
     return launch_bgemm(t->precision, TG_STORE_F32, g, st);
   }
   int cvt(const float* src, void* dst, int64_t n) const { return launch_cvt(t->precision, src, dst, n, st); }
-  // Row-complete residual product (rowgemm_train.hip, bf16): the layer loop names the norm of the sub-layer that runs NEXT
-  // (next_ln / next_h) before it calls a sub-layer; that sub-layer's residual product then writes h as well and the next
-  // sub-layer's norm() finds its work done.  M2M_TRAIN_ROWNORM=0: the product and the norm as two launches.
-  mutable int64_t next_ln = -1;
-  mutable void* next_h = nullptr;
-  mutable const float* normed_x = nullptr;
-  mutable const void* normed_h = nullptr;
-  mutable int64_t normed_ln = -1;
-  static bool rownorm_on() { const char* v = getenv("M2M_TRAIN_ROWNORM"); return !(v && v[0] == '0'); }      // (read per pass: tests run both forms in one process)
+  // (A row-complete residual product that carries the next sub-layer's RMSNorm in its epilogue — 32 whole rows per workgroup, the
+  //  weight matrix streamed through every one of the 131 workgroups by DMA — was built and measured in round 3 (commit 0a97748,
+  //  tools/shared_stream.hip for the streaming ceiling): 13.4 us at K = 512 and 23.9 us at K = 1 152 against 9.6 + 5.2 and 13.9 + 5.2 us
+  //  for the product and the norm as two launches.  Per 64-deep step a workgroup moves 52 KB into LDS and reads 64 KB of fragments
+  //  back: ~0.6 us of LDS and L2-to-CU time per step on HALF the CUs, where the tiled product spreads the same 54 MB over all of them.)
   int mm_resid(const void* A, int64_t w_off, float* x_out, int M, int N, int K, const float* x_in, int site) const {
-    void* const nh = next_h;
-    const int64_t nl = next_ln;
-    next_h = nullptr; next_ln = -1;
-    if (sizeof(T) == 2 && use_tuned && rownorm_on() && !(t->fp8 && t->fp8_fwd) && rowgemm_norm_ok(M, N, K)) {
-      RowGemmArgs a{};
-      a.A = (const bf16_t*)A; a.W = (const bf16_t*)W(w_off); a.M = M; a.N = N; a.K = K; a.resid = x_in; a.x_out = x_out;
-      a.norm_w = nh ? P + nl : nullptr; a.h_out = (bf16_t*)nh; a.eps = t->g.layer_norm_eps;
-      const bool dr = dropping(site);
-      a.dk = dr ? key(site) : DropKey{nullptr, 0}; a.thresh = dr ? t->drop_thresh : 0u; a.scale = t->drop_scale;
-      const int rc = launch_rowgemm_norm(a, st);
-      if (rc == M2M_OK && nh) { normed_x = x_out; normed_h = nh; normed_ln = nl; }
-      return rc;
-    }
     return mm(TG_RESID_F32, A, K, 0, W(w_off), K, 0, x_out, N, M, N, K, x_in, site);
   }
-  int norm(const float* x, int64_t w_off, void* out, int M) const {
-    if (normed_x == x && normed_h == out && normed_ln == w_off) { normed_x = nullptr; normed_h = nullptr; normed_ln = -1; return M2M_OK; }      // written by the product before
-    return launch_rmsnorm(t->precision, x, P + w_off, out, M, t->g.d_model, t->g.layer_norm_eps, st);
-  }
-  // final norm of a stack + the dropout behind it
+  int norm(const float* x, int64_t w_off, void* out, int M) const { return launch_rmsnorm(t->precision, x, P + w_off, out, M, t->g.d_model, t->g.layer_norm_eps, st); }
   int norm_drop(const float* x, int64_t w_off, void* out, int M, int site) const {
     if (!dropping(site)) return norm(x, w_off, out, M);
     hipLaunchKernelGGL(rmsnorm_drop_kernel<T>, dim3(ceil_div(M, 4)), dim3(256), 0, st, x, P + w_off, (T*)out, M, t->g.d_model, t->g.layer_norm_eps, key(site),
@@ -3094,10 +3073,8 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
   }
   for (int l = 0; l < Le; ++l) {
     const EncOff& e = t->enc[l];
-    o.next_ln = e.ln1; o.next_h = t->h1e[l];
     RC(attn_self_fwd<T>(o, t->xe[2 * l], t->xe[2 * l + 1], e.ln0, e.qkv, e.o, t->h0e[l], t->qkve[l], t->Pe[l], t->aoe[l], B, S, t->etab, 0,
                         SITE_ENC + 16 * l, t->kte[l], t->lse_e[l]));
-    if (l + 1 < Le) { o.next_ln = t->enc[l + 1].ln0; o.next_h = t->h0e[l + 1]; }
     RC(ff_fwd<T>(o, t->xe[2 * l + 1], t->xe[2 * l + 2], e.ln1, e.wi, e.wo, t->h1e[l], t->abe[l], t->mide[l], Me, SITE_ENC + 16 * l));
   }
   RC(o.norm_drop(t->xe[2 * Le], t->o_eln, t->hE, Me, SITE_ENC + SITE_FIN));
@@ -3114,7 +3091,6 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
   const bool fuse_c_pv = fuse_c && (o.fuse_mode() & 1), fuse_c_dq = fuse_c && (o.fuse_mode() & 2);
   for (int l = 0; l < Ld; ++l) {
     const DecOff& e = t->dec[l];
-    o.next_ln = e.ln1; o.next_h = t->h1d[l];
     RC(attn_self_fwd<T>(o, t->xd[3 * l], t->xd[3 * l + 1], e.ln0, e.qkv, e.o, t->h0d[l], t->qkvd[l], t->Pd[l], t->aod[l], B, L, t->dtab, 1,
                         SITE_DEC + 16 * l, t->ktd[l], t->lse_d[l]));
     // cross-attention (hf: modeling_t5.py:319-342: K/V from the encoder output, zero bias, no mask)
@@ -3141,9 +3117,7 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
     if (!head_c && !fuse_c_pv)
       RC(o.mmbh(TG_STORE_T, Pu, lps, 0, sPc1, sPc2, ckv + inner, 2 * inner, 1, (int64_t)S * 2 * inner, DK, t->aocd[l], inner,
                 (int64_t)L * inner, DK, B, L, DK, S));
-    o.next_ln = e.ln2; o.next_h = t->h2d[l];
     RC(o.mm_resid(t->aocd[l], e.co, t->xd[3 * l + 2], Md, d, inner, t->xd[3 * l + 1], SITE_DEC + 16 * l + PL_CROSS_OUT));
-    if (l + 1 < Ld) { o.next_ln = t->dec[l + 1].ln0; o.next_h = t->h0d[l + 1]; }
     RC(ff_fwd<T>(o, t->xd[3 * l + 2], t->xd[3 * l + 3], e.ln2, e.wi, e.wo, t->h2d[l], t->abd[l], t->midd[l], Md, SITE_DEC + 16 * l));
   }
   RC(o.norm_drop(t->xd[3 * Ld], t->o_dln, t->hD, Md, SITE_DEC + SITE_FIN));
