@@ -471,6 +471,52 @@ def train_step_record(model_module, cfg, geom, dev, B: int, precision: str, step
     return rec
 
 
+def train_surface_record(cfg, state, dev, B: int, steps: int, warmup: int):
+    """The same step through the CLASS surface a reference-shaped trainer calls (ref model.py:27-43, train.py:40-41):
+    ``Music2MIDI.training_step`` (host tokenisation of the notes as ref model.py:33 does it per step, log-mel, forward + backward
+    enqueued, loss left on the device) + ``optimizer.step()``, driven by ``fit_batches`` — no host synchronisation inside the loop."""
+    from music2midi_amd import synth
+    from music2midi_amd.checkpoint import load_t5_state
+    from music2midi_amd.input import ModelInputs
+    from music2midi_amd.model import Music2MIDI
+    c = cfg.to_dict()
+    c["dataloader"]["batch_size"] = B
+    c["trainer"]["log_every_n_steps"] = 10 ** 9            # the periodic train/score (a greedy decode) is not part of a step
+    m = Music2MIDI(c)
+    load_t5_state(m.model, state, strict=False)
+    m = m.to(dev)
+    m.train_precision = "bf16"
+    m.train()
+    notes = []
+    for b in range(B):                                      # ~54 notes in 3 s per clip: 256 label positions after bucketing, as the main record
+        n = 52 + (7 * b) % 4
+        u = synth.uniform01(300 + b, "surface_notes", n * 3).reshape(n, 3)
+        on = np.sort(u[:, 0] * 2.8)
+        notes.append(np.stack([on, on + 0.05 + u[:, 1] * 0.3, np.floor(40 + u[:, 2] * 40), np.full(n, 80.0)], axis=1))
+    wav = torch.from_numpy(synth.waveform_batch(0, B, TRAIN_SAMPLES)).to(dev)
+    cond = torch.from_numpy(synth.cond_index_batch(0, B)).to(dev)
+    batch = ModelInputs(input_waveform=wav, notes_batch=tuple(notes), cond_index=cond)
+    opt = m.configure_optimizers()[0][0]
+    m.fit_batches([batch] * max(2, warmup), optimizer=opt)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    losses = m.fit_batches([batch] * steps, optimizer=opt)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    t1 = time.perf_counter()
+    for _ in range(20):
+        labels = m._labels(batch.notes_batch)
+    tok = (time.perf_counter() - t1) / 20
+    rec = {"ms_per_step": dt * 1e3, "clips_per_s": B / dt, "label_positions": int(labels.shape[1]), "host_tokenizer_ms_per_step": tok * 1e3,
+           "loss_first_last": [losses[0], losses[-1]],
+           "what": "Music2MIDI.fit_batches over one repeated batch: training_step (notes tokenised on the host every step as ref model.py:33, log-mel, "
+                   "forward + backward enqueued, device-resident loss) + Adafactor step; bf16, dropout 0.1 (train() mode); no host sync inside the loop"}
+    if m._trainer is not None:
+        m._trainer.close()
+    return rec
+
+
+
 # ------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -720,6 +766,7 @@ def main():
         if args.cpu_tokens > 0:
             out["train_configs4"]["cpu_baseline"] = cpu_train_baseline(cfg, state, 16)
         del mt
+        out["train_configs4"]["class_surface"] = train_surface_record(cfg, state, dev, 16, 20, 3)
 
     if rank == 0 and world == 1 and args.cpu_tokens > 0:
         out["cpu_baseline"] = cpu_baseline(cfg, state, args.cpu_tokens)
