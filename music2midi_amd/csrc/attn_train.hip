@@ -112,7 +112,7 @@ __device__ inline float ah_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44
 
 // ------------------------------------------------------------------------------------------------------------ forward
 template <bool CAUSAL, bool BIAS, bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_head_fwd_kernel(HeadAttnArgs a) {
+__global__ __launch_bounds__(512, 2) void attn_head_fwd_kernel(HeadAttnArgs a) {
   extern __shared__ __align__(1024) unsigned char ah_smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int bh = blockIdx.y, b = bh / a.H, hh = bh - b * a.H;
@@ -122,13 +122,18 @@ __global__ __launch_bounds__(256, 2) void attn_head_fwd_kernel(HeadAttnArgs a) {
   float* bias_s = reinterpret_cast<float*>(Vs + AH_IMG);
   const bf16_t* Kg = a.K + b * a.sKb + hh * 64;
   const bf16_t* Vg = a.V + b * a.sVb + hh * 64;
-  const int nw = blockDim.x >> 6;                              // waves per workgroup: 3 or 4, whichever wastes fewer on this block count
-  ah_stage(Ks, Kg, a.ldk, a.Sk, Skp, wave, lane, nw);
-  ah_stage(Vs, Vg, a.ldv, a.Sk, Skp, wave, lane, nw);
+  // A query block is walked by `split` waves, each over its share of the key tiles; their (m, l, O) meet in LDS at the end.  A kernel of
+  // this family cannot end before one wave has walked its tiles (12 us for 9 tiles with a quarter of the heads), and at 16 clips there
+  // are only 1.1 waves per SIMD to begin with: two half-length walks per block halve that chain and give every SIMD a second wave to
+  // switch to.  nw = query blocks per workgroup, blockDim = 64 nw split.
+  const int nwaves = blockDim.x >> 6, split = a.key_split, nw = nwaves / split;
+  ah_stage(Ks, Kg, a.ldk, a.Sk, Skp, wave, lane, nwaves);
+  ah_stage(Vs, Vg, a.ldv, a.Sk, Skp, wave, lane, nwaves);
   if (BIAS)
     for (int i = threadIdx.x; i < a.tab_stride + 32; i += blockDim.x) bias_s[i] = i < a.tab_stride ? a.bias_tab[(int64_t)hh * a.tab_stride + i] * AH_LOG2E : 0.f;
-  // this wave's query block
-  const int qi = nw * blockIdx.x + wave;
+  // this wave's query block and its part of the key tiles
+  const int part = wave / nw, wq = wave - part * nw;
+  const int qi = nw * blockIdx.x + wq;
   const bool active = qi * 32 < a.Sq;
   const int q = qi * 32 + r, qc = min(q, a.Sq - 1);
   Frag<bf16_t> qf[4];
@@ -204,17 +209,51 @@ __global__ __launch_bounds__(256, 2) void attn_head_fwd_kernel(HeadAttnArgs a) {
         for (int db = 0; db < 2; ++db) mma16(oacc[db], ah_tr_frag_at(Kt + AH_IMG, lo, s, db), pf);      // O^T += V^T P^T
       }
     };
-    for (int j = 0; j < jend; ++j) {
+    const int per = (jend + split - 1) / split;              // tiles [part * per, (part + 1) * per) n [0, jend)
+    const int j0 = part * per, j1 = min(jend, j0 + per);
+    for (int j = j0; j < j1; ++j) {
       if ((CAUSAL && j == qi) || (ragged && j == nk - 1)) tile(j, std::true_type{});
       else tile(j, std::false_type{});
     }
     l += lane_xor<32>(l);
   }
-  __syncthreads();                                                   // every wave is done with K / V: their LDS becomes the output staging
+  __syncthreads();                                                   // every wave is done with K / V: their LDS becomes merge / output staging
+  constexpr int OP = 72;                                             // staging pitch (elements)
+  if (split > 1) {
+    // parts 1.. leave (m, l, O^T accumulators) in LDS — [part - 1][query block][lane][34 floats], behind the output staging — and part 0 folds them in
+    float* Mg = reinterpret_cast<float*>(Ks + 4 * 32 * OP);
+    if (part > 0 && active) {
+      float* dst = Mg + ((size_t)((part - 1) * nw + wq) * 64 + lane) * 36;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(dst + 16 * db + 4 * g) = make_float4(oacc[db][4 * g], oacc[db][4 * g + 1], oacc[db][4 * g + 2], oacc[db][4 * g + 3]);
+      dst[32] = m; dst[33] = l;
+    }
+    __syncthreads();
+    if (part > 0) return;
+    if (active) {
+      for (int p = 1; p < split; ++p) {
+        const float* src = Mg + ((size_t)((p - 1) * nw + wq) * 64 + lane) * 36;
+        const float m1 = src[32], l1 = src[33];
+        const float mn = fmaxf(m, m1);
+        const float a0 = __builtin_amdgcn_exp2f(m - mn), a1 = __builtin_amdgcn_exp2f(m1 - mn);      // (a part without tiles: m1 = -1e30, l1 = 0, O = 0)
+        l = l * a0 + l1 * a1;
+        m = mn;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 o1 = *reinterpret_cast<const float4*>(src + 16 * db + 4 * g);
+            oacc[db][4 * g] = oacc[db][4 * g] * a0 + o1.x * a1; oacc[db][4 * g + 1] = oacc[db][4 * g + 1] * a0 + o1.y * a1;
+            oacc[db][4 * g + 2] = oacc[db][4 * g + 2] * a0 + o1.z * a1; oacc[db][4 * g + 3] = oacc[db][4 * g + 3] * a0 + o1.w * a1;
+          }
+      }
+    }
+  }
   if (!active) return;
   const float inv = (DROP ? a.scale : 1.0f) / l;
-  constexpr int OP = 72;                                             // staging pitch (elements)
-  bf16_t* Os = Ks + wave * 32 * OP;
+  bf16_t* Os = Ks + wq * 32 * OP;
 #pragma unroll
   for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -246,7 +285,7 @@ static int ah_waves(int blocks) {
 size_t attn_head_fwd_smem(int Sk, bool bias, int tab_stride) {
   (void)Sk;
   const size_t kv = 2 * (size_t)AH_IMG * sizeof(bf16_t), bias_b = bias ? ((size_t)(tab_stride + 32) * 4 + 15) / 16 * 16 : 0;
-  const size_t out_stage = (size_t)4 * 32 * 72 * sizeof(bf16_t);          // the four waves' output tiles re-use the K / V (/ bias) bytes
+  const size_t out_stage = (size_t)4 * 32 * 72 * sizeof(bf16_t) + (size_t)4 * 64 * 36 * sizeof(float);      // output tiles + (split - 1) nw <= 4 merge records re-use the K / V (/ bias) bytes
   return kv + bias_b > out_stage ? kv + bias_b : out_stage;
 }
 
@@ -258,12 +297,21 @@ int launch_attn_head_fwd(const HeadAttnArgs& a, int nB, hipStream_t st) {
   M2M_REQUIRE(!drop || a.keep_bits, "attn_head: dropout needs the keep-bit buffer");
   const size_t smem = attn_head_fwd_smem(a.Sk, bias, a.tab_stride);
   M2M_REQUIRE(smem <= 78 * 1024, "attn_head: %zu bytes of LDS", smem);
-  const int nw = ah_waves(ceil_div(a.Sq, 32));
+  // two waves per query block (halves of the key tiles) when the head has at least two key tiles; M2M_AH_SPLIT=1 / 2 / 3 forces the count
+  static const int forced_split = [] { const char* v = getenv("M2M_AH_SPLIT"); return v ? atoi(v) : 0; }();
+  const int nkt = ceil_div(a.Sk, 32);
+  const int split = std::max(1, std::min(forced_split >= 1 && forced_split <= 3 ? forced_split : 2, nkt));
+  int nw = ah_waves(ceil_div(a.Sq, 32));
+  if (nw * split > 8) nw = 8 / split;
+  static const int keep4 = [] { const char* v = getenv("M2M_AH_KEEP4"); return v ? atoi(v) : 1; }();
+  if (split > 1 && nw > 3 && !(keep4 && ceil_div(a.Sq, 32) % 4 == 0)) nw = 3;      // (six waves, two workgroups per CU; eight when the blocks come in fours)
+  HeadAttnArgs a2 = a;
+  a2.key_split = split;
   dim3 grid((unsigned)ceil_div(ceil_div(a.Sq, 32), nw), (unsigned)(nB * a.H));
-#define M2M_AH_FWD(C_, B_, D_)                                                                   \
-  do {                                                                                           \
-    M2M_OPT_IN_LDS((attn_head_fwd_kernel<C_, B_, D_>), 158 * 1024);                              \
-    hipLaunchKernelGGL((attn_head_fwd_kernel<C_, B_, D_>), grid, dim3(64 * nw), smem, st, a);    \
+#define M2M_AH_FWD(C_, B_, D_)                                                                           \
+  do {                                                                                                   \
+    M2M_OPT_IN_LDS((attn_head_fwd_kernel<C_, B_, D_>), 158 * 1024);                                      \
+    hipLaunchKernelGGL((attn_head_fwd_kernel<C_, B_, D_>), grid, dim3(64 * nw * split), smem, st, a2);   \
   } while (0)
   if (a.causal) {
     if (bias) { if (drop) M2M_AH_FWD(true, true, true); else M2M_AH_FWD(true, true, false); }

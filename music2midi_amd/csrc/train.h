@@ -85,6 +85,7 @@ struct HeadAttnArgs {
   DropKey dk;
   uint32_t thresh;
   float scale;
+  int key_split;               // forward: waves per query block (set by the launcher)
   uint32_t* keep_bits;         // with dropout: [B*H][ceil(Sk/32)][round_up_32(Sq)] words, bit k of word (key block j, query q) = probability (q, 32 j + k)
                                // is kept.  The forward pass hashes once and writes them; both backward orientations read them instead of hashing again.
 };

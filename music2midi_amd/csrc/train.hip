@@ -1845,7 +1845,15 @@ __global__ __launch_bounds__(256) void af_pass_a2(const AfTensor* __restrict__ t
     for (int r = threadIdx.x; r < t.rows; r += 256) rfac[t.row_off + r] = rsqrtf(R[r] / rmean);
     for (int c = threadIdx.x; c < t.cols; c += 256) {
       float cs = 0.f;
-      for (int b = 0; b < t.nblocks; ++b) cs += colpart[t.col_off + (int64_t)b * t.cols + c];
+      int b = 0;
+      for (; b + 8 <= t.nblocks; b += 8) {            // eight partial rows in flight (the plain loop paid a memory round trip per row block: 28 us per step)
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = colpart[t.col_off + (int64_t)(b + u) * t.cols + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cs += v[u];
+      }
+      for (; b < t.nblocks; ++b) cs += colpart[t.col_off + (int64_t)b * t.cols + c];
       const float v = beta2t * C[c] + (1.f - beta2t) * (cs / (float)t.rows);
       C[c] = v;
       cfac[t.cfac_off + c] = rsqrtf(v);
