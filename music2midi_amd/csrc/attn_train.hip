@@ -38,25 +38,13 @@ __device__ inline int ah_g(int row) { return (((row >> 1) & 1) << 2) | ((row >> 
 __device__ inline int ah_off(int row, int chunk) { return row * 64 + ((chunk ^ ah_g(row)) << 3); }
 
 typedef short ah_v4s __attribute__((ext_vector_type(4)));
-// Fragment of X^T for one 32x32x16 step: rows = 32 columns [32 db, +32) of the LDS image X, k = the 16 image rows
-// {p0 + 4h + (0..3)} u {p0 + 8 + 4h + (0..3)} (h = lane >> 5) — the order in which an accumulator lane holds its rows, so that a
-// probability tile feeds the next product from the registers it was computed in.
-__device__ inline Frag<bf16_t> ah_tr_frag(const bf16_t* X, int p0, int db, int lane) {
-  typedef ah_v4s __attribute__((address_space(3))) * lds_v4s;
-  const int li = lane & 15, q = li >> 2, pp = li & 3, gq = lane >> 4, h = lane >> 5;
-  const int c = 4 * db + 2 * (gq & 1) + (pp >> 1), sub = (pp & 1) * 4;
-  const int r0 = p0 + 4 * h + q, r1 = r0 + 8;
-  const ah_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(X + ah_off(r0, c) + sub));
-  const ah_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(X + ah_off(r1, c) + sub));
-  Frag<bf16_t> f;
-  f.v = make_uint4(__builtin_bit_cast(uint2, lo).x, __builtin_bit_cast(uint2, lo).y, __builtin_bit_cast(uint2, hi).x, __builtin_bit_cast(uint2, hi).y);
-  return f;
-}
-// natural fragment: row `row` of the image, k = d in [16 s + 8 h, +8)
-__device__ inline Frag<bf16_t> ah_nat_frag(const bf16_t* X, int row, int s, int h) { return load_frag(X + ah_off(row, 2 * s + h)); }
 // The swizzle of a row depends on its low five bits only, so inside a 32-row tile every fragment address is (tile base) + (a lane
 // constant): the loops below keep these constants in registers and add the tile base — the index arithmetic of ah_off / ah_tr_frag per
 // fragment and tile was a quarter of the VALU instructions of a tile.
+// natural fragment s: row (lane & 31) of the tile, k = d in [16 s + 8 h, +8)           (h = lane >> 5)
+// transposing fragment (s, db) = a fragment of X^T: rows = the image's columns [32 db, +32), k = the 16 image rows
+//   {16 s + 4 h + (0..3)} u {16 s + 8 + 4 h + (0..3)} — the order in which an accumulator lane holds ITS rows, so a probability tile
+//   feeds the next product from the registers it was computed in (two ds_read_b64_tr_b16, each four rows x 64 bytes)
 struct AhLaneOffs {
   int nat[4];        // natural fragment s of tile row (lane & 31)
   int tr[2][2];      // transposing fragment: [db][first / second group of four rows], + 16 s * 64 for substep s
@@ -108,7 +96,6 @@ __device__ inline void ah_stage(bf16_t* X, const bf16_t* G, int64_t ld, int n_va
 __device__ inline uint32_t ah_bit_mask(uint32_t w, int bit) { return (uint32_t)((int32_t)(w << (31 - bit)) >> 31); }
 constexpr float AH_LOG2E = 1.4426950408889634f;
 constexpr float AH_LAZY = 6.0f;
-__device__ inline float ah_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 
 // ------------------------------------------------------------------------------------------------------------ forward
 template <bool CAUSAL, bool BIAS, bool DROP>
@@ -303,8 +290,7 @@ int launch_attn_head_fwd(const HeadAttnArgs& a, int nB, hipStream_t st) {
   const int split = std::max(1, std::min(forced_split >= 1 && forced_split <= 3 ? forced_split : 2, nkt));
   int nw = ah_waves(ceil_div(a.Sq, 32));
   if (nw * split > 8) nw = 8 / split;
-  static const int keep4 = [] { const char* v = getenv("M2M_AH_KEEP4"); return v ? atoi(v) : 1; }();
-  if (split > 1 && nw > 3 && !(keep4 && ceil_div(a.Sq, 32) % 4 == 0)) nw = 3;      // (six waves, two workgroups per CU; eight when the blocks come in fours)
+  if (split > 1 && nw > 3 && ceil_div(a.Sq, 32) % 4 != 0) nw = 3;      // (six waves, two workgroups per CU; eight when the blocks come in fours)
   HeadAttnArgs a2 = a;
   a2.key_split = split;
   dim3 grid((unsigned)ceil_div(ceil_div(a.Sq, 32), nw), (unsigned)(nB * a.H));
@@ -344,9 +330,6 @@ __device__ inline void ah_tile_to_global(const bf16_t* Ts, bf16_t* G, int64_t ld
     const int idx = lane + 64 * u, rl = idx >> 3, ch = idx & 7;
     if (row0 + rl < n_rows) *reinterpret_cast<uint4*>(G + (int64_t)(row0 + rl) * ld + ch * 8) = *reinterpret_cast<const uint4*>(Ts + rl * AH_TP + ch * 8);
   }
-}
-template <int X> __device__ inline uint32_t ah_quad_bcast(uint32_t v) {      // value of lane X of this lane's quad
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, X * 0x55, 0xF, 0xF, true);
 }
 
 constexpr int AH_SKEW_P = 40;      // pitch (elements) of the skewed dS tile of the bias gradient: 80-byte rows keep its 16-byte column reads conflict-free
