@@ -6,19 +6,22 @@
 // (and reading it back in the backward pass together with a re-emitted dropped copy and dS, 17.6 MB each at 16 clips), and a batched
 // dV | dK product — 27-34 us forward and 47-53 us backward per layer, 1.4 ms of a 4.5 ms step, with matrix cores 4-6 % busy.
 // Here ONE workgroup family per (clip, head) keeps the head's operands in LDS and never writes a probability:
-//   forward   stage K and V (global_load_lds, swizzled), a wave per 32-query block walks the key blocks with an ONLINE softmax in
-//             the S^T = K Q^T orientation (a lane owns one query: row statistics are in-lane + one lane^32 exchange), the dropped
-//             probabilities go from the accumulator STRAIGHT into the next product as its B operand — O^T = V^T P~^T, V^T fragments
-//             by transposing LDS reads (ds_read_b64_tr_b16) in the accumulator's own key order — and only O and the row
-//             log-sum-exp leave the kernel;
-//   backward  recomputes P = exp(S + bias - lse) twice, once per orientation, so that both reductions stay inside a wave:
+//   forward   stage K and V (global_load_lds, swizzled); a query block of 32 is walked by TWO waves, each over half of the key tiles
+//             (their (m, l, O) meet in LDS at the end), with an ONLINE softmax in the S^T = K Q^T orientation (a lane owns one query: row
+//             statistics are in-lane + one lane^32 exchange), in log2 units and with a lazy running maximum; the probabilities go from the
+//             accumulator STRAIGHT into the next product as its B operand — O^T = V^T P^T, V^T fragments by transposing LDS reads
+//             (ds_read_b64_tr_b16) in the accumulator's own key order; the dropout scale is applied once, to O.  Out: O, the row
+//             log-sum-exp and — with dropout — ONE keep-bit word per (query, 32 keys);
+//   backward  recomputes P = exp2(S log2e + bias - lse) twice, once per orientation, so that both reductions stay inside a wave:
 //             pass A, a wave per 32-KEY block (S = Q K^T, a lane owns one key): dV^T += dO^T P~, dK^T += Q^T dS with P~ / dS from
 //             the accumulators as B operands and dO^T / Q^T by transposing reads; pass B, a wave per 32-QUERY block (S^T again):
 //             dQ^T += K^T dS^T.  delta = rowsum(dO o O) replaces sum_k P dP~ (the flash-attention identity, dropout included).
-// The dropout masks are the step's counter-based hash with the SAME element index as before ((clip*H + head) * Sq + query) * ldp
-// + key, so the oracle regenerates them; the relative-position-bias gradient leaves pass B as per-query-block diagonal sums in the
-// layout the stripe kernel used (bias_stripes_sum_kernel / bias_bucket_kernel are unchanged).  fp32 (parity) mode, fp32 storage
-// and sequences beyond AH_MAX_S keep the stripe path.
+//             Both passes read the forward pass's keep-bit words instead of hashing again.
+// The dropout masks are the step's counter-based hash with the SAME element index as the stored-probability path
+// ((clip*H + head) * Sq + query) * ldp + key, hashed ONCE (forward), so the oracle regenerates them; the relative-position-bias
+// gradient leaves pass B as per-query-block diagonal sums — summed on the matrix core from a skewed copy of the dS tile — in the layout
+// the stripe kernel used (bias_stripes_sum_kernel / bias_bucket_kernel are unchanged).  fp32 (parity) mode, fp32 storage and sequences
+// beyond AH_MAX_S keep the stripe path.  DESIGN.md 4.8 has the measurements, including what was tried and removed.
 #include "mma.h"
 #include "t5.h"
 #include "train.h"
