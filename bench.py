@@ -371,8 +371,8 @@ def train_profile_summary(profiles_dir=None):
     """Launches per step and the share of a step's GPU time that is NOT a matrix product, from the newest committed rocprofv3
     kernel-stats summary of the training step (profiles/r*_train_dropout_kernel_stats.csv: `tools/train_gap.py` — the same
     16-clip / S = 261 / 256-label / dropout 0.1 step, directly issued so that every kernel is a launch of its own — under
-    `rocprofv3 --kernel-trace --stats`).  Product kernels = names containing gemm / dw_group / attn_stripe (projections, batched
-    attention products, weight gradients, the fused attention stripes); everything else is row / element-wise work.  {} when no
+    `rocprofv3 --kernel-trace --stats`).  Product kernels = names containing gemm / dw_group / attn_stripe / attn_head (projections, batched
+    attention products, weight gradients, the attention kernels of either generation); everything else is row / element-wise work.  {} when no
     summary is committed."""
     import csv
     files = sorted(Path(profiles_dir or ROOT / "profiles").glob("*train_dropout_kernel_stats.csv"), key=lambda f: (_round_of(f.name), f.name))
@@ -383,7 +383,7 @@ def train_profile_summary(profiles_dir=None):
     if not steps:
         return {}
     tot = sum(float(r["TotalDurationNs"]) for r in rows) / steps / 1e3
-    gemm = sum(float(r["TotalDurationNs"]) for r in rows if any(k in r["Name"] for k in ("gemm", "dw_group", "attn_stripe"))) / steps / 1e3
+    gemm = sum(float(r["TotalDurationNs"]) for r in rows if any(k in r["Name"] for k in ("gemm", "dw_group", "attn_stripe", "attn_head"))) / steps / 1e3
     return {"launches_per_step": round(sum(int(r["Calls"]) for r in rows) / steps, 1), "kernel_us_per_step": round(tot, 1),
             "non_gemm_us": round(tot - gemm, 1), "profile": files[-1].name}
 
