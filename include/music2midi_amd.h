@@ -296,6 +296,8 @@ int m2m_mx8_matmul_bf16a(const uint16_t* a_bf16_dev, const float* b_dev, int M, 
  * ((b*H + h)*Sq + query) * round_up_8(Sk) + key, key = splitmix64(step_key + site_salt)).  Forward: out [B, Sq, H*64] bf16 and the
  * row log-sum-exp lse [B*H][Sq] fp32.  Backward: from q, k, v, out, lse and d_out the gradients dq / dk / dv (layouts of q / k / v) and,
  * with a bias, diag_part [B*H][ceil(Sq/32)][Sk + 31] = per-query-block sums of dS along the diagonals key - local row = x - 31.
+ * keep_bits [B*H][ceil(Sk/32)][round_up_32(Sq)] uint32 (needed when drop_p > 0): the forward pass writes one word per (key block, query) —
+ * bit k = probability (query, 32 * block + k) is kept — and the backward pass reads them instead of hashing again.
  * Test utilities like m2m_mx8_matmul_f32 (they own one device word for the step key and synchronise `stream` to set it). */
 int m2m_attn_head_fwd_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, const float* bias_tab, int B, int H, int Sq, int Sk,
                            int causal, float drop_p, uint64_t step_key, uint64_t site_salt, uint16_t* out, float* lse, uint32_t* keep_bits,
