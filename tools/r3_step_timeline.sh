@@ -11,7 +11,7 @@ python3 - <<'PY'
 import csv, re
 rows=list(csv.DictReader(open('gpurun_out/timeline/trace.csv')))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
-names=[re.sub(r'\(.*','',r['Kernel_Name']).replace('void ','').replace('m2m::','') for r in rows]
+names=[re.sub(r'\(.*','',r['Kernel_Name'].replace('(anonymous namespace)::','').replace('void ','').replace('m2m::','')) for r in rows]
 # steps start at train_prologue_kernel; take the last complete one
 starts=[i for i,n in enumerate(names) if n.startswith('train_prologue_kernel')]
 a,b=starts[-2],starts[-1]
@@ -23,7 +23,7 @@ for i in range(a,b):
     s=int(rows[i]['Start_Timestamp']); e=int(rows[i]['End_Timestamp'])
     gap=(s-busy_end)/1e3
     if gap>0: gaps+=gap
-    print(f"{i-a:4d} {(s-t0)/1e3:9.1f} {(e-s)/1e3:8.1f} {gap:7.1f}  {names[i][:90]} grid={rows[i].get('Grid_Size','')} wg={rows[i].get('Workgroup_Size','')}", file=out)
+    print(f"{i-a:4d} {(s-t0)/1e3:9.1f} {(e-s)/1e3:8.1f} {gap:7.1f}  q{rows[i]['Queue_Id']} {names[i][:90]} grid={rows[i]['Grid_Size_X']}x{rows[i]['Grid_Size_Y']}x{rows[i]['Grid_Size_Z']} wg={rows[i]['Workgroup_Size_X']}", file=out)
     busy_end=max(busy_end,e)
 print(f"step span {(busy_end-t0)/1e3:.1f} us, idle gaps {gaps:.1f} us, dispatches {b-a}", file=out)
 out.close()
