@@ -3512,6 +3512,17 @@ extern "C" int m2m_train_forward_backward(m2m_trainer* t, const float* params_de
     if (split) { slot.gexec = first; slot.gexec2 = last; } else { slot.gexec = last; }
     slot.nodes = n_nodes;
   }
+  // A replayed graph that is not split is launched straight on the CALLER's stream: the inputs were staged there, the loss copy and the
+  // optimizer follow there, so neither hand-over event (ev_in / ev_out: a cross-stream dependency on each side of every step) is needed.
+  // M2M_TRAIN_GRAPH_CALLER=0: on the trainer's own stream, as the directly issued and the split passes run.
+  static const bool graph_on_caller = [] { const char* v = getenv("M2M_TRAIN_GRAPH_CALLER"); return !(v && v[0] == '0'); }();
+  if (slot.gexec && !split && !release_at_end && graph_on_caller) {
+    M2M_CHECK_HIP(hipGraphLaunch(slot.gexec, caller));
+    M2M_CHECK_HIP(hipMemcpyAsync(loss_out_dev, t->loss_dev, 4, hipMemcpyDeviceToDevice, caller));
+    if (logits_out_dev)
+      M2M_CHECK_HIP(hipMemcpyAsync(logits_out_dev, t->logits, (size_t)B * Ld * g.vocab_size * 4, hipMemcpyDeviceToDevice, caller));
+    return M2M_OK;
+  }
   if (slot.gexec) {
     M2M_CHECK_HIP(hipGraphLaunch(slot.gexec, t->s_main));
     if (split) {
