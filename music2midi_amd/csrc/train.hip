@@ -1793,7 +1793,9 @@ __global__ void add_kernel(const float* __restrict__ a, const float* __restrict_
 //   upd  /= max(1, rms(upd) / 1.0);   p <- p - lr * upd
 // Three passes over (p, g) with the reductions between them; one launch per pass for ALL tensors (block -> (tensor,
 // row block) through a table), every reduction in a fixed order.
-constexpr int AF_ROWS = 32;      // rows of a matrix per block (vectors: one "row" of up to AF_VEC elements per block)
+constexpr int AF_ROWS = 16;      // rows of a matrix per block (32 until round 3: 235 registers in pass A, two blocks per CU; 16 rows run pass A / B / C in
+                                 // 51 / 23 / 61 us instead of 64 / 31 / 69; 8 rows gain nothing more and cost pass A2 its partial sums)
+// (vectors: one "row" of up to AF_VEC elements per block)
 
 // pass A: per block: sum p^2, per-row sum of (g^2 + eps1) -> rowsum[tensor rows], per-block column partial sums
 __global__ __launch_bounds__(256) void af_pass_a(const AfBlock* __restrict__ blocks, const AfTensor* __restrict__ tensors,
@@ -2229,8 +2231,8 @@ int build_optimizer(m2m_trainer* t) {
     a.cols = td.cols ? td.cols : td.rows;
     a.row_off = row_off; a.cfac_off = cfac_off; a.col_off = col_off; a.state_off = state_off;
     a.block0 = (int)ab.size();
-    a.nblocks = ceil_div(a.rows, 32);
-    for (int b = 0; b < a.nblocks; ++b) ab.push_back({(int)at.size(), b * 32, col_off + (int64_t)b * a.cols});
+    a.nblocks = ceil_div(a.rows, AF_ROWS);
+    for (int b = 0; b < a.nblocks; ++b) ab.push_back({(int)at.size(), b * AF_ROWS, col_off + (int64_t)b * a.cols});
     row_off += a.rows; cfac_off += a.cols; col_off += (int64_t)a.nblocks * a.cols;
     state_off += (a.rows > 1 ? a.rows : 0) + a.cols;
     at.push_back(a);
