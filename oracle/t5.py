@@ -172,12 +172,14 @@ class T5Oracle:
     # -- public --------------------------------------------------------------
     @torch.no_grad()
     def generate(self, inputs_embeds: torch.Tensor, max_length: int, return_margins: bool = False,
-                 enc_out: Optional[torch.Tensor] = None):
+                 enc_out: Optional[torch.Tensor] = None, logits_hook=None):
         """Greedy decode (hf: generation/utils.py:2783-2973, do_sample=False).
 
         Returns LongTensor [B, L], L <= max_length; column 0 is the start token;
         rows that finished early are right-padded with pad_token_id; generation
         stops when every row has emitted EOS or L == max_length.
+        ``logits_hook(t, logits)`` sees every step's fp32 logits [B, V] (fixture generation: the greedy
+        trajectory's logits ARE the teacher-forced logits along its own ids).
         """
         g = self.g
         if enc_out is None:
@@ -192,6 +194,8 @@ class T5Oracle:
         t = 0
         while ids.shape[1] < max_length:
             logits = self.decode_step(ids[:, -1], t, cache, cross, bias_tab)
+            if logits_hook is not None:
+                logits_hook(t, logits)
             nxt = torch.argmax(logits, dim=-1)
             if return_margins:
                 top2 = torch.topk(logits, 2, dim=-1).values

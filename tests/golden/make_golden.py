@@ -183,6 +183,78 @@ def make_t5_bf16(out_path):
     np.savez_compressed(out_path, **data)
 
 
+# ------------------------------------------------------------------ forced-decode goldens: every position of the headline sequence
+def make_t5_forced(out_path):
+    """Teacher-forced pin of BOTH precision modes along the WHOLE headline sequence (S = 864, 1 023 positions; ref
+    music2midi/transformer.py:41-45).  After a greedy divergence two decodes are different sequences and nothing further compares;
+    forcing the ORACLE's own ids through the device's KV-cached decode kernels compares every position regardless.  The greedy
+    trajectory's per-step logits ARE the teacher-forced logits along its own ids, so one ``generate`` per case yields: ids, top-2
+    margins, the top-4 (value, column) of every step, and the full 400-column logits on a stride of 64 steps.  Cases: the two
+    HF-pinned ``full_s864`` embedding clips and clips 0-1 of bench.py's workload, each under the fp32 oracle (pinned to HF by
+    make_t5) and under ``emulate="bf16"``; ids are asserted equal to the committed t5.npz / t5_bf16.npz."""
+    from oracle.logmel import conditioning
+    cfg = ref_config()
+    geom = T5Geometry(dict(cfg["model"]["t5"]))
+    L, stride = 1024, 64
+    zb, z32 = np.load(HERE / "t5_bf16.npz"), np.load(HERE / "t5.npz")
+    data = {}
+
+    def run(name, sd, x, emulate, want_ids):
+        steps = sorted(set(range(0, L - 1, stride)) | {L - 2})
+        top_v, top_i, full = [], [], []
+
+        def hook(t, logits):
+            v, i = torch.topk(logits, 4, dim=-1)
+            top_v.append(v.clone()); top_i.append(i.clone())
+            if t in steps:
+                full.append(logits.clone())
+
+        ids, margins = T5Oracle(geom, sd, emulate=emulate).generate(x, L, return_margins=True, logits_hook=hook)
+        assert ids.shape == (2, L) and np.array_equal(ids.numpy(), want_ids.astype(np.int64)), f"{name}: ids differ from the committed fixture"
+        data[f"{name}/ids"] = ids.numpy().astype(np.int16)
+        data[f"{name}/margins"] = margins.numpy().astype(np.float32)
+        data[f"{name}/top_vals"] = torch.stack(top_v, 1).numpy().astype(np.float32)          # [2, 1023, 4]
+        data[f"{name}/top_idx"] = torch.stack(top_i, 1).numpy().astype(np.int16)
+        data[f"{name}/full_steps"] = np.asarray(steps, dtype=np.int32)
+        data[f"{name}/full_logits"] = torch.stack(full, 1).numpy().astype(np.float32)       # [2, n, 400]
+        print(f"[t5_forced] {name}: min margin {margins.min():.4f}, positions with margin < 0.5: {(margins < 0.5).sum().item()} of {margins.numel()}, "
+              f"|logit| max {torch.stack(top_v, 1).abs().max():.1f}")
+        if emulate == "bf16":
+            # The emulation's OWN noise floor: the same forced pass with the inputs perturbed by 1e-6 (relative).  bfloat16 rounding
+            # decisions flip under any change of summation order, and the flips compound over 12 layers; two evaluations that are not
+            # bit-identical in every GEMM input — device and emulation sum in different orders — cannot agree better than the
+            # emulation agrees with itself here.  Stored: max / 99.9th percentile / mean of |d logit| on the fixture's samples and of
+            # |d (top-1 - top-2)|, the quantity an arg-max flip depends on.
+            noise = torch.from_numpy(synth.normal(123, "noise", tuple(x.shape), 1.0))
+            _, lg = T5Oracle(geom, sd, emulate="bf16").forward(x * (1 + 1e-6 * noise), ids[:, 1:].clone())
+            lg = lg.numpy().astype(np.float64)
+            tv, ti = data[f"{name}/top_vals"].astype(np.float64), data[f"{name}/top_idx"].astype(np.int64)
+            e = np.abs(np.take_along_axis(lg, ti, 2) - tv)
+            ef = np.abs(lg[:, steps] - data[f"{name}/full_logits"])
+            allv = np.concatenate([e.ravel(), ef.ravel()])
+            pm = np.take_along_axis(lg, ti[:, :, :2], 2)
+            dm = np.abs((pm[:, :, 0] - pm[:, :, 1]) - (tv[:, :, 0] - tv[:, :, 1]))
+            data[f"{name}/self_noise_logit"] = np.asarray([allv.max(), np.quantile(allv, 0.999), allv.mean()])
+            data[f"{name}/self_noise_margin"] = np.asarray([dm.max(), np.quantile(dm, 0.999), dm.mean()])
+            print(f"[t5_forced] {name}: self-noise floor (1e-6 input perturbation) |d logit| max / p99.9 / mean {data[f'{name}/self_noise_logit']}, "
+                  f"|d margin| {data[f'{name}/self_noise_margin']}")
+
+    sd = synth.t5_state_dict(geom, seed=0)
+    synth.perturb_layer_norms(sd, 0)
+    x = embeds(2, 864, geom.d_model)
+    run("full_s864_fp32", sd, x, "fp32", z32["full_s864/ids"])
+    run("full_s864_bf16", sd, x, "bf16", zb["full_s864_bf16/ids"])
+    sd = synth.t5_state_dict(geom, seed=0)
+    sp = cfg["spectrogram"]
+    wav = torch.from_numpy(synth.waveform_batch(0, 2, 220500))
+    idx = torch.from_numpy(synth.cond_index_batch(0, 2))
+    emb = [torch.from_numpy(sd[f"conditioning.embeds.{i}.weight"]) for i in range(2)]
+    xw = conditioning(LogMelOracle(cfg["model"]["sample_rate"], sp["n_fft"], sp["hop_length"], sp["f_min"], geom.d_model)(wav), idx, emb)
+    run("bench_clips_fp32", sd, xw, "fp32", zb["bench_clips_fp32/ids"])
+    run("bench_clips_bf16", sd, xw, "bf16", zb["bench_clips_bf16/ids"])
+    np.savez_compressed(out_path, **data)
+
+
 # ------------------------------------------------------------------ frontend goldens
 def make_frontend(out_path):
     cfg = ref_config()
@@ -340,6 +412,8 @@ if __name__ == "__main__":
         make_train(HERE / "train.npz")
     if not only or "t5_bf16" in only:
         make_t5_bf16(HERE / "t5_bf16.npz")
+    if not only or "t5_forced" in only:
+        make_t5_forced(HERE / "t5_forced.npz")
     for p in sorted(HERE.glob("*.npz")) + sorted(HERE.glob("*.json")):
         print(p.name, p.stat().st_size, "bytes")
     # never leave bytecode in the read-only reference tree

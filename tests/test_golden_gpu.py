@@ -210,11 +210,15 @@ def test_bf16_vs_fp32_ids_at_headline_geometry():
     assert a.min() >= 0 and a.max() < g.vocab_size
 
 
-BF16_NOISE_MARGIN = 0.5      # top-2 logit margin (logits reach |75|) below which a bf16 decode may take the other token: one bf16 ulp of
-                             # a GEMM input moves a logit by ~2^-8 of its size; the same bound test_bf16_mode_tracks_bf16_oracle uses
+def _bf16_noise_margin(golden_dir, case):
+    """Top-2 logit margin below which a bf16 decode may legitimately take the other token: 1.5 x the largest change of the top-1 -
+    top-2 difference the bf16-emulating oracle shows against ITSELF under a 1e-6 input perturbation along the same 1 023 forced
+    positions (tests/golden/t5_forced.npz `self_noise_margin`, generator committed; 0.82 / 0.46 for the two cases) — a measured
+    floor (the device's own errors sit on it: test_every_position_of_the_headline_sequence_forced), replacing round 3's reasoned 0.5."""
+    return 1.5 * float(np.load(golden_dir / "t5_forced.npz")[f"{case}/self_noise_margin"][0])
 
 
-def _bf16_divergence(ids, want, margins, label):
+def _bf16_divergence(ids, want, margins, label, BF16_NOISE_MARGIN):
     """First position per row where the device's bf16 ids leave the bf16-emulating oracle's; fails on a divergence at a margin
     the emulation calls comfortable."""
     rows = []
@@ -244,7 +248,7 @@ def test_bf16_mode_follows_the_bf16_emulating_oracle_at_headline_size(golden_dir
     ids = model.generate_from_embeds(x, max_length=1024).cpu().numpy()
     want = z["full_s864_bf16/ids"].astype(np.int64)
     assert ids.shape == want.shape == (2, 1024)
-    rows = _bf16_divergence(ids, want, z["full_s864_bf16/margins"], "full_s864_bf16")
+    rows = _bf16_divergence(ids, want, z["full_s864_bf16/margins"], "full_s864_bf16", _bf16_noise_margin(golden_dir, "full_s864_bf16"))
     assert all(t < 0 or t >= 4 for _, t, _ in rows)                       # no row parts from the oracle right away
     # the same on waveforms: clips 0 and 1 of bench.py's workload, plain seed-0 weights (no layer-norm perturbation)
     from music2midi_amd.checkpoint import load_t5_state
@@ -259,7 +263,7 @@ def test_bf16_mode_follows_the_bf16_emulating_oracle_at_headline_size(golden_dir
         got = m.generate(ModelInputs(input_waveform=wav, cond_index=idx), max_length=1024).cpu().numpy()
         want = z[f"{key}/ids"].astype(np.int64)
         if precision == "bf16":
-            _bf16_divergence(got, want, z[f"{key}/margins"], key)
+            _bf16_divergence(got, want, z[f"{key}/margins"], key, _bf16_noise_margin(golden_dir, "bench_clips_bf16"))
         else:
             # fp32 mode on oracle log-mel vs device log-mel inputs (<= 1e-4 apart): ids equal unless a margin is at that scale
             d = np.argwhere(got != want)
@@ -270,3 +274,28 @@ def test_bf16_mode_follows_the_bf16_emulating_oracle_at_headline_size(golden_dir
                 assert mg < 5e-3, (b, t, mg)
             else:
                 print(f"[{key}] fp32 ids identical to the fp32 oracle on bench clips 0-1 (1024 tokens)")
+
+
+@pytest.mark.parametrize("mode", ["step", "batched"])
+@pytest.mark.parametrize("case,precision", [("full_s864_bf16", "bf16"), ("bench_clips_bf16", "bf16"),
+                                            ("full_s864_fp32", "fp32"), ("bench_clips_fp32", "fp32")])
+def test_every_position_of_the_headline_sequence_forced(golden_dir, case, precision, mode):
+    """the pin of a precision mode along ALL 1 023 positions of the S = 864 sequence, not only up to the first greedy
+    divergence.  The oracle's own ids (fp32 oracle pinned to HF; bf16 = the same code rounding where the device stores bfloat16) are
+    fed to the device in forced mode through the KV-cached decode kernels ("step": 1 023 decode steps on a 32-clip batch = the
+    benchmark's batch, 16 tiled copies of the fixture's two clips, every copy bit-identical) and through the batched teacher-forced
+    pass.  At every position: device arg-max == oracle id wherever the oracle's top-2 margin exceeds 2 x the logit error bound, and
+    |device logit - oracle logit| <= the bound on the fixture's samples (tests/forced_check.py); the measured errors are printed."""
+    from forced_check import case_inputs, forced_check
+    from music2midi_amd.checkpoint import load_t5_state
+    from music2midi_amd.transformer import T5Transformer
+    g = T5Geometry(DEFAULT_CONFIG["model"]["t5"])
+    sd, x = case_inputs(case, g, "cuda")
+    m = T5Transformer(DEFAULT_CONFIG, precision=precision)
+    load_t5_state(m, sd, strict=False)
+    m = m.cuda().eval()
+    rec = forced_check(m, x, case, precision, copies=16 if mode == "step" else 2, mode=mode, z=np.load(golden_dir / "t5_forced.npz"))
+    print(f"[forced {case} {mode}] {rec}")
+    assert rec["positions"] == 2 * 1023
+    # the check must actually bite: the great majority of positions are asserted by arg-max, not waved through
+    assert rec["argmax_asserted_positions"] >= 0.8 * rec["positions"]

@@ -134,3 +134,30 @@ def test_bf16_emulating_oracle_reproduces_its_headline_fixture_prefix(golden_dir
     assert np.abs(margins.numpy() - z["full_s864_bf16/margins"][:, :23]).max() < 1e-3
     assert z["bench_clips_bf16/ids"].shape == z["bench_clips_fp32/ids"].shape == (2, 1024)
     assert (z["bench_clips_bf16/ids"][:, 0] == 1).all() and z["bench_clips_bf16/margins"].min() > 0
+
+
+def test_forced_fixture_is_what_the_oracle_computes(golden_dir):
+    """tests/golden/t5_forced.npz (every position of the headline sequence, both precision modes): structure, consistency with the
+    older fixtures (same ids: t5.npz is HF's own output, t5_bf16.npz the emulation's), and the first 8 steps regenerated — top-4
+    logits and the full step-0 logits — for the bf16 emulation (`make_golden.py t5_forced` regenerates all of it in ~1 min)."""
+    z, zb, z32 = (np.load(golden_dir / f) for f in ("t5_forced.npz", "t5_bf16.npz", "t5.npz"))
+    for case in ("full_s864_fp32", "full_s864_bf16", "bench_clips_fp32", "bench_clips_bf16"):
+        assert z[f"{case}/ids"].shape == (2, 1024) and z[f"{case}/margins"].shape == (2, 1023)
+        assert z[f"{case}/top_vals"].shape == (2, 1023, 4) and z[f"{case}/top_idx"].shape == (2, 1023, 4)
+        n = len(z[f"{case}/full_steps"])
+        assert z[f"{case}/full_logits"].shape == (2, n, 400) and z[f"{case}/full_steps"][0] == 0 and z[f"{case}/full_steps"][-1] == 1022
+        tv = z[f"{case}/top_vals"]
+        nxt, am = z[f"{case}/ids"][:, 1:], z[f"{case}/top_idx"][:, :, 0]
+        live = np.cumsum(np.concatenate([np.zeros((2, 1), bool), nxt[:, :-1] == 2], axis=1), axis=1) == 0    # up to and including a row's EOS
+        assert np.array_equal(am[live], nxt[live]) and (nxt[~live] == 0).all()     # greedy: the top column IS the next id; pad after EOS
+        assert np.allclose(tv[:, :, 0] - tv[:, :, 1], z[f"{case}/margins"], atol=1e-5) and (np.diff(tv, axis=2) <= 0).all()
+    assert np.array_equal(z["full_s864_fp32/ids"], z32["full_s864/ids"]) and np.array_equal(z["full_s864_bf16/ids"], zb["full_s864_bf16/ids"])
+    assert np.array_equal(z["bench_clips_fp32/ids"], zb["bench_clips_fp32/ids"]) and np.array_equal(z["bench_clips_bf16/ids"], zb["bench_clips_bf16/ids"])
+    geom = T5Geometry(DEFAULT_CONFIG["model"]["t5"])
+    sd = synth.t5_state_dict(geom, seed=0)
+    synth.perturb_layer_norms(sd, 0)
+    got = []
+    T5Oracle(geom, sd, emulate="bf16").generate(embeds(2, 864, geom.d_model), 9, logits_hook=lambda t, lg: got.append(lg.clone()))
+    got = torch.stack(got, 1).numpy()
+    assert np.abs(np.take_along_axis(got, z["full_s864_bf16/top_idx"][:, :8].astype(np.int64), 2) - z["full_s864_bf16/top_vals"][:, :8]).max() < 1e-3
+    assert np.abs(got[:, 0] - z["full_s864_bf16/full_logits"][:, 0]).max() < 1e-3
