@@ -364,15 +364,16 @@ def dry_run(args):
 
 def dry_run_train(args, rank: int, world: int) -> int:
     """--mode train --dry-run: the data-parallel plumbing of a training step on CPU tensors over gloo — the flat-gradient
-    average in one piece and in the overlapped form's four pieces (real early ranges of the model's layout, derived from the
-    module tree as the trainer lays it out), the sync_dist metric reduction, barrier + max-over-ranks timing — no GPU work."""
+    average in one piece and in the overlapped form's four pieces (two early ranges of the real SIZES — shared embedding + lm_head,
+    the decoder blocks — at stand-in offsets: the native trainer's own layout needs the GPU library; what is exercised here is
+    the splitting, the averaging and the byte count), the sync_dist metric reduction, barrier + max-over-ranks timing — no GPU work."""
     from music2midi_amd import distributed as D
     from music2midi_amd.config import default_config
     from music2midi_amd.transformer import T5Transformer
     cfg = default_config()
     model = T5Transformer(cfg.to_dict(), precision="fp32")
     n = sum(p.numel() for p in model.parameters())
-    # early ranges as the native trainer reports them: [shared + lm_head] in front, the decoder blocks as one block
+    # early ranges of the native trainer's sizes ([shared + lm_head] in front, the decoder blocks as one block further back)
     n_front = model.transformer.shared.weight.numel() + model.transformer.lm_head.weight.numel()
     n_dec = sum(p.numel() for p in model.transformer.decoder.block.parameters())
     early = [(0, n_front), (n - n_dec - 4096, n_dec)]

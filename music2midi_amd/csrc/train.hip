@@ -3340,6 +3340,11 @@ extern "C" int m2m_trainer_create(const m2m_t5_geometry* geom, int n_cond, const
   M2M_REQUIRE(geom->d_kv == DK, "m2m_trainer_create: d_kv=%d unsupported (64 only)", geom->d_kv);
   M2M_REQUIRE(geom->d_model % 64 == 0 && geom->d_model <= 512 && geom->d_ff % 8 == 0, "m2m_trainer_create: d_model must be a multiple of 64 (<= 512), d_ff of 8");
   M2M_REQUIRE(n_cond >= 0 && n_cond <= 8 && max_batch >= 1 && max_enc_len > n_cond && max_dec_len >= 1, "m2m_trainer_create: bad sizes");
+  // embed_bwd_kernel keeps the pass's whole id list in LDS (embed_bwd_smem: 4 bytes per label position + 4 KiB against the 158 KiB opt-in)
+  M2M_REQUIRE(embed_bwd_smem(max_batch * max_dec_len) <= (size_t)158 * 1024,
+              "m2m_trainer_create: max_batch * max_dec_len = %d label positions per pass exceed the %d the shared-embedding gradient kernel "
+              "lists in LDS; use a smaller dataloader batch or shorter label sequences (the reference trains 16 x <= ~360)",
+              max_batch * max_dec_len, (int)((158 * 1024 - 4 * 256 * 4) / 4));
   m2m_trainer* t = new m2m_trainer();
   t->g = *geom; t->precision = precision; t->inner = geom->num_heads * geom->d_kv; t->n_cond = n_cond;
   t->es = precision == M2M_PREC_BF16 ? 2 : 4;

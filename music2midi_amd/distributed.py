@@ -208,6 +208,13 @@ def reduce_logged(metrics: Dict[str, object], device=None) -> Dict[str, float]:
     return {k: (v if k == "batch_size" else v / world) for k, v in zip(names, out)}
 
 
+def is_rank_zero() -> bool:
+    """Global rank 0 of the process group (True in a single process): the rank that writes checkpoints, as in Lightning."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank() == 0
+    return env_world()[0] == 0 or env_world()[2] == 1
+
+
 def barrier() -> None:
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

@@ -9,6 +9,7 @@ sequential token decode follow the reference line by line in behaviour.
 """
 from __future__ import annotations
 
+import os
 from pathlib import Path
 from typing import Optional, Union
 
@@ -132,17 +133,28 @@ class Music2MIDI(nn.Module):
         """A Lightning-layout ``.ckpt`` of the run: ``state_dict`` (``model.*`` keys incl. the torchaudio buffers), the optimizer
         state as ``transformers.optimization.Adafactor.state_dict()`` lays it out (``optimizer_states[0]``), ``global_step``,
         ``hyper_parameters`` — what ``load_from_checkpoint`` and ``fit_batches(ckpt_path=)`` (and the reference's own
-        ``trainer.fit(ckpt_path=)``) read."""
-        tr = self._trainer
-        opt = tr.optimizer_state_hf() if tr is not None else {"state": {}, "param_groups": []}
-        torch.cuda.synchronize(self.device) if self.device.type == "cuda" else None
-        torch.save({
-            "epoch": int(getattr(self, "current_epoch", 0)), "global_step": int(self.global_step), "pytorch-lightning_version": "2.1.0",
-            "state_dict": {k: v.detach().cpu().clone() for k, v in self.state_dict().items()},
-            "callbacks": {}, "optimizer_states": [opt],
-            "lr_schedulers": [{"base_lrs": [0.0], "last_epoch": int(self.global_step), "_step_count": int(self.global_step) + 1}],
-            "hparams_name": "kwargs", "hyper_parameters": dict(self.hparams),
-        }, path)
+        ``trainer.fit(ckpt_path=)``) read.  Under data parallelism only global rank 0 writes (as Lightning does), into a temporary
+        file that is renamed over ``path`` once complete — a reader never sees a torn file — and every rank leaves through a
+        barrier, so a ``resume_from_checkpoint`` that follows on any rank reads the finished file."""
+        if D.is_rank_zero():
+            tr = self._trainer
+            opt = tr.optimizer_state_hf() if tr is not None else {"state": {}, "param_groups": []}     # reads the device: rank 0 only
+            torch.cuda.synchronize(self.device) if self.device.type == "cuda" else None
+            path = Path(path)
+            tmp = path.with_name(f".{path.name}.tmp{os.getpid()}")
+            try:
+                torch.save({
+                    "epoch": int(getattr(self, "current_epoch", 0)), "global_step": int(self.global_step), "pytorch-lightning_version": "2.1.0",
+                    "state_dict": {k: v.detach().cpu().clone() for k, v in self.state_dict().items()},
+                    "callbacks": {}, "optimizer_states": [opt],
+                    "lr_schedulers": [{"base_lrs": [0.0], "last_epoch": int(self.global_step), "_step_count": int(self.global_step) + 1}],
+                    "hparams_name": "kwargs", "hyper_parameters": dict(self.hparams),
+                }, tmp)
+                os.replace(tmp, path)
+            finally:
+                if tmp.exists():
+                    tmp.unlink()
+        D.barrier()
 
     def resume_from_checkpoint(self, path) -> None:
         """Weights, Adafactor state and step counter of a ``.ckpt`` written by ``save_checkpoint`` or by Lightning."""
@@ -182,7 +194,7 @@ class Music2MIDI(nn.Module):
             optimizer = self.configure_optimizers()[0][0]
         log_every = max(1, int(self.config.trainer.log_every_n_steps))
         self.log_history = getattr(self, "log_history", [])
-        losses = []
+        losses, pending = [], []          # host floats so far / device scalars of the steps since the last read
         for i, batch in enumerate(batches):
             loss = self.training_step(batch, i)
             tr = self._trainer
@@ -192,14 +204,20 @@ class Music2MIDI(nn.Module):
                 D.all_reduce_gradients(tr.grads)
             optimizer.step()
             self.global_step += 1
-            losses.append(loss)
+            pending.append(loss)
             if self.global_step % log_every == 0:
                 self.log_history.append(dict(self.logged_metrics(), step=self.global_step))
+                # logged_metrics() has just waited for this step: move the window's losses to the host here, so that a long run
+                # (119 200 steps in the reference's) holds at most log_every device scalars, not one per step
+                losses.extend(float(v) for v in torch.stack(pending).cpu())
+                pending = []
             if save_path is not None and save_every_n_steps and self.global_step % save_every_n_steps == 0:
                 self.save_checkpoint(save_path)
         if save_path is not None:
             self.save_checkpoint(save_path)
-        return [float(v) for v in torch.stack(losses).cpu()] if losses else []
+        if pending:
+            losses.extend(float(v) for v in torch.stack(pending).cpu())
+        return losses
 
     def validation_step(self, inputs: ModelInputs, batch_idx):
         """ref model.py:45-54: teacher-forced loss + chroma score of a greedy decode; returns the LOSS (as the

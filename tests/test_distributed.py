@@ -197,3 +197,46 @@ def test_gloo_world2_logged_metrics_are_averaged_like_sync_dist():
         assert p.exitcode == 0
     assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]
     assert D.reduce_logged({"val/loss": torch.tensor(3.0), "batch_size": 4}) == {"val/loss": 3.0, "batch_size": 4}      # single process
+
+
+def _ckpt_worker(rank, world, port, path, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import copy
+    from pathlib import Path
+    from music2midi_amd.checkpoint import read_checkpoint
+    from music2midi_amd.config import DEFAULT_CONFIG
+    from music2midi_amd.model import Music2MIDI
+    D.init_process_group("gloo")
+    cfg = copy.deepcopy(DEFAULT_CONFIG)
+    cfg["model"]["t5"].update(d_model=128, d_ff=256, num_layers=1, num_decoder_layers=1, num_heads=2)
+    torch.manual_seed(7 + rank)                      # the ranks hold DIFFERENT weights: whose file it is shows in the content
+    m = Music2MIDI(cfg)
+    m.global_step = 11 + rank
+    assert D.is_rank_zero() == (rank == 0)
+    for _ in range(3):                               # rewritten in place, as save_every_n_steps does
+        m.save_checkpoint(path)
+        ck = read_checkpoint(path)                   # every rank, right after the call: the barrier makes the finished file visible
+        assert int(ck["global_step"]) == 11
+        w = ck["state_dict"]["model.transformer.lm_head.weight"]
+        torch.manual_seed(7)
+        assert torch.equal(torch.as_tensor(w), Music2MIDI(cfg).model.transformer.lm_head.weight.detach())
+    D.barrier()
+    assert [p.name for p in Path(path).parent.iterdir()] == [Path(path).name]        # no temporary file left behind
+    dist.destroy_process_group()
+    q.put(rank)
+
+
+def test_gloo_world2_checkpoint_is_written_by_rank_zero_only(tmp_path):
+    """fit_batches(save_path=) called save_checkpoint on every data-parallel rank onto one path.  Now rank 0
+    writes (temporary file + rename), every rank leaves through a barrier; Lightning writes on global rank 0 only (ref train.py:40-41)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    path = str(tmp_path / "run.ckpt")
+    procs = [ctx.Process(target=_ckpt_worker, args=(r, 2, port, path, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]

@@ -305,8 +305,13 @@ def test_fp8_mode_matches_the_mx_emulating_oracle(cfg_name, B, F, Ld, parts, mon
     assert abs(loss.item() - loss_o.item()) < 1e-2 * abs(loss_o.item())
     assert abs(loss.item() - loss_plain.item()) < 3e-2 * abs(loss_plain.item())
     assert cmed > fmed - 0.015 and cmin > fmin - 0.03      # (the minimum over the tensors is itself a noisy draw: wider)
-    if cfg_name == "full_1layer":
-        assert cmin > 0.98 and cmed > 0.99
+    # ABSOLUTE floors beside the relative bar: a regression that makes device AND emulation noisier, or an emulation
+    # that follows a device bug, must not pass on the relative bar alone.  Against the MX emulation (measured 0.981 / 0.987 tiny,
+    # 0.995 / 0.997 one layer, 0.946-0.950 / 0.958-0.960 full) and — the independent check, an oracle with no device-mirroring
+    # flags at all — against plain fp32 autograd (measured min / median 0.953 / 0.968, 0.972 / 0.982, 0.915 / 0.931).
+    abs_floor = {"tiny": (0.97, 0.98, 0.94, 0.955), "full_1layer": (0.98, 0.99, 0.96, 0.97), "full": (0.93, 0.95, 0.90, 0.92)}[cfg_name]
+    assert cmin > abs_floor[0] and cmed > abs_floor[1], (cmin, cmed, abs_floor)
+    assert pmin > abs_floor[2] and pmed > abs_floor[3], (pmin, pmed, abs_floor)
     if cfg_name == "tiny":                            # and it trains (Adafactor's warm-up steps are ~1e-6: the first few do not
         loss0 = loss.item()                           # move an FP8-quantised weight at all, so give it a while); NB `loss` is
         for _ in range(150):                          # the trainer's own device scalar, overwritten by every call
@@ -616,3 +621,16 @@ def test_whole_head_attention_step_against_autograd_and_the_stripe_path(cfg_name
     assert wh < 1.3 * wst + 1e-2                                 # no further from autograd than the stored-probability path is
     assert med < 4e-2 and worst < 8e-2
     tr_head.close(); tr_stripe.close()
+
+
+def test_trainer_rejects_more_label_positions_than_the_embedding_gradient_lists():
+    """embed_bwd_kernel keeps the pass's id list in LDS (4 B per label position + 4 KiB, 158 KiB opt-in); a trainer
+    sized beyond that failed at its first launch with a generic HIP error.  Now m2m_trainer_create says so (64 x 640 labels), and
+    the size just inside the limit is accepted."""
+    from music2midi_amd import native
+    from music2midi_amd.training import NativeTrainer
+    cfg = tiny_config()
+    model = T5Transformer(cfg, precision="fp32").cuda()
+    with pytest.raises(native.NativeError, match="label positions per pass"):
+        NativeTrainer(model, 64, 23, 640, precision="bf16")
+    NativeTrainer(model, 64, 23, 608, precision="bf16").close()          # 38 912 positions <= 39 424

@@ -67,9 +67,14 @@ for i, r in enumerate(u):
         if not np.isfinite(e) or not bool(torch.isfinite(g).all()): e = float("inf")
         elif prec == "fp8" and Ld <= 2 and name.endswith("decoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"):
             # two label positions: this tensor is ONE softmax row's dS (norm 8e-2 against 1e1-1e2 elsewhere) and the MX-emulating oracle
-            # moves it by 2.2x its own norm under a 1e-4 input perturbation (seed 2, case 16: measured on the host) — no bar between two
-            # evaluations that are not bit-identical means anything there; finiteness is still required
-            e = 0.0
+            # moves it by 2.2x its own norm under a 1e-4 input perturbation (seed 2, case 16: measured on the host) — a bar relative to
+            # its OWN norm means nothing there.  It is still held on the scale of its neighbour: the absolute error against the norm of
+            # the same sub-layer's q-weight gradient (a wrong diagonal sum in the whole-head backward is of that order, not 1e-2 of it).
+            qn = float(grads_o[name.replace("relative_attention_bias.weight", "q.weight")].norm())
+            e_abs = float((g - grads_o[name]).norm()) / (qn + 1e-12)
+            print(f"    [carve-out] case {i}: fp8, Ld={Ld}: {name.split('.')[-2]} held to |err| / |dW_q| = {e_abs:.2e} (< 0.05) instead of its own norm "
+                  f"(|ref| {float(grads_o[name].norm()):.2e}, own-norm error {e:.2e})", flush=True)
+            e = 0.0 if e_abs < 0.05 else float("inf")
         if e > worst: worst, wname = e, name
         per.append((e, name, float(grads_o[name].norm())))
     ltol, gtol = {"fp32": (1e-4, 1e-4), "bf16": (1e-2, 0.12), "fp8": (5e-2, 0.6)}[prec]   # fp8: one or two labels on a d_model=128 random model flip fp8 codes; the bound catches NaNs and wrong terms, test_train_gpu holds the tight cosine
