@@ -316,6 +316,93 @@ def forced_parity_record(cfg, geom, dev, model_bf16, model_fp32, x_bench2) -> di
     return out
 
 
+def ragged_eos_record(cfg, geom, dev, B: int, S: int, eos_scale: float = 1.6, reps: int = 3) -> dict:
+    """Rows that END: real checkpoints finish a segment after tens to hundreds of tokens of the 1 024 budget, the synthetic headline
+    workload never emits EOS.  Weights crafted with synth.force_eos_head so that the rows of a batch stop at different steps;
+    timed with the finished-row early-out of the decode attention kernels on (default) and off (M2M_FINISHED_SKIP=0: a finished
+    row keeps streaming its K/V until the whole chain is done, as HF does and as rounds 1-3 did).  The ids must be identical.
+    `useful` tokens = tokens up to and including each row's EOS (or the budget).  Inputs are synthetic encoder embeddings
+    (N(0, 3^2), as the parity tests use): on white-noise waveforms the crafted head never wins, every row runs to the budget
+    (tools/eos_scale_probe.py); the record is about the decode loop, the frontend is not part of it."""
+    from music2midi_amd import synth
+    from music2midi_amd.checkpoint import load_t5_state
+    from music2midi_amd.input import ModelInputs
+    from music2midi_amd.transformer import T5Transformer
+    sd = synth.t5_state_dict(geom, seed=0)
+    synth.perturb_layer_norms(sd, 0)
+    synth.force_eos_head(sd, geom, active=340, eos_scale=eos_scale)
+    x = torch.from_numpy(synth.normal(21, "embeds", (B, S, geom.d_model), 3.0)).to(dev)
+    out, ids = {}, {}
+    old = os.environ.get("M2M_FINISHED_SKIP")
+    try:
+        for leg, env in (("skip_on", None), ("skip_off", "0")):
+            if env is None:
+                os.environ.pop("M2M_FINISHED_SKIP", None)
+            else:
+                os.environ["M2M_FINISHED_SKIP"] = env
+            m = T5Transformer(cfg.to_dict(), precision="bf16")        # a session of its own: the flag is baked into its captured graphs
+            load_t5_state(m, sd, strict=False)
+            m = m.to(dev).eval()
+            ids[leg] = m.generate_from_embeds(x, max_length=MAX_LENGTH)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                m.generate_from_embeds(x, max_length=MAX_LENGTH)
+            torch.cuda.synchronize(dev)
+            out[leg] = (time.perf_counter() - t0) / reps
+            del m
+    finally:
+        if old is None:
+            os.environ.pop("M2M_FINISHED_SKIP", None)
+        else:
+            os.environ["M2M_FINISHED_SKIP"] = old
+    a = ids["skip_on"].cpu().numpy()
+    L = a.shape[1]
+    ends = []
+    for r in range(B):
+        e = np.nonzero(a[r] == geom.eos_token_id)[0]
+        ends.append(int(e[0]) if len(e) else L - 1)
+    useful = int(sum(ends))
+    qs = sorted(ends)
+    return {"workload": f"{B} clips, encoder length S={S} (synthetic embeddings), bf16, max_length {MAX_LENGTH}, lm_head crafted (force_eos_head active=340, "
+                        f"eos_scale={eos_scale}) so rows end at different steps; encoder + greedy decode",
+            "eos_position_quartiles": [qs[int(q * (B - 1))] for q in (0, 0.25, 0.5, 0.75, 1.0)],
+            "rows_with_eos": int(sum(1 for r in range(B) if (a[r] == geom.eos_token_id).any())), "output_length": int(L),
+            "eos_position_min_median_max": [int(min(ends)), int(np.median(ends)), int(max(ends))], "useful_tokens": useful,
+            "decoded_positions": int(B * (L - 1)),
+            "ids_identical_with_and_without_skip": bool(torch.equal(ids["skip_on"], ids["skip_off"])),
+            "ms_per_batch_skip_on": out["skip_on"] * 1e3, "ms_per_batch_skip_off": out["skip_off"] * 1e3,
+            "useful_tokens_per_s_skip_on": useful / out["skip_on"], "useful_tokens_per_s_skip_off": useful / out["skip_off"],
+            "speedup": out["skip_off"] / out["skip_on"]}
+
+
+def reference_native_record(model, cfg, geom, dev, reps: int = 3) -> dict:
+    """The reference's own inference geometry (ref config.yaml:16,46-47, model.py:115-134): one `inference.batch_size` = 128 chunk of
+    3 s segments at 16 kHz (48 000 samples -> S = 190), max_length 1024, bf16, same random-init weights (no EOS: 1 023 tokens per row)."""
+    from music2midi_amd import synth
+    from music2midi_amd.input import ModelInputs
+    Bn, Tn = int(cfg.inference.batch_size), int(cfg.model.sample_rate * cfg.dataset.segment_duration)
+    Sn = 1 + Tn // 256 + 2
+    wav = torch.from_numpy(synth.waveform_batch(1000, Bn, Tn)).to(dev)
+    cond = torch.from_numpy(synth.cond_index_batch(1000, Bn)).to(dev)
+    inputs = ModelInputs(input_waveform=wav, cond_index=cond)
+    toks = model.generate(inputs, max_length=MAX_LENGTH)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        toks = model.generate(inputs, max_length=MAX_LENGTH)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / reps
+    n_steps = toks.shape[1] - 1
+    step_bytes = decode_bytes_per_step(Bn, Sn, (1 + n_steps) / 2.0, 2)
+    step_us = dt / n_steps * 1e6              # encoder + frontend included (an upper bound on the step: they are ~1 % of the batch)
+    return {"workload": f"reference-native geometry: {Bn} segments x {Tn} samples (3 s @ 16 kHz, S={Sn}), bf16, max_length {MAX_LENGTH}",
+            "tokens_per_s": Bn * n_steps / dt, "ms_per_batch": dt * 1e3, "new_tokens_per_clip": int(n_steps),
+            "step_algorithmic_bytes": step_bytes, "step_mean_us": step_us, "step_achieved_GBs": step_bytes / (step_us * 1e-6) / 1e9,
+            "step_frac": step_bytes / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "note": "step bytes = decoder weights 30.4 MB + 128 clips x 12 288 B x (190 + mean t) (SURVEY 8d formula at this geometry)"}
+
+
 def decode_bytes_per_step(B: int, S: int, t_mean: float, esize: int) -> float:
     """Algorithmic HBM bytes of one decode step: the decoder weights once for the whole
     batch + per clip the cross K/V (6 layers x 2 x 512 x S) and the self K/V cache up to position t."""
@@ -570,6 +657,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the fp32 parity-mode record")
     ap.add_argument("--no-frontend", action="store_true", help="skip the configs[1] frontend record")
+    ap.add_argument("--no-native", action="store_true", help="skip the reference-native-geometry and ragged-EOS records")
     ap.add_argument("--mode", default="generate", choices=["generate", "train"],
                     help="train: BASELINE configs[4] (forward+backward+Adafactor, 16 clips/GPU, gradient all-reduce over RCCL)")
     ap.add_argument("--no-train", action="store_true", help="skip the configs[4] training-step record of the default line")
@@ -756,6 +844,13 @@ def main():
             rec["gpu_over_cpu"] = rec["cpu_torch_stft"]["ms_per_batch"] * 1e3 / us
         out["frontend_configs1"] = rec
         del wav64, buf
+
+    # ---- the reference's own geometry (128 x 3 s segments) and a batch whose rows END (finished-row early-out) ----
+    if rank == 0 and world == 1 and not args.no_native and args.precision == "bf16":
+        out["reference_native"] = reference_native_record(model, cfg, geom, dev)
+        out["ragged_eos"] = ragged_eos_record(cfg, geom, dev, B, S)
+        out["ragged_eos_native"] = ragged_eos_record(cfg, geom, dev, int(cfg.inference.batch_size),
+                                                     1 + int(cfg.model.sample_rate * cfg.dataset.segment_duration) // 256 + 2)
 
     # ---- parity mode: fp32 (bit-exact against the fp32 reference) on the same workload ----
     if rank == 0 and world == 1 and not args.no_parity and args.precision == "bf16":

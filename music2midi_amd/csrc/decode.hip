@@ -552,6 +552,12 @@ struct DecAttnArgs {
   int64_t* tokens;             // [B, max_len]
   int max_len, V, pad_id, eos_id;
   int book;                    // cross: head 0's workgroup of every row does the row's bookkeeping at its end
+  // Finished-row early-out (greedy loop): fin_skip[b * fin_stride] != 0 -> row b has emitted EOS; its tokens are pad whatever
+  // is computed (hf generation/utils.py:2929), so its workgroups stop re-requesting K/V after the entry prefetch.  Never null:
+  // "never skip" is a pointer to DecState::zero with stride 0 (an unconditional scalar load: a branch around it would split
+  // the prologue's block of loads, see the kernel).
+  const int* fin_skip;
+  int fin_stride;
 };
 
 // K/V rows are read once per step.  When the per-step K/V working set is larger than the 256 MB
@@ -650,6 +656,10 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = blockIdx.x, b = blockIdx.y;   // grid (H, B): linear id = 8 b + h as before (a head's clips on one XCD), no division
+  // finished-row flag (scalar, requested with the loop state; first consumed after the prologue).  In the layer-0 cross kernel
+  // head 0 of the row WRITES the flag at its end while its siblings may still be starting: they can disagree at the one step in
+  // which the row finishes — harmless, that step's output is the first one forced to pad.
+  const int row_fin = a.fin_skip[(int64_t)b * a.fin_stride];
   const int sub = lane % LPR;
   const int kslot = wave * KPW + lane / LPR;
   T* Kb = reinterpret_cast<T*>(a.Kc) + ((int64_t)b * a.H + hh) * a.kv_stride * DK;
@@ -811,6 +821,10 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
 
   // ---- 3. single-pass attention: each group of LPR lanes walks its keys with a running
   //         (max, sum, weighted-V) triple; no workgroup-wide step until the end ----
+  // A finished row walks NO cached keys: the two rounds requested at entry are dropped, nothing is re-requested (32 KB instead
+  // of the whole stream for this workgroup); the self kernel still appends and visits this step's own key, the cross kernel's
+  // empty softmax gives a zero head output below.  Nothing of a finished row is observable: its tokens are pad.
+  const int n_live = row_fin ? 0 : n_prev;
   float qv[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) qv[e] = qs[sub * E + e];
@@ -844,25 +858,25 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
     float vrow[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) vrow[e] = vs.get(e);
-    if (reissue == 1 || (reissue == 2 && k0 + (u + PF) * KPB < n_prev)) {   // workgroup-uniform, no lane is predicated
+    if (reissue == 1 || (reissue == 2 && k0 + (u + PF) * KPB < n_live)) {   // workgroup-uniform, no lane is predicated
       const int64_t off = (int64_t)min(key + PF * KPB, last) * DK + sub * E;
       ks.v = M2M_KV_LOAD(reinterpret_cast<const V16*>(Kb + off));
       vs.v = M2M_KV_LOAD(reinterpret_cast<const V16*>(Vb + off));
     }
-    if (key < n_prev) {   // VALU-only predicate
+    if (key < n_live) {   // VALU-only predicate
       if (SELF) s += biasl[t - key];
       visit(s, vrow);
     }
   };
   int k0 = 0;
   // main loop: all PF re-requests of the iteration exist (the last one targets round k0 / KPB + 2 PF - 1)
-  for (; k0 + (2 * PF - 1) * KPB < n_prev; k0 += PF * KPB) {
+  for (; k0 + (2 * PF - 1) * KPB < n_live; k0 += PF * KPB) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) round(k0, u, kv[u], vv[u], 1);
   }
   // tail (at most two iterations): past the end nothing is requested, so the merge barrier below does
   // not wait for a useless round trip
-  for (; k0 < n_prev; k0 += PF * KPB) {
+  for (; k0 < n_live; k0 += PF * KPB) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) round(k0, u, kv[u], vv[u], 2);
   }
@@ -949,7 +963,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
         s += redo[wv][tid];
         L += redlf[wv];
       }
-      put_in<T>(oh, tid, s / L);                 // the projection input is rounded to T, as every GEMM input
+      put_in<T>(oh, tid, L > 0.f ? s / L : 0.f);     // the projection input is rounded to T, as every GEMM input (L = 0: a finished row's empty cross softmax)
     }
     __syncthreads();
     M2M_STAMP(6 + (SELF ? 1 : 0), 7);
@@ -1213,7 +1227,13 @@ static xq_t* xbuf(m2m_session* s, const DecView& v, int which) {
   return reinterpret_cast<xq_t*>(s->x_dec) + (size_t)which * stride + (size_t)v.b0 * s->m->g.d_model;
 }
 
-int decode_launch_attn(m2m_session* s, const DecView& v, bool self, int layer, int self_len, hipStream_t st, bool headless) {
+// M2M_FINISHED_SKIP=0: finished rows keep streaming their K/V (the behaviour before round 4; bench.py's ragged_eos "before" leg)
+bool decode_finished_skip_on() {
+  const char* v = getenv("M2M_FINISHED_SKIP");      // read per launch (graphs bake it at capture: the bench re-creates the session)
+  return !(v && v[0] == '0');
+}
+
+int decode_launch_attn(m2m_session* s, const DecView& v, bool self, int layer, int self_len, hipStream_t st, bool headless, bool skip_finished) {
   const m2m_model* m = s->m;
   const m2m_t5_geometry& g = m->g;
   const size_t es = m->esize;
@@ -1236,6 +1256,8 @@ int decode_launch_attn(m2m_session* s, const DecView& v, bool self, int layer, i
   a.x = xbuf(s, v, self ? 0 : 1); a.x_out = xbuf(s, v, self ? 1 : 2); a.x_zero = xbuf(s, v, self ? 2 : 0);
   a.eps = g.layer_norm_eps; a.d = g.d_model;
   a.H = H; a.inner = m->inner; a.state = v.state;
+  if (skip_finished && decode_finished_skip_on()) { a.fin_skip = s->finished + v.b0; a.fin_stride = 1; }
+  else { a.fin_skip = &v.state->zero; a.fin_stride = 0; }
   if (headless && layer == 0) {            // the greedy loop without the head kernel: layer 0 takes over its work
     a.keys = s->keys + v.b0; a.finished = s->finished + v.b0; a.tokens = s->tokens + (int64_t)v.b0 * s->max_dec;
     a.max_len = s->max_dec; a.V = g.vocab_size; a.pad_id = g.pad_token_id; a.eos_id = g.eos_token_id;
@@ -1273,9 +1295,9 @@ int decode_launch_step(m2m_session* s, const DecView& v, bool forced, float* log
     const DecLayerPacked& L = m->dec[l];
     // 1. RMSNorm + per-head QKV projection + KV-cache append + causal self-attention + per-head
     //    output projection accumulated into the residual stream (one kernel)
-    if ((rc = decode_launch_attn(s, v, true, l, 0, st, headless))) return rc;
+    if ((rc = decode_launch_attn(s, v, true, l, 0, st, headless, !forced))) return rc;
     // 2. the same for cross-attention over the S encoder positions (query projection only)
-    if ((rc = decode_launch_attn(s, v, false, l, 0, st, headless))) return rc;
+    if ((rc = decode_launch_attn(s, v, false, l, 0, st, headless, !forced))) return rc;
     // 3. feed-forward sub-layer, one kernel: reads C (the stream after both attention sub-layers),
     //    accumulates C + FF(C) into A (zeroed by the cross-attention kernel) and leaves B zeroed for
     //    the next layer's self-attention

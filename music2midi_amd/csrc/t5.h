@@ -64,7 +64,7 @@ struct DecState {
   int overflow;      // sticky: a value outside the fixed-point residual range (|v| >= 2^21, Inf, NaN) was produced
   int t_copy;        // headless greedy loop: t of the current step, rewritten every step by the layer-0 cross kernel (the lm_head
                      // kernel, which ADVANCES t at its end, reads this stable copy instead of t itself)
-  int pad[1];
+  int zero;          // always 0 (cleared with the rest of the state, never written): what a "never skip" row flag points at
 };
 
 }  // namespace m2m
@@ -85,7 +85,7 @@ struct DecGroup {
   hipEvent_t ev_done = nullptr;
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
-  int graph_key[5] = {-1, -1, -1, -1, -1};   // B, S, b0, nb, steps per graph
+  int graph_key[6] = {-1, -1, -1, -1, -1, -1};   // B, S, b0, nb, steps per graph, finished-row skip on / off (baked into the launches)
 };
 }  // namespace m2m
 
@@ -191,7 +191,9 @@ int launch_fill_zero(void* dst, int64_t bytes, hipStream_t st);
 // decoder-side (decode.hip)
 int decode_init(m2m_session* s, const DecView& v, int max_steps, bool forced, hipStream_t st);
 int decode_launch_step(m2m_session* s, const DecView& v, bool forced, float* logits_out, int Ld, hipStream_t st);
-int decode_launch_attn(m2m_session* s, const DecView& v, bool self, int layer, int self_len, hipStream_t st, bool headless = false);
+bool decode_finished_skip_on();
+int decode_launch_attn(m2m_session* s, const DecView& v, bool self, int layer, int self_len, hipStream_t st, bool headless = false,
+                       bool skip_finished = false);
 int decode_finalize(m2m_session* s, const DecView& v, hipStream_t st);   // headless greedy loop: write the last token, close the chain
 bool decode_headless();
 

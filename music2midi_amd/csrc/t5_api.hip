@@ -367,7 +367,7 @@ static int plan_groups(m2m_session* s) {
 // One graph = `steps` consecutive decode steps of one chain (kernels read the step index from
 // device memory, so the same graph replays for every position; steps past the end are no-ops).
 static int ensure_graph(m2m_session* s, DecGroup& gr, int steps) {
-  const int key[5] = {s->B, s->S, gr.view.b0, gr.view.nb, steps};
+  const int key[6] = {s->B, s->S, gr.view.b0, gr.view.nb, steps, decode_finished_skip_on() ? 1 : 0};
   if (gr.graph_exec && memcmp(key, gr.graph_key, sizeof(key)) == 0) return M2M_OK;
   if (gr.graph_exec) { (void)hipGraphExecDestroy(gr.graph_exec); gr.graph_exec = nullptr; }
   if (gr.graph) { (void)hipGraphDestroy(gr.graph); gr.graph = nullptr; }

@@ -99,9 +99,9 @@ def case_inputs(case: str, geom, device):
     <= 1e-4, which the frontend tests pin on their own)."""
     from music2midi_amd import synth
     sd = synth.t5_state_dict(geom, seed=0)
-    if case.startswith("full_s864"):
+    if case.startswith("full_s864") or case.startswith("native_s190"):
         synth.perturb_layer_norms(sd, 0)
-        x = torch.from_numpy(synth.normal(7, "embeds", (2, 864, geom.d_model), 3.0))
+        x = torch.from_numpy(synth.normal(7, "embeds", (2, 864 if case.startswith("full_s864") else 190, geom.d_model), 3.0))
     else:
         from oracle.logmel import LogMelOracle, conditioning
         wav = torch.from_numpy(synth.waveform_batch(0, 2, 220500))

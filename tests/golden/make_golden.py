@@ -210,7 +210,8 @@ def make_t5_forced(out_path):
                 full.append(logits.clone())
 
         ids, margins = T5Oracle(geom, sd, emulate=emulate).generate(x, L, return_margins=True, logits_hook=hook)
-        assert ids.shape == (2, L) and np.array_equal(ids.numpy(), want_ids.astype(np.int64)), f"{name}: ids differ from the committed fixture"
+        assert ids.shape == (2, L) and (want_ids is None or np.array_equal(ids.numpy(), np.asarray(want_ids).astype(np.int64))), \
+            f"{name}: ids differ from the committed fixture / from HuggingFace"
         data[f"{name}/ids"] = ids.numpy().astype(np.int16)
         data[f"{name}/margins"] = margins.numpy().astype(np.float32)
         data[f"{name}/top_vals"] = torch.stack(top_v, 1).numpy().astype(np.float32)          # [2, 1023, 4]
@@ -252,6 +253,17 @@ def make_t5_forced(out_path):
     xw = conditioning(LogMelOracle(cfg["model"]["sample_rate"], sp["n_fft"], sp["hop_length"], sp["f_min"], geom.d_model)(wav), idx, emb)
     run("bench_clips_fp32", sd, xw, "fp32", zb["bench_clips_fp32/ids"])
     run("bench_clips_bf16", sd, xw, "bf16", zb["bench_clips_bf16/ids"])
+    # The reference's OWN inference geometry (ref config.yaml:16,46-47, model.py:115-134: 3 s segments at 16 kHz -> S = 190,
+    # max_length 1024): the two clips of the `full_s190` case, decoded to the full 1 024 tokens by HuggingFace itself here — the
+    # fp32 oracle's ids are asserted equal to HF's over all 1 024 — and the bf16 emulation beside it.
+    sd = synth.t5_state_dict(geom, seed=0)
+    synth.perturb_layer_norms(sd, 0)
+    x190 = embeds(2, 190, geom.d_model)
+    with torch.no_grad():
+        ids_hf = build_hf(dict(cfg["model"]["t5"]), sd).generate(inputs_embeds=x190, max_length=L, do_sample=False)
+    assert ids_hf.shape == (2, L) and np.array_equal(ids_hf[:, :128].numpy(), z32["full_s190/ids"].astype(np.int64))
+    run("native_s190_fp32", sd, x190, "fp32", ids_hf.numpy())
+    run("native_s190_bf16", sd, x190, "bf16", None)
     np.savez_compressed(out_path, **data)
 
 

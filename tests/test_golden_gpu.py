@@ -299,3 +299,70 @@ def test_every_position_of_the_headline_sequence_forced(golden_dir, case, precis
     assert rec["positions"] == 2 * 1023
     # the check must actually bite: the great majority of positions are asserted by arg-max, not waved through
     assert rec["argmax_asserted_positions"] >= 0.8 * rec["positions"]
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_reference_native_geometry_batch128(golden_dir, precision):
+    """The reference's OWN inference geometry at full size (ref config.yaml:16,46-47 + model.py:115-134: chunks of
+    inference.batch_size = 128 segments of 3 s at 16 kHz -> S = 190, max_length 1024) — what evaluate.py / webui.py run.  128 clips =
+    64 tiled copies of the two `full_s190` clips, whose 1 024-token ids HuggingFace itself produced (tests/golden/t5_forced.npz
+    `native_s190_fp32`, generator committed).  fp32: greedy ids of rows 0-1 bit-identical to HF's over all 1 024 tokens and every
+    copy identical (batch invariance at B = 128, two chains of 64); both modes: the forced check at every position on the same
+    128-clip batch (bf16 against the emulating oracle and its measured noise floor)."""
+    from forced_check import case_inputs, forced_check
+    from music2midi_amd.checkpoint import load_t5_state
+    from music2midi_amd.transformer import T5Transformer
+    z = np.load(golden_dir / "t5_forced.npz")
+    g = T5Geometry(DEFAULT_CONFIG["model"]["t5"])
+    case = f"native_s190_{precision}"
+    sd, x = case_inputs(case, g, "cuda")
+    assert x.shape == (2, 190, 384)
+    m = T5Transformer(DEFAULT_CONFIG, precision=precision)
+    load_t5_state(m, sd, strict=False)
+    m = m.cuda().eval()
+    ids = m.generate_from_embeds(x.repeat(64, 1, 1).contiguous(), max_length=1024).cpu().numpy()
+    assert ids.shape[0] == 128 and ids.shape[1] <= 1024
+    if ids.shape[1] < 1024:           # every row emitted EOS before the budget (bf16: both clips do): the rest is pad, as HF pads
+        ids = np.concatenate([ids, np.full((128, 1024 - ids.shape[1]), g.pad_token_id, dtype=ids.dtype)], axis=1)
+    for c in range(1, 64):
+        assert np.array_equal(ids[2 * c: 2 * c + 2], ids[:2]), f"copy {c} decodes differently from copy 0 at B = 128"
+    want = z[f"{case}/ids"].astype(np.int64)
+    if precision == "fp32":
+        assert np.array_equal(ids[:2], want), f"first mismatch at {np.argwhere(ids[:2] != want)[:1]}"
+    else:
+        _bf16_divergence(ids[:2], want, z[f"{case}/margins"], case, 1.5 * float(z[f"{case}/self_noise_margin"][0]))   # (row 0 parts at step 2, margin 0.08)
+    rec = forced_check(m, x, case, precision, copies=64, mode="step", z=z)
+    print(f"[forced {case} step, B = 128] {rec}")
+    assert rec["positions"] == 2 * 1023 and rec["argmax_asserted_positions"] >= 0.8 * rec["positions"]
+
+
+def test_reference_native_waveform_batch128_properties():
+    """128 x 48 000-sample segments (one full `inference.batch_size` chunk of ref model.py:115-134) through the public generate(), bf16:
+    determinism, start / pad structure and independence of a segment's ids from its batch mates (sub-batches of 5 and 1)."""
+    from music2midi_amd.checkpoint import load_t5_state
+    from music2midi_amd.transformer import T5Transformer
+    g = T5Geometry(DEFAULT_CONFIG["model"]["t5"])
+    sd = synth.t5_state_dict(g, seed=0)
+    synth.force_eos_head(sd, g, active=340, eos_scale=1.6)          # (on white-noise waveforms few or no rows end: the EOS side of this
+    m = T5Transformer(DEFAULT_CONFIG, precision="bf16")              #  geometry is test_finished_row_early_out_does_not_change_ids)
+    load_t5_state(m, sd, strict=False)
+    m = m.cuda().eval()
+    wav = torch.from_numpy(synth.waveform_batch(40, 128, 48000)).cuda()
+    idx = torch.from_numpy(synth.cond_index_batch(40, 128)).cuda()
+    a = m.generate(ModelInputs(input_waveform=wav, cond_index=idx), max_length=1024)
+    b = m.generate(ModelInputs(input_waveform=wav, cond_index=idx), max_length=1024)
+    assert a.shape[0] == 128 and a.shape[1] <= 1024 and torch.equal(a, b)
+    assert (a[:, 0] == g.decoder_start_token_id).all()
+    eos = a == g.eos_token_id
+    lens = []
+    for r in range(128):
+        if eos[r].any():
+            first = int(eos[r].float().argmax())
+            assert (a[r, first + 1:] == g.pad_token_id).all()
+            lens.append(first)
+    print(f"B = 128 native geometry: output length {a.shape[1]}, rows with EOS {len(lens)}, EOS positions min / median / max "
+          f"{min(lens) if lens else -1} / {int(np.median(lens)) if lens else -1} / {max(lens) if lens else -1}")
+    for lo, hi in ((17, 22), (99, 100)):
+        sub = m.generate(ModelInputs(input_waveform=wav[lo:hi].contiguous(), cond_index=idx[lo:hi].contiguous()), max_length=1024)
+        n = min(sub.shape[1], a.shape[1])
+        assert torch.equal(sub[:, :n], a[lo:hi, :n]) and (a[lo:hi, n:] == g.pad_token_id).all() and (sub[:, n:] == g.pad_token_id).all()

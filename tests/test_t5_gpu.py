@@ -234,3 +234,36 @@ def test_large_activation_fp32_still_matches_oracle():
     from oracle.t5 import T5Oracle
     x = embeds(3, 19, geom.d_model)
     assert torch.equal(model.generate_from_embeds(x.cuda(), max_length=24).cpu(), T5Oracle(geom, sd).generate(x, 24))
+
+
+@pytest.mark.parametrize("precision,B,S", [("bf16", 32, 190), ("fp32", 9, 61), ("bf16", 5, 864)])
+def test_finished_row_early_out_does_not_change_ids(monkeypatch, precision, B, S):
+    """Round 4: a (clip, head) workgroup of the decode attention kernels whose row has emitted EOS stops re-requesting K/V
+    (csrc/decode.hip `row_fin`).  HF keeps computing such rows and forces their tokens to pad (hf generation/utils.py:2929), so
+    nothing of them is observable: ids with the early-out (default) == ids without it (M2M_FINISHED_SKIP=0, a session of its own)
+    == the oracle's (fp32), rows ending at different steps, one and two chains, K/V streamed non-temporally and not."""
+    cfg = DEFAULT_CONFIG
+    geom = T5Geometry(load_config(cfg).model.t5)
+    sd = synth.t5_state_dict(geom, seed=0)
+    synth.perturb_layer_norms(sd, 0)
+    synth.force_eos_head(sd, geom, active=340, eos_scale=1.6)
+    x = embeds(B, S, geom.d_model, seed=21)
+    outs = {}
+    for leg, env in (("on", None), ("off", "0")):
+        if env is None:
+            monkeypatch.delenv("M2M_FINISHED_SKIP", raising=False)
+        else:
+            monkeypatch.setenv("M2M_FINISHED_SKIP", env)
+        m = T5Transformer(cfg, precision=precision)
+        load_t5_state(m, sd, strict=False)
+        m = m.cuda().eval()
+        outs[leg] = m.generate_from_embeds(x.cuda(), max_length=1024).cpu()
+        del m
+    a = outs["on"]
+    ends = [int((a[r] == geom.eos_token_id).float().argmax()) if (a[r] == geom.eos_token_id).any() else -1 for r in range(B)]
+    print(f"early-out {precision} B={B} S={S}: output length {a.shape[1]}, EOS positions {sorted(ends)}")
+    assert torch.equal(a, outs["off"])
+    assert sum(1 for e in ends if e > 0) >= B // 2 and len(set(ends)) > 1        # the case does exercise finished rows
+    if precision == "fp32":
+        from oracle.t5 import T5Oracle
+        assert torch.equal(a, T5Oracle(geom, sd).generate(x, 1024))

@@ -70,9 +70,10 @@ for i, r in enumerate(u):
             # moves it by 2.2x its own norm under a 1e-4 input perturbation (seed 2, case 16: measured on the host) — a bar relative to
             # its OWN norm means nothing there.  It is still held on the scale of its neighbour: the absolute error against the norm of
             # the same sub-layer's q-weight gradient (a wrong diagonal sum in the whole-head backward is of that order, not 1e-2 of it).
-            qn = float(grads_o[name.replace("relative_attention_bias.weight", "q.weight")].norm())
+            # (one label: a single key, dS = 0 and dW_q = 0 exactly — the scale is then the sub-layer's largest projection gradient)
+            qn = max(float(grads_o[name.replace("relative_attention_bias.weight", f"{w}.weight")].norm()) for w in "qkvo")
             e_abs = float((g - grads_o[name]).norm()) / (qn + 1e-12)
-            print(f"    [carve-out] case {i}: fp8, Ld={Ld}: {name.split('.')[-2]} held to |err| / |dW_q| = {e_abs:.2e} (< 0.05) instead of its own norm "
+            print(f"    [carve-out] case {i}: fp8, Ld={Ld}: {name.split('.')[-2]} held to |err| / max|dW_qkvo| = {e_abs:.2e} (< 0.05) instead of its own norm "
                   f"(|ref| {float(grads_o[name].norm()):.2e}, own-norm error {e:.2e})", flush=True)
             e = 0.0 if e_abs < 0.05 else float("inf")
         if e > worst: worst, wname = e, name
