@@ -41,8 +41,8 @@ struct FrontendDev {
   const float2* tw1024;   // [1024]  exp(-2 pi i k / 1024)
   const float2* tw2048;   // [1024]  exp(-2 pi i k / 2048)
   const int* fb_start;    // [n_mels] first frequency bin with a tap
-  const float* fb_wpad;   // [sum_j gmax[j]][64]: tap c of filter 64 j + lane at ((goff[j] + c) * 64 + lane); zero beyond the filter's own taps
-  int gmax[8];            // taps walked for the 64 filters of group j (= the widest filter of the group): wave-uniform trip counts
+  const float* fb_wpad;   // [sum_j gq[j]][64][4]: taps 4 q .. 4 q + 3 of filter 64 j + lane at ((goff[j] + q) * 64 + lane) * 4; zero beyond the filter's own taps
+  int gq[8];              // 4-tap chunks walked for the 64 filters of group j (= ceil(widest filter of the group / 4)): wave-uniform trip counts
   int n_wpad;             // floats in fb_wpad
   int n_mels;
   int hop;
@@ -110,6 +110,7 @@ constexpr int FE_FBW_LDS = 6144;    // padded tap table kept in LDS when it has 
 #ifndef M2M_FE_WGS_PER_CU
 #define M2M_FE_WGS_PER_CU 2
 #endif
+template <bool TAPS_LDS>      // the padded tap table in LDS (<= FE_FBW_LDS floats: every configuration the reference uses) or read from memory
 __global__ __launch_bounds__(FE_THREADS, M2M_FE_WGS_PER_CU) void logmel_kernel(
     const float* __restrict__ wav, int T, int F, FrontendDev fe, float* __restrict__ out,
     int64_t out_bstride, int row_offset, int FR, int NCH) {
@@ -125,23 +126,20 @@ __global__ __launch_bounds__(FE_THREADS, M2M_FE_WGS_PER_CU) void logmel_kernel(
   float2* cbase = reinterpret_cast<float2*>(smem_raw + (size_t)((span_max + 3) & ~3) * sizeof(float));
   float2* cbuf = cbase + wave * WAVE_C2;
   float* pbuf = reinterpret_cast<float*>(cbuf);          // aliases cbuf: written only after every Z read of the wave
-  float* fbw_s = reinterpret_cast<float*>(cbase + FE_WAVES * WAVE_C2);
+  float2* tw2048_s = cbase + FE_WAVES * WAVE_C2;         // [1024] split/post-process twiddles, one copy per workgroup (8 KB)
+  float* fbw_s = reinterpret_cast<float*>(tw2048_s + HALF);
   const int nnz = fe.n_wpad;
-#ifdef M2M_FE_TAPS_GLOBAL       // diagnostic builds only
-  const bool fbw_in_lds = false;
-#else
-  const bool fbw_in_lds = nnz <= FE_FBW_LDS;
-#endif
+  constexpr bool fbw_in_lds = TAPS_LDS;
 
   const int b = blockIdx.y;
   if (fbw_in_lds)
     for (int i = tid; i < nnz; i += FE_THREADS) fbw_s[i] = fe.fb_wpad[i];
+  for (int i = tid; i < HALF; i += FE_THREADS) tw2048_s[i] = fe.tw2048[i];   // visible after the first chunk's barrier
 
   // ---- per-lane constants, loaded once ----
   float2 win[16];   // window[2n], window[2n+1] for n = 64*n1 + lane
   float2 tw_a[16];  // W1024^(lane*k1)
   float2 tw_b[16];  // W64^(m2*q1) = W1024^(16*m2*q1)
-  float2 tw_p[8];   // W2048^(lane + 64 i)
   const int k1_lane = lane >> 2, m2 = lane & 3;
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
@@ -149,8 +147,6 @@ __global__ __launch_bounds__(FE_THREADS, M2M_FE_WGS_PER_CU) void logmel_kernel(
     tw_a[j] = fe.tw1024[lane * j];
     tw_b[j] = fe.tw1024[16 * m2 * j];
   }
-#pragma unroll
-  for (int i = 0; i < 8; ++i) tw_p[i] = fe.tw2048[lane + 64 * i];
   // this lane's mel filters: m = lane + 64 j (first tap bin; the taps come from the padded per-group table)
   const int n_mels = fe.n_mels;
   int fb_s[FE_MAXJ];
@@ -159,6 +155,10 @@ __global__ __launch_bounds__(FE_THREADS, M2M_FE_WGS_PER_CU) void logmel_kernel(
 
   const float sg2 = (m2 & 2) ? -1.f : 1.f, sg1 = (m2 & 1) ? -1.f : 1.f;
   const float rc = (m2 == 3) ? 0.f : 1.f, rs_ = (m2 == 3) ? 1.f : 0.f;
+  // Every table load above is complete before the frame loops start: the only vector-memory operations inside them are the
+  // output stores, and nothing may wait for THOSE (a lazily placed counted wait for a table register turns, from the second
+  // frame on, into a wait for the previous frame's stores to be acknowledged by memory: ~1 us per frame, found in the ISA).
+  __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0) only
 
   // A workgroup walks NCH consecutive chunks of FR frames: the ~110 table loads per lane above and the launch are
   // paid once per NCH * FR frames instead of once per FR.
@@ -246,12 +246,13 @@ __global__ __launch_bounds__(FE_THREADS, M2M_FE_WGS_PER_CU) void logmel_kernel(
     __builtin_amdgcn_wave_barrier();
     // post-process pairs (k, 1024-k): X[k] = E + W2048^k O, X[1024-k] = conj(E - W2048^k O).
     // All Z values are read into registers first: the power bins overwrite the Z image.
-    float2 zk[8], zn[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    float2 zk[8], zn[8], tw_p[8];   // tw_p: W2048^(lane + 64 i), lane-contiguous reads of the workgroup's copy (were 16 registers
+#pragma unroll                      // per lane for the whole kernel: with them the kernel spilled, and a spill reload inside the
+    for (int i = 0; i < 8; ++i) {   // frame loop is a vmcnt(0) wait behind the frame's output stores)
       const int k = lane + 64 * i;
       zk[i] = cbuf[zidx(k)];
       zn[i] = cbuf[zidx((HALF - k) & (HALF - 1))];
+      tw_p[i] = tw2048_s[k];
     }
     const float2 z512 = cbuf[zidx(512)];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -272,33 +273,52 @@ __global__ __launch_bounds__(FE_THREADS, M2M_FE_WGS_PER_CU) void logmel_kernel(
     if (lane < 48) pbuf[1025 + lane] = 0.f;                          // the padded taps of the last filters read (and ignore) these
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // ---- mel filterbank + clamp + log, this wave's frame.  The 64 filters of a group walk the SAME number of taps
-    //      (the widest filter of the group; the table is zero-padded), so the trip counts are wave-uniform scalars:
-    //      no exec masking, and the weights are read lane-contiguous (tap c of the group's 64 filters is one 256-byte row).
+    // ---- mel filterbank + clamp + log, this wave's frame.  The 64 filters of a group walk the SAME number of 4-tap chunks
+    //      (the widest filter of the group, rounded up; the table is zero-padded), so the trip counts are wave-uniform scalars:
+    //      no exec masking.  A chunk is one 16-byte weight read (lane-contiguous: conflict-free) + four power-bin reads, and
+    //      the NEXT chunk's reads are issued before this chunk's multiply-adds, so a group costs one LDS round trip plus its
+    //      arithmetic instead of one round trip per tap (the first form: 39 dependent round trips per frame).
     {
       float* orow = out + (int64_t)b * out_bstride + (int64_t)(row_offset + f0 + fl) * n_mels;
       int wrow = 0;
+      float res[FE_MAXJ];
+#pragma unroll
+      for (int j = 0; j < FE_MAXJ; ++j) {
+        res[j] = 0.f;
+        if (64 * j >= n_mels) break;                               // uniform
+#ifdef M2M_FE_SKIP_MEL     // diagnostic builds only
+        const int nq = 1;
+#else
+        const int nq = fe.gq[j];
+#endif
+        const float* p = pbuf + fb_s[j];
+        // (two call sites so that each keeps its address space: a pointer that may be LDS or global compiles to flat loads)
+        auto group = [&](const float4* fw) {
+          float4 w = fw[0];
+          float p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3];
+          float acc = 0.f;
+          for (int q = 1; q < nq; ++q) {
+            const float4 wn = fw[q * 64];
+            const float n0 = p[4 * q], n1 = p[4 * q + 1], n2 = p[4 * q + 2], n3 = p[4 * q + 3];
+            acc = fmaf(p0, w.x, acc); acc = fmaf(p1, w.y, acc); acc = fmaf(p2, w.z, acc); acc = fmaf(p3, w.w, acc);
+            w = wn; p0 = n0; p1 = n1; p2 = n2; p3 = n3;
+          }
+          acc = fmaf(p0, w.x, acc); acc = fmaf(p1, w.y, acc); acc = fmaf(p2, w.z, acc); acc = fmaf(p3, w.w, acc);
+          return acc;
+        };
+        float acc;
+        if constexpr (TAPS_LDS) acc = group(reinterpret_cast<const float4*>(fbw_s) + wrow * 64 + lane);
+        else acc = group(reinterpret_cast<const float4*>(fe.fb_wpad) + wrow * 64 + lane);
+        wrow += nq;
+        res[j] = acc;
+      }
+      // clamp(min=1e-6).log(): the floor is the correctly rounded fp32 ln(1e-6f), so silent (zero-padded) regions are
+      // bit-identical to the reference's constant.  All groups' logarithms and stores together, after the last LDS read.
 #pragma unroll
       for (int j = 0; j < FE_MAXJ; ++j) {
         if (64 * j >= n_mels) break;                               // uniform
-#ifdef M2M_FE_SKIP_MEL     // diagnostic builds only
-        const int gm = 1;
-#else
-        const int gm = fe.gmax[j];
-#endif
-        const float* p = pbuf + fb_s[j];
-        float acc = 0.f;
-        if (fbw_in_lds) {
-          const float* fw = fbw_s + wrow * 64 + lane;
-          for (int c = 0; c < gm; ++c) acc = fmaf(p[c], fw[c * 64], acc);
-        } else {
-          const float* fw = fe.fb_wpad + wrow * 64 + lane;
-          for (int c = 0; c < gm; ++c) acc = fmaf(p[c], fw[c * 64], acc);
-        }
-        wrow += gm;
         const int m = lane + 64 * j;
-        // clamp(min=1e-6).log(): the floor is the correctly rounded fp32 ln(1e-6f), so silent
-        // (zero-padded) regions are bit-identical to the reference's constant.
+        const float acc = res[j];
 #ifdef M2M_FE_SKIP_LOG      // diagnostic builds only
         if (m < n_mels) orow[m] = acc;
 #elif defined(M2M_FE_SKIP_STORE)
@@ -360,16 +380,17 @@ extern "C" int m2m_frontend_create(const m2m_frontend_desc* d, m2m_frontend** ou
     start[m] = lo < 0 ? 0 : lo;
     count[m] = lo < 0 ? 0 : hi - lo + 1;
   }
-  // per group of 64 filters: the widest filter's tap count; the table holds tap c of filter 64 j + lane at
-  // ((goff[j] + c) * 64 + lane), zero where c is past the filter's own taps (interior zeros of a filter stay zeros)
-  int gmax[8] = {0, 0, 0, 0, 0, 0, 0, 0}, goff[9] = {0};
-  for (int m = 0; m < n_mels; ++m) gmax[m / 64] = std::max(gmax[m / 64], count[m]);
-  for (int j = 0; j < 8; ++j) goff[j + 1] = goff[j] + gmax[j];
-  M2M_REQUIRE(gmax[0] + 0 <= 48 && *std::max_element(gmax, gmax + 8) <= 48,
+  // per group of 64 filters: the widest filter's tap count in 4-tap chunks; the table holds taps 4 q .. 4 q + 3 of filter
+  // 64 j + lane at ((goff[j] + q) * 64 + lane) * 4, zero where a tap is past the filter's own (interior zeros stay zeros)
+  int gq[8] = {0, 0, 0, 0, 0, 0, 0, 0}, goff[9] = {0};
+  for (int m = 0; m < n_mels; ++m) gq[m / 64] = std::max(gq[m / 64], (count[m] + 3) / 4);
+  for (int j = 0; j < 8; ++j) { if (64 * j < n_mels) gq[j] = std::max(gq[j], 1); goff[j + 1] = goff[j] + gq[j]; }
+  M2M_REQUIRE(4 * *std::max_element(gq, gq + 8) <= 48,
               "m2m_frontend_create: a mel filter spans more than 48 frequency bins (the kernel keeps 48 spare power bins for the padded taps)");
-  std::vector<float> w((size_t)goff[8] * 64, 0.0f);
+  std::vector<float> w((size_t)goff[8] * 256, 0.0f);
   for (int m = 0; m < n_mels; ++m)
-    for (int c = 0; c < count[m]; ++c) w[((size_t)goff[m / 64] + c) * 64 + (m % 64)] = d->fb_host[(size_t)(start[m] + c) * n_mels + m];
+    for (int c = 0; c < count[m]; ++c)
+      w[(((size_t)goff[m / 64] + c / 4) * 64 + (m % 64)) * 4 + (c % 4)] = d->fb_host[(size_t)(start[m] + c) * n_mels + m];
   std::vector<float2> tw1(HALF), tw2(HALF);
   for (int k = 0; k < HALF; ++k) {
     double a1 = -2.0 * M_PI * k / 1024.0, a2 = -2.0 * M_PI * k / 2048.0;
@@ -408,7 +429,7 @@ extern "C" int m2m_frontend_create(const m2m_frontend_desc* d, m2m_frontend** ou
   fe->dev.tw2048 = (const float2*)(base + o_tw2);
   fe->dev.fb_start = (const int*)(base + o_st);
   fe->dev.fb_wpad = (const float*)(base + o_w);
-  for (int j = 0; j < 8; ++j) fe->dev.gmax[j] = gmax[j];
+  for (int j = 0; j < 8; ++j) fe->dev.gq[j] = gq[j];
   fe->dev.n_wpad = (int)w.size();
   fe->dev.n_mels = n_mels;
   fe->dev.hop = d->hop_length;
@@ -438,7 +459,7 @@ static size_t frontend_smem_bytes(int FR, int hop, int nnz) {
 #ifdef M2M_FE_TAPS_GLOBAL
   nnz = FE_FBW_LDS + 1;
 #endif
-  return span * sizeof(float) + (size_t)FE_WAVES * WAVE_C2 * sizeof(float2) +
+  return span * sizeof(float) + (size_t)FE_WAVES * WAVE_C2 * sizeof(float2) + (size_t)HALF * sizeof(float2) +
          (nnz <= FE_FBW_LDS ? (size_t)nnz * sizeof(float) : 0);
 }
 
@@ -453,7 +474,7 @@ extern "C" int m2m_logmel_f32(const m2m_frontend* fe, const float* wav_dev, int 
               "m2m_logmel_f32: out_batch_stride %lld smaller than (row_offset+frames)*n_mels", (long long)out_batch_stride);
   // 16 frames per workgroup: waveform re-read factor 1.44 at hop 256, two workgroups per CU.
   int FR = getenv("M2M_FE_FR") ? atoi(getenv("M2M_FE_FR")) : 16;
-  while (FR > 4 && frontend_smem_bytes(FR, fe->hop, fe->n_wpad) > 78 * 1024) FR -= 4;
+  while (FR > 4 && frontend_smem_bytes(FR, fe->hop, fe->n_wpad) > 80 * 1024) FR -= 4;      // two workgroups per CU (160 KB)
   const size_t smem = frontend_smem_bytes(FR, fe->hop, fe->n_wpad);
   // chunks of FR frames per workgroup.  Measured on MI355X (B = 64 / 32, us per launch): 1 chunk 199.9 / 108.3,
   // 2 chunks 196.0 / 112.5, 3 chunks 208.1 / 136.9: the table loads are not what bounds the kernel, so one chunk
@@ -461,9 +482,20 @@ extern "C" int m2m_logmel_f32(const m2m_frontend* fe, const float* wav_dev, int 
   int NCH = ((int64_t)ceil_div(F, FR * 2) * B >= 1536) ? 2 : 1;
   if (const char* v = getenv("M2M_FE_CHUNKS")) NCH = atoi(v) > 0 ? atoi(v) : NCH;
   dim3 grid((unsigned)ceil_div(F, FR * NCH), (unsigned)B);
-  M2M_OPT_IN_LDS(logmel_kernel, 160 * 1024);
-  hipLaunchKernelGGL(logmel_kernel, grid, dim3(FE_THREADS), smem, (hipStream_t)stream, wav_dev, T, F, fe->dev,
-                     out_dev, out_batch_stride, row_offset, FR, NCH);
+#ifdef M2M_FE_TAPS_GLOBAL       // diagnostic builds only
+  const bool taps_lds = false;
+#else
+  const bool taps_lds = fe->n_wpad <= FE_FBW_LDS;
+#endif
+  if (taps_lds) {
+    M2M_OPT_IN_LDS(logmel_kernel<true>, 160 * 1024);
+    hipLaunchKernelGGL(logmel_kernel<true>, grid, dim3(FE_THREADS), smem, (hipStream_t)stream, wav_dev, T, F, fe->dev,
+                       out_dev, out_batch_stride, row_offset, FR, NCH);
+  } else {
+    M2M_OPT_IN_LDS(logmel_kernel<false>, 160 * 1024);
+    hipLaunchKernelGGL(logmel_kernel<false>, grid, dim3(FE_THREADS), smem, (hipStream_t)stream, wav_dev, T, F, fe->dev,
+                       out_dev, out_batch_stride, row_offset, FR, NCH);
+  }
   M2M_CHECK_HIP(hipGetLastError());
   return M2M_OK;
 }
