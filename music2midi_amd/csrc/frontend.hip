@@ -334,6 +334,281 @@ __global__ __launch_bounds__(FE_THREADS, M2M_FE_WGS_PER_CU) void logmel_kernel(
   }  // chunks
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Second form of the same transform (round 4): ONE workgroup of WAVES waves per CU, a frame per wave per chunk.
+//
+// What the first form above cannot have is occupancy: its window / twiddle tables sit in 112 VGPRs per lane and its
+// 16 x 68 complex transpose buffer takes 8.7 KB of LDS per wave: two waves per SIMD.  tools/valu_rate.hip measures what that
+// costs on this machine before any latency is counted: a SIMD issues one plain vector instruction every 2.9 cycles with two
+// resident waves and every 1.96 with four (packed-f32: 5.0 -> 3.3).  Here
+//   * every table lives ONCE in LDS per workgroup (window pairs, stage twiddles in lane order, split twiddles, tap table, filter
+//     starts: 34 KB), read lane-contiguously (ds_read_b64) right where it is used;
+//   * the two exchanges go through LDS one PLANE at a time (real parts, then imaginary parts, through the same 16 x 68 floats):
+//     4.25 KB per wave instead of 8.7, and the 1 025 power bins alias it; the pitch / padding make every access conflict-free;
+//   * 16 waves x <= 128 VGPRs = four waves per SIMD;
+//   * a workgroup walks NCH consecutive chunks of its clip with the NEXT chunk's samples in flight (requested into registers when
+//     a chunk starts, written to the other sample buffer when it ends: one barrier per chunk, no wave waits for memory).
+// LDS (hop 256, 16 waves): 2 x 23.0 KB samples + 16 x 4.25 KB planes + 34 KB tables = 148 KB.
+#ifndef M2M_FE2_SKIP        // diagnostic builds only (timing of the kernel with a part removed; results are wrong):
+#define M2M_FE2_SKIP 0      // 1 mel taps, 2 exchange 1, 4 exchange 2, 8 the two radix-16 passes, 16 table reads, 32 logf, 64 stores, 128 DPP stage
+#endif
+constexpr int V2_PITCH = 68;                 // floats per k1 row of a transpose plane
+constexpr int V2_SCR = 16 * V2_PITCH;        // floats of per-wave scratch (planes, then the 1 025 + 48 power bins)
+constexpr int V2_NPRE = 6;                   // prefetch registers per thread (samples of the next chunk: 5 888 / 1 024 threads at hop 256)
+__device__ inline int zidx8(int k) { return k + 8 * (k >> 8); }   // plane layout of Z[0..1023]: lanes (k1, q2) hit 32 different banks
+
+struct V2Layout {      // float offsets into dynamic LDS (host and device agree through this one function)
+  int span_pad, samples1, scr, win2, twa, twb, twp, fbs, fbw, total;
+};
+__host__ __device__ inline V2Layout v2_layout(int waves, int hop, int n_wpad) {
+  V2Layout l;
+  l.span_pad = (((waves - 1) * hop + NFFT) + 3) & ~3;
+  l.samples1 = l.span_pad;
+  l.scr = 2 * l.span_pad;
+  l.win2 = l.scr + waves * V2_SCR;
+  l.twa = l.win2 + 2 * HALF;        // float2 [1024]
+  l.twb = l.twa + 2 * 16 * 64;      // float2 [16][64]
+  l.twp = l.twb + 2 * 16 * 4;       // float2 [16][4]
+  l.fbs = l.twp + 2 * 512;          // float2 [512]
+  l.fbw = l.fbs + 512;              // int [512]
+  l.total = l.fbw + ((n_wpad + 3) & ~3);
+  return l;
+}
+
+// ln(x) for x > 1e-6: the hardware log2 (1 ulp) times ln 2 — absolute error <= |log2 x| 2^-23 ln 2 + one rounding < 2e-6 over the
+// 20 octaves above the clamp, against the 1e-4 the frontend is held to; the accurate logf is ~20 instructions per value.
+__device__ inline float fe_log(float x) {
+#ifdef M2M_FE_ACCURATE_LOG
+  return logf(x);
+#else
+  return __builtin_amdgcn_logf(x) * 0.6931471805599453f;
+#endif
+}
+
+template <int WAVES, int NJ>     // NJ: groups of 64 mel filters (6 for the reference's 384; 8 = the general form, n_mels <= 512)
+__global__ __launch_bounds__(64 * WAVES) void logmel_v2_kernel(const float* __restrict__ wav, int T, int F, FrontendDev fe,
+                                                               float* __restrict__ out, int64_t out_bstride, int row_offset, int NCH) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  constexpr int NT = 64 * WAVES, FR = WAVES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hop = fe.hop, n_mels = fe.n_mels;
+  const V2Layout L = v2_layout(WAVES, hop, fe.n_wpad);
+  float* const lds = reinterpret_cast<float*>(smem_raw);
+  float* const scr = lds + L.scr + wave * V2_SCR;
+  const float2* const win2_s = reinterpret_cast<const float2*>(lds + L.win2);
+  const float2* const twa_s = reinterpret_cast<const float2*>(lds + L.twa);
+  const float2* const twb_s = reinterpret_cast<const float2*>(lds + L.twb);
+  const float2* const twp_s = reinterpret_cast<const float2*>(lds + L.twp);
+  const int* const fbs_s = reinterpret_cast<const int*>(lds + L.fbs);
+  const float* const fbw_s = lds + L.fbw;
+  const int b = blockIdx.y;
+  const float* const w = wav + (int64_t)b * T;
+  const int m2 = lane & 3;
+
+  // samples of chunk f0 -> registers (reflect padding as torch.stft center=True, pad_mode="reflect"); element i = tid + NT * u
+  auto fetch = [&](int f0, float (&pre)[V2_NPRE]) {
+    const int nfr = min(FR, F - f0), span = (nfr - 1) * hop + NFFT, base = f0 * hop - NFFT / 2;
+#pragma unroll
+    for (int u = 0; u < V2_NPRE; ++u) {
+      const int i = tid + NT * u;
+      int j = base + min(i, span - 1);
+      if (j < 0) j = -j;
+      else if (j >= T) j = 2 * (T - 1) - j;
+      pre[u] = w[j];
+    }
+  };
+  auto deposit = [&](float* dst, const float (&pre)[V2_NPRE]) {
+#pragma unroll
+    for (int u = 0; u < V2_NPRE; ++u) {
+      const int i = tid + NT * u;
+      if (i < L.span_pad) dst[i] = pre[u];
+    }
+  };
+
+  int f0 = blockIdx.x * NCH * FR;
+  if (f0 >= F) return;                                           // uniform
+  float pre[V2_NPRE];
+  fetch(f0, pre);
+  // ---- tables, once per workgroup ----
+  {
+    float2* win2_w = reinterpret_cast<float2*>(lds + L.win2);
+    float2* twa_w = reinterpret_cast<float2*>(lds + L.twa);
+    float2* twb_w = reinterpret_cast<float2*>(lds + L.twb);
+    float2* twp_w = reinterpret_cast<float2*>(lds + L.twp);
+    int* fbs_w = reinterpret_cast<int*>(lds + L.fbs);
+    float* fbw_w = lds + L.fbw;
+    for (int i = tid; i < HALF; i += NT) {
+      win2_w[i] = *reinterpret_cast<const float2*>(fe.window + 2 * i);
+      twa_w[i] = fe.tw1024[(i & 63) * (i >> 6)];                 // [k1][lane] = W1024^(lane k1)
+    }
+    for (int i = tid; i < 64; i += NT) twb_w[i] = fe.tw1024[16 * (i & 3) * (i >> 2)];   // [q1][m2] = W64^(m2 q1)
+    for (int i = tid; i < 512; i += NT) {
+      twp_w[i] = fe.tw2048[i];
+      fbs_w[i] = fe.fb_start[min(i, n_mels - 1)];
+    }
+    for (int i = tid; i < fe.n_wpad; i += NT) fbw_w[i] = fe.fb_wpad[i];
+  }
+  deposit(lds, pre);
+  __syncthreads();
+
+  const float sg2 = (m2 & 2) ? -1.f : 1.f, sg1 = (m2 & 1) ? -1.f : 1.f;
+  const float rc = (m2 == 3) ? 0.f : 1.f, rs_ = (m2 == 3) ? 1.f : 0.f;
+
+  for (int ch = 0; ch < NCH; ++ch, f0 += FR) {
+    if (f0 >= F) break;                                          // uniform
+    const float* const samples = lds + ((ch & 1) ? L.samples1 : 0);
+    const bool more = (ch + 1 < NCH) && (f0 + FR < F);           // uniform
+    if (more) fetch(f0 + FR, pre);                               // in flight under this chunk's transform
+    const int fl = wave;
+    if (f0 + fl < F) {                                           // wave-uniform
+      // An opaque per-frame copy of the lane id: every per-lane LDS address below is ONE base register plus compile-time offsets,
+      // formed inside the frame.  Derived from threadIdx they are loop invariants: the compiler hoists ~40 of them (and the filter
+      // starts it finds in LDS) out of the chunk loop, runs out of the 128 registers four waves per SIMD allow, and reloads its
+      // spills in every frame — a vmcnt(0) wait behind the previous frame's output stores each time.
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      const int k1l = ln >> 2, m2l = ln & 3, q2l = ((m2l & 1) << 1) | (m2l >> 1);
+      const float2* const sp = reinterpret_cast<const float2*>(samples + fl * hop) + ln;   // 8-byte aligned: hop is even (checked on the host)
+      const float2* const wp = win2_s + ln;
+      const float2* const tap = twa_s + ln;
+      const float2* const tbp = twb_s + m2l;
+      float* const sw = scr + ln;                                // plane rows: [k1][lane]
+      const float* const sr = scr + k1l * V2_PITCH + m2l;        // lane (k1, m2) reads l = 4 m1 + m2 of its row
+      float* const zw = scr + k1l + 264 * q2l;                   // zidx8(k1 + 16 q1 + 256 q2) = k1 + 264 q2 + 16 q1
+      const float* const zr = scr + ln;                          // zidx8(lane + 64 i) = lane + 64 i + 8 (i >> 2)
+      const float* const znr = scr + (1048 - 456) - ln;          // zidx8(1024 - lane - 64 i) = 1048 - lane - 64 i - 8 (i >> 2)  (lane >= 1)
+      float2 z[16];
+      // stage 1: lane holds n = 64 n1 + lane
+#pragma unroll
+      for (int n1 = 0; n1 < 16; ++n1) {
+        const float2 sv = sp[64 * n1];
+        const float2 wv = (M2M_FE2_SKIP & 16) ? make_float2(0.5f, 0.25f) : wp[64 * n1];
+        z[n1] = make_float2(sv.x * wv.x, sv.y * wv.y);
+      }
+      if (!(M2M_FE2_SKIP & 8)) fft16(z);
+#pragma unroll
+      for (int k1 = 1; k1 < 16; ++k1) z[k1] = cmul(z[k1], (M2M_FE2_SKIP & 16) ? make_float2(0.6f, 0.8f) : tap[64 * k1]);
+      // exchange 1, one plane at a time: lane (k1, m2) takes l = 4 m1 + m2 of row k1
+      if (!(M2M_FE2_SKIP & 2)) {
+      float zre[16];
+#pragma unroll
+      for (int k1 = 0; k1 < 16; ++k1) sw[k1 * V2_PITCH] = z[k1].x;
+#pragma unroll
+      for (int m1 = 0; m1 < 16; ++m1) zre[m1] = sr[4 * m1];
+#pragma unroll
+      for (int k1 = 0; k1 < 16; ++k1) sw[k1 * V2_PITCH] = z[k1].y;
+#pragma unroll
+      for (int m1 = 0; m1 < 16; ++m1) z[m1] = make_float2(zre[m1], sr[4 * m1]);
+      }
+      if (!(M2M_FE2_SKIP & 8)) fft16(z);
+#pragma unroll
+      for (int q1 = 1; q1 < 16; ++q1) z[q1] = cmul(z[q1], (M2M_FE2_SKIP & 16) ? make_float2(0.6f, 0.8f) : tbp[4 * q1]);
+      // stage 3: radix-4 across the quad (m2 = lane & 3) by two DPP exchanges; after it lane m2 holds Y[q1 + 16 q2], q2 = bitrev2(m2)
+#pragma unroll
+      for (int q1 = 0; q1 < ((M2M_FE2_SKIP & 128) ? 0 : 16); ++q1) {
+        float2 v = z[q1];
+        float2 pp = make_float2(dpp_quad<DPP_XOR2>(v.x), dpp_quad<DPP_XOR2>(v.y));
+        v = make_float2(fmaf(sg2, v.x, pp.x), fmaf(sg2, v.y, pp.y));
+        v = make_float2(fmaf(rc, v.x, rs_ * v.y), fmaf(rc, v.y, -rs_ * v.x));   // lane 3: (x, y) -> (y, -x)
+        pp = make_float2(dpp_quad<DPP_XOR1>(v.x), dpp_quad<DPP_XOR1>(v.y));
+        z[q1] = make_float2(fmaf(sg1, v.x, pp.x), fmaf(sg1, v.y, pp.y));
+      }
+      // exchange 2 (Z image -> pairs (k, 1024 - k), k = lane + 64 i), again by planes.  Lane 0's partners are irregular: k = 0
+      // pairs with itself, k = 256 with Z[768], which sits behind one more padding step than the other lanes' partners.
+      float2 zk[8], zn[8];
+      float z512x, z512y, z768x, z768y;
+      if (M2M_FE2_SKIP & 4) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { zk[i] = z[i]; zn[i] = z[8 + i]; }
+        z512x = z[0].x; z512y = z[1].y; z768x = z[2].x; z768y = z[3].y;
+      } else {
+#pragma unroll
+      for (int q1 = 0; q1 < 16; ++q1) zw[16 * q1] = z[q1].x;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        zk[i].x = zr[64 * i + 8 * (i >> 2)];
+        zn[i].x = znr[456 - 64 * i - 8 * (i >> 2)];
+      }
+      z512x = scr[zidx8(512)];
+      z768x = scr[zidx8(768)];
+#pragma unroll
+      for (int q1 = 0; q1 < 16; ++q1) zw[16 * q1] = z[q1].y;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        zk[i].y = zr[64 * i + 8 * (i >> 2)];
+        zn[i].y = znr[456 - 64 * i - 8 * (i >> 2)];
+      }
+      z512y = scr[zidx8(512)];
+      z768y = scr[zidx8(768)];
+      }
+      if (ln == 0) { zn[0] = zk[0]; zn[4] = make_float2(z768x, z768y); }
+      // split / post-process: X[k] = E + W2048^k O, X[1024 - k] = conj(E - W2048^k O); the power bins overwrite the planes
+      // (the LDS executes a wave's operations in order: every read above is served before the writes below)
+      float* const pk = scr + ln;                                  // bins lane + 64 i
+      float* const pn = scr + 1024 - ln;                           // bins 1024 - lane - 64 i
+      const float2* const tpp = twp_s + ln;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float2 c = make_float2(zn[i].x, -zn[i].y);  // conj
+        const float2 e = make_float2(0.5f * (zk[i].x + c.x), 0.5f * (zk[i].y + c.y));
+        const float2 d = make_float2(0.5f * (zk[i].x - c.x), 0.5f * (zk[i].y - c.y));
+        const float2 o = make_float2(d.y, -d.x);  // d / i
+        const float2 t = cmul((M2M_FE2_SKIP & 16) ? make_float2(0.6f, 0.8f) : tpp[64 * i], o);
+        const float2 xp = cadd(e, t), xm = csub(e, t);
+        pk[64 * i] = xp.x * xp.x + xp.y * xp.y;
+        pn[-64 * i] = xm.x * xm.x + xm.y * xm.y;
+      }
+      if (ln == 0) scr[512] = z512x * z512x + z512y * z512y;      // k = 512: E = Re Z, O = Im Z, W2048^512 = -i
+      if (ln < 48) scr[1025 + ln] = 0.f;                           // the padded taps of the last filters read (and ignore) these
+      // mel filterbank (4-tap chunks: one aligned 16-byte weight read + four power-bin reads; the next chunk is requested before
+      // this chunk's multiply-adds) + clamp + log.  The power-bin reads are dword reads from per-lane starts a few bins apart:
+      // they collide on the 32 banks a b32 read sees (272 LDS cycles per frame for 48 reads = every bank conflict the kernel has,
+      // SQ_LDS_BANK_CONFLICT).  The obvious remedy was built and measured: ONE ds_read_b128 per chunk from the 4-byte-aligned start
+      // (gfx950 serves it — tools/lds_unaligned.hip — hipcc splits such a load, so it was issued by inline asm; 12 reads on 64
+      // banks, ~100 cycles by the bank model): results identical, kernel 158 -> 190 us.  A misaligned wide LDS read is replayed
+      // (a single wave sees 192 cycles per read against 101 for the four dword reads).  Dword reads stay.
+      float* orow = out + (int64_t)b * out_bstride + (int64_t)(row_offset + f0 + fl) * n_mels + ln;
+      float res[NJ];
+      {
+        const int* const fsp = fbs_s + ln;
+        const float4* fw = reinterpret_cast<const float4*>(fbw_s) + ln;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          res[j] = 0.f;
+          if (64 * j >= n_mels) break;                             // uniform
+          const int nq = (M2M_FE2_SKIP & 1) ? 1 : fe.gq[j];
+          const float* p = scr + fsp[64 * j];
+          float4 wq = fw[0];
+          float p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3];
+          float acc = 0.f;
+          for (int q = 1; q < nq; ++q) {
+            const float4 wn = fw[q * 64];
+            const float n0 = p[4 * q], n1 = p[4 * q + 1], n2 = p[4 * q + 2], n3 = p[4 * q + 3];
+            acc = fmaf(p0, wq.x, acc); acc = fmaf(p1, wq.y, acc); acc = fmaf(p2, wq.z, acc); acc = fmaf(p3, wq.w, acc);
+            wq = wn; p0 = n0; p1 = n1; p2 = n2; p3 = n3;
+          }
+          acc = fmaf(p0, wq.x, acc); acc = fmaf(p1, wq.y, acc); acc = fmaf(p2, wq.z, acc); acc = fmaf(p3, wq.w, acc);
+          fw += nq * 64;
+          res[j] = acc;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        if (64 * j >= n_mels) break;                               // uniform
+        // clamp(min=1e-6).log(): the floor is the correctly rounded fp32 ln(1e-6f), so silence is bit-identical to the reference's constant
+        if (M2M_FE2_SKIP & 64) { if (ln + 64 * j < n_mels && res[j] == 12345.678f) orow[64 * j] = res[j]; }
+        else if (M2M_FE2_SKIP & 32) { if (ln + 64 * j < n_mels) orow[64 * j] = res[j]; }
+        else if (ln + 64 * j < n_mels) orow[64 * j] = (res[j] > 1e-6f) ? fe_log(res[j]) : -13.815510749816895f;
+      }
+    }
+    if (more) {
+      deposit(lds + ((ch & 1) ? 0 : L.samples1), pre);           // the buffer chunk ch - 1 used: every wave left it a barrier ago
+      __syncthreads();
+    }
+  }
+}
+
 struct CondArgs {
   const float* tables[8];
   int rows[8];
@@ -472,6 +747,33 @@ extern "C" int m2m_logmel_f32(const m2m_frontend* fe, const float* wav_dev, int 
   const int F = 1 + T / fe->hop;
   M2M_REQUIRE(out_batch_stride >= (int64_t)(row_offset + F) * fe->n_mels,
               "m2m_logmel_f32: out_batch_stride %lld smaller than (row_offset+frames)*n_mels", (long long)out_batch_stride);
+  // Second form (one 16-wave workgroup per CU, tables and half-plane exchanges in LDS, four waves per SIMD) whenever its LDS image
+  // fits: every configuration the reference uses (hop 256, 384 mels).  M2M_FE_V2=0 keeps the first form (and other hops use it).
+  {
+    constexpr int WAVES = 16;
+    const V2Layout L = v2_layout(WAVES, fe->hop, fe->n_wpad);
+    static const bool v2_on = [] { const char* v = getenv("M2M_FE_V2"); return !(v && v[0] == '0'); }();
+    if (v2_on && (size_t)L.total * sizeof(float) <= 160 * 1024 && L.span_pad <= V2_NPRE * 64 * WAVES && fe->n_mels <= 512) {
+      const int cpc = ceil_div(F, WAVES);                              // chunks per clip
+      static const int n_cu = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+      int per_clip = (n_cu + B / 2) / B;                               // workgroups per clip: about one per CU in total
+      per_clip = per_clip < 1 ? 1 : (per_clip > cpc ? cpc : per_clip);
+      int NCH = ceil_div(cpc, per_clip);
+      if (const char* v = getenv("M2M_FE_CHUNKS")) NCH = atoi(v) > 0 ? atoi(v) : NCH;
+      dim3 grid((unsigned)ceil_div(cpc, NCH), (unsigned)B);
+      if (fe->n_mels <= 384) {
+        M2M_OPT_IN_LDS((logmel_v2_kernel<WAVES, 6>), 160 * 1024);
+        hipLaunchKernelGGL((logmel_v2_kernel<WAVES, 6>), grid, dim3(64 * WAVES), (size_t)L.total * sizeof(float), (hipStream_t)stream, wav_dev, T, F,
+                           fe->dev, out_dev, out_batch_stride, row_offset, NCH);
+      } else {
+        M2M_OPT_IN_LDS((logmel_v2_kernel<WAVES, 8>), 160 * 1024);
+        hipLaunchKernelGGL((logmel_v2_kernel<WAVES, 8>), grid, dim3(64 * WAVES), (size_t)L.total * sizeof(float), (hipStream_t)stream, wav_dev, T, F,
+                           fe->dev, out_dev, out_batch_stride, row_offset, NCH);
+      }
+      M2M_CHECK_HIP(hipGetLastError());
+      return M2M_OK;
+    }
+  }
   // 16 frames per workgroup: waveform re-read factor 1.44 at hop 256, two workgroups per CU.
   int FR = getenv("M2M_FE_FR") ? atoi(getenv("M2M_FE_FR")) : 16;
   while (FR > 4 && frontend_smem_bytes(FR, fe->hop, fe->n_wpad) > 80 * 1024) FR -= 4;      // two workgroups per CU (160 KB)

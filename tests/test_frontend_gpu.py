@@ -37,6 +37,31 @@ def test_logmel_matches_oracle(kind, T, B, n_mels):
         assert stats["well_frac"] > 0.35       # the class that matters is not empty
 
 
+@pytest.mark.parametrize("hop,kind", [(512, "noise"), (128, "music"), (256, "tones")])
+def test_logmel_first_form_kernel_other_hops_and_switch(hop, kind, monkeypatch):
+    """The 16-wave workgroup kernel (round 4) covers the reference's hop 256; other hop lengths, and M2M_FE_V2=0, run the first form
+    (four waves, tables in registers).  Both stay held to the oracle; at hop 256 the two forms are compared with each other too."""
+    from oracle.logmel import LogMelOracle
+    import subprocess, sys
+    T, B = 30000, 3
+    wav = torch.from_numpy(synth.waveform_batch(2, B, T, kind))
+    orc = LogMelOracle(16000, 2048, hop, 20.0, 384)
+    out = LogMelSpectrogram(16000, 2048, hop, 20.0, 384)(wav.cuda()).cpu()
+    assert out.shape == (B, 1 + T // hop, 384)
+    check_logmel(out, wav, orc, f"{kind} hop={hop}")
+    if hop == 256:      # the switch is read once per process: ask a child for the first form's output
+        code = ("import sys, torch; sys.path.insert(0, %r); from music2midi_amd import synth; from music2midi_amd.input import LogMelSpectrogram; "
+                "w = torch.from_numpy(synth.waveform_batch(2, %d, %d, %r)).cuda(); torch.save(LogMelSpectrogram(16000, 2048, 256, 20.0, 384)(w).cpu(), sys.argv[1])"
+                % (str(__import__("pathlib").Path(__file__).resolve().parents[1]), B, T, kind))
+        import os, tempfile
+        with tempfile.TemporaryDirectory() as d:
+            f = os.path.join(d, "v1.pt")
+            subprocess.run([sys.executable, "-c", code, f], check=True, env=dict(os.environ, M2M_FE_V2="0"), timeout=600)
+            v1 = torch.load(f)
+        check_logmel(v1, wav, orc, f"{kind} hop=256 first form")
+        print(f"two kernel forms, hop 256 {kind}: max |v2 - v1| = {(out - v1).abs().max():.2e}")
+
+
 def test_logmel_writes_in_place_with_cond_rows():
     B, T, d = 4, 8000, 384
     wav = torch.from_numpy(synth.waveform_batch(3, B, T)).cuda()

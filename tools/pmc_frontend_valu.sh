@@ -6,7 +6,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=${PMC_OUT:-gpurun_out/pmc_frontend_valu}
 mkdir -p $OUT
-for G in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_WAVES" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM"; do
+for G in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_WAVES" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_SCA"; do
   N=$(echo $G | cut -d' ' -f1)
   rocprofv3 --kernel-trace --pmc $G --output-format csv -d $OUT -o $N -- python3 tools/frontend_bench.py 64 > $OUT/$N.log 2>&1 || tail -3 $OUT/$N.log
 done
@@ -17,13 +17,13 @@ agg = collections.defaultdict(float); n = collections.Counter(); dur = 0.0; nd =
 for f in glob.glob(f"{out}/*_counter_collection.csv"):
     seen = set()
     for r in csv.DictReader(open(f)):
-        if "logmel_kernel" not in r["Kernel_Name"]: continue
+        if "logmel" not in r["Kernel_Name"]: continue
         agg[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
         if r["Dispatch_Id"] not in seen and r["Counter_Name"].startswith("SQ_INSTS_VALU"):
             seen.add(r["Dispatch_Id"]); dur += float(r["End_Timestamp"]) - float(r["Start_Timestamp"]); nd += 1
 lines = []
 for k in sorted(agg):
-    lines.append(f"logmel_kernel B=64  {k:24s} per launch {agg[k] / max(n[k], 1):16.1f}   ({n[k]} launches)")
+    lines.append(f"logmel kernel B=64  {k:24s} per launch {agg[k] / max(n[k], 1):16.1f}   ({n[k]} launches)")
 frames = 64 * 862
 if "SQ_INSTS_VALU" in agg:
     v = agg["SQ_INSTS_VALU"] / n["SQ_INSTS_VALU"]
