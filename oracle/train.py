@@ -185,8 +185,15 @@ class T5TrainOracle:
         lm_head is not a ``_lin`` product: it stays in the bf16 mode's arithmetic on the device too."""
         w = self.w(wname)
         if getattr(self, "mx8", False):
-            return _MxLinear.apply(x, w, bool(self.mx8_dw), self.mx8_grad_fmt)
-        return x @ self._r(w, True, False).T            # bf16 mode: the product reads a bf16 copy of the fp32 master weight
+            y = _MxLinear.apply(x, w, bool(self.mx8_dw), self.mx8_grad_fmt)
+        else:
+            y = x @ self._r(w, True, False).T           # bf16 mode: the product reads a bf16 copy of the fp32 master weight
+        cap = getattr(self, "capture", None)            # tests: {weight name: {}} -> the product's input, output and output gradient
+        if cap is not None and wname in cap:
+            rec = cap[wname]
+            rec["x"], rec["y"] = x.detach().clone(), y.detach().clone()
+            y.register_hook(lambda g, rec=rec: rec.__setitem__("dy", g.detach().clone()))
+        return y
 
     def _attn(self, hq, hkv, prefix, bias, site_probs=-1):
         B, Lq, _ = hq.shape

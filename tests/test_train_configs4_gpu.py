@@ -158,7 +158,81 @@ def test_fp8_mode_matches_the_mx_emulating_autograd_at_the_config_shape(c4, part
           f"vs unquantised autograd min {min(ps)[0]:.4f} / median {np.median([c for c, _ in ps]):.4f}")
     assert abs(loss.item() - loss_o.item()) < 5e-3 * abs(loss_o.item())
     assert np.median([c for c, _ in cs]) > fmed - 0.015 and cmin[0] > fmin - 0.03      # (the minimum over 146 tensors is itself a noisy draw: wider)
+    # absolute floors beside the relative bar (measured 0.958 / 0.975 against the emulation, 0.92 / 0.94 against plain autograd)
+    assert cmin[0] > 0.93 and np.median([c for c, _ in cs]) > 0.95
+    assert min(ps)[0] > 0.88 and np.median([c for c, _ in ps]) > 0.91
     tr.close()
+
+
+FP8_PRODUCTS = ["encoder.block.0.layer.0.SelfAttention.q.weight", "encoder.block.0.layer.1.DenseReluDense.wi_0.weight",
+                "encoder.block.0.layer.1.DenseReluDense.wo.weight", "encoder.block.5.layer.0.SelfAttention.v.weight",
+                "encoder.block.5.layer.1.DenseReluDense.wi_1.weight", "encoder.block.5.layer.1.DenseReluDense.wo.weight",
+                "decoder.block.5.layer.0.SelfAttention.q.weight", "decoder.block.5.layer.1.EncDecAttention.k.weight",
+                "decoder.block.5.layer.1.EncDecAttention.o.weight", "decoder.block.5.layer.2.DenseReluDense.wo.weight"]
+
+
+def test_fp8_products_of_layers_0_5_11_teacher_forced_at_the_config_shape(c4):
+    """VERDICT r3 #5.  The end-to-end fp8 bar above is the emulation's own chaos floor (~0.95 at 6 + 6 layers): a wrong scale on ONE
+    late product would hide under it.  Here the compounding is taken out: the MX-emulating oracle runs once at the config shape
+    (16 x 261 x 256) and records, for ten projections of the first encoder layer, the last encoder layer and the last decoder layer
+    (the 12th), the product's bf16 input x, its output gradient dy and its weight; the DEVICE then computes each of the three
+    products from those same tensors — forward y = Qk(x) Qk(W)^T and dX = Qn(dy) Qn(W^T)^T through the kernel the fp8 step runs
+    (mxgemm_q_kernel: bf16 operand quantised in the staging, m2m_mx8_matmul_bf16a fused), dW = Qm(dy^T) Qm(x^T)^T through the
+    quantiser + product pair (m2m_mx8_matmul_f32) — and each is held to the emulation of THAT product: relative l2 <= 3e-4
+    (measured on MI355X: 3.4e-6 ... 4.1e-5 over the 30 products — the matrix core's limited-precision accumulate; the one-layer
+    whole-step bar is cosine 0.98: a product on its own has no flips to compound, so it is held three orders tighter).  The forward outputs are also compared with what the oracle's own pass produced (same tensors: bit-for-bit the
+    emulation formula)."""
+    import ctypes as C
+    from music2midi_amd import native
+    from oracle.mx8 import mx_quant_dequant
+    lib = native.load()
+    orc = c4["orc"]
+    orc.capture = {k: {} for k in FP8_PRODUCTS}
+    orc.mx8, orc.mx8_dw, orc.bf16 = True, True, True
+    try:
+        orc.loss_and_grads(c4["feats"], c4["cond"], c4["labels"])
+    finally:
+        orc.mx8, orc.mx8_dw, orc.bf16 = False, False, False
+        cap, orc.capture = orc.capture, None
+
+    def dev_bf16a(a, b):            # a [M, K] (bf16-representable), b [N, K] fp32 -> fp32 [M, N]; the fused-quantisation kernel of the step
+        a16 = a.to(torch.bfloat16).cuda().contiguous()
+        b_d = b.cuda().contiguous()
+        c_d = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32, device="cuda")
+        native.check(lib.m2m_mx8_matmul_bf16a(a16.data_ptr(), b_d.data_ptr(), a.shape[0], b.shape[0], a.shape[1], 0, 1, c_d.data_ptr(), native.stream_handle()),
+                     "m2m_mx8_matmul_bf16a")
+        return c_d.cpu()
+
+    def dev_f32(a, b):
+        a_d, b_d = a.cuda().contiguous(), b.cuda().contiguous()
+        c_d = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32, device="cuda")
+        native.check(lib.m2m_mx8_matmul_f32(a_d.data_ptr(), b_d.data_ptr(), a.shape[0], b.shape[0], a.shape[1], 0, c_d.data_ptr(), native.stream_handle()),
+                     "m2m_mx8_matmul_f32")
+        return c_d.cpu()
+
+    def agree(got, want):
+        g, w = got.reshape(-1).double(), want.reshape(-1).double()
+        return float(torch.dot(g, w) / (g.norm() * w.norm() + 1e-300)), float((g - w).norm() / (w.norm() + 1e-300))
+
+    worst = (1.0, 0.0, "")
+    for name in FP8_PRODUCTS:
+        rec = cap[name]
+        assert {"x", "y", "dy"} <= set(rec), (name, sorted(rec))
+        w = orc.w(name).detach()
+        x2 = rec["x"].reshape(-1, rec["x"].shape[-1]).bfloat16().float()
+        dy2 = rec["dy"].reshape(-1, rec["dy"].shape[-1]).bfloat16().float()
+        want_y = mx_quant_dequant(x2, "e4m3") @ mx_quant_dequant(w, "e4m3").T
+        assert torch.equal(want_y, rec["y"].reshape(want_y.shape)), name                     # the recorded pass used this very formula
+        want_dx = mx_quant_dequant(dy2, "e4m3") @ mx_quant_dequant(w.T.contiguous(), "e4m3").T
+        want_dw = mx_quant_dequant(dy2.T.contiguous(), "e4m3") @ mx_quant_dequant(x2.T.contiguous(), "e4m3").T
+        res = {"fwd": agree(dev_bf16a(x2, w), want_y), "dx": agree(dev_bf16a(dy2, w.T.contiguous()), want_dx),
+               "dw": agree(dev_f32(dy2.T.contiguous(), x2.T.contiguous()), want_dw)}
+        print(f"[fp8 product] {name} x {tuple(x2.shape)} dy {tuple(dy2.shape)}: " + "; ".join(f"{k} cos {c:.7f} rel l2 {r:.2e}" for k, (c, r) in res.items()))
+        for k, (c, r) in res.items():
+            assert np.isfinite(c) and c >= 0.999999 and r <= 3e-4, (name, k, c, r)
+            if c < worst[0]:
+                worst = (c, r, f"{name} {k}")
+    print(f"[fp8 product] worst of {3 * len(FP8_PRODUCTS)} products: cosine {worst[0]:.7f} (rel l2 {worst[1]:.2e}) at {worst[2]}")
 
 
 def test_dropout_step_is_reproducible_and_graph_replay_equals_direct_issue_at_the_config_shape(c4, monkeypatch):
