@@ -21,7 +21,7 @@
 // ((clip*H + head) * Sq + query) * ldp + key, hashed ONCE (forward), so the oracle regenerates them; the relative-position-bias
 // gradient leaves pass B as per-query-block diagonal sums — summed on the matrix core from a skewed copy of the dS tile — in the layout
 // the stripe kernel used (bias_stripes_sum_kernel / bias_bucket_kernel are unchanged).  fp32 (parity) mode, fp32 storage and sequences
-// beyond AH_MAX_S keep the stripe path.  DESIGN.md 4.8 has the measurements, including what was tried and removed.
+// beyond AH_MAX_S keep the stripe path.  DESIGN_HISTORY.md 4.8 has the measurements, including what was tried and removed.
 #include "mma.h"
 #include "t5.h"
 #include "train.h"

@@ -344,7 +344,7 @@ static bool use_graph() { return env_int("M2M_NO_GRAPH", 0) != 1; }
 
 // Split the B encoded clips into independent chains: M2M_GROUP_ROWS clips per chain (default 32:
 // one 32-row MFMA tile of clips per chain), at most MAX_GROUPS chains.  Measured at B = 32 on
-// MI355X: 1 chain 322 ms, 2 chains 315 ms, 4 chains 666 ms (dispatch-bound) - see DESIGN.md.
+// MI355X: 1 chain 322 ms, 2 chains 315 ms, 4 chains 666 ms (dispatch-bound) - see DESIGN_HISTORY.md 4.4.
 static int plan_groups(m2m_session* s) {
   // Default: TWO chains once there are enough clips to split (B >= 24), one otherwise.  Two graph chains on two
   // streams overlap one chain's latency phases (prologue, merge tail, feed-forward, lm_head / head) with the other's

@@ -1623,19 +1623,22 @@ __global__ void cond_gather_kernel(const float* __restrict__ params, const int64
 // ids[i * id_stride + id_off] is the id of activation row (i * x_row_stride + x_row_off).
 // thresh != 0: dx arrives through the dropout on the embeddings (hf: T5Stack dropout(inputs_embeds)); only the rows that are READ
 // here are masked, as they are read.
+// NW waves per block: 16 for the shared embedding (round 4: the hot row's ~700 matches are 6 batches of loads per wave instead of 22;
+// the launch's time IS that row), 4 for the small conditioning tables.
 constexpr int EMB_ROWS_IN_FLIGHT = 8;
-__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, int n_ids, int id_stride, int id_off,
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void embed_bwd_kernel(const int64_t* __restrict__ ids, int n_ids, int id_stride, int id_off,
                                                         const float* __restrict__ dx, int64_t x_row_stride, int64_t x_row_off,
                                                         float* __restrict__ gtab, int d, int pad_to_zero_id, int V, DropKey dk, uint32_t thresh,
                                                         float scale) {
   extern __shared__ __align__(16) int emb_smem[];
   int* list = emb_smem;                                          // [round_up_4(n_ids)]
-  float* part = reinterpret_cast<float*>(list + ((n_ids + 3) & ~3));      // [4][256 * 4]: one column block of the four waves' sums
-  __shared__ int wave_cnt[4];
+  float* part = reinterpret_cast<float*>(list + ((n_ids + 3) & ~3));      // [NW][256]: one column block of the waves' sums
+  __shared__ int wave_cnt[NW];
   const uint64_t dkey = thresh ? drop_site_key(dk) : 0ull;
   const int v = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int cnt = 0;
-  for (int i0 = 0; i0 < n_ids; i0 += 256) {
+  for (int i0 = 0; i0 < n_ids; i0 += 64 * NW) {
     const int i = i0 + threadIdx.x;
     bool match = false;
     if (i < n_ids) {
@@ -1648,7 +1651,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
     __syncthreads();
     int base = cnt, all = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) { const int c = wave_cnt[w]; if (w < wave) base += c; all += c; }
+    for (int w = 0; w < NW; ++w) { const int c = wave_cnt[w]; if (w < wave) base += c; all += c; }
     if (match) list[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
     cnt += all;
     __syncthreads();
@@ -1657,12 +1660,12 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
     const int c = c0 + 4 * lane;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c < d) {
-      for (int k0 = wave; k0 < cnt; k0 += 4 * EMB_ROWS_IN_FLIGHT) {
+      for (int k0 = wave; k0 < cnt; k0 += NW * EMB_ROWS_IN_FLIGHT) {
         float4 rows[EMB_ROWS_IN_FLIGHT];
         uint32_t keep[EMB_ROWS_IN_FLIGHT];
 #pragma unroll
         for (int rr = 0; rr < EMB_ROWS_IN_FLIGHT; ++rr) {
-          const int k = k0 + 4 * rr;
+          const int k = k0 + NW * rr;
           rows[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
           keep[rr] = 0xFu;
           if (k < cnt) {
@@ -1684,11 +1687,17 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
     *reinterpret_cast<float4*>(part + wave * 256 + 4 * lane) = acc;
     __syncthreads();
     const int cc = c0 + threadIdx.x;
-    if (cc < d) gtab[(int64_t)v * d + cc] = ((part[threadIdx.x] + part[256 + threadIdx.x]) + part[512 + threadIdx.x]) + part[768 + threadIdx.x];
+    if (threadIdx.x < 256 && cc < d) {                           // the waves' partial rows in wave order: a fixed order of additions
+      float sum = part[threadIdx.x];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) sum += part[256 * w + threadIdx.x];
+      gtab[(int64_t)v * d + cc] = sum;
+    }
     __syncthreads();
   }
 }
-static size_t embed_bwd_smem(int n_ids) { return (size_t)((n_ids + 3) & ~3) * 4 + 4 * 256 * 4; }
+constexpr int EMB_NW_SHARED = 16;      // waves per block of the shared-embedding launch
+static size_t embed_bwd_smem(int n_ids, int nw = EMB_NW_SHARED) { return (size_t)((n_ids + 3) & ~3) * 4 + (size_t)nw * 256 * 4; }
 // Final norm of a stack with the dropout that follows it (hf: T5Stack dropout(final_layer_norm(x))): y = T(x * rstd * w), then the
 // mask on the ROUNDED value, as the separate in-place pass did — one wave per row, one launch instead of two.
 template <typename T>
@@ -3260,8 +3269,8 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
   // token embedding (decoder inputs; the encoder is fed inputs_embeds) — hf: modeling_t5.py embed_tokens = shared
   {
     const bool dr = o.dropping(SITE_DEC + SITE_EMB);
-    M2M_OPT_IN_LDS(embed_bwd_kernel, 158 * 1024);
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(V), dim3(256), embed_bwd_smem(Md), st, t->dec_in, Md, 1, 0, dcur, (int64_t)1, (int64_t)0, G + t->o_shared, d,
+    M2M_OPT_IN_LDS(embed_bwd_kernel<EMB_NW_SHARED>, 158 * 1024);
+    hipLaunchKernelGGL(embed_bwd_kernel<EMB_NW_SHARED>, dim3(V), dim3(64 * EMB_NW_SHARED), embed_bwd_smem(Md), st, t->dec_in, Md, 1, 0, dcur, (int64_t)1, (int64_t)0, G + t->o_shared, d,
                        g.pad_token_id, V, dr ? o.key(SITE_DEC + SITE_EMB) : DropKey{nullptr, 0}, dr ? t->drop_thresh : 0u, t->drop_scale);
   }
   // Split pass (data-parallel overlap): everything the decoder side deferred is issued now, so the gradients of the shared embedding,
@@ -3305,7 +3314,7 @@ int forward_backward_t(m2m_trainer* t, const float* P, const float* enc_inputs, 
   // conditioning embeddings: rows 0 .. n_cond-1 of every clip's encoder input (ref: music2midi/input.py:57-59)
   for (int i = 0; i < t->n_cond; ++i) {
     const bool dr = o.dropping(SITE_ENC + SITE_EMB);
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(t->cond_rows[i]), dim3(256), embed_bwd_smem(B), small, cond_idx, B, t->n_cond, i, dcur, (int64_t)S, (int64_t)i,
+    hipLaunchKernelGGL(embed_bwd_kernel<4>, dim3(t->cond_rows[i]), dim3(256), embed_bwd_smem(B, 4), small, cond_idx, B, t->n_cond, i, dcur, (int64_t)S, (int64_t)i,
                        G + t->o_cond[i], d, 0, t->cond_rows[i], dr ? o.key(SITE_ENC + SITE_EMB) : DropKey{nullptr, 0}, dr ? t->drop_thresh : 0u,
                        t->drop_scale);
   }
@@ -3340,11 +3349,11 @@ extern "C" int m2m_trainer_create(const m2m_t5_geometry* geom, int n_cond, const
   M2M_REQUIRE(geom->d_kv == DK, "m2m_trainer_create: d_kv=%d unsupported (64 only)", geom->d_kv);
   M2M_REQUIRE(geom->d_model % 64 == 0 && geom->d_model <= 512 && geom->d_ff % 8 == 0, "m2m_trainer_create: d_model must be a multiple of 64 (<= 512), d_ff of 8");
   M2M_REQUIRE(n_cond >= 0 && n_cond <= 8 && max_batch >= 1 && max_enc_len > n_cond && max_dec_len >= 1, "m2m_trainer_create: bad sizes");
-  // embed_bwd_kernel keeps the pass's whole id list in LDS (embed_bwd_smem: 4 bytes per label position + 4 KiB against the 158 KiB opt-in)
+  // embed_bwd_kernel keeps the pass's whole id list in LDS (embed_bwd_smem: 4 bytes per label position + 16 KiB against the 158 KiB opt-in)
   M2M_REQUIRE(embed_bwd_smem(max_batch * max_dec_len) <= (size_t)158 * 1024,
               "m2m_trainer_create: max_batch * max_dec_len = %d label positions per pass exceed the %d the shared-embedding gradient kernel "
               "lists in LDS; use a smaller dataloader batch or shorter label sequences (the reference trains 16 x <= ~360)",
-              max_batch * max_dec_len, (int)((158 * 1024 - 4 * 256 * 4) / 4));
+              max_batch * max_dec_len, (int)((158 * 1024 - EMB_NW_SHARED * 256 * 4) / 4));
   m2m_trainer* t = new m2m_trainer();
   t->g = *geom; t->precision = precision; t->inner = geom->num_heads * geom->d_kv; t->n_cond = n_cond;
   t->es = precision == M2M_PREC_BF16 ? 2 : 4;

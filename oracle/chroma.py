@@ -21,7 +21,7 @@ holds no test vectors for this path.
 Silent frames: ref evaluation.py:15-18 stores NaN into an int array and then indexes the last element
 of an EMPTY array under ``numba.njit`` (no bounds check): undefined values.  This oracle (and the
 product) read such a frame as *unvoiced* (frequency 0), the reading the metric's own voicing logic
-expects; the difference is documented in DESIGN.md, not imitated.
+expects; the difference is documented in DESIGN_HISTORY.md (section 7), not imitated.
 """
 from __future__ import annotations
 

@@ -10,7 +10,7 @@ KV cache with argmax / pad-after-EOS / stop-at-max_length greedy semantics.
 
 ``emulate="bf16"`` rounds to bfloat16 at exactly the points where the device's
 bf16 mode stores bf16 (weights, GEMM inputs, KV caches); all accumulation,
-norms, softmax and GELU stay fp32 — see DESIGN.md "Precision modes".
+norms, softmax and GELU stay fp32 — see DESIGN.md section 2 (precision modes).
 """
 from __future__ import annotations
 

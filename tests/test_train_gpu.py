@@ -624,7 +624,7 @@ def test_whole_head_attention_step_against_autograd_and_the_stripe_path(cfg_name
 
 
 def test_trainer_rejects_more_label_positions_than_the_embedding_gradient_lists():
-    """embed_bwd_kernel keeps the pass's id list in LDS (4 B per label position + 4 KiB, 158 KiB opt-in); a trainer
+    """embed_bwd_kernel keeps the pass's id list in LDS (4 B per label position + 16 KiB, 158 KiB opt-in); a trainer
     sized beyond that failed at its first launch with a generic HIP error.  Now m2m_trainer_create says so (64 x 640 labels), and
     the size just inside the limit is accepted."""
     from music2midi_amd import native
@@ -633,4 +633,4 @@ def test_trainer_rejects_more_label_positions_than_the_embedding_gradient_lists(
     model = T5Transformer(cfg, precision="fp32").cuda()
     with pytest.raises(native.NativeError, match="label positions per pass"):
         NativeTrainer(model, 64, 23, 640, precision="bf16")
-    NativeTrainer(model, 64, 23, 608, precision="bf16").close()          # 38 912 positions <= 39 424
+    NativeTrainer(model, 64, 23, 560, precision="bf16").close()          # 35 840 positions <= 36 352

@@ -1,4 +1,4 @@
-// Traffic-and-synchronisation MODEL of a persistent, XCD-local decode step ("the one restructuring the numbers do
+// Traffic-and-synchronisation MODEL of a persistent, XCD-local decode step (DESIGN_HISTORY.md 4.5: "the one restructuring the numbers do
 // not rule out"): no arithmetic of the model, only what bounds it — every workgroup streams the bytes its (clip, head) role would
 // stream (projection weights shared per head through the XCD's L2, the self / cross K/V of its clip, its feed-forward weight slice)
 // and hands 384-float partial rows over through the XCD's L2 exactly as tools/xcd_barrier.hip measured it (plain stores, a flag

@@ -7,7 +7,7 @@ i=0
 for C in "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT -o p$i -- \
-    python3 bench.py --steps 1 --warmup 0 --no-roofline --no-parity --no-frontend --no-train --cpu-tokens 0 --max-length 33 > $OUT/p$i.log 2>&1 || tail -3 $OUT/p$i.log
+    python3 bench.py --steps 1 --warmup 0 --no-roofline --no-parity --no-native --no-frontend --no-train --cpu-tokens 0 --max-length 33 > $OUT/p$i.log 2>&1 || tail -3 $OUT/p$i.log
 done
 python3 - <<'PY'
 import csv, collections, glob

@@ -6,7 +6,7 @@ mkdir -p $OUT
 i=0
 for G in "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $G --output-format csv -d $OUT -o p$i -- python3 bench.py --steps 1 --warmup 0 --no-roofline --no-parity --no-frontend --no-train --cpu-tokens 0 --max-length 257 > $OUT/p$i.log 2>&1 || tail -3 $OUT/p$i.log
+  rocprofv3 --kernel-trace --pmc $G --output-format csv -d $OUT -o p$i -- python3 bench.py --steps 1 --warmup 0 --no-roofline --no-parity --no-native --no-frontend --no-train --cpu-tokens 0 --max-length 257 > $OUT/p$i.log 2>&1 || tail -3 $OUT/p$i.log
 done
 python3 - $OUT <<'PY'
 import csv, collections, glob, sys

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=${PMC_OUT:-gpurun_out/pmc_mfma}
 mkdir -p $OUT
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --output-format csv -d $OUT -o mfma -- \
-  python3 bench.py --steps 1 --warmup 0 --no-roofline --no-parity --no-frontend --no-train --cpu-tokens 0 --max-length 33 > $OUT/mfma.log 2>&1 || tail -5 $OUT/mfma.log
+  python3 bench.py --steps 1 --warmup 0 --no-roofline --no-parity --no-native --no-frontend --no-train --cpu-tokens 0 --max-length 33 > $OUT/mfma.log 2>&1 || tail -5 $OUT/mfma.log
 python3 - <<'PY'
 import csv, collections, glob
 import os

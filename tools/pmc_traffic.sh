@@ -8,7 +8,7 @@ OUT=${PMC_OUT:-gpurun_out/pmc_traffic}
 mkdir -p $OUT
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT -o $C -- \
-    python3 bench.py --steps 1 --warmup 0 --no-roofline --no-parity --no-frontend --no-train --cpu-tokens 0 --max-length 49 > $OUT/$C.log 2>&1 || tail -5 $OUT/$C.log
+    python3 bench.py --steps 1 --warmup 0 --no-roofline --no-parity --no-native --no-frontend --no-train --cpu-tokens 0 --max-length 49 > $OUT/$C.log 2>&1 || tail -5 $OUT/$C.log
 done
 python3 - <<'PY'
 import csv, collections, glob
@@ -26,7 +26,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         agg[k][0] += 1; agg[k][1] += float(r["Counter_Value"])
     res[c] = agg
 # clips per decode-kernel launch of the profiled run (bench.py reads this header and refuses a summary without it): the bench
-# decodes 32 clips per GPU as chains of M2M_GROUP_ROWS clips (default: two chains of 16 from 24 clips on)
+# decodes 32 clips per GPU as chains of M2M_GROUP_ROWS clips (default: two chains of 16 from 24 clips on, DESIGN_HISTORY.md 4.4)
 batch = int(os.environ.get("PMC_BATCH", "32"))
 rows = int(os.environ.get("M2M_GROUP_ROWS") or (16 if batch >= 24 else batch))
 with open(out + "/summary.txt", "w") as fh:

@@ -1,5 +1,5 @@
 // Microbenchmark: how fast can ONE workgroup per CU pull a K/V-like stream (16 bytes per lane per load, every byte used
-// once) — the ceiling of the decode attention kernels' stream phase (~38 GB/s per CU measured in-kernel).
+// once) — the ceiling of the decode attention kernels' stream phase (DESIGN_HISTORY.md 4.3: ~38 GB/s per CU measured in-kernel).
 // Sweeps the number of workgroups (128 = one chain of 16 clips, 256 = the whole chip), the rounds each wave keeps in
 // flight, the cache policy (non-temporal / default) and whether the data can sit in the Infinity Cache.
 //   hipcc --offload-arch=gfx950 -O3 tools/stream_rate.hip -o /tmp/stream_rate && /tmp/stream_rate

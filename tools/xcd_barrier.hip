@@ -1,5 +1,5 @@
 // Microbenchmark: can the 8 head-workgroups of a clip hand their partial rows over THROUGH THEIR XCD'S L2, without the
-// memory-side atomics / kernel boundary the decode step pays today (~2 us gap + 2.4 us to read the row back)?
+// memory-side atomics / kernel boundary the decode step pays today (DESIGN_HISTORY.md 4.3: ~2 us gap + 2.4 us to read the row back)?
 // Workgroups find their XCD from HW_REG_XCC_ID, claim a (group, member) slot of that XCD, and every phase:
 //   write a 384-float partial row to part[group][member] -> wait for the stores -> write flag[group][member] = phase ->
 //   poll the 8 flags of the group -> read the 8 partial rows and add them in a fixed order (checked against the exact sum).
