@@ -455,6 +455,9 @@ __global__ __launch_bounds__(64 * WAVES) void logmel_v2_kernel(const float* __re
   const float sg2 = (m2 & 2) ? -1.f : 1.f, sg1 = (m2 & 1) ? -1.f : 1.f;
   const float rc = (m2 == 3) ? 0.f : 1.f, rs_ = (m2 == 3) ? 1.f : 0.f;
 
+  int fstart[NJ];                                                // this lane's filter starts: NJ registers instead of NJ LDS reads per frame
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) fstart[j] = fbs_s[lane + 64 * j];
   for (int ch = 0; ch < NCH; ++ch, f0 += FR) {
     if (f0 >= F) break;                                          // uniform
     const float* const samples = lds + ((ch & 1) ? L.samples1 : 0);
@@ -517,11 +520,15 @@ __global__ __launch_bounds__(64 * WAVES) void logmel_v2_kernel(const float* __re
       // exchange 2 (Z image -> pairs (k, 1024 - k), k = lane + 64 i), again by planes.  Lane 0's partners are irregular: k = 0
       // pairs with itself, k = 256 with Z[768], which sits behind one more padding step than the other lanes' partners.
       float2 zk[8], zn[8];
-      float z512x, z512y, z768x, z768y;
+      // Z[512] and Z[768] are register 0 of lanes 1 and 3 (k = k1 + 16 q1 + 256 q2, q2 = bitrev2(m2)): lane 0, the only lane that
+      // needs them, takes them with v_readlane instead of four more LDS reads per frame
+      const float z512x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z[0].x), 1));
+      const float z512y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z[0].y), 1));
+      const float z768x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z[0].x), 3));
+      const float z768y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z[0].y), 3));
       if (M2M_FE2_SKIP & 4) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) { zk[i] = z[i]; zn[i] = z[8 + i]; }
-        z512x = z[0].x; z512y = z[1].y; z768x = z[2].x; z768y = z[3].y;
       } else {
 #pragma unroll
       for (int q1 = 0; q1 < 16; ++q1) zw[16 * q1] = z[q1].x;
@@ -530,8 +537,6 @@ __global__ __launch_bounds__(64 * WAVES) void logmel_v2_kernel(const float* __re
         zk[i].x = zr[64 * i + 8 * (i >> 2)];
         zn[i].x = znr[456 - 64 * i - 8 * (i >> 2)];
       }
-      z512x = scr[zidx8(512)];
-      z768x = scr[zidx8(768)];
 #pragma unroll
       for (int q1 = 0; q1 < 16; ++q1) zw[16 * q1] = z[q1].y;
 #pragma unroll
@@ -539,8 +544,6 @@ __global__ __launch_bounds__(64 * WAVES) void logmel_v2_kernel(const float* __re
         zk[i].y = zr[64 * i + 8 * (i >> 2)];
         zn[i].y = znr[456 - 64 * i - 8 * (i >> 2)];
       }
-      z512y = scr[zidx8(512)];
-      z768y = scr[zidx8(768)];
       }
       if (ln == 0) { zn[0] = zk[0]; zn[4] = make_float2(z768x, z768y); }
       // split / post-process: X[k] = E + W2048^k O, X[1024 - k] = conj(E - W2048^k O); the power bins overwrite the planes
@@ -571,14 +574,13 @@ __global__ __launch_bounds__(64 * WAVES) void logmel_v2_kernel(const float* __re
       float* orow = out + (int64_t)b * out_bstride + (int64_t)(row_offset + f0 + fl) * n_mels + ln;
       float res[NJ];
       {
-        const int* const fsp = fbs_s + ln;
         const float4* fw = reinterpret_cast<const float4*>(fbw_s) + ln;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           res[j] = 0.f;
           if (64 * j >= n_mels) break;                             // uniform
           const int nq = (M2M_FE2_SKIP & 1) ? 1 : fe.gq[j];
-          const float* p = scr + fsp[64 * j];
+          const float* p = scr + fstart[j];
           float4 wq = fw[0];
           float p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3];
           float acc = 0.f;
