@@ -707,7 +707,9 @@ def main():
         state = synth.t5_state_dict(geom, seed=0)
         load_t5_state(model, state, strict=False)
     model = model.to(dev).eval()
-    bcast_bytes = D.broadcast_module_state(model, src=0)
+    # inference in the bf16 mode: the GEMM weights travel as bf16 (61 MB, SURVEY C4's figure); training and the fp32 mode need the masters
+    bf16_bcast = args.mode != "train" and args.precision == "bf16" and os.environ.get("M2M_BCAST_FP32") != "1"
+    bcast_bytes = D.broadcast_module_state(model, src=0, gemm_dtype=torch.bfloat16 if bf16_bcast else None)
 
     if args.precision == "fp8" and args.mode != "train":
         print("[bench] --precision fp8 is a training mode (use --mode train)", file=sys.stderr)
@@ -768,7 +770,8 @@ def main():
                                    + (f"; configs[3] sharding over {world} GPUs" if world > 1 else ""),
                        "global_batch": B * world, "clips_per_gpu": B, "new_tokens_per_clip": toks.shape[1] - 1,
                        "parallelism": f"clip-sharded x{world}", "weight_broadcast_bytes": bcast_bytes,
-                       "weight_broadcast_dtype": "fp32 master weights (each rank repacks to bf16 locally)",
+                       "weight_broadcast_dtype": ("GEMM weights bf16 + embeddings / norms / tables fp32 (receivers repack bit-identically)" if bf16_bcast
+                                                  else "fp32 master weights (each rank repacks locally)"),
                        "world": torch.distributed.get_world_size() if world > 1 else 1,
                        "backend": torch.distributed.get_backend() if world > 1 else "none"},
         }

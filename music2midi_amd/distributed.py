@@ -55,29 +55,51 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def broadcast_module_state(module: torch.nn.Module, src: int = 0) -> int:
-    """Broadcast every parameter and buffer of ``module`` from ``src`` as one flat fp32 buffer.
+def _gemm_weight(name: str, t: torch.Tensor) -> bool:
+    """The tensors the bf16 mode's kernels read as bf16 GEMM operands (every 2-D weight except the token embedding, the
+    relative-position-bias tables and the conditioning tables, which stay fp32 on the device): the set oracle/t5.py rounds."""
+    return t.dim() == 2 and not any(k in name for k in ("relative_attention_bias", "shared", "embed_tokens", "conditioning", "mel_scale", "spectrogram"))
 
-    Returns the number of bytes sent.  No-op without an initialised process group.
+
+def broadcast_module_state(module: torch.nn.Module, src: int = 0, gemm_dtype: Optional[torch.dtype] = None) -> int:
+    """Broadcast every parameter and buffer of ``module`` from ``src``.
+
+    Default: ONE flat fp32 buffer (121.6 MB for the reference's model: the master weights travel, every rank repacks them
+    identically, either precision mode can follow).  ``gemm_dtype=torch.bfloat16`` — for a run that decodes in the bf16 mode —
+    sends the GEMM weights (``_gemm_weight``: 30.2 M of the 30.4 M parameters) as bfloat16 and the rest in fp32: two buffers,
+    61.4 MB, the size SURVEY C4 gives the broadcast.  Receiving ranks hold the bf16 values upcast to fp32; repacking rounds
+    to bf16 again, which is the identity on them, so every rank's device weights are bit-identical to rank 0's — and to a
+    single-GPU run (rank 0 keeps its fp32 masters).  Returns the number of bytes sent.  No-op without a process group.
     """
-    tensors = [t for t in list(module.parameters()) + list(module.buffers())]
+    named = list(module.named_parameters(remove_duplicate=False)) + list(module.named_buffers(remove_duplicate=False))
     seen, uniq = set(), []
-    for t in tensors:   # shared tensors (embed_tokens aliases) travel once
+    for name, t in named:   # shared tensors (embed_tokens aliases) travel once
         if t.data_ptr() not in seen:
             seen.add(t.data_ptr())
-            uniq.append(t)
+            uniq.append((name, t))
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return 0
-    dev = uniq[0].device
-    flat = torch.cat([t.detach().reshape(-1).to(torch.float32) for t in uniq]).to(dev)
-    dist.broadcast(flat, src=src)
-    off = 0
-    with torch.no_grad():
-        for t in uniq:
-            n = t.numel()
-            t.copy_(flat[off:off + n].view_as(t).to(t.dtype))
-            off += n
-    return flat.numel() * 4
+    dev = uniq[0][1].device
+    groups = [(torch.float32, uniq)]
+    if gemm_dtype is not None and gemm_dtype != torch.float32:
+        groups = [(gemm_dtype, [(n, t) for n, t in uniq if _gemm_weight(n, t)]), (torch.float32, [(n, t) for n, t in uniq if not _gemm_weight(n, t)])]
+    sent = 0
+    is_src = dist.get_rank() == src
+    for dt, items in groups:
+        if not items:
+            continue
+        flat = torch.cat([t.detach().reshape(-1).to(dt) for _, t in items]).to(dev)
+        dist.broadcast(flat, src=src)
+        sent += flat.numel() * flat.element_size()
+        if is_src and dt != torch.float32:
+            continue                      # the source keeps its fp32 masters (its repack rounds them the same way)
+        off = 0
+        with torch.no_grad():
+            for _, t in items:
+                n = t.numel()
+                t.copy_(flat[off:off + n].view_as(t).to(t.dtype))
+                off += n
+    return sent
 
 
 def all_gather_tokens(tokens: torch.Tensor, max_length: int, pad_id: int = 0) -> torch.Tensor:

@@ -240,3 +240,52 @@ def test_gloo_world2_checkpoint_is_written_by_rank_zero_only(tmp_path):
         p.join(180)
         assert p.exitcode == 0
     assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]
+
+
+def _bf16_bcast_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import copy
+    from music2midi_amd.config import DEFAULT_CONFIG
+    from music2midi_amd.transformer import T5Transformer
+    D.init_process_group("gloo")
+    cfg = copy.deepcopy(DEFAULT_CONFIG)
+    cfg["model"]["t5"].update(d_model=128, d_ff=256, num_layers=1, num_decoder_layers=1, num_heads=2)
+    torch.manual_seed(50 + rank)
+    m = T5Transformer(cfg, precision="bf16")
+    torch.manual_seed(50)
+    ref = T5Transformer(cfg, precision="bf16")                  # rank 0's weights, rebuilt locally
+    n_params = sum(p.numel() for p in m.parameters())
+    sent = D.broadcast_module_state(m, src=0, gemm_dtype=torch.bfloat16)
+    got, want = dict(m.named_parameters()), dict(ref.named_parameters())
+    n_gemm = 0
+    for k, w in want.items():
+        gemm = D._gemm_weight(k, w)
+        n_gemm += w.numel() if gemm else 0
+        if rank == 0:
+            assert torch.equal(got[k], w), k                                           # the source keeps its fp32 masters
+        elif gemm:
+            assert torch.equal(got[k], w.detach().bfloat16().float()), k               # bf16 on the wire, upcast on arrival
+            assert torch.equal(got[k].bfloat16(), w.detach().bfloat16()), k            # -> the repacked device weights are bit-identical
+        else:
+            assert torch.equal(got[k], w), k                                           # embeddings / norms / tables: exact fp32
+    assert any(D._gemm_weight(k, w) for k, w in want.items()) and not D._gemm_weight("transformer.shared.weight", want["transformer.shared.weight"])
+    n_buf = sum(b.numel() for b in m.buffers())
+    assert sent == 2 * n_gemm + 4 * (n_params - n_gemm + n_buf), (sent, n_gemm, n_params, n_buf)
+    dist.destroy_process_group()
+    q.put(rank)
+
+
+def test_gloo_world2_bf16_weight_broadcast_repacks_bit_identically():
+    """SURVEY C4 sizes the inference weight broadcast at bf16 (60.8 MB); round 3 sent the fp32 masters (121.6 MB).  With
+    gemm_dtype=bfloat16 the GEMM weights travel as bf16 and everything the device keeps in fp32 travels as fp32: the receiving
+    ranks' repacked weights equal rank 0's bit for bit (rounding to bf16 is idempotent)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bf16_bcast_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]
