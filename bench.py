@@ -583,7 +583,9 @@ def train_step_record(model_module, cfg, geom, dev, B: int, precision: str, step
     flops = 3 * B * (enc + dec)                                    # forward + 2x backward, dense products only (SURVEY 8d formulas)
     peak = MFMA_PEAK_TFLOPS["fp8" if precision == "fp8" else "bf16"]
     rec = {"workload": f"BASELINE configs[4]: train step (log-mel + forward + backward + Adafactor), {precision} GEMM inputs, "
-                       f"{B} clips/GPU x {TRAIN_SAMPLES} samples (S={S}), {TRAIN_LABELS} labels/clip, dropout {'off' if dropout == 0.0 else dropout}",
+                       f"{B} clips/GPU x {TRAIN_SAMPLES} samples (S={S}), {TRAIN_LABELS} labels/clip, dropout {'off' if dropout == 0.0 else dropout}"
+                       + ("; NOTE: at this per-GPU batch the MXFP8 mode is SLOWER than bf16 (4.7 vs 3.9 ms: the products are latency-bound, 8-15 % matrix-core busy)"
+                          if precision == "fp8" else ""),
            "ms_per_step": dt * 1e3, "clips_per_s": B * world / dt, "label_tokens_per_s": B * world * TRAIN_LABELS / dt,
            "model_TFLOPs_per_gpu": flops / dt / 1e12, "loss": float(loss), "grad_allreduce_bytes": nbytes,
            "roofline": {"bound": "mfma", "flops_per_step": flops, "achieved": flops / dt / 1e12, "peak": peak, "unit": "TFLOP/s",
