@@ -136,25 +136,31 @@ class Music2MIDI(nn.Module):
         ``trainer.fit(ckpt_path=)``) read.  Under data parallelism only global rank 0 writes (as Lightning does), into a temporary
         file that is renamed over ``path`` once complete — a reader never sees a torn file — and every rank leaves through a
         barrier, so a ``resume_from_checkpoint`` that follows on any rank reads the finished file."""
+        failure = None
         if D.is_rank_zero():
-            tr = self._trainer
-            opt = tr.optimizer_state_hf() if tr is not None else {"state": {}, "param_groups": []}     # reads the device: rank 0 only
-            torch.cuda.synchronize(self.device) if self.device.type == "cuda" else None
-            path = Path(path)
-            tmp = path.with_name(f".{path.name}.tmp{os.getpid()}")
             try:
-                torch.save({
-                    "epoch": int(getattr(self, "current_epoch", 0)), "global_step": int(self.global_step), "pytorch-lightning_version": "2.1.0",
-                    "state_dict": {k: v.detach().cpu().clone() for k, v in self.state_dict().items()},
-                    "callbacks": {}, "optimizer_states": [opt],
-                    "lr_schedulers": [{"base_lrs": [0.0], "last_epoch": int(self.global_step), "_step_count": int(self.global_step) + 1}],
-                    "hparams_name": "kwargs", "hyper_parameters": dict(self.hparams),
-                }, tmp)
-                os.replace(tmp, path)
-            finally:
-                if tmp.exists():
-                    tmp.unlink()
+                tr = self._trainer
+                opt = tr.optimizer_state_hf() if tr is not None else {"state": {}, "param_groups": []}     # reads the device: rank 0 only
+                torch.cuda.synchronize(self.device) if self.device.type == "cuda" else None
+                path = Path(path)
+                tmp = path.with_name(f".{path.name}.tmp{os.getpid()}")
+                try:
+                    torch.save({
+                        "epoch": int(getattr(self, "current_epoch", 0)), "global_step": int(self.global_step), "pytorch-lightning_version": "2.1.0",
+                        "state_dict": {k: v.detach().cpu().clone() for k, v in self.state_dict().items()},
+                        "callbacks": {}, "optimizer_states": [opt],
+                        "lr_schedulers": [{"base_lrs": [0.0], "last_epoch": int(self.global_step), "_step_count": int(self.global_step) + 1}],
+                        "hparams_name": "kwargs", "hyper_parameters": dict(self.hparams),
+                    }, tmp)
+                    os.replace(tmp, path)
+                finally:
+                    if tmp.exists():
+                        tmp.unlink()
+            except Exception as e:           # the other ranks are on their way to the barrier: meet them there before raising
+                failure = e
         D.barrier()
+        if failure is not None:
+            raise failure
 
     def resume_from_checkpoint(self, path) -> None:
         """Weights, Adafactor state and step counter of a ``.ckpt`` written by ``save_checkpoint`` or by Lightning."""
