@@ -235,3 +235,25 @@ def test_training_surface_fails_loudly_without_gpu_and_binding_matches_header():
     batch = ModelInputs(input_waveform=torch.zeros(1, 4096), notes_batch=(np.array([[0.0, 0.5, 60, 80]]),), cond_index=torch.zeros(1, 2, dtype=torch.long))
     with pytest.raises(native.NativeError):
         m.training_step(batch, 0)
+
+
+def test_bench_uses_the_oracle_only_in_its_cpu_baseline_legs():
+    """bench.py may time the oracle (cpu_baseline / cpu_frontend_baseline / cpu_train_baseline: checker code, outside the timed
+    region) and may read fixtures; nothing else in it — in particular no record computed from device results, such as the forced
+    parity record, which goes through tests/forced_check.py and the committed fixture — may import it."""
+    import ast
+    tree = ast.parse((ROOT / "bench.py").read_text())
+    offenders = []
+    for fn in [n for n in ast.walk(tree) if isinstance(n, (ast.FunctionDef, ast.AsyncFunctionDef))]:
+        for n in ast.walk(fn):
+            mod = n.module if isinstance(n, ast.ImportFrom) else None
+            names = [a.name for a in n.names] if isinstance(n, ast.Import) else []
+            if (mod and mod.split(".")[0] == "oracle") or any(x.split(".")[0] == "oracle" for x in names):
+                if not fn.name.startswith("cpu_"):
+                    offenders.append(fn.name)
+    top = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom))]
+    assert not any((getattr(n, "module", None) or "").startswith("oracle") or any(a.name.startswith("oracle") for a in n.names) for n in top)
+    assert not offenders, offenders
+    # the forced-parity helper bench.py shares with the tests imports the oracle only inside case_inputs(), which bench.py never calls
+    src = (ROOT / "bench.py").read_text()
+    assert "case_inputs" not in src
