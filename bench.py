@@ -252,7 +252,9 @@ def _round_of(name: str) -> int:
 def _bf16_noise_margin(case: str) -> float:
     """1.5 x the largest change of (top-1 - top-2) the bf16-emulating oracle shows against itself under a 1e-6 input perturbation
     along the forced sequence (tests/golden/t5_forced.npz, `self_noise_margin`): the measured floor tests/test_golden_gpu.py uses."""
-    return 1.5 * float(np.load(ROOT / "tests" / "golden" / "t5_forced.npz")[f"{case}/self_noise_margin"][0])
+    sys.path.insert(0, str(ROOT / "tests")) if str(ROOT / "tests") not in sys.path else None
+    from forced_check import bf16_margin_threshold
+    return bf16_margin_threshold(np.load(ROOT / "tests" / "golden" / "t5_forced.npz"), case)
 
 
 def golden_divergence(ids_bf16, ids_fp32) -> dict:
@@ -279,7 +281,7 @@ def golden_divergence(ids_bf16, ids_fp32) -> dict:
     bf = first_div(ids_bf16, z["bench_clips_bf16/ids"].astype(np.int64), z["bench_clips_bf16/margins"])
     fp = first_div(ids_fp32, z["bench_clips_fp32/ids"].astype(np.int64), z["bench_clips_fp32/margins"])
     return {"bf16_vs_bf16_oracle_first_divergence": bf, "bf16_noise_margin": noise_margin,
-            "bf16_noise_margin_source": "1.5 x the bf16-emulating oracle's own largest top-2 margin change under a 1e-6 input perturbation (t5_forced.npz)",
+            "bf16_noise_margin_source": "min(0.5, 1.5 x the bf16-emulating oracle's own largest top-2 margin change under a 1e-6 input perturbation, median of 5 seeds; t5_forced.npz)",
             "bf16_divergences_above_noise_margin": int(sum(1 for r in bf if r["step"] >= 0 and (r["oracle_margin"] is None or r["oracle_margin"] >= noise_margin))),
             "fp32_vs_fp32_oracle_first_divergence": [r["step"] for r in fp]}
 
@@ -310,6 +312,16 @@ def forced_parity_record(cfg, geom, dev, model_bf16, model_fp32, x_bench2) -> di
         out[f"{prec}_forced_p999_logit_err"] = max(r["p999_logit_err"] for r in recs)
         out[f"{prec}_forced_mean_logit_err"] = float(np.mean([r["mean_logit_err"] for r in recs]))
         out[f"{prec}_forced_logit_err_bars"] = [r["logit_err_bars_max_p999_mean"] for r in recs]
+    # ... and the bf16 mode against the FP32 reference itself, to fixed absolute bars (nothing here comes from the emulation)
+    from forced_check import forced_bf16_vs_fp32
+    mfull = T5Transformer(cfg.to_dict(), precision="bf16")
+    load_t5_state(mfull, sd, strict=False)
+    mfull = mfull.to(dev).eval()
+    cross = [forced_bf16_vs_fp32(mfull, x_full, "full_s864_fp32"), forced_bf16_vs_fp32(model_bf16, x_bench2, "bench_clips_fp32")]
+    del mfull
+    out["bf16_vs_fp32_oracle_forced_max_p999_mean_logit_err"] = [r["max_p999_mean_logit_err_vs_fp32_oracle"] for r in cross]
+    out["bf16_vs_fp32_oracle_forced_bars"] = cross[0]["bars"]
+    out["bf16_vs_fp32_oracle_forced_argmax_agree"] = int(sum(r["argmax_agree_with_fp32_oracle"] for r in cross))
     out["forced_note"] = ("oracle ids forced through the KV-cached decode kernels (M2M_FORWARD=step), S=864, 1023 positions x 4 clips, batch 32 "
                           "(16 bit-identical copies); bf16 bars = the bf16-emulating oracle's own noise floor x (1.5, 1.3, 1.2) on (max, p99.9, mean); "
                           "logit scale ~75-85")
@@ -430,6 +442,17 @@ def dry_run(args):
     torch.manual_seed(1234 + rank)                      # ranks start from DIFFERENT weights ...
     model = T5Transformer(cfg.to_dict(), precision=args.precision)
     bcast = D.broadcast_module_state(model, src=0)      # ... and must all end up with rank 0's
+    # first-multi-GPU-run insurance: MIN / MAX all-reduce of a 64-bit checksum of every rank's replica, raising on a
+    # difference; M2M_BENCH_CORRUPT_RANK (test hook) flips one weight on one rank AFTER the broadcast to prove the check bites
+    if os.environ.get("M2M_BENCH_CORRUPT_RANK") == str(rank):
+        with torch.no_grad():
+            model.transformer.lm_head.weight[3, 5] += 1.0
+    try:
+        replicas = D.verify_replicas({"masters_fp32": D.module_checksum(model), "as_bf16_repack": D.module_checksum(model, torch.bfloat16)}, "cpu")
+    except RuntimeError as e:
+        print(f"[bench] rank {rank}: {e}", file=sys.stderr, flush=True)
+        sys.exit(4)
+    per_rank_ms = D.all_gather_floats(1.0 + rank, "cpu")
     probe = float(model.transformer.lm_head.weight.double().sum())
     B = args.batch
     lo = rank * B
@@ -443,10 +466,12 @@ def dry_run(args):
                           "n_gpus": world, "dry_run": True, "backend": torch.distributed.get_backend() if world > 1 else "none",
                           "world": torch.distributed.get_world_size() if world > 1 else 1,
                           "gather_ok": bool(ok), "weights_identical_on_all_ranks": pmin == pmax,
+                          "ranks_seen": replicas["ranks_seen"], "replica_checksums": replicas["checksums"],
+                          "per_rank_ms_per_step": per_rank_ms,
                           "config": {"weight_broadcast_bytes": bcast, "global_batch": B * world}}), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
-    return 0 if ok and pmin == pmax else 1
+    return 0 if ok and pmin == pmax and replicas["ranks_seen"] == world and per_rank_ms == [1.0 + r for r in range(world)] else 1
 
 
 def dry_run_train(args, rank: int, world: int) -> int:
@@ -712,6 +737,14 @@ def main():
     # inference in the bf16 mode: the GEMM weights travel as bf16 (61 MB, SURVEY C4's figure); training and the fp32 mode need the masters
     bf16_bcast = args.mode != "train" and args.precision == "bf16" and os.environ.get("M2M_BCAST_FP32") != "1"
     bcast_bytes = D.broadcast_module_state(model, src=0, gemm_dtype=torch.bfloat16 if bf16_bcast else None)
+    replicas = None
+    if world > 1:
+        # first-multi-GPU-run insurance: every rank's REPACKED device weights (the bytes the kernels read) and its torch-side replica
+        # must checksum alike — MIN / MAX all-reduce, a difference raises on every rank before anything is timed
+        sums = {"torch_replica": D.module_checksum(model, torch.bfloat16 if bf16_bcast else None)}
+        if args.mode != "train":
+            sums["device_repacked"] = model.device_weights_checksum()
+        replicas = D.verify_replicas(sums, dev)
 
     if args.precision == "fp8" and args.mode != "train":
         print("[bench] --precision fp8 is a training mode (use --mode train)", file=sys.stderr)
@@ -753,6 +786,7 @@ def main():
     torch.cuda.synchronize(dev)
     D.barrier()
     elapsed = time.perf_counter() - t0
+    per_rank_ms = [e / args.steps * 1e3 for e in D.all_gather_floats(elapsed, dev)]
     elapsed = D.all_reduce_max(elapsed, dev)
     new_tokens_local = (toks.shape[1] - 1) * B
     total_tokens = D.all_reduce_sum(float(new_tokens_local), dev) * args.steps
@@ -777,6 +811,10 @@ def main():
                        "world": torch.distributed.get_world_size() if world > 1 else 1,
                        "backend": torch.distributed.get_backend() if world > 1 else "none"},
         }
+        if world > 1:     # proof that the collectives saw N ranks with identical replicas, and each rank's own clock
+            out["ranks_seen"] = replicas["ranks_seen"]
+            out["replica_checksums"] = replicas["checksums"]
+            out["per_rank_ms_per_step"] = per_rank_ms
 
     # ---- phase timings + roofline of the dominant kernel (rank 0 only, N = 1) ----
     if rank == 0 and world == 1 and not args.no_roofline:

@@ -146,6 +146,11 @@ int  m2m_model_create(const m2m_t5_geometry* geom, const m2m_t5_weights* w, int 
 void m2m_model_destroy(m2m_model* m);
 int  m2m_model_precision(const m2m_model* m);
 int64_t m2m_model_param_bytes(const m2m_model* m);   /* bytes of repacked weights held */
+/* 64-bit position-weighted checksum of the repacked device weights (sum of word_i * (2 i + 1) mod 2^64 over the
+ * whole packed blob), synchronised before returning.  After the one-time weight broadcast of a multi-GPU run
+ * (ref: train.py:40-41 strategy="ddp") every rank's value must be equal: the ranks all-reduce MIN and
+ * MAX of it and fail loudly on a difference instead of decoding from diverged replicas. */
+int  m2m_model_checksum(const m2m_model* m, uint64_t* out_host, void* stream);
 
 /* T5 relative-position bucket (hf: models/t5/modeling_t5.py:217-262), host-side,
  * exported so the integer table can be tested without a GPU. rel = key_pos - query_pos. */

@@ -353,6 +353,11 @@ __global__ __launch_bounds__(FE_THREADS, M2M_FE_WGS_PER_CU) void logmel_kernel(
 #ifndef M2M_FE2_SKIP        // diagnostic builds only (timing of the kernel with a part removed; results are wrong):
 #define M2M_FE2_SKIP 0      // 1 mel taps, 2 exchange 1, 4 exchange 2, 8 the two radix-16 passes, 16 table reads, 32 logf, 64 stores, 128 DPP stage
 #endif
+// Lanes of a wave exchange data through LDS here.  The hardware executes one wave's LDS operations in order, so no instruction is
+// needed between a write phase and the dependent read phase (or a read phase and the writes that overwrite what it read) — but
+// the COMPILER must not move a ds_read above the ds_write of another lane's value: a wavefront-scope release fence plus
+// wave_barrier emits nothing and pins the order (the first form above does the same at every exchange).
+#define V2_LANES_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 constexpr int V2_PITCH = 68;                 // floats per k1 row of a transpose plane
 constexpr int V2_SCR = 16 * V2_PITCH;        // floats of per-wave scratch (planes, then the 1 025 + 48 power bins)
 constexpr int V2_NPRE = 6;                   // prefetch registers per thread (samples of the next chunk: 5 888 / 1 024 threads at hop 256)
@@ -495,14 +500,19 @@ __global__ __launch_bounds__(64 * WAVES) void logmel_v2_kernel(const float* __re
       // exchange 1, one plane at a time: lane (k1, m2) takes l = 4 m1 + m2 of row k1
       if (!(M2M_FE2_SKIP & 2)) {
       float zre[16];
+      V2_LANES_SYNC();                                             // the previous frame's mel reads are done with the scratch
 #pragma unroll
       for (int k1 = 0; k1 < 16; ++k1) sw[k1 * V2_PITCH] = z[k1].x;
+      V2_LANES_SYNC();
 #pragma unroll
       for (int m1 = 0; m1 < 16; ++m1) zre[m1] = sr[4 * m1];
+      V2_LANES_SYNC();
 #pragma unroll
       for (int k1 = 0; k1 < 16; ++k1) sw[k1 * V2_PITCH] = z[k1].y;
+      V2_LANES_SYNC();
 #pragma unroll
       for (int m1 = 0; m1 < 16; ++m1) z[m1] = make_float2(zre[m1], sr[4 * m1]);
+      V2_LANES_SYNC();
       }
       if (!(M2M_FE2_SKIP & 8)) fft16(z);
 #pragma unroll
@@ -532,22 +542,26 @@ __global__ __launch_bounds__(64 * WAVES) void logmel_v2_kernel(const float* __re
       } else {
 #pragma unroll
       for (int q1 = 0; q1 < 16; ++q1) zw[16 * q1] = z[q1].x;
+      V2_LANES_SYNC();
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         zk[i].x = zr[64 * i + 8 * (i >> 2)];
         zn[i].x = znr[456 - 64 * i - 8 * (i >> 2)];
       }
+      V2_LANES_SYNC();
 #pragma unroll
       for (int q1 = 0; q1 < 16; ++q1) zw[16 * q1] = z[q1].y;
+      V2_LANES_SYNC();
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         zk[i].y = zr[64 * i + 8 * (i >> 2)];
         zn[i].y = znr[456 - 64 * i - 8 * (i >> 2)];
       }
+      V2_LANES_SYNC();                                             // every lane has its pairs: the power bins may overwrite the planes
       }
       if (ln == 0) { zn[0] = zk[0]; zn[4] = make_float2(z768x, z768y); }
       // split / post-process: X[k] = E + W2048^k O, X[1024 - k] = conj(E - W2048^k O); the power bins overwrite the planes
-      // (the LDS executes a wave's operations in order: every read above is served before the writes below)
+      // (the LDS executes a wave's operations in order and V2_LANES_SYNC pins that order for the compiler)
       float* const pk = scr + ln;                                  // bins lane + 64 i
       float* const pn = scr + 1024 - ln;                           // bins 1024 - lane - 64 i
       const float2* const tpp = twp_s + ln;
@@ -564,6 +578,7 @@ __global__ __launch_bounds__(64 * WAVES) void logmel_v2_kernel(const float* __re
       }
       if (ln == 0) scr[512] = z512x * z512x + z512y * z512y;      // k = 512: E = Re Z, O = Im Z, W2048^512 = -i
       if (ln < 48) scr[1025 + ln] = 0.f;                           // the padded taps of the last filters read (and ignore) these
+      V2_LANES_SYNC();                                             // the mel taps below read bins other lanes wrote
       // mel filterbank (4-tap chunks: one aligned 16-byte weight read + four power-bin reads; the next chunk is requested before
       // this chunk's multiply-adds) + clamp + log.  The power-bin reads are dword reads from per-lane starts a few bins apart:
       // they collide on the 32 banks a b32 read sees (272 LDS cycles per frame for 48 reads = every bank conflict the kernel has,
@@ -750,7 +765,8 @@ extern "C" int m2m_logmel_f32(const m2m_frontend* fe, const float* wav_dev, int 
   M2M_REQUIRE(out_batch_stride >= (int64_t)(row_offset + F) * fe->n_mels,
               "m2m_logmel_f32: out_batch_stride %lld smaller than (row_offset+frames)*n_mels", (long long)out_batch_stride);
   // Second form (one 16-wave workgroup per CU, tables and half-plane exchanges in LDS, four waves per SIMD) whenever its LDS image
-  // fits: every configuration the reference uses (hop 256, 384 mels).  M2M_FE_V2=0 keeps the first form (and other hops use it).
+  // fits: hop <= 272 (15 hop + 2048 samples in 6 prefetch registers per thread) and the tap table inside 160 KB, i.e. every configuration
+  // the reference uses (hop 256, 384 mels) and e.g. hop 128.  Longer hops, and M2M_FE_V2=0, run the first form.
   {
     constexpr int WAVES = 16;
     const V2Layout L = v2_layout(WAVES, fe->hop, fe->n_wpad);

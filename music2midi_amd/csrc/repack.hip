@@ -52,6 +52,27 @@ int launch_interleave(int precision, const float* wi0, const float* wi1, void* d
   return M2M_OK;
 }
 
+// 64-bit position-weighted checksum of a device buffer (32-bit words w_i): sum of w_i * (2 i + 1) mod 2^64.  Integer adds in any
+// order give the same value, so it is reproducible; the odd multipliers make it sensitive to WHERE a word sits, not only to the
+// multiset of words.  Used after the multi-GPU weight broadcast: every rank's repacked weights must be the same bytes.
+__global__ __launch_bounds__(256) void checksum_kernel(const uint32_t* __restrict__ w, int64_t n, unsigned long long* __restrict__ acc) {
+  __shared__ unsigned long long part[4];
+  unsigned long long s = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    s += (unsigned long long)w[i] * (unsigned long long)(2 * i + 1);
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(acc, part[0] + part[1] + part[2] + part[3]);
+}
+
+int launch_checksum(const void* buf, int64_t bytes, unsigned long long* acc_dev, hipStream_t st) {
+  const int64_t n = bytes / 4;
+  hipLaunchKernelGGL(checksum_kernel, dim3(grid_for(n)), dim3(256), 0, st, (const uint32_t*)buf, n, acc_dev);
+  M2M_CHECK_HIP(hipGetLastError());
+  return M2M_OK;
+}
+
 int launch_copy_f32(const float* src, float* dst, int64_t n, hipStream_t st) {
   M2M_CHECK_HIP(hipMemcpyAsync(dst, src, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, st));
   return M2M_OK;

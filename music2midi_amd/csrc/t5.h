@@ -187,6 +187,7 @@ int launch_interleave(int precision, const float* wi0, const float* wi1, void* d
                       hipStream_t st);
 int launch_copy_f32(const float* src, float* dst, int64_t n, hipStream_t st);
 int launch_fill_zero(void* dst, int64_t bytes, hipStream_t st);
+int launch_checksum(const void* buf, int64_t bytes, unsigned long long* acc_dev, hipStream_t st);
 
 // decoder-side (decode.hip)
 int decode_init(m2m_session* s, const DecView& v, int max_steps, bool forced, hipStream_t st);

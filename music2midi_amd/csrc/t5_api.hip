@@ -88,6 +88,8 @@ extern "C" int m2m_model_create(const m2m_t5_geometry* geom, const m2m_t5_weight
   }
   unsigned char* base = (unsigned char*)m->blob;
   int rc = M2M_OK;
+  // the alignment gaps between the packed tensors are part of what m2m_model_checksum covers: they must not be allocator garbage
+  if (hipMemsetAsync(m->blob, 0, (size_t)off, st) != hipSuccess) { set_error("m2m_model_create: hipMemsetAsync failed"); rc = M2M_ERR_HIP; }
   auto conv = [&](const float* src, int64_t o, int64_t n) {
     if (rc == M2M_OK && !src) { set_error("m2m_model_create: null layer weight pointer"); rc = M2M_ERR_INVALID; }
     if (rc == M2M_OK) rc = launch_convert(precision, src, base + o, n, st);
@@ -157,6 +159,24 @@ extern "C" void m2m_model_destroy(m2m_model* m) {
 }
 extern "C" int m2m_model_precision(const m2m_model* m) { return m ? m->precision : M2M_ERR_INVALID; }
 extern "C" int64_t m2m_model_param_bytes(const m2m_model* m) { return m ? m->blob_bytes : (int64_t)M2M_ERR_INVALID; }
+
+extern "C" int m2m_model_checksum(const m2m_model* m, uint64_t* out_host, void* stream) {
+  M2M_REQUIRE(m && out_host, "m2m_model_checksum: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  unsigned long long* acc = nullptr;
+  M2M_CHECK_HIP(hipMalloc((void**)&acc, sizeof(unsigned long long)));       // once per run, never on the hot path
+  unsigned long long host = 0;
+  hipError_t e = hipMemsetAsync(acc, 0, sizeof(unsigned long long), st);
+  int rc = M2M_OK;
+  if (e == hipSuccess) rc = launch_checksum(m->blob, m->blob_bytes, acc, st);
+  if (e == hipSuccess && rc == M2M_OK) e = hipMemcpyAsync(&host, acc, sizeof(host), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess && rc == M2M_OK) e = hipStreamSynchronize(st);
+  (void)hipFree(acc);
+  if (rc != M2M_OK) return rc;
+  if (e != hipSuccess) { set_error("m2m_model_checksum: %s", hipGetErrorString(e)); return M2M_ERR_HIP; }
+  *out_host = (uint64_t)host;
+  return M2M_OK;
+}
 
 // ---------------------------------------------------------------- session ---
 namespace {
@@ -579,8 +599,13 @@ extern "C" int m2m_bench_kernel(m2m_session* s, int which, int self_len, int ite
   int rc;
   // every chain sees a live loop in its (self_len)-th step
   DecState hs{}; hs.t = self_len - 1; hs.t_copy = self_len - 1; hs.done = 0; hs.out_len = 1; hs.n_unfinished = 0; hs.max_steps = s->max_dec;
-  for (int i = 0; i < G; ++i)
-    M2M_CHECK_HIP(hipMemcpyAsync(s->groups[i].view.state, &hs, sizeof(hs), hipMemcpyHostToDevice, s->groups[i].stream));
+  for (int i = 0; i < G; ++i) {
+    const DecGroup& gr = s->groups[i];
+    M2M_CHECK_HIP(hipMemcpyAsync(gr.view.state, &hs, sizeof(hs), hipMemcpyHostToDevice, gr.stream));
+    // ... with every row live: after a generate whose rows emitted EOS the finished-row early-out would skip those rows' K/V
+    // streams in the timed launches while bytes_host below counts them in full
+    M2M_CHECK_HIP(hipMemsetAsync(s->finished + gr.view.b0, 0, (size_t)gr.view.nb * sizeof(int), gr.stream));
+  }
   for (int i = 0; i < G; ++i) M2M_CHECK_HIP(hipStreamSynchronize(s->groups[i].stream));
   hipEvent_t e0, e1;
   M2M_CHECK_HIP(hipEventCreate(&e0));

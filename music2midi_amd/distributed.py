@@ -102,6 +102,75 @@ def broadcast_module_state(module: torch.nn.Module, src: int = 0, gemm_dtype: Op
     return sent
 
 
+def module_checksum(module: torch.nn.Module, gemm_dtype: Optional[torch.dtype] = None) -> int:
+    """64-bit position-weighted checksum of a module's parameters and buffers AS A RUN IN ``gemm_dtype`` WILL REPACK THEM (GEMM
+    weights rounded to that type, everything else fp32): sum of word_i * (2 i + 1) mod 2^64 over the 16-bit / 32-bit words, tensor
+    after tensor in ``named_parameters`` + ``named_buffers`` order.  Integer arithmetic on the tensors' own device (plumbing, no
+    kernel of the path).  Equal on two ranks iff their replicas repack to the same bytes — the host-side twin of
+    ``T5Transformer.device_weights_checksum`` (which sums the library's packed blob itself), usable without a GPU (gloo tests)."""
+    named = list(module.named_parameters(remove_duplicate=False)) + list(module.named_buffers(remove_duplicate=False))
+    seen, total, base = set(), 0, 0
+    mask = (1 << 64) - 1
+    for name, t in named:
+        if t.data_ptr() in seen:
+            continue
+        seen.add(t.data_ptr())
+        x = t.detach().reshape(-1)
+        if gemm_dtype is not None and gemm_dtype != torch.float32 and _gemm_weight(name, t):
+            words = x.to(gemm_dtype).contiguous().view(torch.int16).to(torch.int64) & 0xFFFF
+        elif x.dtype == torch.float32:
+            words = x.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+        else:
+            words = x.to(torch.float64).contiguous().view(torch.int64)
+        n = words.numel()
+        if n == 0:
+            continue
+        idx = torch.arange(base, base + n, dtype=torch.int64, device=words.device)
+        # int64 multiply and sum wrap modulo 2^64, which is the arithmetic wanted
+        total = (total + int((words * (2 * idx + 1)).sum().item())) & mask
+        base += n
+    return total
+
+
+def verify_replicas(checksums: Dict[str, int], device) -> Dict[str, object]:
+    """All-reduce MIN and MAX of every named 64-bit checksum over the ranks and raise when a pair differs: a rank whose weights
+    are not rank 0's (a broadcast that did not reach it, a different repack) must stop the run, not decode different tokens.
+    Returns {"ranks_seen": world, "checksums": {name: hex}, "identical": True} — what bench.py prints at N > 1 so that the first
+    multi-GPU run proves RCCL saw N ranks with identical replicas."""
+    names = sorted(checksums)
+    vals = [int(checksums[k]) & ((1 << 64) - 1) for k in names]
+    signed = [v - (1 << 64) if v >= (1 << 63) else v for v in vals]          # two's complement: int64 tensors order consistently
+    world = 1
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        world = dist.get_world_size()
+        dev = torch.device("cpu") if dist.get_backend() == "gloo" else device
+        lo = torch.tensor(signed + [1], dtype=torch.int64, device=dev)
+        hi = lo.clone()
+        cnt = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        world = int(cnt.item())
+        bad = [k for k, a, b in zip(names, lo[:-1].tolist(), hi[:-1].tolist()) if a != b]
+        if bad:
+            raise RuntimeError(f"weight replicas differ between ranks after the broadcast: {bad} (this rank: "
+                               + ", ".join(f"{k}={checksums[k] & ((1 << 64) - 1):#018x}" for k in bad) + ")")
+        if world != dist.get_world_size():
+            raise RuntimeError(f"collective saw {world} ranks, the process group says {dist.get_world_size()}")
+    return {"ranks_seen": world, "checksums": {k: f"{v:#018x}" for k, v in zip(names, vals)}, "identical": True}
+
+
+def all_gather_floats(value: float, device) -> List[float]:
+    """One float per rank, in rank order (per-rank step times of a scaling run)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [float(value)]
+    dev = torch.device("cpu") if dist.get_backend() == "gloo" else device
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    parts = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    return [float(p.item()) for p in parts]
+
+
 def all_gather_tokens(tokens: torch.Tensor, max_length: int, pad_id: int = 0) -> torch.Tensor:
     """Local [B_local, L_local] ids -> global [sum B_local, L_global] in rank (= clip) order.
 
@@ -240,6 +309,18 @@ def is_rank_zero() -> bool:
 def barrier() -> None:
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
+
+
+def broadcast_flag(flag: int, device, src: int = 0) -> int:
+    """Rank ``src``'s integer flag on every rank (a collective: every rank calls it).  The exit of a rank-0-only action — unlike a
+    bare barrier it tells the other ranks whether the action FAILED, so they raise with rank 0 instead of running into the next
+    collective without it."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return int(flag)
+    dev = torch.device("cpu") if dist.get_backend() == "gloo" else device
+    t = torch.tensor([int(flag)], dtype=torch.int64, device=dev)
+    dist.broadcast(t, src=src)
+    return int(t.item())
 
 
 def all_reduce_max(value: float, device) -> float:

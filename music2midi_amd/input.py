@@ -124,10 +124,23 @@ class Conditioning(nn.Module):
         self.n_dim = int(n_dim)
         self.embeds = nn.ModuleList([nn.Embedding(num, n_dim) for num in num_embeds])
 
+    def check_indices(self, indices) -> None:
+        """Raise nn.Embedding's IndexError for a host-side index outside its table (ref: music2midi/input.py:57)."""
+        idx = torch.as_tensor(indices).reshape(-1, len(self.embeds)).long()
+        for i, e in enumerate(self.embeds):
+            col = idx[:, i]
+            if col.numel() and (int(col.min()) < 0 or int(col.max()) >= e.num_embeddings):
+                raise IndexError("index out of range in self")
+
     def write_rows(self, indices: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
         """Write the len(embeds) conditioning rows of every clip into ``out[:, :n, :]``."""
-        native.require_gpu()
         n = len(self.embeds)
+        if not torch.is_tensor(indices) or not indices.is_cuda:
+            # host-side indices (the generate() path hands over a Python list): nn.Embedding's IndexError without a device sync
+            # (ref input.py:57).  Device tensors keep the kernel's NaN-row guard instead — checking them would stall the stream.
+            indices = torch.as_tensor(indices)
+            self.check_indices(indices)
+        native.require_gpu()
         indices = indices.to(device=out.device, dtype=torch.long).contiguous()
         assert indices.shape == (out.shape[0], n), f"cond_index must be (batch, {n})"
         tabs = [e.weight.detach() for e in self.embeds]

@@ -129,15 +129,18 @@ class Music2MIDI(nn.Module):
         return D.reduce_logged(dict(getattr(self, "logged", {}) or {}), device=self.device)
 
     # -- checkpoints of a training run (ref train.py:41: trainer.fit(..., ckpt_path=args.ckpt)) ------------------------------
-    def save_checkpoint(self, path) -> None:
+    def save_checkpoint(self, path, collective: bool = True) -> None:
         """A Lightning-layout ``.ckpt`` of the run: ``state_dict`` (``model.*`` keys incl. the torchaudio buffers), the optimizer
         state as ``transformers.optimization.Adafactor.state_dict()`` lays it out (``optimizer_states[0]``), ``global_step``,
         ``hyper_parameters`` — what ``load_from_checkpoint`` and ``fit_batches(ckpt_path=)`` (and the reference's own
         ``trainer.fit(ckpt_path=)``) read.  Under data parallelism only global rank 0 writes (as Lightning does), into a temporary
         file that is renamed over ``path`` once complete — a reader never sees a torn file — and every rank leaves through a
-        barrier, so a ``resume_from_checkpoint`` that follows on any rank reads the finished file."""
+        broadcast of rank 0's outcome: a ``resume_from_checkpoint`` that follows on any rank reads the finished file, and when
+        rank 0 FAILED (disk full, permissions) every rank raises instead of walking into the next gradient all-reduce without it.
+        Like ``Trainer.save_checkpoint`` this is therefore a collective call: every rank must make it.  A caller that guards it
+        itself (``if rank == 0: model.save_checkpoint(p, collective=False)``) gets the plain single-process behaviour."""
         failure = None
-        if D.is_rank_zero():
+        if D.is_rank_zero() or not collective:
             try:
                 tr = self._trainer
                 opt = tr.optimizer_state_hf() if tr is not None else {"state": {}, "param_groups": []}     # reads the device: rank 0 only
@@ -158,7 +161,10 @@ class Music2MIDI(nn.Module):
                         tmp.unlink()
             except Exception as e:           # the other ranks are on their way to the barrier: meet them there before raising
                 failure = e
-        D.barrier()
+        if collective:
+            failed = D.broadcast_flag(1 if failure is not None else 0, self.device)
+            if failed and failure is None:
+                raise RuntimeError(f"save_checkpoint: global rank 0 failed to write {path} (see its error); nothing was saved")
         if failure is not None:
             raise failure
 
@@ -283,7 +289,9 @@ class Music2MIDI(nn.Module):
         rows = torch.zeros((n_rows, n_embeds))
         if cond_index is not None:
             rows = rows + torch.Tensor(cond_index)
-        return rows.long().to(self.device)
+        rows = rows.long()
+        self.model.conditioning.check_indices(rows)      # IndexError on the host, as nn.Embedding raises it (ref input.py:57)
+        return rows.to(self.device)
 
     @torch.no_grad()
     def sample_tokens(self, waveform: torch.Tensor, split_size: int, split_duration: float,

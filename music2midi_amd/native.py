@@ -76,6 +76,7 @@ _SIGNATURES = {
     "m2m_model_destroy": (None, [C.c_void_p]),
     "m2m_model_precision": (C.c_int, [C.c_void_p]),
     "m2m_model_param_bytes": (C.c_int64, [C.c_void_p]),
+    "m2m_model_checksum": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]),
     "m2m_rel_bucket": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "m2m_session_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "m2m_session_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64,

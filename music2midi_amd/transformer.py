@@ -252,6 +252,16 @@ class T5Transformer(nn.Module):
         self._model_handle, self._model_key = h, key
         return h
 
+    def device_weights_checksum(self) -> int:
+        """64-bit checksum of the REPACKED device weights the kernels read (``m2m_model_checksum``).  After the multi-GPU weight
+        broadcast every rank's value must be the same (``distributed.verify_replicas``)."""
+        h = self._get_model()
+        out = C.c_uint64(0)
+        dev = self.transformer.device
+        with torch.cuda.device(dev):
+            native.check(native.load().m2m_model_checksum(h, C.byref(out), native.stream_handle(dev)), "m2m_model_checksum")
+        return int(out.value)
+
     def _get_session(self, B: int, S: int, L: int):
         model = self._get_model()
         lib = native.load()

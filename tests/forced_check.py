@@ -24,8 +24,22 @@ FIXTURE = Path(__file__).resolve().parent / "golden" / "t5_forced.npz"
 # device's errors ARE that floor (max / 99.9th percentile / mean 0.411 / 0.333 / 0.0781 against 0.488 / 0.342 / 0.0789 on full_s864).
 # Bars: maximum <= 1.5 x, 99.9th percentile <= 1.3 x, mean <= 1.2 x the floor's; arg-max equal wherever the oracle's margin exceeds
 # 1.5 x the floor's largest margin change.  This replaces round 3's reasoned margin of 0.5.
+# Round 5: the floor is the MEDIAN over five perturbation seeds (one draw is one sample of a maximum; the per-seed values
+# are in the fixture), the arg-max threshold is capped at 0.5 — the margin round 3 reasoned, never looser — and the bf16 mode is
+# ALSO held to bars that do not come from the emulation at all: the device's bf16 logits, forced along the FP32 oracle's ids, against
+# the fp32 oracle's logits (`forced_bf16_vs_fp32`, BF16_VS_FP32_ABS: fixed absolute numbers on logits that reach 87; the emulation
+# itself sits at 0.62 / 0.48 / 0.114 there, fixture `bf16_emulation_err`).  A defect the size of the emulation's noise in ONE place
+# can hide under a noise-scaled bar; it cannot also keep the distance to the fp32 reference inside a fixed one.
 FP32_LOGIT_ERR_BOUND = 2e-3
 BF16_FLOOR_FACTORS = (1.5, 1.3, 1.2)          # on (max, 99.9th percentile, mean) of the stored self-noise
+BF16_ARGMAX_MARGIN_CAP = 0.5
+BF16_VS_FP32_ABS = (1.0, 0.70, 0.16)          # |device bf16 logit - fp32 oracle logit|: max, 99.9th percentile, mean
+
+
+def bf16_margin_threshold(z, case: str) -> float:
+    """Oracle top-2 margin above which the device's bf16 arg-max must equal the emulation's: 1.5 x the emulation's own largest margin
+    change (median over the perturbation seeds), never more than 0.5."""
+    return float(min(BF16_FLOOR_FACTORS[0] * float(z[f"{case}/self_noise_margin"][0]), BF16_ARGMAX_MARGIN_CAP))
 
 
 def forced_logits(model, x: torch.Tensor, dec_in: torch.Tensor, mode: str) -> np.ndarray:
@@ -67,7 +81,7 @@ def forced_check(model, x2: torch.Tensor, case: str, precision: str, copies: int
     else:
         floor, floor_m = z[f"{case}/self_noise_logit"], z[f"{case}/self_noise_margin"]
         bars = tuple(float(f * v) for f, v in zip(BF16_FLOOR_FACTORS, floor))
-        margin_thr = float(BF16_FLOOR_FACTORS[0] * floor_m[0])
+        margin_thr = bf16_margin_threshold(z, case)
     err_top = np.abs(np.take_along_axis(dev, top_i, axis=2) - top_v)      # [2, Ld, 4]
     err_full = np.abs(dev[:, steps] - full)                                # [2, n, V]
     errs = np.concatenate([err_top.ravel(), err_full.ravel()])
@@ -90,6 +104,32 @@ def forced_check(model, x2: torch.Tensor, case: str, precision: str, copies: int
                              f"at oracle margin {margins[b, t]:.4f} (> {margin_thr:.4g}); record {rec}")
     got = (rec["max_logit_err"], rec["p999_logit_err"], rec["mean_logit_err"])
     assert all(g <= b for g, b in zip(got, bars)), f"{case} [{precision}, {mode}]: |device - oracle| logit error max / p99.9 / mean {got} above {bars}; record {rec}"
+    return rec
+
+
+def forced_bf16_vs_fp32(model_bf16, x2: torch.Tensor, case_fp32: str, copies: int = 16, z=None) -> dict:
+    """The bf16 mode against the FP32 reference itself: the fp32 oracle's ids (fixture case `*_fp32`, pinned to HuggingFace) forced
+    through the bf16 decode kernels, |device logit - fp32 oracle logit| on the fixture's samples held to the fixed BF16_VS_FP32_ABS,
+    and the arg-max equal wherever the fp32 oracle's margin exceeds twice the measured maximum error."""
+    z = np.load(FIXTURE) if z is None else z
+    ids = z[f"{case_fp32}/ids"].astype(np.int64)
+    margins = z[f"{case_fp32}/margins"].astype(np.float64)
+    top_v, top_i = z[f"{case_fp32}/top_vals"].astype(np.float64), z[f"{case_fp32}/top_idx"].astype(np.int64)
+    steps, full = z[f"{case_fp32}/full_steps"].astype(np.int64), z[f"{case_fp32}/full_logits"].astype(np.float64)
+    Ld = ids.shape[1] - 1
+    dec_in = torch.from_numpy(ids[:, :Ld]).repeat(copies, 1)
+    xx = x2.repeat(copies, 1, 1).contiguous()
+    dev = forced_logits(model_bf16, xx, dec_in.to(xx.device), "step")[:2].astype(np.float64)
+    errs = np.concatenate([np.abs(np.take_along_axis(dev, top_i, axis=2) - top_v).ravel(), np.abs(dev[:, steps] - full).ravel()])
+    got = (float(errs.max()), float(np.quantile(errs, 0.999)), float(errs.mean()))
+    agree = dev.argmax(-1) == top_i[:, :, 0]
+    checked = margins > 2 * got[0]
+    rec = {"case": case_fp32, "positions": int(agree.size), "argmax_agree_with_fp32_oracle": int(agree.sum()),
+           "argmax_asserted_positions": int(checked.sum()), "max_p999_mean_logit_err_vs_fp32_oracle": list(got),
+           "bars": list(BF16_VS_FP32_ABS), "emulation_err_vs_fp32_oracle": [float(v) for v in z[f"{case_fp32}/bf16_emulation_err"]]
+           if f"{case_fp32}/bf16_emulation_err" in z else None, "logit_scale": float(np.abs(top_v).max())}
+    assert all(g <= b for g, b in zip(got, BF16_VS_FP32_ABS)), f"{case_fp32}: bf16 device vs fp32 oracle logit error max / p99.9 / mean {got} above {BF16_VS_FP32_ABS}; {rec}"
+    assert not (checked & ~agree).any(), f"{case_fp32}: bf16 arg-max differs from the fp32 oracle at a margin above twice the measured error; {rec}"
     return rec
 
 

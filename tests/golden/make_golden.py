@@ -184,6 +184,83 @@ def make_t5_bf16(out_path):
 
 
 # ------------------------------------------------------------------ forced-decode goldens: every position of the headline sequence
+NOISE_SEEDS = (123, 124, 125, 126, 127)
+
+
+def _forced_errs(lg, data, name):
+    """|logits - fixture| on the fixture's samples (top-4 of every position + all columns on the stride) and |d (top-1 - top-2)|."""
+    lg = lg.numpy().astype(np.float64)
+    steps = data[f"{name}/full_steps"].astype(np.int64)
+    tv, ti = data[f"{name}/top_vals"].astype(np.float64), data[f"{name}/top_idx"].astype(np.int64)
+    e = np.abs(np.take_along_axis(lg, ti, 2) - tv)
+    ef = np.abs(lg[:, steps] - data[f"{name}/full_logits"])
+    allv = np.concatenate([e.ravel(), ef.ravel()])
+    pm = np.take_along_axis(lg, ti[:, :, :2], 2)
+    dm = np.abs((pm[:, :, 0] - pm[:, :, 1]) - (tv[:, :, 0] - tv[:, :, 1]))
+    return (np.asarray([allv.max(), np.quantile(allv, 0.999), allv.mean()]), np.asarray([dm.max(), np.quantile(dm, 0.999), dm.mean()]))
+
+
+def forced_noise_floor(geom, name, sd, x, data) -> dict:
+    """The bf16 emulation's OWN noise floor along a forced sequence: the same forced pass with the inputs perturbed by 1e-6 (relative).
+    bfloat16 rounding decisions flip under any change of summation order, and the flips compound over 12 layers; two evaluations
+    that are not bit-identical in every GEMM input — device and emulation sum in different orders — cannot agree better than the
+    emulation agrees with itself here.  Stored per perturbation seed (one draw is one sample of a maximum): max / 99.9th
+    percentile / mean of |d logit| on the fixture's samples and of |d (top-1 - top-2)|, the quantity an arg-max flip depends on;
+    `self_noise_*` = the MEDIAN over the seeds of each statistic — what tests/forced_check.py scales its bars from."""
+    ids = torch.from_numpy(data[f"{name}/ids"].astype(np.int64))
+    lo, mg = [], []
+    for seed in NOISE_SEEDS:
+        noise = torch.from_numpy(synth.normal(seed, "noise", tuple(x.shape), 1.0))
+        _, lg = T5Oracle(geom, sd, emulate="bf16").forward(x * (1 + 1e-6 * noise), ids[:, 1:].clone())
+        a, b = _forced_errs(lg, data, name)
+        lo.append(a); mg.append(b)
+        print(f"[t5_forced] {name}: self-noise floor, seed {seed}: |d logit| max / p99.9 / mean {a}, |d margin| {b}", flush=True)
+    lo, mg = np.stack(lo), np.stack(mg)
+    return {f"{name}/self_noise_logit_seeds": lo, f"{name}/self_noise_margin_seeds": mg,
+            f"{name}/self_noise_logit": np.median(lo, 0), f"{name}/self_noise_margin": np.median(mg, 0)}
+
+
+def forced_bf16_vs_fp32(geom, name, sd, x, data) -> dict:
+    """What rounding to bfloat16 costs against the fp32 reference itself, on the oracle side: the bf16 EMULATION forced along the fp32
+    oracle's ids against the fp32 oracle's logits (max / p99.9 / mean on the fixture's samples, and of the top-2 margin).  The GPU
+    test holds the DEVICE's bf16 mode, forced along the same fp32 ids, to a fixed absolute bound next to this figure
+    (tests/forced_check.py BF16_VS_FP32_ABS) — a bar that does not come from the emulation's noise."""
+    ids = torch.from_numpy(data[f"{name}/ids"].astype(np.int64))
+    _, lg = T5Oracle(geom, sd, emulate="bf16").forward(x, ids[:, 1:].clone())
+    a, b = _forced_errs(lg, data, name)
+    print(f"[t5_forced] {name}: bf16 emulation vs the fp32 oracle along the fp32 ids: |d logit| max / p99.9 / mean {a}, |d margin| {b}", flush=True)
+    return {f"{name}/bf16_emulation_err": a, f"{name}/bf16_emulation_margin_err": b}
+
+
+def forced_cases(geom, cfg):
+    """(name stem, state dict, encoder inputs) of the three forced cases."""
+    from oracle.logmel import conditioning
+    sd = synth.t5_state_dict(geom, seed=0)
+    synth.perturb_layer_norms(sd, 0)
+    yield "full_s864", sd, embeds(2, 864, geom.d_model)
+    sd = synth.t5_state_dict(geom, seed=0)
+    sp = cfg["spectrogram"]
+    wav = torch.from_numpy(synth.waveform_batch(0, 2, 220500))
+    idx = torch.from_numpy(synth.cond_index_batch(0, 2))
+    emb = [torch.from_numpy(sd[f"conditioning.embeds.{i}.weight"]) for i in range(2)]
+    yield "bench_clips", sd, conditioning(LogMelOracle(cfg["model"]["sample_rate"], sp["n_fft"], sp["hop_length"], sp["f_min"], geom.d_model)(wav), idx, emb)
+    sd = synth.t5_state_dict(geom, seed=0)
+    synth.perturb_layer_norms(sd, 0)
+    yield "native_s190", sd, embeds(2, 190, geom.d_model)
+
+
+def make_t5_forced_noise(out_path):
+    """Recompute only the noise records of an existing t5_forced.npz (the floors over NOISE_SEEDS, the emulation-vs-fp32 figures) from
+    the ids it stores — the same helpers make_t5_forced calls, without repeating the six 1 023-step greedy decodes."""
+    cfg = ref_config()
+    geom = T5Geometry(dict(cfg["model"]["t5"]))
+    data = dict(np.load(out_path))
+    for stem, sd, x in forced_cases(geom, cfg):
+        data.update(forced_noise_floor(geom, f"{stem}_bf16", sd, x, data))
+        data.update(forced_bf16_vs_fp32(geom, f"{stem}_fp32", sd, x, data))
+    np.savez_compressed(out_path, **data)
+
+
 def make_t5_forced(out_path):
     """Teacher-forced pin of BOTH precision modes along the WHOLE headline sequence (S = 864, 1 023 positions; ref
     music2midi/transformer.py:41-45).  After a greedy divergence two decodes are different sequences and nothing further compares;
@@ -221,24 +298,9 @@ def make_t5_forced(out_path):
         print(f"[t5_forced] {name}: min margin {margins.min():.4f}, positions with margin < 0.5: {(margins < 0.5).sum().item()} of {margins.numel()}, "
               f"|logit| max {torch.stack(top_v, 1).abs().max():.1f}")
         if emulate == "bf16":
-            # The emulation's OWN noise floor: the same forced pass with the inputs perturbed by 1e-6 (relative).  bfloat16 rounding
-            # decisions flip under any change of summation order, and the flips compound over 12 layers; two evaluations that are not
-            # bit-identical in every GEMM input — device and emulation sum in different orders — cannot agree better than the
-            # emulation agrees with itself here.  Stored: max / 99.9th percentile / mean of |d logit| on the fixture's samples and of
-            # |d (top-1 - top-2)|, the quantity an arg-max flip depends on.
-            noise = torch.from_numpy(synth.normal(123, "noise", tuple(x.shape), 1.0))
-            _, lg = T5Oracle(geom, sd, emulate="bf16").forward(x * (1 + 1e-6 * noise), ids[:, 1:].clone())
-            lg = lg.numpy().astype(np.float64)
-            tv, ti = data[f"{name}/top_vals"].astype(np.float64), data[f"{name}/top_idx"].astype(np.int64)
-            e = np.abs(np.take_along_axis(lg, ti, 2) - tv)
-            ef = np.abs(lg[:, steps] - data[f"{name}/full_logits"])
-            allv = np.concatenate([e.ravel(), ef.ravel()])
-            pm = np.take_along_axis(lg, ti[:, :, :2], 2)
-            dm = np.abs((pm[:, :, 0] - pm[:, :, 1]) - (tv[:, :, 0] - tv[:, :, 1]))
-            data[f"{name}/self_noise_logit"] = np.asarray([allv.max(), np.quantile(allv, 0.999), allv.mean()])
-            data[f"{name}/self_noise_margin"] = np.asarray([dm.max(), np.quantile(dm, 0.999), dm.mean()])
-            print(f"[t5_forced] {name}: self-noise floor (1e-6 input perturbation) |d logit| max / p99.9 / mean {data[f'{name}/self_noise_logit']}, "
-                  f"|d margin| {data[f'{name}/self_noise_margin']}")
+            data.update(forced_noise_floor(geom, name, sd, x, data))
+        else:
+            data.update(forced_bf16_vs_fp32(geom, name, sd, x, data))
 
     sd = synth.t5_state_dict(geom, seed=0)
     synth.perturb_layer_norms(sd, 0)
@@ -426,6 +488,8 @@ if __name__ == "__main__":
         make_t5_bf16(HERE / "t5_bf16.npz")
     if not only or "t5_forced" in only:
         make_t5_forced(HERE / "t5_forced.npz")
+    if "t5_forced_noise" in only:
+        make_t5_forced_noise(HERE / "t5_forced.npz")
     for p in sorted(HERE.glob("*.npz")) + sorted(HERE.glob("*.json")):
         print(p.name, p.stat().st_size, "bytes")
     # never leave bytecode in the read-only reference tree

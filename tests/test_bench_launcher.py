@@ -28,6 +28,21 @@ def test_bench_spawns_one_rank_per_gpu_and_rank0_prints_one_json_line():
     assert rec["gather_ok"] and rec["weights_identical_on_all_ranks"]
     assert rec["config"]["global_batch"] == 6
     assert rec["config"]["weight_broadcast_bytes"] > 30_000_000 * 4       # every fp32 parameter travelled once
+    # first-multi-GPU-run insurance: the line proves the collectives saw 2 ranks, carries the replicas' 64-bit
+    # checksums (MIN == MAX over the ranks, or the run would have failed) and every rank's own step time
+    assert rec["ranks_seen"] == 2 and rec["per_rank_ms_per_step"] == [1.0, 2.0]
+    assert set(rec["replica_checksums"]) == {"masters_fp32", "as_bf16_repack"}
+    assert all(v.startswith("0x") and len(v) == 18 for v in rec["replica_checksums"].values())
+    assert rec["replica_checksums"]["masters_fp32"] != rec["replica_checksums"]["as_bf16_repack"]
+
+
+def test_bench_replica_checksum_catches_a_rank_with_different_weights():
+    """One weight of rank 1 changed after the broadcast (test hook): the MIN / MAX all-reduce of the checksums differs and EVERY
+    rank stops with the mismatch named — diverged replicas never reach the timed region."""
+    r = _run({"M2M_BENCH_CORRUPT_RANK": "1"})
+    assert r.returncode != 0
+    assert "weight replicas differ between ranks after the broadcast" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
 def test_bench_launcher_fails_when_a_rank_dies():

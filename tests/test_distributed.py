@@ -222,13 +222,29 @@ def _ckpt_worker(rank, world, port, path, q):
         assert torch.equal(torch.as_tensor(w), Music2MIDI(cfg).model.transformer.lm_head.weight.detach())
     D.barrier()
     assert [p.name for p in Path(path).parent.iterdir()] == [Path(path).name]        # no temporary file left behind
+    # rank 0 failing to write (here: the directory does not exist) must raise on EVERY rank — with a bare barrier the
+    # others returned normally and hung in the next gradient all-reduce
+    bad = str(Path(path).parent / "no_such_dir" / "x.ckpt")
+    try:
+        m.save_checkpoint(bad)
+        raise AssertionError("save_checkpoint into a missing directory did not raise")
+    except AssertionError:
+        raise
+    except Exception as e:
+        assert (rank == 0) or "rank 0 failed" in str(e), e
+    # the guarded calling pattern (`if rank == 0: save`) stays possible: collective=False makes no collective call
+    if rank == 0:
+        m.save_checkpoint(str(Path(path).parent / "guarded.ckpt"), collective=False)
+    D.barrier()
+    assert (Path(path).parent / "guarded.ckpt").exists()
     dist.destroy_process_group()
     q.put(rank)
 
 
 def test_gloo_world2_checkpoint_is_written_by_rank_zero_only(tmp_path):
     """fit_batches(save_path=) called save_checkpoint on every data-parallel rank onto one path.  Now rank 0
-    writes (temporary file + rename), every rank leaves through a barrier; Lightning writes on global rank 0 only (ref train.py:40-41)."""
+    writes (temporary file + rename), every rank leaves through a broadcast of rank 0's outcome (round 5: a failed write raises on
+    every rank); Lightning writes on global rank 0 only (ref train.py:40-41)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

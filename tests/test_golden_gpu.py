@@ -213,9 +213,10 @@ def test_bf16_vs_fp32_ids_at_headline_geometry():
 def _bf16_noise_margin(golden_dir, case):
     """Top-2 logit margin below which a bf16 decode may legitimately take the other token: 1.5 x the largest change of the top-1 -
     top-2 difference the bf16-emulating oracle shows against ITSELF under a 1e-6 input perturbation along the same 1 023 forced
-    positions (tests/golden/t5_forced.npz `self_noise_margin`, generator committed; 0.82 / 0.46 for the two cases) — a measured
-    floor (the device's own errors sit on it: test_every_position_of_the_headline_sequence_forced), replacing round 3's reasoned 0.5."""
-    return 1.5 * float(np.load(golden_dir / "t5_forced.npz")[f"{case}/self_noise_margin"][0])
+    positions (tests/golden/t5_forced.npz `self_noise_margin`, median over five perturbation seeds, generator committed), capped at
+    round 3's reasoned 0.5 (round 5): 0.5 / 0.43 / 0.5 for the three cases."""
+    from forced_check import bf16_margin_threshold
+    return bf16_margin_threshold(np.load(golden_dir / "t5_forced.npz"), case)
 
 
 def _bf16_divergence(ids, want, margins, label, BF16_NOISE_MARGIN):
@@ -366,3 +367,24 @@ def test_reference_native_waveform_batch128_properties():
         sub = m.generate(ModelInputs(input_waveform=wav[lo:hi].contiguous(), cond_index=idx[lo:hi].contiguous()), max_length=1024)
         n = min(sub.shape[1], a.shape[1])
         assert torch.equal(sub[:, :n], a[lo:hi, :n]) and (a[lo:hi, n:] == g.pad_token_id).all() and (sub[:, n:] == g.pad_token_id).all()
+
+
+@pytest.mark.parametrize("case", ["full_s864_fp32", "bench_clips_fp32"])
+def test_bf16_mode_against_the_fp32_reference_fixed_bars(golden_dir, case):
+    """the bf16 bars of test_every_position_... scale with the emulating oracle's OWN noise; a defect of that size in one
+    place could pass them.  Here nothing comes from the emulation: the FP32 oracle's ids (pinned to HuggingFace) are forced through
+    the bf16 decode kernels on the 32-clip batch and the logits are held against the fp32 oracle's to FIXED absolute bars
+    (forced_check.BF16_VS_FP32_ABS = 1.0 / 0.70 / 0.16 on max / 99.9th percentile / mean; logits reach 87; the emulation itself
+    measures 0.62 / 0.48 / 0.114 and 0.46 / 0.31 / 0.064 on the two cases), arg-max equal wherever the fp32 margin exceeds twice the
+    measured maximum."""
+    from forced_check import case_inputs, forced_bf16_vs_fp32
+    from music2midi_amd.checkpoint import load_t5_state
+    from music2midi_amd.transformer import T5Transformer
+    g = T5Geometry(DEFAULT_CONFIG["model"]["t5"])
+    sd, x = case_inputs(case, g, "cuda")
+    m = T5Transformer(DEFAULT_CONFIG, precision="bf16")
+    load_t5_state(m, sd, strict=False)
+    m = m.cuda().eval()
+    rec = forced_bf16_vs_fp32(m, x, case, copies=16, z=np.load(golden_dir / "t5_forced.npz"))
+    print(f"[bf16 vs fp32 oracle, {case}] {rec}")
+    assert rec["positions"] == 2 * 1023 and rec["argmax_asserted_positions"] >= 0.5 * rec["positions"]

@@ -257,3 +257,26 @@ def test_bench_uses_the_oracle_only_in_its_cpu_baseline_legs():
     # the forced-parity helper bench.py shares with the tests imports the oracle only inside case_inputs(), which bench.py never calls
     src = (ROOT / "bench.py").read_text()
     assert "case_inputs" not in src
+
+
+def test_conditioning_index_out_of_range_raises_index_error_on_the_host():
+    """ref: music2midi/input.py:57 — nn.Embedding raises IndexError for an index outside its table.  For host-side indices (the
+    Python list `Music2MIDI.generate(cond_index=[genre, difficulty])` hands over) the product raises the same error before any
+    launch; device tensors keep the kernel's NaN-row guard (no sync on the hot path)."""
+    from music2midi_amd.input import Conditioning
+    from music2midi_amd.model import Music2MIDI
+    cond = Conditioning(8, [6, 3])
+    cond.check_indices(torch.tensor([[5, 2], [0, 0]]))
+    for bad in ([[6, 0]], [[0, 3]], [[-1, 0]]):
+        with pytest.raises(IndexError):
+            cond.check_indices(torch.tensor(bad))
+        with pytest.raises(IndexError):     # write_rows checks host tensors before touching the device
+            try:
+                cond.write_rows(torch.tensor(bad), torch.zeros(1, 2, 8))
+            except native.NativeError:      # no GPU here: the native layer would refuse first only if the check were missing
+                raise AssertionError("native layer reached before the host-side index check")
+    m = Music2MIDI(DEFAULT_CONFIG)
+    assert m._cond_rows(3, [5, 2]).tolist() == [[5, 2]] * 3
+    assert m._cond_rows(2, None).tolist() == [[0, 0]] * 2
+    with pytest.raises(IndexError):
+        m._cond_rows(3, [6, 0])
