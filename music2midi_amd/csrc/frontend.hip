@@ -357,7 +357,11 @@ __global__ __launch_bounds__(FE_THREADS, M2M_FE_WGS_PER_CU) void logmel_kernel(
 // needed between a write phase and the dependent read phase (or a read phase and the writes that overwrite what it read) — but
 // the COMPILER must not move a ds_read above the ds_write of another lane's value: a wavefront-scope release fence plus
 // wave_barrier emits nothing and pins the order (the first form above does the same at every exchange).
+#ifdef M2M_FE2_NOFENCE      // diagnostic builds only (the round-4 kernel, for the same-box A/B of the fences' cost)
+#define V2_LANES_SYNC() do {} while (0)
+#else
 #define V2_LANES_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#endif
 constexpr int V2_PITCH = 68;                 // floats per k1 row of a transpose plane
 constexpr int V2_SCR = 16 * V2_PITCH;        // floats of per-wave scratch (planes, then the 1 025 + 48 power bins)
 constexpr int V2_NPRE = 6;                   // prefetch registers per thread (samples of the next chunk: 5 888 / 1 024 threads at hop 256)
