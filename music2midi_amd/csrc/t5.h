@@ -158,9 +158,20 @@ struct GemmArgs {
   // epilogue turns each tile straight into the gate pair's gradient, out = dab [M][2N] = [dmid~ * b * gelu'(a) | dmid~ * gelu(a)]
   // (ldo = 2N) with dmid~ = dropout mask of the forward applied to bf16(dmid) and a | b read from ab_out [M][2N]; dmid itself is
   // never stored.
+  // launch_norm_gemm (the product's A operand is RMSNorm(nx) over the K = d_model wide fp32 residual rows; `A` is then only the scratch the
+  // two-kernel fallback normalises into): nx [M][K] fp32, nw [K] the norm weight, neps; h_out (optional) [M][K] T receives the
+  // normalised rows as well (the training pass keeps them for the weight gradients).
+  const float* nx;
+  const float* nw;
+  float neps;
+  void* h_out;
 };
 
 int launch_gemm(int precision, int epi, const GemmArgs& a, hipStream_t st);
+// out = epilogue(RMSNorm(a.nx; a.nw, a.neps) . W^T): one kernel in the bf16 mode (row panel normalised once into LDS and kept there for
+// every column tile), rmsnorm_kernel into a.A + launch_gemm otherwise (fp32 parity mode, K beyond the LDS panel, M2M_NORM_GEMM=0).
+// Epilogues: EPI_HEADS, EPI_GATED, EPI_GATED16, EPI_STORE_F32.  Bit-identical to the two-kernel path (tests/test_t5_gpu.py).
+int launch_norm_gemm(int precision, int epi, const GemmArgs& a, hipStream_t st);
 bool gemm_takes_gated_train(int precision, int M, int N, int K);
 bool gemm_takes_gated_bwd(int precision, int M, int N, int K);
 int launch_rmsnorm(int precision, const float* x, const float* w, void* out, int M, int d, float eps, hipStream_t st);

@@ -319,13 +319,14 @@ extern "C" int m2m_encode(m2m_session* s, const float* inputs_embeds_dev, int B,
   int rc;
   for (int l = 0; l < g.num_layers; ++l) {
     const EncLayerPacked& L = m->enc[l];
-    if ((rc = launch_rmsnorm(P, s->x_enc, L.ln0, s->h_enc, M, d, g.layer_norm_eps, st))) return rc;
+    // RMSNorm + QKV projection: one kernel in the bf16 mode (launch_norm_gemm), norm into h_enc + GEMM otherwise
     GemmArgs a{};
     const int Sp = ceil_div(S, 64) * 64;
     a.A = s->h_enc; a.W = L.wqkv; a.M = M; a.N = 3 * m->inner; a.K = d; a.out = s->qkv_enc;
     a.Bsz = B; a.S = S; a.H = g.num_heads; a.inner = m->inner;
     a.vt_which = 2; a.vt_out = s->vt_enc; a.Sp = Sp;
-    if ((rc = launch_gemm(P, EPI_HEADS, a, st))) return rc;
+    a.nx = s->x_enc; a.nw = L.ln0; a.neps = g.layer_norm_eps;
+    if ((rc = launch_norm_gemm(P, EPI_HEADS, a, st))) return rc;
     AttnArgs at{};
     at.Q = s->qkv_enc; at.K = (const unsigned char*)s->qkv_enc + (size_t)M * m->inner * m->esize; at.Vt = s->vt_enc; at.Sp = Sp;
     at.bias_tab = s->enc_bias_tab; at.tab_stride = 2 * s->max_enc - 1; at.tab_center = s->max_enc - 1;
@@ -334,22 +335,27 @@ extern "C" int m2m_encode(m2m_session* s, const float* inputs_embeds_dev, int B,
     a = GemmArgs{}; a.vt_which = -1;
     a.A = s->attn_enc; a.W = L.wo; a.M = M; a.N = d; a.K = m->inner; a.out = s->x_enc; a.ldo = d;
     if ((rc = launch_gemm(P, EPI_RESID, a, st))) return rc;
-    if ((rc = launch_rmsnorm(P, s->x_enc, L.ln1, s->h_enc, M, d, g.layer_norm_eps, st))) return rc;
     a = GemmArgs{}; a.vt_which = -1;
     a.A = s->h_enc; a.W = L.wi; a.M = M; a.N = 2 * g.d_ff; a.K = d; a.out = s->mid_enc; a.ldo = g.d_ff;
-    if ((rc = launch_gemm(P, EPI_GATED, a, st))) return rc;
+    a.nx = s->x_enc; a.nw = L.ln1; a.neps = g.layer_norm_eps;
+    if ((rc = launch_norm_gemm(P, EPI_GATED, a, st))) return rc;
     a = GemmArgs{}; a.vt_which = -1;
     a.A = s->mid_enc; a.W = L.wo_ff; a.M = M; a.N = d; a.K = g.d_ff; a.out = s->x_enc; a.ldo = d;
     if ((rc = launch_gemm(P, EPI_RESID, a, st))) return rc;
   }
   // final norm -> GEMM input (T) and, if asked, the fp32 encoder states
-  if ((rc = launch_final_norm_f32(s->x_enc, m->enc_final_ln, enc_out_dev, s->h_enc, P, M, d, g.layer_norm_eps, st))) return rc;
   // cross-attention K/V of every decoder layer in one GEMM, written in decode layout
   GemmArgs a{};
   a.vt_which = -1;
   a.A = s->h_enc; a.W = m->wckv; a.M = M; a.N = g.num_decoder_layers * 2 * m->inner; a.K = d; a.out = s->cross_kv;
   a.Bsz = B; a.S = S; a.H = g.num_heads; a.inner = m->inner;
-  if ((rc = launch_gemm(P, EPI_HEADS, a, st))) return rc;
+  if (enc_out_dev) {        // the caller wants the fp32 encoder states too: the norm runs as its own kernel (both outputs), then the product
+    if ((rc = launch_final_norm_f32(s->x_enc, m->enc_final_ln, enc_out_dev, s->h_enc, P, M, d, g.layer_norm_eps, st))) return rc;
+    if ((rc = launch_gemm(P, EPI_HEADS, a, st))) return rc;
+  } else {                  // generate(): the final norm is the cross-K/V product's own prologue
+    a.nx = s->x_enc; a.nw = m->enc_final_ln; a.neps = g.layer_norm_eps;
+    if ((rc = launch_norm_gemm(P, EPI_HEADS, a, st))) return rc;
+  }
   s->B = B; s->S = S; s->encoded = true;
   return M2M_OK;
 }
@@ -513,11 +519,11 @@ static int forward_batched(m2m_session* s, const int64_t* ids, int Ld, float* lo
   for (int l = 0; l < g.num_decoder_layers; ++l) {
     const DecLayerPacked& L = m->dec[l];
     // --- causal self-attention
-    if ((rc = launch_rmsnorm(P, s->x_enc, L.ln0, s->h_enc, M, d, g.layer_norm_eps, st))) return rc;
     GemmArgs a{};
     a.A = s->h_enc; a.W = L.wqkv; a.M = M; a.N = 3 * m->inner; a.K = d; a.out = qkv;
     a.Bsz = B; a.S = Ld; a.H = H; a.inner = m->inner; a.vt_which = 2; a.vt_out = s->vt_enc; a.Sp = Lp;
-    if ((rc = launch_gemm(P, EPI_HEADS, a, st))) return rc;
+    a.nx = s->x_enc; a.nw = L.ln0; a.neps = g.layer_norm_eps;
+    if ((rc = launch_norm_gemm(P, EPI_HEADS, a, st))) return rc;
     AttnArgs at{};
     at.Q = qkv; at.K = qkv + (size_t)M * m->inner * es; at.Vt = s->vt_enc; at.Sp = Lp;
     at.bias_tab = s->dec_bias_full_tab; at.tab_stride = 2 * s->max_dec - 1; at.tab_center = s->max_dec - 1;
@@ -527,11 +533,11 @@ static int forward_batched(m2m_session* s, const int64_t* ids, int Ld, float* lo
     a.A = s->attn_enc; a.W = L.wo; a.M = M; a.N = d; a.K = m->inner; a.out = s->x_enc; a.ldo = d;
     if ((rc = launch_gemm(P, EPI_RESID, a, st))) return rc;
     // --- cross-attention over the cached encoder K/V
-    if ((rc = launch_rmsnorm(P, s->x_enc, L.ln1, s->h_enc, M, d, g.layer_norm_eps, st))) return rc;
     a = GemmArgs{};
     a.A = s->h_enc; a.W = L.wcq; a.M = M; a.N = m->inner; a.K = d; a.out = qkv;
     a.Bsz = B; a.S = Ld; a.H = H; a.inner = m->inner; a.vt_which = -1;
-    if ((rc = launch_gemm(P, EPI_HEADS, a, st))) return rc;
+    a.nx = s->x_enc; a.nw = L.ln1; a.neps = g.layer_norm_eps;
+    if ((rc = launch_norm_gemm(P, EPI_HEADS, a, st))) return rc;
     const unsigned char* ck = (const unsigned char*)s->cross_kv + ((size_t)l * 2 + 0) * per_enc * es;
     const unsigned char* cv = (const unsigned char*)s->cross_kv + ((size_t)l * 2 + 1) * per_enc * es;
     if ((rc = launch_transpose_v(P, cv, s->cross_vt, B * H, S, Sp, st))) return rc;
@@ -543,19 +549,19 @@ static int forward_batched(m2m_session* s, const int64_t* ids, int Ld, float* lo
     a.A = s->attn_enc; a.W = L.wco; a.M = M; a.N = d; a.K = m->inner; a.out = s->x_enc; a.ldo = d;
     if ((rc = launch_gemm(P, EPI_RESID, a, st))) return rc;
     // --- gated feed-forward (the decoder's 16-row interleave of wi)
-    if ((rc = launch_rmsnorm(P, s->x_enc, L.ln2, s->h_enc, M, d, g.layer_norm_eps, st))) return rc;
     a = GemmArgs{}; a.vt_which = -1;
     a.A = s->h_enc; a.W = L.wi; a.M = M; a.N = 2 * g.d_ff; a.K = d; a.out = s->mid_enc; a.ldo = g.d_ff;
-    if ((rc = launch_gemm(P, EPI_GATED16, a, st))) return rc;
+    a.nx = s->x_enc; a.nw = L.ln2; a.neps = g.layer_norm_eps;
+    if ((rc = launch_norm_gemm(P, EPI_GATED16, a, st))) return rc;
     a = GemmArgs{}; a.vt_which = -1;
     a.A = s->mid_enc; a.W = L.wo_ff; a.M = M; a.N = d; a.K = g.d_ff; a.out = s->x_enc; a.ldo = d;
     if ((rc = launch_gemm(P, EPI_RESID, a, st))) return rc;
   }
-  if ((rc = launch_rmsnorm(P, s->x_enc, m->dec_final_ln, s->h_enc, M, d, g.layer_norm_eps, st))) return rc;
   GemmArgs a{};
   a.vt_which = -1;
   a.A = s->h_enc; a.W = m->lm_head; a.M = M; a.N = g.vocab_size; a.K = d; a.out = logits_out; a.ldo = g.vocab_size;
-  return launch_gemm(P, EPI_STORE_F32, a, st);
+  a.nx = s->x_enc; a.nw = m->dec_final_ln; a.neps = g.layer_norm_eps;
+  return launch_norm_gemm(P, EPI_STORE_F32, a, st);
 }
 
 extern "C" int m2m_decode_forced(m2m_session* s, const int64_t* dec_input_ids_dev, int Ld, float* logits_out_dev, void* stream) {

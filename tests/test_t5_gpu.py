@@ -267,3 +267,24 @@ def test_finished_row_early_out_does_not_change_ids(monkeypatch, precision, B, S
     if precision == "fp32":
         from oracle.t5 import T5Oracle
         assert torch.equal(a, T5Oracle(geom, sd).generate(x, 1024))
+
+
+@pytest.mark.parametrize("cfg_name,B,S,Ld", [("tiny", 3, 19, 12), ("tiny", 2, 130, 131), ("full", 2, 190, 24), ("full", 5, 864, 40), ("full", 33, 40, 129)])
+def test_norm_gemm_fused_kernel_is_bit_identical_to_the_two_kernel_path(monkeypatch, cfg_name, B, S, Ld):
+    """Round 5: RMSNorm fused into the following product — `norm_gemm_kernel` normalises a 128-row panel once into LDS
+    and sweeps every column tile with it — must change NOTHING: same norm arithmetic and rounding point, same k order per output
+    element as rmsnorm_kernel + gemm_kernel (M2M_NORM_GEMM=0).  The batched teacher-forced pass goes through every epilogue of the
+    fused kernel (head-major q/k, transposed V, gated GELU in both weight interleaves, cross-q, cross-K/V with the final encoder norm
+    as its prologue, fp32 lm_head): its logits and the greedy ids must be bit-identical with the switch on and off."""
+    cfg = tiny_config() if cfg_name == "tiny" else DEFAULT_CONFIG
+    model, _, g = build(cfg, "bf16")
+    x = embeds(B, S, g.d_model).cuda()
+    dec = torch.from_numpy((synth.uniform01(11, "dec", B * Ld) * (g.vocab_size - 3)).astype(np.int64).reshape(B, Ld) + 3).cuda()
+    dec[:, 0] = g.decoder_start_token_id
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("M2M_NORM_GEMM", flag)
+        out[flag] = (model.logits_from_embeds(x, dec).cpu(), model.generate_from_embeds(x, max_length=min(Ld, 24)).cpu())
+    assert torch.isfinite(out["1"][0]).all()
+    assert torch.equal(out["1"][0], out["0"][0]), f"fused norm+GEMM logits differ: max |d| {(out['1'][0] - out['0'][0]).abs().max():.3e}"
+    assert torch.equal(out["1"][1], out["0"][1])
