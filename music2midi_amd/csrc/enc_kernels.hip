@@ -678,65 +678,81 @@ int launch_gemm(int precision, int epi, const GemmArgs& a, hipStream_t st) {
 //
 // The two-kernel path (rmsnorm_kernel -> h in memory -> gemm_kernel) tiles the product 128 x 128: with K = 384 a tile lives for six
 // k-steps, so its load -> LDS prologue and its staged epilogue are a large part of it, every one of the 12-48 column tiles of a row
-// block stages the SAME activation tile again, and h makes a round trip through memory.  K = d_model is small enough for the whole
-// normalised row panel to stay in LDS: here a workgroup of 8 waves
+// block stages the SAME activation tile again, and h makes a round trip through memory.  K = d_model is small enough for a whole
+// normalised row panel to stay ON CHIP for every column tile: here a workgroup of 8 waves
 //   1. reads its 128 rows of x ONCE (fp32), normalises them with exactly rmsnorm_kernel's arithmetic (a wave per row, the same
-//      lane -> column map, the same reduction order, the same rounding point) and keeps the bf16 panel in LDS (100 KB at K = 384);
-//   2. sweeps ALL column tiles with it: the weight tile streams through an 18 KB LDS buffer in 64-wide k chunks, prefetched into
-//      registers one chunk ahead ACROSS tile boundaries (one prologue per workgroup, not per tile); W is 1.2-4.7 MB and comes from L2;
-//   3. stages each 128 x 128 result through its own LDS buffer (whole 128-byte lines to memory, as the EPI_HEADS / EPI_GATED
-//      epilogues above) while the next tile's k loop is already running.
-// Per output element the k order and the MFMA operand roles are those of gemm_kernel, and the A fragments are the same bf16 values:
-// results are BIT-IDENTICAL to the two-kernel path (asserted by tests/test_t5_gpu.py::test_norm_gemm_* with M2M_NORM_GEMM=0 as the
-// other leg).  L2 -> LDS traffic per 128 rows: one pass over W (the 128 x 128 tiling: one pass over W plus one over the A panel per
-// column tile); the 13 norm launches of an encoder pass are gone.
+//      lane -> column map, the same reduction order, the same rounding point) into a bf16 panel in LDS (100 KB at K = 384);
+//   2. every wave takes ITS 32 rows of the panel into registers as MFMA fragments (24 fragments = 96 VGPRs at K = 384) — the
+//      activations are never read from LDS again — and the panel's bytes become a three-stage ring for the weight chunks;
+//   3. sweeps ALL column tiles: [128 x 64] weight chunks stream L2 -> registers (three chunks in flight per thread, ACROSS tile
+//      boundaries: one prologue per workgroup, not per tile) -> ring; a step multiplies chunk t while the fragments of chunk t + 1 are
+//      being read and chunk t + 2 is being stored: one barrier per step, LDS reads overlap the matrix core;
+//   4. stages each 128 x 128 result through its own LDS buffer with 8-byte writes — the MFMA operand roles are chosen per tile so
+//      that the four values a lane holds of one accumulator column run along the staged row (weights as the A operand for row-major
+//      outputs, activations as the A operand for the transposed V tile) — and stores whole 128-byte lines while the next tile runs.
+// Per output element the k order is gemm_kernel's and the fragments hold the same bf16 values: results are BIT-IDENTICAL to the
+// two-kernel path (tests/test_t5_gpu.py::test_norm_gemm_*, M2M_NORM_GEMM=0 is the other leg).  L2 -> LDS traffic per 128 rows: one
+// pass over W (the 128 x 128 tiling: one pass over W plus one over the A panel per column tile); the 13 norm launches of an encoder
+// pass are gone.
+#ifndef M2M_NG_SKIP          // diagnostic builds only (timing with a part removed; results are wrong): 1 output stores, 2 weight loads from
+#define M2M_NG_SKIP 0       // memory (one chunk re-used), 4 the MFMAs, 8 the x loads of the prologue (one row re-used)
+#endif
 constexpr int NG_BM = 128, NG_BN = 128, NG_BK = 64, NG_THREADS = 512;
-constexpr int NG_BP = NG_BK + 8;                   // pitch of the weight chunk (elements)
+constexpr int NG_BP = NG_BK + 8;                   // pitch of a weight chunk in the ring (elements)
 constexpr int NG_CP = NG_BN + 8;                   // pitch of the staged result tile
+constexpr int NG_STAGES = 3, NG_STAGE = NG_BN * NG_BP;
 
+// LDS: the normalised panel [128][K + 8] — after every wave has taken its A fragments the same bytes hold the ring [3][128][72] —
+// and the staged result tile [128][136]
 __host__ __device__ inline size_t ng_lds_bytes(int K) {
-  return ((size_t)NG_BM * (K + 8) + (size_t)NG_BN * NG_BP + (size_t)NG_BM * NG_CP) * 2;
+  const size_t panel = (size_t)NG_BM * (K + 8), ring = (size_t)NG_STAGES * NG_STAGE;
+  return ((panel > ring ? panel : ring) + (size_t)NG_BM * NG_CP) * 2;
 }
+
+__device__ inline uint2 ng_pack4(float a, float b, float c, float d) { return make_uint2(pack2_bf16(a, b), pack2_bf16(c, d)); }
 
 template <int EPI, int NK>        // NK = K / 64 k chunks per column tile (d_model 128 / 256 / 384: 2 / 4 / 6)
 __global__ __launch_bounds__(NG_THREADS) void norm_gemm_kernel(GemmArgs g) {
   using T = bf16_t;
   static_assert(EPI == EPI_HEADS || EPI == EPI_GATED || EPI == EPI_GATED16 || EPI == EPI_STORE_F32, "epilogues of the fused-norm products");
+  static_assert(NK == 2 || NK == 4 || NK == 6, "chunk -> register set / ring stage / fragment buffer mapping below");
   extern __shared__ __align__(16) unsigned char ng_smem[];
   constexpr int K = NK * NG_BK, PP = K + 8;
-  T* const panel = reinterpret_cast<T*>(ng_smem);               // [128][K + 8]
-  T* const Bs = panel + NG_BM * PP;                              // [128][72]
-  T* const Cs = Bs + NG_BN * NG_BP;                              // [128][136] (transposed V tile: [128 cols][136])
+  constexpr int RING = NG_STAGES * NG_STAGE, FRONT = NG_BM * PP > RING ? NG_BM * PP : RING;
+  T* const panel = reinterpret_cast<T*>(ng_smem);               // [128][K + 8], then:
+  T* const Bs = panel;                                           // [3][128][72] weight-chunk ring
+  T* const Cs = panel + FRONT;                                   // [128][136] (transposed V tile: [128 cols][136])
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;                       // 4 x 2 waves, 32 x 64 outputs each
+  const int wm = wave >> 1, wn = wave & 1;                       // 4 x 2 waves: 32 rows x 64 columns each
   const int r = lane & 31, h = lane >> 5;
   const int m0 = blockIdx.x * NG_BM;
   const int ntn = (g.N + NG_BN - 1) / NG_BN;
   const T* W = reinterpret_cast<const T*>(g.W);
 
-  // weight chunk staging: 128 rows x 8 chunks of 16 bytes = 2 per thread, named scalars (arrays across the loop go to scratch)
+  // weight chunk staging: 128 rows x 8 chunks of 16 bytes = 2 per thread, named scalars (arrays across the loop go to scratch).
+  // THREE chunks stay in flight per thread (register sets a, b, c in rotation; the k loop is unrolled, so the set of a chunk is a
+  // compile-time choice): with one workgroup per CU nothing else hides a chunk's L2 round trip — one chunk ahead measured ~1 us per
+  // k step (QKV 78 us), the whole round trip exposed at every one of the 72 steps.
   const int c0 = tid, c1 = tid + NG_THREADS;
   const int br0 = c0 >> 3, bc0 = (c0 & 7) * 8, br1 = c1 >> 3, bc1 = (c1 & 7) * 8;
-  // THREE chunks stay in flight per thread (register sets A, B, C in rotation; the k loop is unrolled, so the set of a chunk is
-  // a compile-time choice): with one workgroup per CU nothing else hides a chunk's L2 round trip — one chunk ahead measured
-  // ~1 us per k step (QKV 78 us), the whole round trip exposed at every one of the 72 steps.
-  constexpr int NG_D = 3;
-  static_assert(NK % NG_D == 0 || NK == 2 || NK == 4, "chunk -> register set mapping below");
   uint4 ra0, ra1, rb0, rb1, rc0, rc1;
-  ra0 = ra1 = rb0 = rb1 = rc0 = rc1 = make_uint4(0, 0, 0, 0);
-  // flat chunk index t = nt * NK + kt over the whole sweep; chunk t lives in set t % 3
+  // flat chunk index t = nt * NK + kt over the whole sweep; chunk t lives in register set t % 3 and goes to ring stage t % 3
 #define NG_LOADB(set_, t_)                                                                                         \
-  {                                                                                                                \
+  if (!(M2M_NG_SKIP & 2) || (t_) < 3) {                                                                            \
     const int tt_ = (t_);                                                                                          \
     const int n0_ = (tt_ / NK) * NG_BN, k0_ = (tt_ % NK) * NG_BK;                                                  \
     r##set_##0 = *reinterpret_cast<const uint4*>(W + (int64_t)min(n0_ + br0, g.N - 1) * K + k0_ + bc0);           \
     r##set_##1 = *reinterpret_cast<const uint4*>(W + (int64_t)min(n0_ + br1, g.N - 1) * K + k0_ + bc1);           \
   }
-#define NG_STOREB(set_)                                                                                            \
+#define NG_STOREB(set_, stage_)                                                                                    \
   {                                                                                                                \
-    *reinterpret_cast<uint4*>(Bs + br0 * NG_BP + bc0) = r##set_##0;                                                \
-    *reinterpret_cast<uint4*>(Bs + br1 * NG_BP + bc1) = r##set_##1;                                                \
+    *reinterpret_cast<uint4*>(Bs + (stage_) * NG_STAGE + br0 * NG_BP + bc0) = r##set_##0;                          \
+    *reinterpret_cast<uint4*>(Bs + (stage_) * NG_STAGE + br1 * NG_BP + bc1) = r##set_##1;                          \
   }
+  // loads are UNCONDITIONAL (past the end the last chunk is fetched again and never used): behind a runtime test the compiler cannot
+  // count the loads in flight and waits vmcnt(0) at every step
+#define NG_LOADB_SET(set_i_, t_) { if ((set_i_) == 0) NG_LOADB(a, t_) else if ((set_i_) == 1) NG_LOADB(b, t_) else NG_LOADB(c, t_) }
+#define NG_STOREB_SET(set_i_) { if ((set_i_) == 0) NG_STOREB(a, 0) else if ((set_i_) == 1) NG_STOREB(b, 1) else NG_STOREB(c, 2) }
   const int nchunks = ntn * NK;
   NG_LOADB(a, 0)                                                 // in flight under the panel's prologue
   NG_LOADB(b, min(1, nchunks - 1))
@@ -752,7 +768,7 @@ __global__ __launch_bounds__(NG_THREADS) void norm_gemm_kernel(GemmArgs g) {
       float4 v0[RB], v1[RB];
 #pragma unroll
       for (int i = 0; i < RB; ++i) {
-        const float* xr = g.nx + (int64_t)min(m0 + wave * (NG_BM / 8) + rb + i, g.M - 1) * K;
+        const float* xr = g.nx + (int64_t)((M2M_NG_SKIP & 8) ? 0 : min(m0 + wave * (NG_BM / 8) + rb + i, g.M - 1)) * K;
         v0[i] = one ? *reinterpret_cast<const float4*>(xr + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         v1[i] = two ? *reinterpret_cast<const float4*>(xr + lane * 4 + 256) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
@@ -782,12 +798,58 @@ __global__ __launch_bounds__(NG_THREADS) void norm_gemm_kernel(GemmArgs g) {
     }
   }
 
-  // ---- 2. all column tiles against the resident panel ----
-  const T* const pa = panel + (wm * 32 + r) * PP + 8 * h;        // this lane's A fragments: + kt * 64 + s * 16
-  const T* const pb = Bs + (wn * 64 + r) * NG_BP + 8 * h;        // B fragments: + j * 32 rows, + s * 16
-  // The register set of chunk t = nt * NK + kt is t % 3.  NK % 3 == 0 (K = 384): the set depends on kt alone.  Otherwise (NK = 2, 4:
-  // d_model 128 / 256, the small geometries) the tile loop walks three tiles per trip so that the pattern repeats.
-  constexpr int TPT = (NK % NG_D == 0) ? 1 : NG_D;               // tiles per trip of the outer loop
+  // ---- 2. this wave's A fragments -> registers (32 rows x K: NK * 4 fragments, 4 VGPRs each), then the panel's LDS becomes the ring ----
+  __syncthreads();                                               // the panel is complete
+  Frag<T> af[NK][NG_BK / 16];
+  {
+    const T* const pa = panel + (wm * 32 + r) * PP + 8 * h;
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt)
+#pragma unroll
+      for (int s = 0; s < NG_BK / 16; ++s) af[kt][s] = load_frag(pa + kt * NG_BK + s * 16);
+  }
+  __syncthreads();                                               // every wave has its fragments: the panel bytes are free
+  NG_STOREB(a, 0)                                                // chunks 0, 1 -> stages 0, 1; their sets take chunks 3, 4
+  NG_STOREB(b, 1)
+  NG_LOADB(a, min(3, nchunks - 1))
+  NG_LOADB(b, min(4, nchunks - 1))
+  __syncthreads();
+  // Weight fragments: this wave's 64 columns (two 32-column MFMA blocks) of one 16-wide k step, read TWO k steps ahead of their
+  // MFMAs into three rotating slots (24 VGPRs; a whole chunk ahead would be 64 and spills) — continuously, across chunk and tile
+  // boundaries: the matrix core never waits for an LDS round trip.
+  Frag<T> fws[3][2];                                             // [slot][block]; flat k-step index U: slot U % 3
+  const T* const pb = Bs + (wn * 64 + r) * NG_BP + 8 * h;
+#define NG_READ1(slot_, stage_, s_)                                                                                \
+  {                                                                                                                \
+    fws[slot_][0] = load_frag(pb + (stage_) * NG_STAGE + (s_) * 16);                                               \
+    fws[slot_][1] = load_frag(pb + (stage_) * NG_STAGE + 32 * NG_BP + (s_) * 16);                                  \
+  }
+  NG_READ1(0, 0, 0)
+  NG_READ1(1, 0, 1)
+
+  // ---- 3. all column tiles.  Body t (chunk t, four k steps): each k step first requests the fragments of the step two ahead (the
+  //         last two steps of a body read chunk t + 1: stage (t + 1) % 3, complete since the previous barrier), then multiplies; then
+  //         chunk t + 2 goes from its register set into stage (t + 2) % 3 (last read in body t - 1) and the set is refilled with
+  //         chunk t + 5; ONE barrier.  Chunk -> set / stage (t % 3) and k step -> slot depend on kt alone when NK % 3 == 0
+  //         (K = 384); the small geometries (NK = 2, 4) walk three tiles per trip of the outer loop so that the pattern repeats. ----
+  constexpr int TPT = (NK % 3 == 0) ? 1 : 3;
+  // SW_: weights as the MFMA A operand (a lane then holds 4 consecutive OUTPUT COLUMNS of one row: row-major staging with 8-byte
+  // writes); !SW_: activations as the A operand (4 consecutive ROWS of one column: the transposed V tile)
+#define NG_KLOOP(SW_)                                                                                              \
+  _Pragma("unroll") for (int kt = 0; kt < NK; ++kt) {                                                              \
+    const int t = nt * NK + kt;                                                                                    \
+    const int q = ti * NK + kt;                         /* == t modulo 3: compile-time after unrolling */           \
+    _Pragma("unroll") for (int s = 0; s < NG_BK / 16; ++s) {                                                       \
+      const int U = q * (NG_BK / 16) + s;                                                                          \
+      NG_READ1((U + 2) % 3, (q + ((s + 2) >> 2)) % 3, (s + 2) & 3)                                                 \
+      if (M2M_NG_SKIP & 4) { acc0[s] += __uint_as_float(fws[U % 3][0].v.x ^ af[kt][s].v.x); acc1[s] += __uint_as_float(fws[U % 3][1].v.y ^ af[kt][s].v.w); } \
+      else if (SW_) { mma16(acc0, fws[U % 3][0], af[kt][s]); mma16(acc1, fws[U % 3][1], af[kt][s]); }              \
+      else { mma16(acc0, af[kt][s], fws[U % 3][0]); mma16(acc1, af[kt][s], fws[U % 3][1]); }                       \
+    }                                                                                                              \
+    NG_STOREB_SET((q + 2) % 3)                                                                                     \
+    NG_LOADB_SET((q + 2) % 3, min(t + 5, nchunks - 1))                                                             \
+    __syncthreads();                                                                                               \
+  }
   for (int nt0 = 0; nt0 < ntn; nt0 += TPT) {
 #pragma unroll
   for (int ti = 0; ti < TPT; ++ti) {
@@ -795,56 +857,46 @@ __global__ __launch_bounds__(NG_THREADS) void norm_gemm_kernel(GemmArgs g) {
     if (nt >= ntn) break;                                         // uniform
     const int n0 = nt * NG_BN;
     f32x16 acc0 = zero_acc(), acc1 = zero_acc();
-#pragma unroll
-    for (int kt = 0; kt < NK; ++kt) {
-      constexpr int dummy = 0; (void)dummy;
-      const int t = nt * NK + kt;
-      const int set = (ti * NK + kt) % NG_D;                      // compile-time after unrolling
-      __syncthreads();                                           // Bs free (and, first step, the panel complete)
-      if (set == 0) NG_STOREB(a) else if (set == 1) NG_STOREB(b) else NG_STOREB(c)
-      __syncthreads();
-      // the set just stored takes the chunk three steps ahead — UNCONDITIONALLY (past the end the last chunk is fetched again and
-      // never used): behind a runtime test the compiler cannot count the loads in flight and waits vmcnt(0) at every step
-      {
-        const int tn = min(t + NG_D, nchunks - 1);
-        if (set == 0) NG_LOADB(a, tn) else if (set == 1) NG_LOADB(b, tn) else NG_LOADB(c, tn)
-      }
-#pragma unroll
-      for (int s = 0; s < NG_BK / 16; ++s) {
-        const Frag<T> fa = load_frag(pa + kt * NG_BK + s * 16);
-        const Frag<T> fb0 = load_frag(pb + s * 16), fb1 = load_frag(pb + 32 * NG_BP + s * 16);
-        mma16(acc0, fa, fb0);
-        mma16(acc1, fa, fb1);
-      }
-    }
-    // ---- epilogue of this tile (Cs is its own buffer: the stores below overlap the next tile's first k steps; the next write of
-    //      Cs is a whole k loop of barriers away) ----
+    // ---- epilogue of this tile follows its k loop (Cs is its own buffer: the stores overlap the next tile's first k steps; the
+    //      next write of Cs is a whole k loop of barriers away) ----
     if constexpr (EPI == EPI_STORE_F32) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = m0 + wm * 32 + acc_row(e, lane);
-        if (row >= g.M) continue;
-        const int col = n0 + wn * 64 + r;
+      NG_KLOOP(true)
+      const int row = m0 + wm * 32 + r;
+      if (row < g.M) {
         float* o = reinterpret_cast<float*>(g.out) + (int64_t)row * g.ldo;
-        if (col < g.N) o[col] = acc0[e];
-        if (col + 32 < g.N) o[col + 32] = acc1[e];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const f32x16& ac = j ? acc1 : acc0;
+            const int col = n0 + wn * 64 + j * 32 + 8 * q4 + 4 * h;
+            if (col + 4 <= g.N && (g.ldo & 3) == 0) *reinterpret_cast<float4*>(o + col) = make_float4(ac[4 * q4], ac[4 * q4 + 1], ac[4 * q4 + 2], ac[4 * q4 + 3]);
+            else
+              for (int k2 = 0; k2 < 4; ++k2) if (col + k2 < g.N) o[col + k2] = ac[4 * q4 + k2];
+          }
       }
     } else if constexpr (EPI == EPI_HEADS) {
       const int which = n0 / g.inner;
       const bool transposed = (which == g.vt_which);
+      if (transposed) {
+        NG_KLOOP(false)
+        // accumulator element e of lane (r, h): row wm * 32 + (e & 3) + 8 (e >> 2) + 4 h, column wn * 64 + j * 32 + r
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int rl = wm * 32 + acc_row(e, lane), cl = wn * 64 + r;
-        if (transposed) {
-          Cs[cl * NG_CP + rl] = from_f32<T>(acc0[e]);
-          Cs[(cl + 32) * NG_CP + rl] = from_f32<T>(acc1[e]);
-        } else {
-          Cs[rl * NG_CP + cl] = from_f32<T>(acc0[e]);
-          Cs[rl * NG_CP + cl + 32] = from_f32<T>(acc1[e]);
+        for (int q4 = 0; q4 < 4; ++q4) {
+          *reinterpret_cast<uint2*>(Cs + (wn * 64 + r) * NG_CP + wm * 32 + 8 * q4 + 4 * h) = ng_pack4(acc0[4 * q4], acc0[4 * q4 + 1], acc0[4 * q4 + 2], acc0[4 * q4 + 3]);
+          *reinterpret_cast<uint2*>(Cs + (wn * 64 + 32 + r) * NG_CP + wm * 32 + 8 * q4 + 4 * h) = ng_pack4(acc1[4 * q4], acc1[4 * q4 + 1], acc1[4 * q4 + 2], acc1[4 * q4 + 3]);
+        }
+      } else {
+        NG_KLOOP(true)
+        // swapped roles: element e of lane (r, h): row wm * 32 + r, column wn * 64 + j * 32 + (e & 3) + 8 (e >> 2) + 4 h
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          *reinterpret_cast<uint2*>(Cs + (wm * 32 + r) * NG_CP + wn * 64 + 8 * q4 + 4 * h) = ng_pack4(acc0[4 * q4], acc0[4 * q4 + 1], acc0[4 * q4 + 2], acc0[4 * q4 + 3]);
+          *reinterpret_cast<uint2*>(Cs + (wm * 32 + r) * NG_CP + wn * 64 + 32 + 8 * q4 + 4 * h) = ng_pack4(acc1[4 * q4], acc1[4 * q4 + 1], acc1[4 * q4 + 2], acc1[4 * q4 + 3]);
         }
       }
       __syncthreads();
-      for (int idx = tid; idx < NG_BM * (NG_BN / 8); idx += NG_THREADS) {
+      for (int idx = tid; idx < ((M2M_NG_SKIP & 1) ? 0 : NG_BM * (NG_BN / 8)); idx += NG_THREADS) {
         if (!transposed) {
           const int rl = idx >> 4, ch = idx & 15;
           const int row = m0 + rl, col = n0 + ch * 8;
@@ -878,23 +930,27 @@ __global__ __launch_bounds__(NG_THREADS) void norm_gemm_kernel(GemmArgs g) {
       }
     } else {   // EPI_GATED (64-row chunks: 32 rows of wi_0 then the matching 32 of wi_1) / EPI_GATED16 (16-row groups: 8 + 8)
       constexpr int GP = NG_BN / 2 + 8;
+      NG_KLOOP(true)
+      T* const crow = Cs + (wm * 32 + r) * GP;
+      if constexpr (EPI == EPI_GATED) {     // the wave's 64 weight rows are [32 of wi_0 | the matching 32 of wi_1]: acc0 = a, acc1 = b
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int rl = wm * 32 + acc_row(e, lane);
-        if constexpr (EPI == EPI_GATED) {
-          Cs[rl * GP + wn * 32 + r] = from_f32<T>(gelu_new_t<T>(acc0[e]) * acc1[e]);
-        } else {
-          const float va = acc0[e], vb = acc1[e];
-          const float pa_ = lane_xor<8>(va), pb_ = lane_xor<8>(vb);
-          const int cl = wn * 64 + r;
-          if ((cl & 8) == 0) {
-            Cs[rl * GP + (cl >> 4) * 8 + (cl & 7)] = from_f32<T>(gelu_new_t<T>(va) * pa_);
-            Cs[rl * GP + ((cl + 32) >> 4) * 8 + (cl & 7)] = from_f32<T>(gelu_new_t<T>(vb) * pb_);
+        for (int q4 = 0; q4 < 4; ++q4)
+          *reinterpret_cast<uint2*>(crow + wn * 32 + 8 * q4 + 4 * h) =
+              ng_pack4(gelu_new_t<T>(acc0[4 * q4]) * acc1[4 * q4], gelu_new_t<T>(acc0[4 * q4 + 1]) * acc1[4 * q4 + 1],
+                       gelu_new_t<T>(acc0[4 * q4 + 2]) * acc1[4 * q4 + 2], gelu_new_t<T>(acc0[4 * q4 + 3]) * acc1[4 * q4 + 3]);
+      } else {                               // tile column c: a gate value if (c & 8) == 0, its partner at c + 8 = element e + 4 of the same lane
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g2 = 0; g2 < 2; ++g2) {
+            const f32x16& ac = j ? acc1 : acc0;
+            *reinterpret_cast<uint2*>(crow + (wn * 4 + j * 2 + g2) * 8 + 4 * h) =
+                ng_pack4(gelu_new_t<T>(ac[8 * g2]) * ac[8 * g2 + 4], gelu_new_t<T>(ac[8 * g2 + 1]) * ac[8 * g2 + 5],
+                         gelu_new_t<T>(ac[8 * g2 + 2]) * ac[8 * g2 + 6], gelu_new_t<T>(ac[8 * g2 + 3]) * ac[8 * g2 + 7]);
           }
-        }
       }
       __syncthreads();
-      for (int idx = tid; idx < NG_BM * (NG_BN / 16); idx += NG_THREADS) {
+      for (int idx = tid; idx < ((M2M_NG_SKIP & 1) ? 0 : NG_BM * (NG_BN / 16)); idx += NG_THREADS) {
         const int rl = idx >> 3, ch = idx & 7;
         const int row = m0 + rl, oc = n0 / 2 + ch * 8;
         if (row < g.M && 2 * oc < g.N)
@@ -903,6 +959,10 @@ __global__ __launch_bounds__(NG_THREADS) void norm_gemm_kernel(GemmArgs g) {
     }
   }   // tiles of a trip
   }
+#undef NG_KLOOP
+#undef NG_READ1
+#undef NG_LOADB_SET
+#undef NG_STOREB_SET
 #undef NG_LOADB
 #undef NG_STOREB
 }
