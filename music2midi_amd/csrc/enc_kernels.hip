@@ -723,7 +723,10 @@ __global__ __launch_bounds__(NG_THREADS) void norm_gemm_kernel(GemmArgs g) {
   T* const Bs = panel;                                           // [3][128][72] weight-chunk ring
   T* const Cs = panel + FRONT;                                   // [128][136] (transposed V tile: [128 cols][136])
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;                       // 4 x 2 waves: 32 rows x 64 columns each
+  const int wm = wave >> 1, wn = wave & 1;                       // 4 x 2 waves: 32 rows x 64 columns each.  (Measured alternative: 4 waves
+                                                                 // of 64 x 64 — ONE wave per SIMD, 192 VGPRs of A fragments, every weight
+                                                                 // fragment feeding two MFMAs, half the LDS reads — QKV 54.8 -> 70.1 us:
+                                                                 // a lone wave per SIMD does not hide its own LDS / barrier latencies.)
   const int r = lane & 31, h = lane >> 5;
   const int m0 = blockIdx.x * NG_BM;
   const int ntn = (g.N + NG_BN - 1) / NG_BN;
@@ -738,8 +741,8 @@ __global__ __launch_bounds__(NG_THREADS) void norm_gemm_kernel(GemmArgs g) {
   uint4 ra0, ra1, rb0, rb1, rc0, rc1;
   // flat chunk index t = nt * NK + kt over the whole sweep; chunk t lives in register set t % 3 and goes to ring stage t % 3
 #define NG_LOADB(set_, t_)                                                                                         \
-  if (!(M2M_NG_SKIP & 2) || (t_) < 3) {                                                                            \
-    const int tt_ = (t_);                                                                                          \
+  {                                                                                                                \
+    const int tt_ = (M2M_NG_SKIP & 2) ? min((t_), 2) : (t_);                                                       \
     const int n0_ = (tt_ / NK) * NG_BN, k0_ = (tt_ % NK) * NG_BK;                                                  \
     r##set_##0 = *reinterpret_cast<const uint4*>(W + (int64_t)min(n0_ + br0, g.N - 1) * K + k0_ + bc0);           \
     r##set_##1 = *reinterpret_cast<const uint4*>(W + (int64_t)min(n0_ + br1, g.N - 1) * K + k0_ + bc1);           \
