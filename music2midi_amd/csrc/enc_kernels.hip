@@ -861,7 +861,9 @@ __global__ __launch_bounds__(NG_THREADS) void norm_gemm_kernel(GemmArgs g) {
     const int n0 = nt * NG_BN;
     f32x16 acc0 = zero_acc(), acc1 = zero_acc();
     // ---- epilogue of this tile follows its k loop (Cs is its own buffer: the stores overlap the next tile's first k steps; the
-    //      next write of Cs is a whole k loop of barriers away) ----
+    //      next write of Cs is a whole k loop of barriers away).  Measured alternative: the staged tile leaving in pieces, one per
+    //      k chunk of the NEXT tile (no burst, every store three chunks ahead of the first vmcnt wait that covers it): QKV 54.8 ->
+    //      60.0 us, cross-K/V 219 -> 236 — the stores' cost (30 % of the kernel by ablation) is memory write time, not their burst ----
     if constexpr (EPI == EPI_STORE_F32) {
       NG_KLOOP(true)
       const int row = m0 + wm * 32 + r;
