@@ -972,10 +972,17 @@ __global__ __launch_bounds__(NG_THREADS) void norm_gemm_kernel(GemmArgs g) {
 #undef NG_STOREB
 }
 
-static bool norm_gemm_on(int epi) {   // read per launch (a dozen launches per pass): the parity test toggles it in one process
-  const char* v = getenv("M2M_NORM_GEMM");            // "0": never; "e<digits>": not for the listed epilogue ids (diagnostic)
+// One workgroup per 128 rows and no second workgroup per CU: the fused kernel needs about a chip's worth of row blocks to beat the
+// 128 x 128 tiling (which spreads a small problem over rows AND columns).  B = 32 x S = 864 gives 216, the reference-native 128 x 190
+// gives 190; below M2M_NORM_GEMM_MIN_BLOCKS (default 160) the two-kernel path runs.  M2M_NORM_GEMM: "0" never, "force" whatever the
+// size (the parity tests), "e<digits>" not for the listed epilogue ids (diagnostic).  Read per launch: a dozen launches per pass.
+static bool norm_gemm_on(int epi, int M) {
+  const char* v = getenv("M2M_NORM_GEMM");
+  if (v && v[0] == '0') return false;
   if (v && v[0] == 'e') { for (const char* c = v + 1; *c; ++c) if (*c - '0' == epi) return false; return true; }
-  return !(v && v[0] == '0');
+  if (v && v[0] == 'f') return true;
+  static const int min_blocks = [] { const char* e = getenv("M2M_NORM_GEMM_MIN_BLOCKS"); return e ? atoi(e) : 160; }();
+  return ceil_div(M, 128) >= min_blocks;
 }
 
 int launch_norm_gemm(int precision, int epi, const GemmArgs& a_in, hipStream_t st) {
@@ -983,7 +990,7 @@ int launch_norm_gemm(int precision, int epi, const GemmArgs& a_in, hipStream_t s
   const GemmArgs& a = a_in;
   M2M_REQUIRE(a.nx && a.nw && a.A, "norm_gemm: null input (nx, nw, and A as the fallback's scratch for the normalised rows)");
   M2M_REQUIRE(epi == EPI_HEADS || epi == EPI_GATED || epi == EPI_GATED16 || epi == EPI_STORE_F32, "norm_gemm: epilogue %d not supported", epi);
-  const bool fused = precision == M2M_PREC_BF16 && norm_gemm_on(epi) && (a.K == 128 || a.K == 256 || a.K == 384) &&
+  const bool fused = precision == M2M_PREC_BF16 && norm_gemm_on(epi, a.M) && (a.K == 128 || a.K == 256 || a.K == 384) &&
                      ng_lds_bytes(a.K) <= 160 * 1024 && (epi != EPI_HEADS || a.inner % NG_BN == 0) &&
                      (epi != EPI_GATED || a.N % 64 == 0) && (epi != EPI_GATED16 || a.N % 16 == 0);
   if (!fused) {
