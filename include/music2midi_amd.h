@@ -191,6 +191,15 @@ int m2m_encode(m2m_session* s, const float* inputs_embeds_dev, int B, int S, flo
 int m2m_generate_greedy(m2m_session* s, int max_length, int64_t* tokens_out_dev, int* out_len_host, void* stream);
 
 /*
+ * Rows end at different steps (ref: music2midi/model.py:115-135 decodes chunks of inference.batch_size = 128 three-second
+ * segments to max_length 1024; a trained checkpoint ends a segment after tens to hundreds of tokens).  Once a quarter of the
+ * rows still being decoded have emitted EOS, m2m_generate_greedy re-packs the live rows into the first slots of the batch at its
+ * next host poll (every 64 steps) and goes on with smaller launches; ids do not depend on it.  This returns how often that
+ * happened in the last call and how many rows were moved (M2M_COMPACT=0 in the environment disables the re-packing).
+ */
+int m2m_session_repack_stats(const m2m_session* s, int* repacks_out, int* rows_moved_out);
+
+/*
  * Teacher-forced decoder pass, replaces the decoder half of
  * ref: music2midi/transformer.py:35-37 (logits only; the loss is a host-side reduction).
  * dec_input_ids_dev [B, Ld] int64 (= shift_right(labels)), logits_out_dev [B, Ld, V] fp32.

@@ -549,7 +549,8 @@ struct DecAttnArgs {
   const float* emb;            // self: [V, d] token embedding — the input row is emb[token decoded from keys[b]]
   unsigned long long* keys;    // [B] arg-max keys of the previous step (self: read; cross with `book`: read, then cleared)
   int* finished;               // [B]
-  int64_t* tokens;             // [B, max_len]
+  int64_t* tokens;             // [session rows, max_len]: the WHOLE token matrix; row of slot b = tok_row[b]
+  const int* tok_row;          // [B] clip (token-matrix row) decoded in slot b of this chain: identity until live rows are re-packed
   int max_len, V, pad_id, eos_id;
   int book;                    // cross: head 0's workgroup of every row does the row's bookkeeping at its end
   // Finished-row early-out (greedy loop): fin_skip[b * fin_stride] != 0 -> row b has emitted EOS; its tokens are pad whatever
@@ -990,7 +991,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
     if (!st_done) {
       const int fin = a.finished[b];
       const int next = amax_key_token(a.keys[b], fin, a.V, a.pad_id);
-      if (st_t < a.max_len) a.tokens[(int64_t)b * a.max_len + st_t] = next;
+      if (st_t < a.max_len) a.tokens[(int64_t)a.tok_row[b] * a.max_len + st_t] = next;
       const int nf = fin | (next == a.eos_id);
       a.finished[b] = nf;
       if (!nf) atomicAdd(&a.state->n_unfinished, 1);
@@ -1034,7 +1035,9 @@ struct DecHeadArgs {
   const float* shared;     // [V, d] embedding
   xq_t* x;                 // [B, d] next-step input (fixed-point residual stream, buffer A)
   xq_t* x_zero;            // [B, d] buffer B: zeroed by the init kernel (later by every FFN down projection)
-  int64_t* tokens;         // [B, max_len] generated ids (col 0 = start)
+  int64_t* tokens;         // [session rows, max_len] generated ids (col 0 = start): the whole matrix, row of slot b = tok_row[b]
+  int* tok_row;            // [B] (chain view) clip decoded in slot b; written by the init kernel (identity: row0 + b)
+  int row0;                // first slot of this chain in the session
   int max_len;
   int* finished;           // [B]
   unsigned long long* keys;// [B] (headless greedy loop; null otherwise)
@@ -1110,7 +1113,7 @@ __global__ __launch_bounds__(1024) void dec_head_kernel(DecHeadArgs a) {
       // hf generation/utils.py:2925-2937: argmax; finished rows emit pad; EOS finishes a row
       next = fin ? a.pad_id : (bi == 0x7fffffff ? 0 : bi);
       if (l32 == 0 && live) {
-        if (t + 1 < a.max_len) a.tokens[(int64_t)b * a.max_len + t + 1] = next;
+        if (t + 1 < a.max_len) a.tokens[(int64_t)a.tok_row[b] * a.max_len + t + 1] = next;
         const int nf = fin | (next == a.eos_id);
         a.finished[b] = nf;
         if (!nf) atomicAdd(&s_unfinished, 1);
@@ -1150,10 +1153,13 @@ __global__ void dec_init_kernel(DecHeadArgs a, int start_id, int max_steps) {
   }
   for (int b = tid; b < a.B; b += nthreads) {
     a.finished[b] = 0;
+    a.tok_row[b] = a.row0 + b;
     if (a.keys) a.keys[b] = amax_key(0.f, start_id);         // headless: step 0 "decodes" the start token
   }
-  if (!a.forced)
-    for (int i = tid; i < a.B * a.max_len; i += nthreads) a.tokens[i] = (i % a.max_len == 0) ? start_id : a.pad_id;
+  if (!a.forced) {
+    int64_t* tk = a.tokens + (int64_t)a.row0 * a.max_len;
+    for (int i = tid; i < a.B * a.max_len; i += nthreads) tk[i] = (i % a.max_len == 0) ? start_id : a.pad_id;
+  }
   for (int i = tid; i < a.B * a.d; i += nthreads) {
     const int b = i / a.d, c = i - b * a.d;
     int tok = a.forced ? (int)a.forced[(int64_t)b * a.Ld] : start_id;
@@ -1171,7 +1177,7 @@ __global__ void dec_final_kernel(DecHeadArgs a) {
   for (int b = threadIdx.x; b < a.B; b += blockDim.x) {
     const int fin = a.finished[b];
     const int next = amax_key_token(a.keys[b], fin, a.V, a.pad_id);
-    if (t < a.max_len) a.tokens[(int64_t)b * a.max_len + t] = next;
+    if (t < a.max_len) a.tokens[(int64_t)a.tok_row[b] * a.max_len + t] = next;
     a.finished[b] = fin | (next == a.eos_id);
   }
   __syncthreads();
@@ -1184,6 +1190,75 @@ bool decode_headless() {
   return on;
 }
 
+// ============================================================ live-row re-packing ====
+// Clips end at different steps (a real checkpoint ends a 3 s segment after tens to hundreds of its 1 024 tokens).  The finished-row
+// early-out above stops a finished row's K/V stream, but its workgroups still launch and the chain still pays its latency floor for
+// every slot.  At a host poll the decode loop (t5_api.hip) therefore RE-PACKS the live rows into the first slots and relaunches
+// smaller chains: every per-clip buffer has the clip index outermost, so a row is moved by copying its planes — self K/V up to the
+// current position, cross K/V, the pending arg-max key, the residual row — from a slot behind the packed range into the slot of a
+// finished row in front of it (source and destination sets are disjoint: one launch, no ordering).  Token rows do NOT move: slot ->
+// clip is the tok_row table.  Nothing of this changes an id: a row's arithmetic never depended on its slot.
+struct MoveArgs {
+  int n;                        // moves in this launch (<= 64)
+  short src[64], dst[64];
+  unsigned char* self_k; unsigned char* self_v; unsigned char* cross_kv;
+  int64_t self_row, self_layer;     // bytes between rows / layers of the self caches ([L][maxB][H][Lmax][64])
+  int64_t self_head; int self_len_bytes;   // bytes between heads, bytes of the t valid keys of one head
+  int H;
+  int64_t cross_row, cross_plane;   // bytes of one row's [H][S][64] block, bytes between (layer, k|v) planes ([L][2][B][H][S][64])
+  int L;
+  unsigned long long* keys; int* finished; int* tok_row;
+  xq_t* x0; int d;                  // residual buffer A
+};
+
+__global__ __launch_bounds__(256) void dec_move_rows_kernel(MoveArgs a) {
+  const int mv = blockIdx.x, plane = blockIdx.y, part = blockIdx.z, nparts = gridDim.z;
+  const int src = a.src[mv], dst = a.dst[mv];
+  const int tid = threadIdx.x;
+  if (plane < 2 * a.L) {                              // self K (even) / V (odd) of layer plane / 2: H pieces of self_len_bytes
+    unsigned char* base = (plane & 1) ? a.self_v : a.self_k;
+    const int64_t lo = (int64_t)(plane >> 1) * a.self_layer;
+    const int per_head = a.self_len_bytes / 16;       // 16-byte units (64 elements * es is a multiple of 16)
+    const int total = a.H * per_head;
+    for (int i = part * 256 + tid; i < total; i += nparts * 256) {
+      const int hh = i / per_head, u = i - hh * per_head;
+      const int64_t off = lo + (int64_t)hh * a.self_head + (int64_t)u * 16;
+      *reinterpret_cast<uint4*>(base + off + (int64_t)dst * a.self_row) = *reinterpret_cast<const uint4*>(base + off + (int64_t)src * a.self_row);
+    }
+  } else if (plane < 4 * a.L) {                       // cross K/V plane (layer, k|v): one contiguous block per row
+    const int64_t lo = (int64_t)(plane - 2 * a.L) * a.cross_plane;
+    const int64_t total = a.cross_row / 16;
+    for (int64_t i = part * 256 + tid; i < total; i += nparts * 256)
+      *reinterpret_cast<uint4*>(a.cross_kv + lo + (int64_t)dst * a.cross_row + i * 16) =
+          *reinterpret_cast<const uint4*>(a.cross_kv + lo + (int64_t)src * a.cross_row + i * 16);
+  } else if (part == 0) {                             // the row's small state
+    for (int c = tid; c < a.d; c += 256) a.x0[(int64_t)dst * a.d + c] = a.x0[(int64_t)src * a.d + c];
+    if (tid == 0) { a.keys[dst] = a.keys[src]; a.finished[dst] = a.finished[src]; a.tok_row[dst] = a.tok_row[src]; }
+  }
+}
+
+// src[i] -> dst[i] for i < n (slots of the session; the sets are disjoint); t = keys already cached per row
+int decode_move_rows(m2m_session* s, const int* src, const int* dst, int n, int t, hipStream_t st) {
+  const m2m_model* m = s->m;
+  const m2m_t5_geometry& g = m->g;
+  const int64_t es = (int64_t)m->esize;
+  for (int at = 0; at < n; at += 64) {
+    MoveArgs a{};
+    a.n = n - at < 64 ? n - at : 64;
+    for (int i = 0; i < a.n; ++i) { a.src[i] = (short)src[at + i]; a.dst[i] = (short)dst[at + i]; }
+    a.self_k = (unsigned char*)s->self_k; a.self_v = (unsigned char*)s->self_v; a.cross_kv = (unsigned char*)s->cross_kv;
+    a.self_head = (int64_t)s->max_dec * DK * es; a.self_row = (int64_t)g.num_heads * a.self_head;
+    a.self_layer = (int64_t)s->max_batch * a.self_row; a.self_len_bytes = (int)((int64_t)t * DK * es);
+    a.H = g.num_heads; a.L = g.num_decoder_layers;
+    a.cross_row = (int64_t)g.num_heads * s->S * DK * es; a.cross_plane = (int64_t)s->B * a.cross_row;
+    a.keys = s->keys; a.finished = s->finished; a.tok_row = s->tok_row;
+    a.x0 = reinterpret_cast<xq_t*>(s->x_dec); a.d = g.d_model;
+    hipLaunchKernelGGL(dec_move_rows_kernel, dim3((unsigned)a.n, (unsigned)(4 * a.L + 1), 8), dim3(256), 0, st, a);
+    M2M_CHECK_HIP(hipGetLastError());
+  }
+  return M2M_OK;
+}
+
 // ============================================================ step driver ====
 static xq_t* xbuf(m2m_session* s, const DecView& v, int which);
 // All per-clip buffers are [B][...] with the clip index outermost, so a view is a pointer offset.
@@ -1192,7 +1267,7 @@ static DecHeadArgs head_args(m2m_session* s, const DecView& v, bool forced, floa
   DecHeadArgs h{};
   h.logits = s->logits + (int64_t)v.b0 * m->vocab_pad; h.ldl = m->vocab_pad; h.V = m->g.vocab_size; h.B = v.nb;
   h.d = m->g.d_model; h.shared = m->shared; h.x = xbuf(s, v, 0); h.x_zero = xbuf(s, v, 1);
-  h.tokens = s->tokens + (int64_t)v.b0 * s->max_dec; h.max_len = s->max_dec;
+  h.tokens = s->tokens; h.tok_row = s->tok_row + v.b0; h.row0 = v.b0; h.max_len = s->max_dec;
   h.finished = s->finished + v.b0; h.state = v.state; h.pad_id = m->g.pad_token_id; h.eos_id = m->g.eos_token_id;
   h.keys = (!forced && decode_headless()) ? s->keys + v.b0 : nullptr;
   h.forced = forced ? s->forced_ids + (int64_t)v.b0 * Ld : nullptr; h.Ld = Ld;
@@ -1259,7 +1334,7 @@ int decode_launch_attn(m2m_session* s, const DecView& v, bool self, int layer, i
   if (skip_finished && decode_finished_skip_on()) { a.fin_skip = s->finished + v.b0; a.fin_stride = 1; }
   else { a.fin_skip = &v.state->zero; a.fin_stride = 0; }
   if (headless && layer == 0) {            // the greedy loop without the head kernel: layer 0 takes over its work
-    a.keys = s->keys + v.b0; a.finished = s->finished + v.b0; a.tokens = s->tokens + (int64_t)v.b0 * s->max_dec;
+    a.keys = s->keys + v.b0; a.finished = s->finished + v.b0; a.tokens = s->tokens; a.tok_row = s->tok_row + v.b0;
     a.max_len = s->max_dec; a.V = g.vocab_size; a.pad_id = g.pad_token_id; a.eos_id = g.eos_token_id;
     if (self) a.emb = m->shared; else a.book = 1;
   }

@@ -83,9 +83,13 @@ struct DecGroup {
   DecState* state_host = nullptr;   // pinned
   hipStream_t stream = nullptr;
   hipEvent_t ev_done = nullptr;
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t graph_exec = nullptr;
-  int graph_key[6] = {-1, -1, -1, -1, -1, -1};   // B, S, b0, nb, steps per graph, finished-row skip on / off (baked into the launches)
+  hipGraphExec_t graph_exec = nullptr;           // the graph of the current view (an entry of `graphs`)
+  // captured graphs by (B, S, b0, nb, steps per graph, finished-row skip on / off) — all baked into the launches.  Re-packing the live
+  // rows changes (b0, nb) several times per batch, and the next batch starts from the full views again: a small cache instead of
+  // a re-capture (~1 ms per 8-step graph) at every change
+  struct GraphEntry { int key[6]; hipGraph_t graph; hipGraphExec_t exec; unsigned long long used; };
+  std::vector<GraphEntry> graphs;
+  unsigned long long graph_clock = 0;
 };
 }  // namespace m2m
 
@@ -112,11 +116,13 @@ struct m2m_session {
   float* logits;           // [B, vocab_pad]
   int64_t* tokens;         // [B, max_dec]
   int* finished;           // [B]
+  int* tok_row;            // [B] slot -> clip (row of `tokens`) of the greedy loop: identity until live rows are re-packed (decode.hip)
   unsigned long long* keys;// [B] headless greedy loop: packed (logit, vocabulary index) arg-max keys of the previous step
   m2m::DecState* states;   // device [MAX_GROUPS]
   int64_t* forced_ids;     // [B, max_dec]
   // current problem
   int B = 0, S = 0;
+  int repacks = 0, rows_moved = 0;   // live-row re-packings / rows moved by them in the last m2m_generate_greedy
   bool encoded = false;
   // decode chains
   hipEvent_t ev_in = nullptr;
@@ -206,6 +212,7 @@ int decode_launch_step(m2m_session* s, const DecView& v, bool forced, float* log
 bool decode_finished_skip_on();
 int decode_launch_attn(m2m_session* s, const DecView& v, bool self, int layer, int self_len, hipStream_t st, bool headless = false,
                        bool skip_finished = false);
+int decode_move_rows(m2m_session* s, const int* src, const int* dst, int n, int t, hipStream_t st);   // live-row re-packing (decode.hip)
 int decode_finalize(m2m_session* s, const DecView& v, hipStream_t st);   // headless greedy loop: write the last token, close the chain
 bool decode_headless();
 

@@ -182,7 +182,7 @@ extern "C" int m2m_model_checksum(const m2m_model* m, uint64_t* out_host, void* 
 namespace {
 struct WsLayout {
   int64_t x_enc, h_enc, qkv_enc, vt_enc, attn_enc, mid_enc, enc_bias, dec_bias, dec_bias_full, cross_vt, cross_kv, self_k, self_v;
-  int64_t x_dec, logits, tokens, finished, keys, state, forced, total;
+  int64_t x_dec, logits, tokens, finished, tok_row, keys, state, forced, total;
 };
 
 WsLayout ws_layout(const m2m_model* m, int B, int S, int L) {
@@ -210,6 +210,7 @@ WsLayout ws_layout(const m2m_model* m, int B, int S, int L) {
   w.logits = take(Bp * m->vocab_pad * 4);
   w.tokens = take((int64_t)B * L * 8);
   w.finished = take((int64_t)B * 4);
+  w.tok_row = take((int64_t)B * 4);
   w.keys = take((int64_t)B * 8);
   w.state = take(sizeof(DecState) * MAX_GROUPS);
   w.forced = take((int64_t)B * L * 8);
@@ -250,7 +251,7 @@ extern "C" int m2m_session_create(const m2m_model* m, int max_batch, int max_enc
   s->dec_bias_full_tab = (float*)(b + w.dec_bias_full); s->cross_vt = b + w.cross_vt;
   s->x_dec = (b + w.x_dec);
   s->logits = (float*)(b + w.logits); s->tokens = (int64_t*)(b + w.tokens);
-  s->finished = (int*)(b + w.finished); s->keys = (unsigned long long*)(b + w.keys); s->states = (DecState*)(b + w.state); s->forced_ids = (int64_t*)(b + w.forced);
+  s->finished = (int*)(b + w.finished); s->tok_row = (int*)(b + w.tok_row); s->keys = (unsigned long long*)(b + w.keys); s->states = (DecState*)(b + w.state); s->forced_ids = (int64_t*)(b + w.forced);
 
   // relative-position bias tables (fp32), built on the host from the bucket function
   const m2m_t5_geometry& g = m->g;
@@ -294,8 +295,11 @@ extern "C" void m2m_session_destroy(m2m_session* s) {
   if (!s) return;
   for (int i = 0; i < MAX_GROUPS; ++i) {
     DecGroup& gr = s->groups[i];
-    if (gr.graph_exec) (void)hipGraphExecDestroy(gr.graph_exec);
-    if (gr.graph) (void)hipGraphDestroy(gr.graph);
+    for (auto& ge : gr.graphs) {
+      if (ge.exec) (void)hipGraphExecDestroy(ge.exec);
+      if (ge.graph) (void)hipGraphDestroy(ge.graph);
+    }
+    gr.graphs.clear();
     if (gr.ev_done) (void)hipEventDestroy(gr.ev_done);
     if (gr.stream) (void)hipStreamDestroy(gr.stream);
     if (gr.state_host) (void)hipHostFree(gr.state_host);
@@ -371,16 +375,17 @@ static bool use_graph() { return env_int("M2M_NO_GRAPH", 0) != 1; }
 // Split the B encoded clips into independent chains: M2M_GROUP_ROWS clips per chain (default 32:
 // one 32-row MFMA tile of clips per chain), at most MAX_GROUPS chains.  Measured at B = 32 on
 // MI355X: 1 chain 322 ms, 2 chains 315 ms, 4 chains 666 ms (dispatch-bound) - see DESIGN_HISTORY.md 4.4.
-static int plan_groups(m2m_session* s) {
+static int plan_groups(m2m_session* s, int rows = -1) {       // rows: the packed slots to decode (default: the whole encoded batch)
   // Default: TWO chains once there are enough clips to split (B >= 24), one otherwise.  Two graph chains on two
   // streams overlap one chain's latency phases (prologue, merge tail, feed-forward, lm_head / head) with the other's
   // K/V stream: B = 32 -> 2 x 16 clips is +3.7 % over one chain of 32 (tools/chain_sweep.py); more than two chains do
   // not help (the dependent-dispatch rate of the command processor becomes the limit: 4 x 8 = 1 x 32, 8 x 4 is 4x slower).
+  const int nrows = rows < 0 ? s->B : rows;
   const int rows_env = env_int("M2M_GROUP_ROWS", 0);
-  int G = rows_env > 0 ? ceil_div(s->B, rows_env) : (s->B >= 24 ? 2 : 1);
+  int G = rows_env > 0 ? ceil_div(nrows, rows_env) : (nrows >= 24 ? 2 : 1);
   if (G < 1) G = 1;
   if (G > MAX_GROUPS) G = MAX_GROUPS;
-  const int base = s->B / G, extra = s->B % G;
+  const int base = nrows / G, extra = nrows % G;
   int b0 = 0;
   for (int i = 0; i < G; ++i) {
     s->groups[i].view.b0 = b0;
@@ -394,9 +399,18 @@ static int plan_groups(m2m_session* s) {
 // device memory, so the same graph replays for every position; steps past the end are no-ops).
 static int ensure_graph(m2m_session* s, DecGroup& gr, int steps) {
   const int key[6] = {s->B, s->S, gr.view.b0, gr.view.nb, steps, decode_finished_skip_on() ? 1 : 0};
-  if (gr.graph_exec && memcmp(key, gr.graph_key, sizeof(key)) == 0) return M2M_OK;
-  if (gr.graph_exec) { (void)hipGraphExecDestroy(gr.graph_exec); gr.graph_exec = nullptr; }
-  if (gr.graph) { (void)hipGraphDestroy(gr.graph); gr.graph = nullptr; }
+  ++gr.graph_clock;
+  for (auto& ge : gr.graphs)
+    if (memcmp(key, ge.key, sizeof(key)) == 0) { ge.used = gr.graph_clock; gr.graph_exec = ge.exec; return M2M_OK; }
+  constexpr size_t MAX_CACHED = 12;
+  if (gr.graphs.size() >= MAX_CACHED) {                      // evict the least recently used entry
+    size_t lru = 0;
+    for (size_t i = 1; i < gr.graphs.size(); ++i) if (gr.graphs[i].used < gr.graphs[lru].used) lru = i;
+    (void)hipGraphExecDestroy(gr.graphs[lru].exec);
+    (void)hipGraphDestroy(gr.graphs[lru].graph);
+    gr.graphs.erase(gr.graphs.begin() + (long)lru);
+  }
+  gr.graph_exec = nullptr;
   M2M_CHECK_HIP(hipStreamBeginCapture(gr.stream, hipStreamCaptureModeThreadLocal));
   int rc = M2M_OK;
   for (int i = 0; i < steps && rc == M2M_OK; ++i) rc = decode_launch_step(s, gr.view, false, nullptr, 0, gr.stream);
@@ -404,9 +418,14 @@ static int ensure_graph(m2m_session* s, DecGroup& gr, int steps) {
   hipError_t e = hipStreamEndCapture(gr.stream, &gph);
   if (rc != M2M_OK) { if (gph) (void)hipGraphDestroy(gph); return rc; }
   if (e != hipSuccess) { set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return M2M_ERR_HIP; }
-  gr.graph = gph;
-  M2M_CHECK_HIP(hipGraphInstantiate(&gr.graph_exec, gr.graph, nullptr, nullptr, 0));
-  memcpy(gr.graph_key, key, sizeof(key));
+  hipGraphExec_t ex = nullptr;
+  e = hipGraphInstantiate(&ex, gph, nullptr, nullptr, 0);
+  if (e != hipSuccess) { (void)hipGraphDestroy(gph); set_error("hipGraphInstantiate: %s", hipGetErrorString(e)); return M2M_ERR_HIP; }
+  DecGroup::GraphEntry ge{};
+  memcpy(ge.key, key, sizeof(key));
+  ge.graph = gph; ge.exec = ex; ge.used = gr.graph_clock;
+  gr.graphs.push_back(ge);
+  gr.graph_exec = ex;
   return M2M_OK;
 }
 
@@ -432,9 +451,12 @@ extern "C" int m2m_generate_greedy(m2m_session* s, int max_length, int64_t* toke
 
 static int generate_greedy_impl(m2m_session* s, int max_length, int64_t* tokens_out_dev, int* out_len_host, hipStream_t caller) {
   const int steps = max_length - 1;
-  const int G = plan_groups(s);
+  int G = plan_groups(s);
   const bool graph = use_graph();
   const int U = env_int("M2M_GRAPH_STEPS", 8) < 1 ? 1 : env_int("M2M_GRAPH_STEPS", 8);   // decode steps per graph
+  // Live-row re-packing at the host polls (decode.hip "live-row re-packing"): once a quarter of the packed rows have emitted EOS the
+  // live ones are moved into the first slots and smaller chains take over.  M2M_COMPACT=0: rows keep their slots (round 4).
+  const bool compact = env_int("M2M_COMPACT", 1) != 0;
   int rc;
   // order every chain after whatever the caller enqueued (encode ran on the caller's stream)
   M2M_CHECK_HIP(hipEventRecord(s->ev_in, caller));
@@ -450,7 +472,12 @@ static int generate_greedy_impl(m2m_session* s, int max_length, int64_t* tokens_
   // no-ops once their chain's state.done is set).
   const int CHUNK = 64;
   int launched = 0;
+  int cur_rows = s->B;                 // packed slots still being decoded
+  s->repacks = 0; s->rows_moved = 0;
+  int out_len = 1;                     // longest finished chain so far (chains retired by a re-packing included)
+  bool range_error = false;
   bool all_done = steps == 0;
+  std::vector<int> fin_host, mv_src, mv_dst;
   while (!all_done && launched < steps) {
     const int n = steps - launched < CHUNK ? steps - launched : CHUNK;
     for (int k = 0; k < n; k += (graph ? U : 1)) {
@@ -473,14 +500,49 @@ static int generate_greedy_impl(m2m_session* s, int max_length, int64_t* tokens_
       M2M_CHECK_HIP(hipStreamSynchronize(gr.stream));
       if (!gr.state_host->done) all_done = false;
     }
+    // ---- re-pack the live rows (every chain is idle here) ----
+    if (compact && !all_done && steps - launched >= CHUNK && cur_rows >= 2 && cur_rows < 32000) {
+      fin_host.resize((size_t)cur_rows);
+      M2M_CHECK_HIP(hipMemcpy(fin_host.data(), s->finished, (size_t)cur_rows * sizeof(int), hipMemcpyDeviceToHost));
+      int live = 0;
+      for (int b = 0; b < cur_rows; ++b) live += fin_host[(size_t)b] ? 0 : 1;
+      if (live >= 1 && (cur_rows - live) * 4 >= cur_rows) {
+        int t_cur = -1;
+        for (int i = 0; i < G; ++i) {                             // retire the current chains: keep what they report
+          const DecState& hs = *s->groups[i].state_host;
+          range_error |= hs.overflow != 0;
+          if (hs.done) { if (hs.out_len > out_len) out_len = hs.out_len; }
+          else t_cur = hs.t;
+        }
+        M2M_REQUIRE(t_cur >= 0, "m2m_generate_greedy: no running chain at a re-packing point");
+        mv_src.clear(); mv_dst.clear();
+        for (int hole = 0, tail = live; hole < live; ++hole) {    // finished slots in front take the live rows from behind the packed range
+          if (!fin_host[(size_t)hole]) continue;
+          while (tail < cur_rows && fin_host[(size_t)tail]) ++tail;
+          mv_src.push_back(tail++); mv_dst.push_back(hole);
+        }
+        hipStream_t st0 = s->groups[0].stream;
+        if (!mv_src.empty() && (rc = decode_move_rows(s, mv_src.data(), mv_dst.data(), (int)mv_src.size(), t_cur, st0))) return rc;
+        M2M_CHECK_HIP(hipStreamSynchronize(st0));
+        s->repacks += 1; s->rows_moved += (int)mv_src.size();
+        cur_rows = live;
+        G = plan_groups(s, cur_rows);
+        for (int i = 0; i < G; ++i) {
+          DecGroup& gr = s->groups[i];
+          DecState hs{};
+          hs.t = t_cur; hs.t_copy = t_cur; hs.done = 0; hs.out_len = 1; hs.n_unfinished = 0; hs.max_steps = steps;
+          *gr.state_host = hs;
+          M2M_CHECK_HIP(hipMemcpyAsync(gr.view.state, gr.state_host, sizeof(DecState), hipMemcpyHostToDevice, gr.stream));
+          if (graph && (rc = ensure_graph(s, gr, U))) return rc;
+        }
+      }
+    }
   }
   // headless loop: the last step's arg-max is still a pending key (no later step consumed it)
   if (steps > 0)
     for (int i = 0; i < G; ++i)
       if ((rc = decode_finalize(s, s->groups[i].view, s->groups[i].stream))) return rc;
   // valid length = the longest chain (one process decoding the whole batch stops when EVERY row has finished)
-  int out_len = 1;
-  bool range_error = false;
   for (int i = 0; i < G; ++i) {
     DecGroup& gr = s->groups[i];
     M2M_CHECK_HIP(hipMemcpyAsync(gr.state_host, gr.view.state, sizeof(DecState), hipMemcpyDeviceToHost, gr.stream));
@@ -564,6 +626,12 @@ static int forward_batched(m2m_session* s, const int64_t* ids, int Ld, float* lo
   return launch_norm_gemm(P, EPI_STORE_F32, a, st);
 }
 
+extern "C" int m2m_session_repack_stats(const m2m_session* s, int* repacks_out, int* rows_moved_out) {
+  M2M_REQUIRE(s && repacks_out && rows_moved_out, "m2m_session_repack_stats: null argument");
+  *repacks_out = s->repacks; *rows_moved_out = s->rows_moved;
+  return M2M_OK;
+}
+
 extern "C" int m2m_decode_forced(m2m_session* s, const int64_t* dec_input_ids_dev, int Ld, float* logits_out_dev, void* stream) {
   M2M_REQUIRE(s && dec_input_ids_dev && logits_out_dev, "m2m_decode_forced: null argument");
   if (!s->encoded) { set_error("m2m_decode_forced: call m2m_encode first"); return M2M_ERR_STATE; }
@@ -605,6 +673,11 @@ extern "C" int m2m_bench_kernel(m2m_session* s, int which, int self_len, int ite
   int rc;
   // every chain sees a live loop in its (self_len)-th step
   DecState hs{}; hs.t = self_len - 1; hs.t_copy = self_len - 1; hs.done = 0; hs.out_len = 1; hs.n_unfinished = 0; hs.max_steps = s->max_dec;
+  {   // slot -> clip table of the greedy loop: identity (a fresh session has none, a re-packed generate leaves a permutation)
+    std::vector<int> ident((size_t)s->B);
+    for (int b = 0; b < s->B; ++b) ident[(size_t)b] = b;
+    M2M_CHECK_HIP(hipMemcpy(s->tok_row, ident.data(), ident.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
   for (int i = 0; i < G; ++i) {
     const DecGroup& gr = s->groups[i];
     M2M_CHECK_HIP(hipMemcpyAsync(gr.view.state, &hs, sizeof(hs), hipMemcpyHostToDevice, gr.stream));

@@ -84,6 +84,7 @@ _SIGNATURES = {
     "m2m_session_destroy": (None, [C.c_void_p]),
     "m2m_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "m2m_generate_greedy": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]),
+    "m2m_session_repack_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "m2m_decode_forced": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "m2m_trainer_create": (C.c_int, [C.POINTER(T5GeometryC), C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.POINTER(C.c_void_p)]),

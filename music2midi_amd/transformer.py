@@ -341,6 +341,16 @@ class T5Transformer(nn.Module):
                                                              native.stream_handle(x.device)), "m2m_decode_forced")
             return logits
 
+    def repack_stats(self):
+        """(re-packings, rows moved) of the last greedy decode on the current session: how often the live rows were moved into
+        the first slots after a quarter of them had emitted EOS (``m2m_session_repack_stats``)."""
+        with self._lock:
+            if self._session is None:
+                return 0, 0
+            a, b = C.c_int(0), C.c_int(0)
+            native.check(native.load().m2m_session_repack_stats(self._session, C.byref(a), C.byref(b)), "m2m_session_repack_stats")
+            return int(a.value), int(b.value)
+
     def bench_kernel(self, which: int, self_len: int, iters: int):
         """Time one decode kernel in isolation on the current session (after an encode):
         returns (avg microseconds per launch, algorithmic bytes per launch)."""

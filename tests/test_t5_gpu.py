@@ -288,3 +288,49 @@ def test_norm_gemm_fused_kernel_is_bit_identical_to_the_two_kernel_path(monkeypa
     assert torch.isfinite(out["force"][0]).all()
     assert torch.equal(out["force"][0], out["0"][0]), f"fused norm+GEMM logits differ: max |d| {(out['force'][0] - out['0'][0]).abs().max():.3e}"
     assert torch.equal(out["force"][1], out["0"][1])
+
+
+@pytest.mark.parametrize("precision,B,S", [("bf16", 32, 190), ("fp32", 9, 61), ("bf16", 5, 864), ("bf16", 128, 40), ("fp32", 33, 30)])
+def test_live_row_repacking_does_not_change_ids(monkeypatch, precision, B, S):
+    """Round 5: at a host poll of the greedy loop, once a quarter of the rows still being decoded have emitted EOS,
+    the live rows are MOVED into the first slots (self K/V up to the current position, cross K/V, pending arg-max key, residual row;
+    token rows stay, slot -> clip is a table) and smaller chains take over — merging two chains into one when the live rows fit.
+    A row's arithmetic never depended on its slot, so ids with re-packing (default) == ids without (M2M_COMPACT=0) == the oracle's
+    (fp32); the case must really re-pack (rows moved), and the session must decode a following full batch correctly
+    (graphs of every view are cached, the slot table is reset by the next decode)."""
+    cfg = DEFAULT_CONFIG
+    geom = T5Geometry(load_config(cfg).model.t5)
+    sd = synth.t5_state_dict(geom, seed=0)
+    synth.perturb_layer_norms(sd, 0)
+    synth.force_eos_head(sd, geom, active=340, eos_scale=1.6)
+    x = embeds(B, S, geom.d_model, seed=21)
+    m = T5Transformer(cfg, precision=precision)
+    load_t5_state(m, sd, strict=False)
+    m = m.cuda().eval()
+    outs = {}
+    for leg, env in (("on", "1"), ("off", "0"), ("on_again", "1")):
+        monkeypatch.setenv("M2M_COMPACT", env)
+        outs[leg] = m.generate_from_embeds(x.cuda(), max_length=1024).cpu()
+        stats = m.repack_stats()
+        if env == "1":
+            print(f"re-packing {precision} B={B} S={S}: {stats[0]} re-packings, {stats[1]} rows moved, output length {outs[leg].shape[1]}")
+            assert stats[0] >= 1 and stats[1] >= 1
+        else:
+            assert stats == (0, 0)
+    assert torch.equal(outs["on"], outs["off"]) and torch.equal(outs["on_again"], outs["off"])
+    a = outs["on"]
+    ends = [int((a[r] == geom.eos_token_id).float().argmax()) if (a[r] == geom.eos_token_id).any() else -1 for r in range(B)]
+    assert sum(1 for e in ends if e > 0) >= B // 2 and len(set(ends)) > 2
+    if precision == "fp32":
+        from oracle.t5 import T5Oracle
+        assert torch.equal(a, T5Oracle(geom, sd).generate(x, 1024))
+    # a batch without EOS on the same session afterwards: full-size chains again, nothing left over from the permuted slots
+    sd2 = synth.t5_state_dict(geom, seed=0)
+    synth.perturb_layer_norms(sd2, 0)
+    m2 = T5Transformer(cfg, precision=precision)
+    load_t5_state(m2, sd2, strict=False)
+    m2 = m2.cuda().eval()
+    want = m2.generate_from_embeds(x.cuda(), max_length=96).cpu()
+    load_t5_state(m, sd2, strict=False)
+    got = m.generate_from_embeds(x.cuda(), max_length=96).cpu()
+    assert torch.equal(got, want)
