@@ -344,14 +344,17 @@ def ragged_eos_record(cfg, geom, dev, B: int, S: int, eos_scale: float = 1.6, re
     synth.perturb_layer_norms(sd, 0)
     synth.force_eos_head(sd, geom, active=340, eos_scale=eos_scale)
     x = torch.from_numpy(synth.normal(21, "embeds", (B, S, geom.d_model), 3.0)).to(dev)
-    out, ids = {}, {}
-    old = os.environ.get("M2M_FINISHED_SKIP")
+    out, ids, repacks = {}, {}, (0, 0)
+    old = {k: os.environ.get(k) for k in ("M2M_FINISHED_SKIP", "M2M_COMPACT")}
     try:
-        for leg, env in (("skip_on", None), ("skip_off", "0")):
-            if env is None:
-                os.environ.pop("M2M_FINISHED_SKIP", None)
-            else:
-                os.environ["M2M_FINISHED_SKIP"] = env
+        # three legs: the product (finished-row early-out + live-row re-packing at the host polls, round 5), the early-out alone
+        # (round 4), and neither (every row computed to the end of the chain, as HF does and as rounds 1-3 did)
+        for leg, skip, comp in (("repack", None, None), ("skip_on", None, "0"), ("skip_off", "0", "0")):
+            for k, v in (("M2M_FINISHED_SKIP", skip), ("M2M_COMPACT", comp)):
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
             m = T5Transformer(cfg.to_dict(), precision="bf16")        # a session of its own: the flag is baked into its captured graphs
             load_t5_state(m, sd, strict=False)
             m = m.to(dev).eval()
@@ -362,12 +365,15 @@ def ragged_eos_record(cfg, geom, dev, B: int, S: int, eos_scale: float = 1.6, re
                 m.generate_from_embeds(x, max_length=MAX_LENGTH)
             torch.cuda.synchronize(dev)
             out[leg] = (time.perf_counter() - t0) / reps
+            if leg == "repack":
+                repacks = m.repack_stats()
             del m
     finally:
-        if old is None:
-            os.environ.pop("M2M_FINISHED_SKIP", None)
-        else:
-            os.environ["M2M_FINISHED_SKIP"] = old
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     a = ids["skip_on"].cpu().numpy()
     L = a.shape[1]
     ends = []
@@ -382,10 +388,14 @@ def ragged_eos_record(cfg, geom, dev, B: int, S: int, eos_scale: float = 1.6, re
             "rows_with_eos": int(sum(1 for r in range(B) if (a[r] == geom.eos_token_id).any())), "output_length": int(L),
             "eos_position_min_median_max": [int(min(ends)), int(np.median(ends)), int(max(ends))], "useful_tokens": useful,
             "decoded_positions": int(B * (L - 1)),
-            "ids_identical_with_and_without_skip": bool(torch.equal(ids["skip_on"], ids["skip_off"])),
-            "ms_per_batch_skip_on": out["skip_on"] * 1e3, "ms_per_batch_skip_off": out["skip_off"] * 1e3,
-            "useful_tokens_per_s_skip_on": useful / out["skip_on"], "useful_tokens_per_s_skip_off": useful / out["skip_off"],
-            "speedup": out["skip_off"] / out["skip_on"]}
+            "ids_identical_with_and_without_skip": bool(torch.equal(ids["skip_on"], ids["skip_off"]) and torch.equal(ids["repack"], ids["skip_off"])),
+            "repackings_per_batch": int(repacks[0]), "rows_moved_per_batch": int(repacks[1]),
+            "ms_per_batch": out["repack"] * 1e3, "ms_per_batch_skip_on": out["skip_on"] * 1e3, "ms_per_batch_skip_off": out["skip_off"] * 1e3,
+            "useful_tokens_per_s": useful / out["repack"], "useful_tokens_per_s_skip_on": useful / out["skip_on"],
+            "useful_tokens_per_s_skip_off": useful / out["skip_off"],
+            "speedup": out["skip_off"] / out["repack"], "speedup_early_out_alone": out["skip_off"] / out["skip_on"],
+            "legs": "ms_per_batch = early-out + live-row re-packing (product); _skip_on = early-out alone (M2M_COMPACT=0, round 4); "
+                    "_skip_off = every row computed to the end (M2M_FINISHED_SKIP=0 M2M_COMPACT=0, HF's behaviour, rounds 1-3); speedup = _skip_off / product"}
 
 
 def reference_native_record(model, cfg, geom, dev, reps: int = 3) -> dict:

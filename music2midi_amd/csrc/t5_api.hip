@@ -479,7 +479,10 @@ static int generate_greedy_impl(m2m_session* s, int max_length, int64_t* tokens_
   bool all_done = steps == 0;
   std::vector<int> fin_host, mv_src, mv_dst;
   while (!all_done && launched < steps) {
-    const int n = steps - launched < CHUNK ? steps - launched : CHUNK;
+    // the first polls come sooner (after 16, 32, 64, 128 steps, then every 64): many rows of a real batch end within their first
+    // tens of tokens, and a poll costs one drained pipeline (~a step) while every step before a re-packing costs the full batch
+    const int chunk = compact ? (launched < 32 ? 16 : (launched < 128 ? 32 : CHUNK)) : CHUNK;
+    const int n = steps - launched < chunk ? steps - launched : chunk;
     for (int k = 0; k < n; k += (graph ? U : 1)) {
       for (int i = 0; i < G; ++i) {
         DecGroup& gr = s->groups[i];
