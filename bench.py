@@ -157,6 +157,19 @@ def pin_host_threads(world: int) -> int:
 
 
 # ------------------------------------------------------------------ CPU baselines (oracle; checker code, timed only)
+def host_cpu_share() -> dict:
+    """What this process may use of the host: visible CPUs and the cgroup quota (cpu.max = "<quota> <period>" in microseconds).
+    The GPU boxes show 256 CPUs with a quota of 16: a 16-thread figure IS the whole share (round-4 review asked for a whole-host
+    figure next to it; tools/cpu_threads_probe.py's 32 / 64 / 128-thread runs were slower because they oversubscribe that quota)."""
+    out = {"visible_cpus": os.cpu_count(), "cgroup_cpu_quota": None}
+    try:
+        q, per = Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]
+        out["cgroup_cpu_quota"] = None if q == "max" else round(int(q) / int(per), 2)
+    except Exception:
+        pass
+    return out
+
+
 def cpu_baseline(cfg, state, new_tokens: int, clips: int = 8, threads: int = 16):
     """Oracle on the host cores, fp32: `clips` clips batched (frontend + encoder + `new_tokens` greedy
     steps each) and ONE clip alone (BASELINE configs[0]).
@@ -188,7 +201,10 @@ def cpu_baseline(cfg, state, new_tokens: int, clips: int = 8, threads: int = 16)
 
     single, dt1, n1 = run(1)
     batched, dtb, nb = run(clips)
-    return {"value": batched, "unit": "tokens/s", "cores": threads, "kind": "port",
+    share = host_cpu_share()
+    return {"value": batched, "unit": "tokens/s", "cores": threads, "kind": "port", "host_share": share,
+            "whole_share_note": (f"the box grants this job {share['cgroup_cpu_quota']} CPUs (cgroup cpu.max) of {share['visible_cpus']} visible: "
+                                 f"{threads} threads use the whole share" if share["cgroup_cpu_quota"] else "no cgroup CPU quota found"),
             "sample": f"{clips} clips x {N_SAMPLES} samples in one batch: log-mel + encoder (S=864) + {nb} greedy "
                       f"decode steps each, fp32 torch-CPU oracle, {dtb:.1f} s wall, {threads} threads of "
                       f"os.cpu_count()={os.cpu_count()}",
