@@ -1059,7 +1059,7 @@ template <> __device__ inline uint4 zero_tail<bf16_t>(uint4 v, int nvalid) {
 }
 
 template <typename T, bool CAUSAL, bool BIAS>
-__global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void attn_kernel(AttnArgs a) {
   using Cfg = AttnCfg<T>;
   constexpr int EPC = 16 / sizeof(T);
   extern __shared__ __align__(16) unsigned char smem[];
