@@ -334,3 +334,29 @@ def test_live_row_repacking_does_not_change_ids(monkeypatch, precision, B, S):
     load_t5_state(m, sd2, strict=False)
     got = m.generate_from_embeds(x.cuda(), max_length=96).cpu()
     assert torch.equal(got, want)
+
+
+def test_live_row_repacking_without_graphs_and_with_small_chains(monkeypatch):
+    """The re-packing path under the other launch modes: direct launches instead of replayed graphs (M2M_NO_GRAPH=1) and four
+    chains of 8 clips (M2M_GROUP_ROWS=8: re-planning then shrinks the NUMBER of chains, not only their width)."""
+    cfg = DEFAULT_CONFIG
+    geom = T5Geometry(load_config(cfg).model.t5)
+    sd = synth.t5_state_dict(geom, seed=0)
+    synth.perturb_layer_norms(sd, 0)
+    synth.force_eos_head(sd, geom, active=340, eos_scale=1.6)
+    x = embeds(32, 61, geom.d_model, seed=21)
+    m = T5Transformer(cfg, precision="fp32")
+    load_t5_state(m, sd, strict=False)
+    m = m.cuda().eval()
+    monkeypatch.setenv("M2M_COMPACT", "0")
+    want = m.generate_from_embeds(x.cuda(), max_length=400).cpu()
+    monkeypatch.setenv("M2M_COMPACT", "1")
+    for env in ({"M2M_NO_GRAPH": "1"}, {"M2M_GROUP_ROWS": "8"}, {"M2M_GROUP_ROWS": "8", "M2M_NO_GRAPH": "1"}):
+        for k in ("M2M_NO_GRAPH", "M2M_GROUP_ROWS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got = m.generate_from_embeds(x.cuda(), max_length=400).cpu()
+        stats = m.repack_stats()
+        print(f"re-packing under {env}: {stats}")
+        assert stats[0] >= 1 and torch.equal(got, want), env
