@@ -830,6 +830,10 @@ def main():
             "config": {"workload": "BASELINE configs[2]: full generate (log-mel + encoder + KV-cached greedy decode), "
                                    f"{args.precision}, batch {B} clips/GPU x {N_SAMPLES} samples, S={S}, max_length {args.max_length}"
                                    + (f"; configs[3] sharding over {world} GPUs" if world > 1 else ""),
+                       "precision_note": ("throughput mode: bf16 GEMM inputs and K/V caches; its ids follow a bf16-emulating oracle and equal the "
+                                          "fp32 CPU reference's on about half of the tokens (parity_mode.bf16_vs_fp32_id_agreement); the mode with "
+                                          "bit-exact greedy ids is fp32: parity_mode.tokens_per_s") if args.precision == "bf16" else
+                                         "fp32 parity mode: greedy ids bit-identical to the fp32 CPU reference",
                        "global_batch": B * world, "clips_per_gpu": B, "new_tokens_per_clip": toks.shape[1] - 1,
                        "parallelism": f"clip-sharded x{world}", "weight_broadcast_bytes": bcast_bytes,
                        "weight_broadcast_dtype": ("GEMM weights bf16 + embeddings / norms / tables fp32 (receivers repack bit-identically)" if bf16_bcast
