@@ -662,6 +662,140 @@ bool gemm_takes_gated_train(int precision, int M, int N, int K) {     // bf16, a
 
 bool gemm_takes_gated_bwd(int precision, int M, int N, int K) { return precision == M2M_PREC_BF16 && N % 64 == 0 && K % 128 == 0 && M >= 1; }
 
+// ===================================================== row-panel residual product ====
+// x[M][N] += A[M][K] . W[N][K]^T with N = d_model (the attention output projection and the feed-forward down projection:
+// hf modeling_t5.py:363-369, :128-141 + the residual adds of :403 / :135).  The 128 x 128 tiling runs these as three column tiles per
+// row block, each streaming the same A tile again (0.33 of HBM, 12 % matrix-core busy: profiles/r5_a).  N = 384 is one row of the
+// residual stream: here a workgroup of 8 waves owns 128 COMPLETE rows — A streams through LDS once, in [128 x 64] chunks beside the
+// [N x 64] weight chunks (W is 0.4-0.9 MB and comes from L2), two chunks in flight in registers and two stages in LDS (one barrier
+// per chunk); 2 x 4 waves of 64 rows x N/4 columns each, so every A fragment feeds N/128 MFMAs and every weight fragment two
+// (0.83 KB of LDS reads per MFMA at N = 384); the fp32 rows are read, added to and written back straight from the accumulators.
+// Same k order per output element and the same operand roles as gemm_kernel<bf16, EPI_RESID>: bit-identical (tests).
+constexpr int RP_BM = 128, RP_BK = 64, RP_THREADS = 512, RP_P = RP_BK + 8;
+
+template <int NB>      // NB = N / 128: 32-column MFMA blocks per wave (N = 128 / 256 / 384)
+__global__ __launch_bounds__(RP_THREADS) void resid_panel_kernel(GemmArgs g) {
+  using T = bf16_t;
+  constexpr int N = 128 * NB, STAGE = (RP_BM + N) * RP_P;
+  extern __shared__ __align__(16) unsigned char rp_smem[];
+  T* const lds = reinterpret_cast<T*>(rp_smem);                 // [2 stages][A 128 x 72 | W N x 72]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;                       // 2 x 4 waves
+  const int r = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.x * RP_BM, K = g.K, nk = K / RP_BK;
+  const T* A = reinterpret_cast<const T*>(g.A);
+  const T* W = reinterpret_cast<const T*>(g.W);
+  // staging pieces of this thread: row tid >> 3 (+ 64 j), 16-byte piece tid & 7
+  const int pr = tid >> 3, pc = (tid & 7) * 8;
+  const T* const ap0 = A + (int64_t)min(m0 + pr, g.M - 1) * K + pc;
+  const T* const ap1 = A + (int64_t)min(m0 + pr + 64, g.M - 1) * K + pc;
+  const T* const wp = W + (int64_t)pr * K + pc;                  // rows pr + 64 j, j < 2 NB (N is a multiple of 128: no clamp)
+  // two register sets (chunk c lives in set c & 1 and goes to stage c & 1); named scalars: arrays across the loop go to scratch
+  uint4 sa0, sa1, sw0, sw1, sw2, sw3, sw4, sw5, ta0, ta1, tw0, tw1, tw2, tw3, tw4, tw5;
+  sw2 = sw3 = sw4 = sw5 = tw2 = tw3 = tw4 = tw5 = make_uint4(0, 0, 0, 0);
+#define RP_LOAD(p_, c_)                                                                                 \
+  {                                                                                                     \
+    const int k0_ = min((c_), nk - 1) * RP_BK;      /* past the end: the last chunk again, never used */ \
+    p_##a0 = *reinterpret_cast<const uint4*>(ap0 + k0_); p_##a1 = *reinterpret_cast<const uint4*>(ap1 + k0_); \
+    p_##w0 = *reinterpret_cast<const uint4*>(wp + k0_); p_##w1 = *reinterpret_cast<const uint4*>(wp + (int64_t)64 * K + k0_); \
+    if constexpr (NB >= 2) { p_##w2 = *reinterpret_cast<const uint4*>(wp + (int64_t)128 * K + k0_); p_##w3 = *reinterpret_cast<const uint4*>(wp + (int64_t)192 * K + k0_); } \
+    if constexpr (NB >= 3) { p_##w4 = *reinterpret_cast<const uint4*>(wp + (int64_t)256 * K + k0_); p_##w5 = *reinterpret_cast<const uint4*>(wp + (int64_t)320 * K + k0_); } \
+  }
+#define RP_STORE(p_, stage_)                                                                            \
+  {                                                                                                     \
+    T* const sA_ = lds + (stage_) * STAGE; T* const sW_ = sA_ + RP_BM * RP_P;                           \
+    *reinterpret_cast<uint4*>(sA_ + pr * RP_P + pc) = p_##a0; *reinterpret_cast<uint4*>(sA_ + (pr + 64) * RP_P + pc) = p_##a1; \
+    *reinterpret_cast<uint4*>(sW_ + pr * RP_P + pc) = p_##w0; *reinterpret_cast<uint4*>(sW_ + (pr + 64) * RP_P + pc) = p_##w1; \
+    if constexpr (NB >= 2) { *reinterpret_cast<uint4*>(sW_ + (pr + 128) * RP_P + pc) = p_##w2; *reinterpret_cast<uint4*>(sW_ + (pr + 192) * RP_P + pc) = p_##w3; } \
+    if constexpr (NB >= 3) { *reinterpret_cast<uint4*>(sW_ + (pr + 256) * RP_P + pc) = p_##w4; *reinterpret_cast<uint4*>(sW_ + (pr + 320) * RP_P + pc) = p_##w5; } \
+  }
+  RP_LOAD(s, 0)
+  RP_LOAD(t, 1)
+  f32x16 acc[2][NB];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) acc[i][j] = zero_acc();
+  RP_STORE(s, 0)
+  RP_LOAD(s, 2)
+  __syncthreads();
+  // body of chunk c (stage c & 1): multiply, then the OTHER register set (chunk c + 1) goes to the other stage and takes chunk c + 3
+#define RP_BODY(c_, st_, nxt_)                                                                          \
+  {                                                                                                     \
+    const T* const fa_ = lds + (st_) * STAGE + (wm * 64 + r) * RP_P + 8 * h;                             \
+    const T* const fb_ = lds + (st_) * STAGE + RP_BM * RP_P + (wn * 32 * NB + r) * RP_P + 8 * h;         \
+    _Pragma("unroll") for (int s4 = 0; s4 < RP_BK / 16; ++s4) {                                          \
+      Frag<T> a0_ = load_frag(fa_ + s4 * 16), a1_ = load_frag(fa_ + 32 * RP_P + s4 * 16);               \
+      _Pragma("unroll") for (int j = 0; j < NB; ++j) {                                                   \
+        const Frag<T> b_ = load_frag(fb_ + j * 32 * RP_P + s4 * 16);                                     \
+        mma16(acc[0][j], a0_, b_);                                                                       \
+        mma16(acc[1][j], a1_, b_);                                                                       \
+      }                                                                                                 \
+    }                                                                                                   \
+    RP_STORE(nxt_, (st_) ^ 1)                                                                            \
+    RP_LOAD(nxt_, (c_) + 3)                                                                              \
+    __syncthreads();                                                                                    \
+  }
+  int c = 0;
+  for (; c + 1 < nk; c += 2) {
+    RP_BODY(c, 0, t)
+    RP_BODY(c + 1, 1, s)
+  }
+  if (c < nk) RP_BODY(c, 0, t)
+#undef RP_BODY
+#undef RP_STORE
+#undef RP_LOAD
+  // ---- x += acc: element e of lane (r, h), blocks (i, j): row wm * 64 + i * 32 + (e & 3) + 8 (e >> 2) + 4 h, column wn * 32 NB + j * 32 + r ----
+  // The reads go out a row block at a time (NB x 16 loads in flight, clamped rows, no branch between them: one load -> wait ->
+  // store per element behind `if (row < M)` serialised 96 memory round trips per lane — 35 of the first version's 45 us).
+  float* const xo = reinterpret_cast<float*>(g.out);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float xv[NB][16];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = min(m0 + wm * 64 + i * 32 + acc_row(e, lane), g.M - 1);
+        xv[j][e] = xo[(int64_t)row * g.ldo + wn * 32 * NB + j * 32 + r];
+      }
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 64 + i * 32 + acc_row(e, lane);
+        if (row < g.M) xo[(int64_t)row * g.ldo + wn * 32 * NB + j * 32 + r] = xv[j][e] + acc[i][j][e];
+      }
+  }
+}
+
+// bf16, plain in-place residual add (no separate source, no dropout: the inference paths), N = 128 / 256 / 384, K a multiple of 64, and
+// about a chip's worth of row blocks (one workgroup per 128 rows and CU).  M2M_RESID_PANEL: "0" never, "force" whatever the size.
+static bool resid_panel_takes(int precision, int epi, const GemmArgs& a) {
+  if (precision != M2M_PREC_BF16 || epi != EPI_RESID || a.resid || a.drop_thresh) return false;
+  if (!(a.N == 128 || a.N == 256 || a.N == 384) || a.K % 64 != 0 || a.K < 128 || a.ldo != a.N) return false;
+  const char* v = getenv("M2M_RESID_PANEL");
+  if (v && v[0] == '0') return false;
+  if (v && v[0] == 'f') return true;
+  static const int min_blocks = [] { const char* e = getenv("M2M_NORM_GEMM_MIN_BLOCKS"); return e ? atoi(e) : 160; }();
+  return ceil_div(a.M, RP_BM) >= min_blocks;
+}
+
+static int launch_resid_panel(const GemmArgs& a, hipStream_t st) {
+  const int NB = a.N / 128;
+  const size_t smem = (size_t)2 * (RP_BM + a.N) * RP_P * 2;
+  dim3 grid((unsigned)ceil_div(a.M, RP_BM));
+#define RP_GO(NB_)                                                                              \
+  do {                                                                                          \
+    M2M_OPT_IN_LDS((resid_panel_kernel<NB_>), 160 * 1024);                                      \
+    hipLaunchKernelGGL((resid_panel_kernel<NB_>), grid, dim3(RP_THREADS), smem, st, a);         \
+  } while (0)
+  if (NB == 3) RP_GO(3); else if (NB == 2) RP_GO(2); else RP_GO(1);
+#undef RP_GO
+  M2M_CHECK_HIP(hipGetLastError());
+  return M2M_OK;
+}
+
 int launch_gemm(int precision, int epi, const GemmArgs& a, hipStream_t st) {
   if (epi == EPI_GATED_BWD) M2M_REQUIRE(gemm_takes_gated_bwd(precision, a.M, a.N, a.K) && a.ab_out && a.ldo == 2 * a.N, "gemm: shape / arguments outside the gate-gradient epilogue");
   if (epi == EPI_GATED_TRAIN) M2M_REQUIRE(gemm_takes_gated_train(precision, a.M, a.N, a.K) && a.ab_out && a.ldo == a.N / 2, "gemm: shape / arguments outside the training gate epilogue");
@@ -669,6 +803,7 @@ int launch_gemm(int precision, int epi, const GemmArgs& a, hipStream_t st) {
   M2M_REQUIRE(a.M >= 1 && a.N >= 1, "gemm: empty problem");
   if (epi == EPI_GATED) M2M_REQUIRE(a.N % 64 == 0, "gemm: gated epilogue needs N %% 64 == 0 (d_ff %% 32 == 0)");
   if (epi == EPI_GATED16) M2M_REQUIRE(a.N % 16 == 0, "gemm: 16-row gated epilogue needs N %% 16 == 0");
+  if (resid_panel_takes(precision, epi, a)) return launch_resid_panel(a, st);
   return precision == M2M_PREC_BF16 ? launch_gemm_t<bf16_t>(epi, a, st) : launch_gemm_t<float>(epi, a, st);
 }
 

@@ -284,6 +284,7 @@ def test_norm_gemm_fused_kernel_is_bit_identical_to_the_two_kernel_path(monkeypa
     out = {}
     for flag in ("force", "0"):          # "force": the fused kernel whatever the size (by default problems under 160 row blocks keep the two-kernel path)
         monkeypatch.setenv("M2M_NORM_GEMM", flag)
+        monkeypatch.setenv("M2M_RESID_PANEL", flag)      # the row-panel residual products (attention output / feed-forward down projection) likewise
         out[flag] = (model.logits_from_embeds(x, dec).cpu(), model.generate_from_embeds(x, max_length=min(Ld, 24)).cpu())
     assert torch.isfinite(out["force"][0]).all()
     assert torch.equal(out["force"][0], out["0"][0]), f"fused norm+GEMM logits differ: max |d| {(out['force'][0] - out['0'][0]).abs().max():.3e}"
