@@ -671,6 +671,10 @@ bool gemm_takes_gated_bwd(int precision, int M, int N, int K) { return precision
 // per chunk); 2 x 4 waves of 64 rows x N/4 columns each, so every A fragment feeds N/128 MFMAs and every weight fragment two
 // (0.83 KB of LDS reads per MFMA at N = 384); the fp32 rows are read, added to and written back straight from the accumulators.
 // Same k order per output element and the same operand roles as gemm_kernel<bf16, EPI_RESID>: bit-identical (tests).
+// (Measured and dropped: chunk-tiled copies of the weights — every [128 x 64] chunk one contiguous 16 KB block, 1 KB runs per wave
+// load instead of eight 128-byte pieces at a 0.8-2.3 KB stride — for this kernel and norm_gemm_kernel: no change (QKV 54.0, gated 72.4,
+// O-proj 28.3, down-proj 51.1 us): the weight stream is served by L2 hits at 14 % of that cache's peak either way — TCC hit / miss
+// counters in tools/pmc_enc_l2.sh — so neither its layout nor L2 channel camping is what these kernels wait for.)
 constexpr int RP_BM = 128, RP_BK = 64, RP_THREADS = 512, RP_P = RP_BK + 8;
 
 template <int NB>      // NB = N / 128: 32-column MFMA blocks per wave (N = 128 / 256 / 384)
