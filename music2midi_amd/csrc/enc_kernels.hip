@@ -671,11 +671,24 @@ bool gemm_takes_gated_bwd(int precision, int M, int N, int K) { return precision
 // per chunk); 2 x 4 waves of 64 rows x N/4 columns each, so every A fragment feeds N/128 MFMAs and every weight fragment two
 // (0.83 KB of LDS reads per MFMA at N = 384); the fp32 rows are read, added to and written back straight from the accumulators.
 // Same k order per output element and the same operand roles as gemm_kernel<bf16, EPI_RESID>: bit-identical (tests).
+// Shader-clock stamps of one workgroup (-DM2M_RP_STAMP, tools/rp_stamps.py; down projection, 18 chunks): prologue 9 %, 18 x ~2 800
+// ticks per chunk 65 %, epilogue 27 %.  Same-box A/Bs (tools/ab_resid.sh) of what the stamps suggested: a 16-wave form (4 x 4 waves
+// of 32 rows: four waves per SIMD against the fragment reads' LDS round trips) spends the SAME 2 600 ticks per chunk (kernel 40.2
+// against 37.7 us) — a chunk waits neither for LDS nor for the matrix core but for its 64 KB of operands: ~25 GB/s per CU, the
+// ingest rate of every one-workgroup-per-CU stream on this chip (DESIGN_HISTORY 4.3-4.5); the weights as the MFMA's A operand, so
+// that a lane adds into four consecutive columns with 16-byte accesses (32 rows x 32 bytes per instruction instead of 2 rows x
+// 128): 40.5 against 37.7 us — the scalar form's whole-line accesses win.
 // (Measured and dropped: chunk-tiled copies of the weights — every [128 x 64] chunk one contiguous 16 KB block, 1 KB runs per wave
 // load instead of eight 128-byte pieces at a 0.8-2.3 KB stride — for this kernel and norm_gemm_kernel: no change (QKV 54.0, gated 72.4,
 // O-proj 28.3, down-proj 51.1 us): the weight stream is served by L2 hits at 14 % of that cache's peak either way — TCC hit / miss
 // counters in tools/pmc_enc_l2.sh — so neither its layout nor L2 channel camping is what these kernels wait for.)
 constexpr int RP_BM = 128, RP_BK = 64, RP_THREADS = 512, RP_P = RP_BK + 8;
+#ifdef M2M_RP_STAMP       // diagnostic builds only (tools/rp_stamps.py): shader-clock stamps of one workgroup at every chunk boundary
+__device__ unsigned long long g_rp_stamp[64];
+#define RP_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 77 && (i) < 64) g_rp_stamp[i] = clock64(); } while (0)
+#else
+#define RP_STAMP(i) do {} while (0)
+#endif
 
 template <int NB>      // NB = N / 128: 32-column MFMA blocks per wave (N = 128 / 256 / 384)
 __global__ __launch_bounds__(RP_THREADS) void resid_panel_kernel(GemmArgs g) {
@@ -713,6 +726,7 @@ __global__ __launch_bounds__(RP_THREADS) void resid_panel_kernel(GemmArgs g) {
     if constexpr (NB >= 2) { *reinterpret_cast<uint4*>(sW_ + (pr + 128) * RP_P + pc) = p_##w2; *reinterpret_cast<uint4*>(sW_ + (pr + 192) * RP_P + pc) = p_##w3; } \
     if constexpr (NB >= 3) { *reinterpret_cast<uint4*>(sW_ + (pr + 256) * RP_P + pc) = p_##w4; *reinterpret_cast<uint4*>(sW_ + (pr + 320) * RP_P + pc) = p_##w5; } \
   }
+  RP_STAMP(0);
   RP_LOAD(s, 0)
   RP_LOAD(t, 1)
   f32x16 acc[2][NB];
@@ -723,6 +737,7 @@ __global__ __launch_bounds__(RP_THREADS) void resid_panel_kernel(GemmArgs g) {
   RP_STORE(s, 0)
   RP_LOAD(s, 2)
   __syncthreads();
+  RP_STAMP(1);
   // body of chunk c (stage c & 1): multiply, then the OTHER register set (chunk c + 1) goes to the other stage and takes chunk c + 3
 #define RP_BODY(c_, st_, nxt_)                                                                          \
   {                                                                                                     \
@@ -739,6 +754,7 @@ __global__ __launch_bounds__(RP_THREADS) void resid_panel_kernel(GemmArgs g) {
     RP_STORE(nxt_, (st_) ^ 1)                                                                            \
     RP_LOAD(nxt_, (c_) + 3)                                                                              \
     __syncthreads();                                                                                    \
+    RP_STAMP(2 + (c_));                                                                                 \
   }
   int c = 0;
   for (; c + 1 < nk; c += 2) {
@@ -770,6 +786,7 @@ __global__ __launch_bounds__(RP_THREADS) void resid_panel_kernel(GemmArgs g) {
         const int row = m0 + wm * 64 + i * 32 + acc_row(e, lane);
         if (row < g.M) xo[(int64_t)row * g.ldo + wn * 32 * NB + j * 32 + r] = xv[j][e] + acc[i][j][e];
       }
+    RP_STAMP(40 + i);
   }
 }
 
@@ -1468,6 +1485,11 @@ int launch_embed_rows(const int64_t* ids, const float* table, float* x, int M, i
 
 }  // namespace m2m
 
+#ifdef M2M_RP_STAMP
+extern "C" int m2m_debug_rp_stamps(unsigned long long* out_host) {      // diagnostic builds only (not declared in the public header)
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(m2m::g_rp_stamp), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef M2M_GEMM_STAMP
 // diagnostic builds only (not declared in the public header)
 extern "C" int m2m_debug_gemm_stamps(unsigned long long* out_host) {
