@@ -5,8 +5,10 @@
 
 A "step" is one pass of the whole hot path over one batch of synthetic clips:
 fused STFT/log-mel frontend -> conditioning rows -> T5 encoder -> cross-K/V
-projection -> 1023 KV-cached greedy decode steps (max_length 1024; random-init
-weights never emit EOS, so every clip yields exactly 1023 new tokens).
+projection -> 1023 KV-cached greedy decode steps (max_length 1024; the headline
+clips' trajectories under the random-init weights hold no EOS, so every clip
+yields 1023 new tokens; the line counts tokens up to a row's EOS and reports
+`config.rows_with_eos`, so a trajectory that did end would not be over-counted).
 Workload = BASELINE.json configs[2] (bf16, batch 32 per GPU, 220 500-sample
 clips -> encoder length 864); with N > 1 every rank decodes its own 32 clips
 (weak scaling, configs[3]) after one RCCL weight broadcast, and the decoded
@@ -814,9 +816,15 @@ def main():
     elapsed = time.perf_counter() - t0
     per_rank_ms = [e / args.steps * 1e3 for e in D.all_gather_floats(elapsed, dev)]
     elapsed = D.all_reduce_max(elapsed, dev)
-    new_tokens_local = (toks.shape[1] - 1) * B
-    total_tokens = D.all_reduce_sum(float(new_tokens_local), dev) * args.steps
     assert toks.shape[0] == B * world, toks.shape
+    # tokens that count: per clip, up to and including its EOS, or the whole budget when it has none.  (Random-init weights emit EOS
+    # now and then; the headline clips' trajectories have had none so far — `rows_with_eos` says so in the line — but a row that ends
+    # early costs less from there on (finished-row early-out), so padding must never be counted as decoded tokens.)
+    is_eos = toks[:, 1:] == geom.eos_token_id
+    has_eos = is_eos.any(dim=1)
+    useful = torch.where(has_eos, is_eos.float().argmax(dim=1) + 1, torch.full_like(has_eos, toks.shape[1] - 1, dtype=torch.long))
+    rows_with_eos = int(has_eos.sum())
+    total_tokens = float(useful.sum()) * args.steps        # `toks` is the all-gathered matrix: every rank's clips
 
     out = None
     es = 2 if args.precision == "bf16" else 4
@@ -835,6 +843,7 @@ def main():
                                           "bit-exact greedy ids is fp32: parity_mode.tokens_per_s") if args.precision == "bf16" else
                                          "fp32 parity mode: greedy ids bit-identical to the fp32 CPU reference",
                        "global_batch": B * world, "clips_per_gpu": B, "new_tokens_per_clip": toks.shape[1] - 1,
+                       "rows_with_eos": rows_with_eos, "counted_tokens_per_step": int(useful.sum()),
                        "parallelism": f"clip-sharded x{world}", "weight_broadcast_bytes": bcast_bytes,
                        "weight_broadcast_dtype": ("GEMM weights bf16 + embeddings / norms / tables fp32 (receivers repack bit-identically)" if bf16_bcast
                                                   else "fp32 master weights (each rank repacks locally)"),

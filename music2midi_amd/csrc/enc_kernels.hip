@@ -1240,7 +1240,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
   const T* Vtg = reinterpret_cast<const T*>(a.Vt) + (int64_t)bh * DK * Sp;      // V^T of this (clip, head): [64][Sp]
 
   if constexpr (BIAS) {
-    for (int i = tid; i < Sq + Sk - 1; i += 256) tb[i] = a.bias_tab[(int64_t)hh * a.tab_stride + a.tab_center - (Sq - 1) + i];
+    // 8 entries per thread in flight at once (the plain loop compiles to one load -> wait -> store round trip per iteration)
+    const float* tabg = a.bias_tab + (int64_t)hh * a.tab_stride + a.tab_center - (Sq - 1);
+    const int ntab = Sq + Sk - 1;
+    float tv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) tv[j] = tabg[min(tid + j * 256, ntab - 1)];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (tid + j * 256 < ntab) tb[tid + j * 256] = tv[j];
+    for (int i = tid + 2048; i < ntab; i += 256) tb[i] = tabg[i];
     if (tid < TB_PAD) tb[tid - TB_PAD] = 0.f;     // only reached by query rows past Sq, which are never stored
   }
 
@@ -1290,13 +1299,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     const int key = c / (DK / EPC), dc = c % (DK / EPC);                                      \
     *reinterpret_cast<uint4*>(Ks + key * Cfg::KP + dc * EPC) = kr##i;                         \
   }
-  // columns past Sk of the V^T rows are uninitialised memory: zero them (0 * NaN would poison P.V)
+  // columns past Sk of the V^T rows are uninitialised memory: zero them (0 * NaN would poison P.V) — in the one tile that
+  // holds the end of the keys only (wave-uniform `tail`): done for every tile the masking was 50 of ~450 VALU instructions per tile
 #define M2M_AT_STV(i, kt)                                                                     \
   {                                                                                           \
     const int c = tid + (i) * 256;                                                            \
     const int d = c / (AK / EPC), kc = c % (AK / EPC);                                        \
     const int nvalid = Sk - ((kt) * AK + kc * EPC);               /* valid elements of this chunk */ \
-    const uint4 vv = zero_tail<T>(vr##i, nvalid);                                             \
+    const uint4 vv = tail ? zero_tail<T>(vr##i, nvalid) : vr##i;                              \
     const int kl = kc * EPC;                                                                  \
     T* dst = Vt + d * Cfg::VP + (kl & 32);                                                    \
     if constexpr (EPC == 8) {                                                                 \
@@ -1311,6 +1321,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     __syncthreads();
     // ---- stage K (row-major) and V^T (already transposed in memory; key slots permuted to the
     //      accumulator k-order in whole 4-key groups, so it is 8/16-byte copies) ----
+#ifdef M2M_ATTN_R4
+    const bool tail = true;
+#else
+    const bool tail = (kt + 1) * AK > Sk;
+#endif
     M2M_AT_STK(0) M2M_AT_STK(1) if constexpr (KCH == 4) { M2M_AT_STK(2) M2M_AT_STK(3) }
     M2M_AT_STV(0, kt) M2M_AT_STV(1, kt) if constexpr (VCH == 4) { M2M_AT_STV(2, kt) M2M_AT_STV(3, kt) }
     __syncthreads();
@@ -1366,10 +1381,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
       const float mneg = -m_new * L2E;
       const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run, L2E, mneg));
       float psum = 0.f;
+#ifndef M2M_ATTN_R4
+      if constexpr (sizeof(T) == 2) {
+        // bf16 mode: the exponents' arguments as 8 packed fmas (the same values as 16 scalar ones) and the row sum as two
+        // interleaved partial sums (8 packed adds; the fp32 mode keeps the sequential order its ids were pinned with)
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 l2 = {L2E, L2E}, mn = {mneg, mneg};
+        f32x2 ps = {0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        p[i] = __builtin_amdgcn_exp2f(fmaf(p[i], L2E, mneg));
-        psum += p[i];
+        for (int i = 0; i < 16; i += 2) {
+          f32x2 v = {p[i], p[i + 1]};
+          v = __builtin_elementwise_fma(v, l2, mn);
+          v.x = __builtin_amdgcn_exp2f(v.x);
+          v.y = __builtin_amdgcn_exp2f(v.y);
+          ps += v;
+          p[i] = v.x;
+          p[i + 1] = v.y;
+        }
+        psum = ps.x + ps.y;
+      } else
+#endif
+      {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          p[i] = __builtin_amdgcn_exp2f(fmaf(p[i], L2E, mneg));
+          psum += p[i];
+        }
       }
       psum += lane_xor<32>(psum);
       l_run = l_run * alpha + psum;
@@ -1413,13 +1450,326 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
   }
 }
 
+// ---- bf16 form, round 5: 64 keys per softmax step, double-buffered tiles ----
+// The kernel above is bound by neither pipe (PMC at B = 32, S = 864: VALU issue 51 %, matrix core 23 %, 2.3 waves per SIMD
+// resident, each alive for 2 550 cycles per 32-key step against ~600 cycles of its own instructions): a wave's 32-key step is ONE
+// dependent chain — four K-fragment reads -> four MFMAs into one accumulator -> maximum -> exponentials -> pack -> four MFMAs —
+// and a tile costs two workgroup barriers.  This form (bf16 only: the running maximum moves every 64 keys instead of 32 and the
+// row sum is kept per half-wave until the end, so results differ in the last bits, and the fp32 mode's ids are pinned to the
+// arithmetic above) gives a wave two independent score chains per step (keys 0-31 and 32-63 of the tile, the accumulators
+// initialised WITH the bias, so there is no add after the product), one maximum / exchange / rescale per 64 keys, and one barrier
+// per tile: tile kt + 1 is written to the other LDS buffer at the top of step kt (every wave has left step kt - 1, which was the
+// last reader of that buffer) while tile kt + 2 travels from memory to registers.
+#ifdef M2M_AW_STAMP       // diagnostic builds only (tools/aw_stamps.py): shader-clock stamps of wave 0 of one workgroup, pinned in program order
+__device__ unsigned long long g_aw_stamp[64];
+#define AW_STAMP(i)                                                                               \
+  do {                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    if (threadIdx.x == 0 && blockIdx.x == 801 && (i) >= 0 && (i) < 64) g_aw_stamp[i] = clock64(); \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+  } while (0)
+#else
+#define AW_STAMP(i) do {} while (0)
+#endif
+
+template <bool CAUSAL, bool BIAS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void attn_wide_kernel(AttnArgs a) {
+  using T = bf16_t;
+  using Cfg = AttnCfg<T>;
+  constexpr int EPC = 8;
+  constexpr int KBUF = AK * Cfg::KP, VBUF = DK * Cfg::VP;
+  extern __shared__ __align__(16) unsigned char smem[];
+  T* Ks0 = reinterpret_cast<T*>(smem);                      // [2][AK][KP]
+  T* Vt0 = Ks0 + 2 * KBUF;                                  // [2][DK][VP]  (transposed, permuted key slots)
+  float* tb = reinterpret_cast<float*>(Vt0 + 2 * VBUF) + TB_PAD;
+
+  const int B = a.B, H = a.H, Sq = a.Sq, Sk = a.Sk, Sp = a.Sp;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int nq = (Sq + AQ - 1) / AQ;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int bh = xcd + 8 * (slot / nq), qt = slot - (slot / nq) * nq;
+  if (bh >= B * H) return;
+  const int b = bh / H, hh = bh - b * H;
+  const int q0 = qt * AQ + wave * 32;
+  const T* Q = reinterpret_cast<const T*>(a.Q) + (int64_t)bh * Sq * DK;
+  const T* Kg = reinterpret_cast<const T*>(a.K) + (int64_t)bh * Sk * DK;
+  const T* Vtg = reinterpret_cast<const T*>(a.Vt) + (int64_t)bh * DK * Sp;
+  AW_STAMP(0);
+
+  // the bias table of this head, 8 entries per thread in flight at once (a plain `for (i = tid; i < n; i += 256) tb[i] = tab[i]`
+  // compiles to one load -> wait -> store round trip per iteration when the trip count (7 at S = 864) is below the unroll factor:
+  // 6 600 of a wave's 56 700 cycles, stamped); Q and the first tile are requested before any of it is waited for
+  const float* tabg = a.bias_tab + (int64_t)hh * a.tab_stride + a.tab_center - (Sq - 1);
+  const int ntab = Sq + Sk - 1;
+  float tv[8];
+  if constexpr (BIAS) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) tv[j] = tabg[min(tid + j * 256, ntab - 1)];
+  }
+  const int qrow = min(q0 + r, Sq - 1);
+  Frag<T> qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) qf[s] = load_frag(Q + (int64_t)qrow * DK + s * 16 + 8 * h);
+
+  f32x16 o[2] = {zero_acc(), zero_acc()};
+  float m_run = -1e30f, l_run = 0.f;       // l_run: this half-wave's keys only; the halves meet after the loop
+  const int my_q = q0 + r;
+  const int kend = CAUSAL ? min(Sk, qt * AQ + AQ) : Sk;
+  const int ntiles = ceil_div(kend, AK);
+  constexpr float L2E = 1.4426950408889634f;
+
+  // One register set of staged tiles: tile t + 1 goes to LDS at the top of step t and the set is re-issued for tile t + 2 at once.
+  // (Measured and dropped: two sets, a tile requested two steps ahead — 87.1 against 85.0 us on the same box, +21 registers: the
+  // top of a step does not wait for the loads.)
+  uint4 ka0, ka1, va0, va1;
+  // thread -> chunk maps of the two staging copies (256 threads x 2 chunks of 16 bytes each for K and for V^T)
+  const int kkey0 = tid / (DK / EPC), kdc = tid % (DK / EPC);            // K chunk 0: key kkey0, chunk 1: key kkey0 + 32
+  const int vd0 = tid / (AK / EPC), vkc = tid % (AK / EPC);              // V^T chunk 0: row vd0, chunk 1: row vd0 + 32
+  const int vslot = (vkc * EPC & 32) + vt_pos(vkc * EPC & 31);
+  auto fetch = [&](int kt, uint4& k0, uint4& k1, uint4& v0, uint4& v1) __attribute__((always_inline)) {
+    k0 = *reinterpret_cast<const uint4*>(Kg + (int64_t)min(kt * AK + kkey0, Sk - 1) * DK + kdc * EPC);
+    k1 = *reinterpret_cast<const uint4*>(Kg + (int64_t)min(kt * AK + kkey0 + 32, Sk - 1) * DK + kdc * EPC);
+    v0 = *reinterpret_cast<const uint4*>(Vtg + (int64_t)vd0 * Sp + kt * AK + vkc * EPC);
+    v1 = *reinterpret_cast<const uint4*>(Vtg + (int64_t)(vd0 + 32) * Sp + kt * AK + vkc * EPC);
+  };
+  // V^T columns past Sk are uninitialised memory: zeroed in the one tile that holds the end of the keys (0 * NaN would poison P.V)
+  auto store = [&](int kt, const uint4& k0, const uint4& k1, uint4 v0, uint4 v1) __attribute__((always_inline)) {
+    T* kb = Ks0 + (kt & 1) * KBUF;
+    T* vb = Vt0 + (kt & 1) * VBUF;
+    *reinterpret_cast<uint4*>(kb + kkey0 * Cfg::KP + kdc * EPC) = k0;
+    *reinterpret_cast<uint4*>(kb + (kkey0 + 32) * Cfg::KP + kdc * EPC) = k1;
+    if ((kt + 1) * AK > Sk) {
+      const int nvalid = Sk - (kt * AK + vkc * EPC);
+      v0 = zero_tail<T>(v0, nvalid);
+      v1 = zero_tail<T>(v1, nvalid);
+    }
+    *reinterpret_cast<uint2*>(vb + vd0 * Cfg::VP + vslot) = make_uint2(v0.x, v0.y);
+    *reinterpret_cast<uint2*>(vb + vd0 * Cfg::VP + vslot + 8) = make_uint2(v0.z, v0.w);
+    *reinterpret_cast<uint2*>(vb + (vd0 + 32) * Cfg::VP + vslot) = make_uint2(v1.x, v1.y);
+    *reinterpret_cast<uint2*>(vb + (vd0 + 32) * Cfg::VP + vslot + 8) = make_uint2(v1.z, v1.w);
+  };
+  // top of step kt: tile kt + 1 to the buffer step kt - 1 read last, the set re-issued for tile kt + 2
+#define M2M_AW_TOP(kt)                                             \
+  if ((kt) + 1 < ntiles) {                                         \
+    store((kt) + 1, ka0, ka1, va0, va1);                           \
+    if ((kt) + 2 < ntiles) fetch((kt) + 2, ka0, ka1, va0, va1);    \
+  }
+  if (ntiles > 0) fetch(0, ka0, ka1, va0, va1);
+  if constexpr (BIAS) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (tid + j * 256 < ntab) tb[tid + j * 256] = tv[j];
+    for (int i = tid + 2048; i < ntab; i += 256) tb[i] = tabg[i];      // tables past 2 048 entries (Sq + Sk > 2 049)
+    if (tid < TB_PAD) tb[tid - TB_PAD] = 0.f;
+  }
+  if (ntiles > 0) {
+    store(0, ka0, ka1, va0, va1);
+    if (ntiles > 1) fetch(1, ka0, ka1, va0, va1);
+  }
+  __syncthreads();
+  AW_STAMP(1);
+  const bool live = q0 < Sq;      // a wave whose 32 queries all lie past Sq (S = 864: one of 28) stages and synchronises, nothing else
+
+  // ---- 64 keys, every one of them exists and is visible to every query of this wave ----
+  auto wide_step = [&](int kt) __attribute__((always_inline)) {
+    const T* Kb = Ks0 + (kt & 1) * KBUF;
+    const T* Vb = Vt0 + (kt & 1) * VBUF;
+    const int kbase = kt * AK;
+    f32x16 s0, s1;
+    if constexpr (BIAS) {
+      const float* tbp = tb + (kbase - my_q + (Sq - 1) + 4 * h);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        s0[i] = tbp[(i & 3) + 8 * (i >> 2)];
+        s1[i] = tbp[32 + (i & 3) + 8 * (i >> 2)];
+      }
+    } else {
+      s0 = zero_acc();
+      s1 = zero_acc();
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const Frag<T> kf0 = load_frag(Kb + r * Cfg::KP + s * 16 + 8 * h);
+      const Frag<T> kf1 = load_frag(Kb + (32 + r) * Cfg::KP + s * 16 + 8 * h);
+      mma16(s0, kf0, qf[s]);
+      mma16(s1, kf1, qf[s]);
+    }
+    AW_STAMP(kt >= 4 && kt < 8 ? 4 + (kt - 4) * 8 : -1);
+    // two running chains of max3 (a pair-wise tree makes the compiler canonicalise every matrix-core output first: 3 ops per pair)
+    float mx = s0[0], my = s1[0];
+#pragma unroll
+    for (int i = 1; i < 16; i += 2) {
+      mx = fmaxf(fmaxf(mx, s0[i]), s0[(i + 1) & 15]);
+      my = fmaxf(fmaxf(my, s1[i]), s1[(i + 1) & 15]);
+    }
+    mx = fmaxf(mx, my);
+    mx = fmaxf(mx, lane_xor<32>(mx));
+    const float m_new = fmaxf(m_run, mx);
+    const float mneg = -m_new * L2E;
+    const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run, L2E, mneg));
+    AW_STAMP(kt >= 4 && kt < 8 ? 5 + (kt - 4) * 8 : -1);
+    float ps0 = 0.f, ps1 = 0.f, ps2 = 0.f, ps3 = 0.f;
+    float p[32];
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+      const float u0 = __builtin_amdgcn_exp2f(fmaf(s0[i], L2E, mneg)), u1 = __builtin_amdgcn_exp2f(fmaf(s0[i + 1], L2E, mneg));
+      const float v0 = __builtin_amdgcn_exp2f(fmaf(s1[i], L2E, mneg)), v1 = __builtin_amdgcn_exp2f(fmaf(s1[i + 1], L2E, mneg));
+      ps0 += u0;
+      ps1 += u1;
+      ps2 += v0;
+      ps3 += v1;
+      p[i] = u0;
+      p[i + 1] = u1;
+      p[16 + i] = v0;
+      p[16 + i + 1] = v1;
+    }
+    l_run = fmaf(l_run, alpha, (ps0 + ps1) + (ps2 + ps3));
+    m_run = m_new;
+    AW_STAMP(kt >= 4 && kt < 8 ? 6 + (kt - 4) * 8 : -1);
+    if (__ballot(alpha != 1.0f) != 0ull) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        o[0][i] *= alpha;
+        o[1][i] *= alpha;
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float pp[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pp[j] = p[8 * g + j];
+      const Frag<T> pf = pack_frag<T>(pp);
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const Frag<T> vf = load_frag(Vb + (db * 32 + r) * Cfg::VP + g * 16 + 8 * h);
+        mma16(o[db], vf, pf);
+      }
+    }
+  };
+  // ---- the tile with the end of the keys (and, causal, the tiles on the diagonal): 32 keys at a time, masked ----
+  auto masked_step = [&](int kt) __attribute__((always_inline)) {
+    const T* Kb = Ks0 + (kt & 1) * KBUF;
+    const T* Vb = Vt0 + (kt & 1) * VBUF;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const int kb32 = kt * AK + sub * 32;
+      if (kb32 >= kend) break;  // uniform
+      f32x16 st = zero_acc();
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const Frag<T> kf = load_frag(Kb + (sub * 32 + r) * Cfg::KP + s * 16 + 8 * h);
+        mma16(st, kf, qf[s]);
+      }
+      float p[16];
+      float mx = -1e30f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int key = kb32 + acc_row(i, lane);
+        float sc = -1e30f;
+        if (key < Sk && (!CAUSAL || key <= my_q)) {
+          sc = st[i];
+          if constexpr (BIAS) {
+            int rel = key - my_q + (Sq - 1);
+            rel = min(max(rel, -TB_PAD), Sq + Sk - 2);
+            sc += tb[rel];
+          }
+        }
+        p[i] = sc;
+        mx = fmaxf(mx, sc);
+      }
+      mx = fmaxf(mx, lane_xor<32>(mx));
+      const float m_new = fmaxf(m_run, mx);
+      const float mneg = -m_new * L2E;
+      const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run, L2E, mneg));
+      float psum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        p[i] = __builtin_amdgcn_exp2f(fmaf(p[i], L2E, mneg));
+        psum += p[i];
+      }
+      l_run = fmaf(l_run, alpha, psum);
+      m_run = m_new;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        o[0][i] *= alpha;
+        o[1][i] *= alpha;
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        float pp[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pp[j] = p[8 * s2 + j];
+        const Frag<T> pf = pack_frag<T>(pp);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const Frag<T> vf = load_frag(Vb + (db * 32 + r) * Cfg::VP + sub * 32 + s2 * 16 + 8 * h);
+          mma16(o[db], vf, pf);
+        }
+      }
+    }
+  };
+
+  // Leading tiles whose 64 keys all exist and are visible to every query of this wave take the wide step, the rest follow in a loop of
+  // their own (two loops, not one with a branch: with both bodies in one loop the compiler copied the 32 output accumulators between
+  // two register sets every step).  Every wave of the workgroup passes ntiles barriers whichever loop it is in.
+  int n_wide = min(ntiles, Sk / AK);
+  if constexpr (CAUSAL) n_wide = min(n_wide, max(0, (q0 + 1) / AK));
+  if (!live) n_wide = 0;
+  int kt = 0;
+  for (; kt < n_wide; ++kt) {
+    AW_STAMP(kt >= 4 && kt < 8 ? 2 + (kt - 4) * 8 : -1);
+    M2M_AW_TOP(kt)
+    AW_STAMP(kt >= 4 && kt < 8 ? 3 + (kt - 4) * 8 : -1);
+    wide_step(kt);
+    AW_STAMP(kt >= 4 && kt < 8 ? 7 + (kt - 4) * 8 : -1);
+    __syncthreads();
+    AW_STAMP(kt >= 4 && kt < 8 ? 8 + (kt - 4) * 8 : -1);
+  }
+  AW_STAMP(40);
+  for (; kt < ntiles; ++kt) {
+    M2M_AW_TOP(kt)
+    if (live) masked_step(kt);      // (a branch inside the wide loop made the compiler copy the output accumulators every step)
+    __syncthreads();
+  }
+#undef M2M_AW_TOP
+  AW_STAMP(41);
+  l_run += lane_xor<32>(l_run);
+  if (my_q < Sq) {
+    const float inv = 1.0f / l_run;
+    T* orow = reinterpret_cast<T*>(a.out) + ((int64_t)b * Sq + my_q) * (H * DK) + hh * DK;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) orow[db * 32 + acc_row(i, lane)] = from_f32<T>(o[db][i] * inv);
+  }
+  AW_STAMP(42);
+}
+
+// M2M_ATTN_WIDE=0: the bf16 mode runs the first kernel as well (A/B, and the test that holds the two forms to each other)
+static bool attn_wide_on() {
+  const char* e = getenv("M2M_ATTN_WIDE");
+  return !(e && e[0] == '0');
+}
+
 template <typename T, bool CAUSAL, bool BIAS>
 static int launch_attn_tt(const AttnArgs& a, hipStream_t st) {
   using Cfg = AttnCfg<T>;
-  const size_t smem = (size_t)(AK * Cfg::KP + DK * Cfg::VP) * sizeof(T) + (BIAS ? (size_t)(a.Sq + a.Sk - 1 + TB_PAD) * sizeof(float) : 0);
+  const size_t tiles = (size_t)(AK * Cfg::KP + DK * Cfg::VP) * sizeof(T);
+  const size_t table = BIAS ? (size_t)(a.Sq + a.Sk - 1 + TB_PAD) * sizeof(float) : 0;
+  size_t smem = tiles + table;
   M2M_REQUIRE(smem <= 150 * 1024, "attention: Sq=%d, Sk=%d too long for the LDS bias table", a.Sq, a.Sk);
-  M2M_OPT_IN_LDS((attn_kernel<T, CAUSAL, BIAS>), 160 * 1024);
   dim3 grid((unsigned)(ceil_div(a.Sq, AQ) * ceil_div(a.B * a.H, 8) * 8));
+  if constexpr (sizeof(T) == 2) {
+    if (attn_wide_on() && 2 * tiles + table <= 150 * 1024) {
+      smem = 2 * tiles + table;
+      M2M_OPT_IN_LDS((attn_wide_kernel<CAUSAL, BIAS>), 160 * 1024);
+      hipLaunchKernelGGL((attn_wide_kernel<CAUSAL, BIAS>), grid, dim3(256), smem, st, a);
+      M2M_CHECK_HIP(hipGetLastError());
+      return M2M_OK;
+    }
+  }
+  M2M_OPT_IN_LDS((attn_kernel<T, CAUSAL, BIAS>), 160 * 1024);
   hipLaunchKernelGGL((attn_kernel<T, CAUSAL, BIAS>), grid, dim3(256), smem, st, a);
   M2M_CHECK_HIP(hipGetLastError());
   return M2M_OK;
@@ -1485,6 +1835,11 @@ int launch_embed_rows(const int64_t* ids, const float* table, float* x, int M, i
 
 }  // namespace m2m
 
+#ifdef M2M_AW_STAMP
+extern "C" int m2m_debug_aw_stamps(unsigned long long* out_host) {      // diagnostic builds only (not declared in the public header)
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(m2m::g_aw_stamp), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef M2M_RP_STAMP
 extern "C" int m2m_debug_rp_stamps(unsigned long long* out_host) {      // diagnostic builds only (not declared in the public header)
   return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(m2m::g_rp_stamp), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;

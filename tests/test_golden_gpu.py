@@ -248,7 +248,10 @@ def test_bf16_mode_follows_the_bf16_emulating_oracle_at_headline_size(golden_dir
     x = embeds(2, 864, g.d_model).cuda()
     ids = model.generate_from_embeds(x, max_length=1024).cpu().numpy()
     want = z["full_s864_bf16/ids"].astype(np.int64)
-    assert ids.shape == want.shape == (2, 1024)
+    # after a legitimate divergence the device decodes a different sequence, which may END (random-init weights emit EOS now and
+    # then: the first attention kernel's trajectory had one at step 712, the 64-key form's has both rows done by 521): pad to compare
+    assert want.shape == (2, 1024) and ids.shape[0] == 2 and 5 <= ids.shape[1] <= 1024
+    ids = np.pad(ids, ((0, 0), (0, 1024 - ids.shape[1])), constant_values=g.pad_token_id)
     rows = _bf16_divergence(ids, want, z["full_s864_bf16/margins"], "full_s864_bf16", _bf16_noise_margin(golden_dir, "full_s864_bf16"))
     assert all(t < 0 or t >= 4 for _, t, _ in rows)                       # no row parts from the oracle right away
     # the same on waveforms: clips 0 and 1 of bench.py's workload, plain seed-0 weights (no layer-norm perturbation)
@@ -263,6 +266,7 @@ def test_bf16_mode_follows_the_bf16_emulating_oracle_at_headline_size(golden_dir
         idx = torch.from_numpy(synth.cond_index_batch(0, 2)).cuda()
         got = m.generate(ModelInputs(input_waveform=wav, cond_index=idx), max_length=1024).cpu().numpy()
         want = z[f"{key}/ids"].astype(np.int64)
+        got = np.pad(got, ((0, 0), (0, want.shape[1] - got.shape[1])), constant_values=g.pad_token_id)
         if precision == "bf16":
             _bf16_divergence(got, want, z[f"{key}/margins"], key, _bf16_noise_margin(golden_dir, "bench_clips_bf16"))
         else:

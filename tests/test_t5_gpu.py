@@ -291,6 +291,39 @@ def test_norm_gemm_fused_kernel_is_bit_identical_to_the_two_kernel_path(monkeypa
     assert torch.equal(out["force"][1], out["0"][1])
 
 
+@pytest.mark.parametrize("cfg_name,B,S,Ld", [("tiny", 3, 19, 12), ("tiny", 2, 130, 131), ("full", 2, 190, 70), ("full", 3, 864, 40), ("full", 2, 61, 300), ("full", 9, 1000, 8)])
+def test_attention_wide_form_against_the_first_form(monkeypatch, cfg_name, B, S, Ld):
+    """Round 5: the bf16 mode's flash attention takes 64 keys per softmax step from double-buffered tiles (`attn_wide_kernel`);
+    the fp32 mode keeps the first kernel, 32 keys per step.  The two forms round the same probabilities at different running maxima
+    and add the row sums in a different order, so they are NOT bit-identical; both are held to the oracle by the forced / golden
+    tests, and here to each other through the batched teacher-forced pass (encoder self-attention with bias, S not a multiple of 64;
+    decoder causal self-attention incl. Ld > 256: wide tiles below the diagonal, masked ones on it; cross-attention without bias):
+    the logits may differ by bf16 re-rounding only (measured 4e-3 .. 7e-3 relative l2, the size of the bf16 mode's own noise floor against
+    the emulating oracle) — bar 2 %; the fp32 mode must not change at all."""
+    cfg = tiny_config() if cfg_name == "tiny" else DEFAULT_CONFIG
+    model, _, g = build(cfg, "bf16")
+    x = embeds(B, S, g.d_model).cuda()
+    dec = torch.from_numpy((synth.uniform01(12, "dec", B * Ld) * (g.vocab_size - 3)).astype(np.int64).reshape(B, Ld) + 3).cuda()
+    dec[:, 0] = g.decoder_start_token_id
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("M2M_ATTN_WIDE", flag)
+        out[flag] = model.logits_from_embeds(x, dec).float().cpu()
+    assert torch.isfinite(out["1"]).all()
+    d = (out["1"] - out["0"]).double()
+    rel = float(d.norm() / out["0"].double().norm())
+    print(f"attention forms {cfg_name} B={B} S={S} Ld={Ld}: rel l2 {rel:.2e}, max |d| {float(d.abs().max()):.3e} on logits of max {float(out['0'].abs().max()):.1f}")
+    if S >= 128:           # at least one 64-key step (shorter inputs take the masked 32-key steps in both forms)
+        assert not torch.equal(out["1"], out["0"]), "the switch did not change the kernel"
+    assert rel < 2e-2
+    m32, _, _ = build(cfg, "fp32")
+    o32 = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("M2M_ATTN_WIDE", flag)
+        o32[flag] = m32.logits_from_embeds(x, dec).cpu()
+    assert torch.equal(o32["1"], o32["0"])
+
+
 @pytest.mark.parametrize("precision,B,S", [("bf16", 32, 190), ("fp32", 9, 61), ("bf16", 5, 864), ("bf16", 128, 40), ("fp32", 33, 30)])
 def test_live_row_repacking_does_not_change_ids(monkeypatch, precision, B, S):
     """Round 5: at a host poll of the greedy loop, once a quarter of the rows still being decoded have emitted EOS,
