@@ -1472,6 +1472,11 @@ __device__ unsigned long long g_aw_stamp[64];
 #define AW_STAMP(i) do {} while (0)
 #endif
 
+#ifndef M2M_AW_CUT        // diagnostic builds only (tools/aw_variants.sh): bit i leaves a phase of the wide step out at COMPILE time
+#define M2M_AW_CUT 0      // (a run-time mask distorted the code: 177 registers, accumulator copies); results are garbage, times are not
+#endif
+#define AW_KEEP(bit) (!((M2M_AW_CUT) & (1 << (bit))))
+
 template <bool CAUSAL, bool BIAS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void attn_wide_kernel(AttnArgs a) {
   using T = bf16_t;
@@ -1568,6 +1573,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     if (ntiles > 1) fetch(1, ka0, ka1, va0, va1);
   }
   __syncthreads();
+  // Q must have ARRIVED here, as far as the compiler's wait-count bookkeeping goes: without this it kept the four Q loads pending
+  // into the loop and put s_waitcnt vmcnt(3) .. vmcnt(0) in front of the Q.K MFMAs — which in the steady state wait for the four
+  // tile loads issued a moment earlier, a full memory latency inside every step (found in the ISA; cut-variant timings: the Q.K
+  // phase 17.6 us and the staging 12 us of a 92 us kernel)
+#pragma unroll
+  for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[s].v.x), "+v"(qf[s].v.y), "+v"(qf[s].v.z), "+v"(qf[s].v.w));
   AW_STAMP(1);
   const bool live = q0 < Sq;      // a wave whose 32 queries all lie past Sq (S = 864: one of 28) stages and synchronises, nothing else
 
@@ -1577,7 +1588,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     const T* Vb = Vt0 + (kt & 1) * VBUF;
     const int kbase = kt * AK;
     f32x16 s0, s1;
-    if constexpr (BIAS) {
+    if constexpr (BIAS && AW_KEEP(5)) {
       const float* tbp = tb + (kbase - my_q + (Sq - 1) + 4 * h);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -1588,12 +1599,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
       s0 = zero_acc();
       s1 = zero_acc();
     }
+    if constexpr (AW_KEEP(2)) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const Frag<T> kf0 = load_frag(Kb + r * Cfg::KP + s * 16 + 8 * h);
-      const Frag<T> kf1 = load_frag(Kb + (32 + r) * Cfg::KP + s * 16 + 8 * h);
-      mma16(s0, kf0, qf[s]);
-      mma16(s1, kf1, qf[s]);
+      for (int s = 0; s < 4; ++s) {
+        const Frag<T> kf0 = load_frag(Kb + r * Cfg::KP + s * 16 + 8 * h);
+        const Frag<T> kf1 = load_frag(Kb + (32 + r) * Cfg::KP + s * 16 + 8 * h);
+        mma16(s0, kf0, qf[s]);
+        mma16(s1, kf1, qf[s]);
+      }
+    } else {
+      s0[0] += __builtin_bit_cast(float, qf[0].v.x ^ qf[1].v.y ^ qf[2].v.z ^ qf[3].v.w);
     }
     AW_STAMP(kt >= 4 && kt < 8 ? 4 + (kt - 4) * 8 : -1);
     // two running chains of max3 (a pair-wise tree makes the compiler canonicalise every matrix-core output first: 3 ops per pair)
@@ -1604,7 +1619,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
       my = fmaxf(fmaxf(my, s1[i]), s1[(i + 1) & 15]);
     }
     mx = fmaxf(mx, my);
-    mx = fmaxf(mx, lane_xor<32>(mx));
+    if constexpr (AW_KEEP(6)) mx = fmaxf(mx, lane_xor<32>(mx));
     const float m_new = fmaxf(m_run, mx);
     const float mneg = -m_new * L2E;
     const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run, L2E, mneg));
@@ -1613,8 +1628,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     float p[32];
 #pragma unroll
     for (int i = 0; i < 16; i += 2) {
+#if (M2M_AW_CUT) & 1
+      const float u0 = fmaf(s0[i], L2E, mneg), u1 = fmaf(s0[i + 1], L2E, mneg), v0 = fmaf(s1[i], L2E, mneg), v1 = fmaf(s1[i + 1], L2E, mneg);
+#else
       const float u0 = __builtin_amdgcn_exp2f(fmaf(s0[i], L2E, mneg)), u1 = __builtin_amdgcn_exp2f(fmaf(s0[i + 1], L2E, mneg));
       const float v0 = __builtin_amdgcn_exp2f(fmaf(s1[i], L2E, mneg)), v1 = __builtin_amdgcn_exp2f(fmaf(s1[i + 1], L2E, mneg));
+#endif
       ps0 += u0;
       ps1 += u1;
       ps2 += v0;
@@ -1643,11 +1662,62 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
 #pragma unroll
       for (int j = 0; j < 8; ++j) pp[j] = p[8 * g + j];
       const Frag<T> pf = pack_frag<T>(pp);
+      if constexpr (AW_KEEP(1)) {
 #pragma unroll
-      for (int db = 0; db < 2; ++db) {
-        const Frag<T> vf = load_frag(Vb + (db * 32 + r) * Cfg::VP + g * 16 + 8 * h);
-        mma16(o[db], vf, pf);
+        for (int db = 0; db < 2; ++db) {
+          const Frag<T> vf = load_frag(Vb + (db * 32 + r) * Cfg::VP + g * 16 + 8 * h);
+          mma16(o[db], vf, pf);
+        }
+      } else {
+        o[0][g] += __builtin_bit_cast(float, pf.v.x ^ pf.v.y ^ pf.v.z ^ pf.v.w);
       }
+    }
+  };
+  // ---- a last tile of exactly 32 keys, all visible (S = 864 = 13 x 64 + 32): one chain of the wide step, no masks ----
+  auto half_step = [&](int kt) __attribute__((always_inline)) {
+    const T* Kb = Ks0 + (kt & 1) * KBUF;
+    const T* Vb = Vt0 + (kt & 1) * VBUF;
+    f32x16 s0;
+    if constexpr (BIAS) {
+      const float* tbp = tb + (kt * AK - my_q + (Sq - 1) + 4 * h);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s0[i] = tbp[(i & 3) + 8 * (i >> 2)];
+    } else {
+      s0 = zero_acc();
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) mma16(s0, load_frag(Kb + r * Cfg::KP + s * 16 + 8 * h), qf[s]);
+    float mx = s0[0];
+#pragma unroll
+    for (int i = 1; i < 16; i += 2) mx = fmaxf(fmaxf(mx, s0[i]), s0[(i + 1) & 15]);
+    mx = fmaxf(mx, lane_xor<32>(mx));
+    const float m_new = fmaxf(m_run, mx);
+    const float mneg = -m_new * L2E;
+    const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run, L2E, mneg));
+    float ps0 = 0.f, ps1 = 0.f;
+    float p[16];
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+      p[i] = __builtin_amdgcn_exp2f(fmaf(s0[i], L2E, mneg));
+      p[i + 1] = __builtin_amdgcn_exp2f(fmaf(s0[i + 1], L2E, mneg));
+      ps0 += p[i];
+      ps1 += p[i + 1];
+    }
+    l_run = fmaf(l_run, alpha, ps0 + ps1);
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      o[0][i] *= alpha;
+      o[1][i] *= alpha;
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      float pp[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pp[j] = p[8 * g + j];
+      const Frag<T> pf = pack_frag<T>(pp);
+#pragma unroll
+      for (int db = 0; db < 2; ++db) mma16(o[db], load_frag(Vb + (db * 32 + r) * Cfg::VP + g * 16 + 8 * h), pf);
     }
   };
   // ---- the tile with the end of the keys (and, causal, the tiles on the diagonal): 32 keys at a time, masked ----
@@ -1722,29 +1792,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
   int kt = 0;
   for (; kt < n_wide; ++kt) {
     AW_STAMP(kt >= 4 && kt < 8 ? 2 + (kt - 4) * 8 : -1);
-    M2M_AW_TOP(kt)
+    if constexpr (AW_KEEP(4)) {
+      M2M_AW_TOP(kt)
+    }
     AW_STAMP(kt >= 4 && kt < 8 ? 3 + (kt - 4) * 8 : -1);
     wide_step(kt);
     AW_STAMP(kt >= 4 && kt < 8 ? 7 + (kt - 4) * 8 : -1);
-    __syncthreads();
+    if constexpr (AW_KEEP(3)) __syncthreads();
     AW_STAMP(kt >= 4 && kt < 8 ? 8 + (kt - 4) * 8 : -1);
   }
   AW_STAMP(40);
+  if (live && kt == ntiles - 1 && Sk - kt * AK == 32 && (!CAUSAL || kt * AK + 31 <= q0)) {
+    half_step(kt);          // the last tile: nothing left to stage
+    __syncthreads();
+    ++kt;
+  }
   for (; kt < ntiles; ++kt) {
     M2M_AW_TOP(kt)
     if (live) masked_step(kt);      // (a branch inside the wide loop made the compiler copy the output accumulators every step)
     __syncthreads();
   }
 #undef M2M_AW_TOP
+#undef AW_KEEP
   AW_STAMP(41);
   l_run += lane_xor<32>(l_run);
-  if (my_q < Sq) {
+  // ---- normalise, transpose through LDS, store whole rows: a lane owns 32 values of ONE query at a 2-byte granularity spread over
+  // the row (stored directly: 32 store instructions per lane, each touching 64 lines); its wave's [32 queries][64] block goes to
+  // LDS (the K buffers are free: every wave has passed the last barrier; a wave reads only what it wrote) and leaves as 16-byte
+  // pieces, 8 lanes per 128-byte row ----
+  {
     const float inv = 1.0f / l_run;
-    T* orow = reinterpret_cast<T*>(a.out) + ((int64_t)b * Sq + my_q) * (H * DK) + hh * DK;
+    T* Ow = Ks0 + wave * (32 * Cfg::KP);                  // [32][KP] of this wave (4 x 32 x 72 x 2 B = the two K buffers exactly)
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) orow[db * 32 + acc_row(i, lane)] = from_f32<T>(o[db][i] * inv);
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<uint2*>(Ow + r * Cfg::KP + db * 32 + 8 * j + 4 * h) =
+            make_uint2(pack2_bf16(o[db][4 * j] * inv, o[db][4 * j + 1] * inv), pack2_bf16(o[db][4 * j + 2] * inv, o[db][4 * j + 3] * inv));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    T* obase = reinterpret_cast<T*>(a.out) + ((int64_t)b * Sq + q0) * (H * DK) + hh * DK;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int c = it * 64 + lane, row = c >> 3, col = (c & 7) * 8;
+      const uint4 v = *reinterpret_cast<const uint4*>(Ow + row * Cfg::KP + col);
+      if (q0 + row < Sq) *reinterpret_cast<uint4*>(obase + (int64_t)row * (H * DK) + col) = v;
+    }
   }
   AW_STAMP(42);
 }

@@ -11,7 +11,8 @@ from music2midi_amd.config import T5Geometry, default_config
 from music2midi_amd.transformer import T5Transformer
 cfg = default_config(); geom = T5Geometry(cfg.model.t5); sd = synth.t5_state_dict(geom, 0)
 m = T5Transformer(cfg.to_dict(), precision="bf16"); load_t5_state(m, sd, strict=False); m = m.cuda().eval()
-for B in (4, 8, 12, 16, 24, 32):
+import os
+for B in [int(b) for b in os.environ.get("OCC_BATCHES", "4,8,12,16,24,32").split(",")]:
     x = torch.from_numpy(synth.normal(3, "e", (B, 864, 384), 3.0)).cuda()
     for _ in range(4): m._encode(x, 8)
     torch.cuda.synchronize()
