@@ -1525,8 +1525,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
   constexpr float L2E = 1.4426950408889634f;
 
   // One register set of staged tiles: tile t + 1 goes to LDS at the top of step t and the set is re-issued for tile t + 2 at once.
-  // (Measured and dropped: two sets, a tile requested two steps ahead — 87.1 against 85.0 us on the same box, +21 registers: the
-  // top of a step does not wait for the loads.)
+  // (Measured and dropped, twice: two sets, a tile requested two steps ahead, the loop unrolled by two — 87.1 against 85.0 us on
+  // the same box at 163 registers; after the wait-count fix below 196 registers = two waves per SIMD, and forced to three it
+  // spills: 88.3 against 82.3 us.)
   uint4 ka0, ka1, va0, va1;
   // thread -> chunk maps of the two staging copies (256 threads x 2 chunks of 16 bytes each for K and for V^T)
   const int kkey0 = tid / (DK / EPC), kdc = tid % (DK / EPC);            // K chunk 0: key kkey0, chunk 1: key kkey0 + 32
