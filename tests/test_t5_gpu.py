@@ -37,8 +37,8 @@ def embeds(B, S, d, seed=7):
     return torch.from_numpy(synth.normal(seed, "embeds", (B, S, d), 3.0))
 
 
-@pytest.mark.parametrize("cfg_name,B,S", [("tiny", 3, 19), ("tiny", 2, 130), ("full", 2, 190), ("full", 33, 40)])
-def test_encoder_fp32(cfg_name, B, S):
+@pytest.mark.parametrize("cfg_name,B,S", [("tiny", 3, 19), ("tiny", 2, 130), ("full", 2, 190), ("full", 33, 40), ("full", 1, 1100)])
+def test_encoder_fp32(cfg_name, B, S):      # S = 1100: a relative-position table of more than 2 048 entries (staged in two passes)
     cfg = tiny_config() if cfg_name == "tiny" else DEFAULT_CONFIG
     model, orc, g = build(cfg, "fp32")
     x = embeds(B, S, g.d_model)
@@ -84,8 +84,8 @@ def test_greedy_ids_fp32_bit_exact(cfg_name, B, S, L, eos):
     assert torch.equal(out, ref)
 
 
-@pytest.mark.parametrize("cfg_name,B,S,L", [("tiny", 3, 19, 40), ("full", 2, 190, 64)])
-def test_bf16_mode_tracks_bf16_oracle(cfg_name, B, S, L):
+@pytest.mark.parametrize("cfg_name,B,S,L", [("tiny", 3, 19, 40), ("full", 2, 190, 64), ("full", 1, 1100, 6), ("full", 2, 96, 12)])
+def test_bf16_mode_tracks_bf16_oracle(cfg_name, B, S, L):      # S = 1100: table > 2 048 entries; S = 96: one wide step + the half step
     cfg = tiny_config() if cfg_name == "tiny" else DEFAULT_CONFIG
     model, orc, g = build(cfg, "bf16")
     x = embeds(B, S, g.d_model)
@@ -291,7 +291,7 @@ def test_norm_gemm_fused_kernel_is_bit_identical_to_the_two_kernel_path(monkeypa
     assert torch.equal(out["force"][1], out["0"][1])
 
 
-@pytest.mark.parametrize("cfg_name,B,S,Ld", [("tiny", 3, 19, 12), ("tiny", 2, 130, 131), ("full", 2, 190, 70), ("full", 3, 864, 40), ("full", 2, 61, 300), ("full", 9, 1000, 8)])
+@pytest.mark.parametrize("cfg_name,B,S,Ld", [("tiny", 3, 19, 12), ("tiny", 2, 130, 131), ("full", 2, 190, 70), ("full", 3, 864, 40), ("full", 2, 61, 300), ("full", 9, 1000, 8), ("full", 2, 1100, 5), ("full", 2, 96, 33)])
 def test_attention_wide_form_against_the_first_form(monkeypatch, cfg_name, B, S, Ld):
     """Round 5: the bf16 mode's flash attention takes 64 keys per softmax step from double-buffered tiles (`attn_wide_kernel`);
     the fp32 mode keeps the first kernel, 32 keys per step.  The two forms round the same probabilities at different running maxima
