@@ -1496,7 +1496,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
   const int bh = xcd + 8 * (slot / nq), qt = slot - (slot / nq) * nq;
   if (bh >= B * H) return;
   const int b = bh / H, hh = bh - b * H;
-  const int q0 = qt * AQ + wave * 32;
+  const int q0 = __builtin_amdgcn_readfirstlane(qt * AQ + wave * 32);       // scalar: the branches on it below are wave-uniform
   const T* Q = reinterpret_cast<const T*>(a.Q) + (int64_t)bh * Sq * DK;
   const T* Kg = reinterpret_cast<const T*>(a.K) + (int64_t)bh * Sk * DK;
   const T* Vtg = reinterpret_cast<const T*>(a.Vt) + (int64_t)bh * DK * Sp;
@@ -1523,6 +1523,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
   const int kend = CAUSAL ? min(Sk, qt * AQ + AQ) : Sk;
   const int ntiles = ceil_div(kend, AK);
   constexpr float L2E = 1.4426950408889634f;
+  const int far = a.bias_far;
 
   // One register set of staged tiles: tile t + 1 goes to LDS at the top of step t and the set is re-issued for tile t + 2 at once.
   // (Measured and dropped, twice: two sets, a tile requested two steps ahead, the loop unrolled by two — 87.1 against 85.0 us on
@@ -1589,27 +1590,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     const T* Vb = Vt0 + (kt & 1) * VBUF;
     const int kbase = kt * AK;
     f32x16 s0, s1;
-    if constexpr (BIAS && AW_KEEP(5)) {
-      const float* tbp = tb + (kbase - my_q + (Sq - 1) + 4 * h);
+    // T5's bias is one value per side beyond `far` positions (the last bucket): a tile that far from all 32 queries of the wave
+    // (8 or 9 of the 13 at S = 864) adds a constant c to every score, which moves into the exponent's offset — exp2((s + c - m) log2e)
+    // — and into the maximum; such a step reads no table and starts its accumulators from the literal zero
+    float cfar = 0.f;
+    bool near = true;
+    if constexpr (BIAS) near = far == 0 || (kbase + AK - 1 - q0 > -far && kbase - (q0 + 31) < far);      // wave-uniform (q0 is scalar)
+    {
+      const Frag<T> kf0 = load_frag(Kb + r * Cfg::KP + 8 * h);
+      const Frag<T> kf1 = load_frag(Kb + (32 + r) * Cfg::KP + 8 * h);
+      if (BIAS && near) {
+        const float* tbp = tb + (kbase - my_q + (Sq - 1) + 4 * h);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        s0[i] = tbp[(i & 3) + 8 * (i >> 2)];
-        s1[i] = tbp[32 + (i & 3) + 8 * (i >> 2)];
+        for (int i = 0; i < 16; ++i) {
+          s0[i] = tbp[(i & 3) + 8 * (i >> 2)];
+          s1[i] = tbp[32 + (i & 3) + 8 * (i >> 2)];
+        }
+        mma16(s0, kf0, qf[0]);
+        mma16(s1, kf1, qf[0]);
+      } else {
+        if constexpr (BIAS) cfar = tb[kbase - my_q + (Sq - 1) + 4 * h];
+        s0 = zero_acc();
+        s1 = zero_acc();
+        mma16(s0, kf0, qf[0]);       // the zero is the instruction's literal operand: no register is written for it
+        mma16(s1, kf1, qf[0]);
       }
-    } else {
-      s0 = zero_acc();
-      s1 = zero_acc();
     }
-    if constexpr (AW_KEEP(2)) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const Frag<T> kf0 = load_frag(Kb + r * Cfg::KP + s * 16 + 8 * h);
-        const Frag<T> kf1 = load_frag(Kb + (32 + r) * Cfg::KP + s * 16 + 8 * h);
-        mma16(s0, kf0, qf[s]);
-        mma16(s1, kf1, qf[s]);
-      }
-    } else {
-      s0[0] += __builtin_bit_cast(float, qf[0].v.x ^ qf[1].v.y ^ qf[2].v.z ^ qf[3].v.w);
+    for (int s = 1; s < 4; ++s) {
+      const Frag<T> kf0 = load_frag(Kb + r * Cfg::KP + s * 16 + 8 * h);
+      const Frag<T> kf1 = load_frag(Kb + (32 + r) * Cfg::KP + s * 16 + 8 * h);
+      mma16(s0, kf0, qf[s]);
+      mma16(s1, kf1, qf[s]);
     }
     AW_STAMP(kt >= 4 && kt < 8 ? 4 + (kt - 4) * 8 : -1);
     // two running chains of max3 (a pair-wise tree makes the compiler canonicalise every matrix-core output first: 3 ops per pair)
@@ -1619,11 +1631,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
       mx = fmaxf(fmaxf(mx, s0[i]), s0[(i + 1) & 15]);
       my = fmaxf(fmaxf(my, s1[i]), s1[(i + 1) & 15]);
     }
-    mx = fmaxf(mx, my);
+    mx = fmaxf(mx, my) + cfar;
     if constexpr (AW_KEEP(6)) mx = fmaxf(mx, lane_xor<32>(mx));
     const float m_new = fmaxf(m_run, mx);
-    const float mneg = -m_new * L2E;
-    const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run, L2E, mneg));
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * L2E);
+    const float mneg = (cfar - m_new) * L2E;
     AW_STAMP(kt >= 4 && kt < 8 ? 5 + (kt - 4) * 8 : -1);
     float ps0 = 0.f, ps1 = 0.f, ps2 = 0.f, ps3 = 0.f;
     float p[32];

@@ -106,6 +106,7 @@ struct m2m_session {
   void* attn_enc;          // [B*S, inner] T
   void* mid_enc;           // [B*S, dff] T
   float* enc_bias_tab;     // [H][2*max_enc-1]
+  int enc_bias_far, dec_bias_far;   // AttnArgs::bias_far of the two tables (0 when the table never becomes constant inside its range)
   float* dec_bias_tab;     // [H][max_dec]
   float* dec_bias_full_tab;// [H][2*max_dec-1] the same bias by (key - query) + max_dec - 1 (batched causal pass)
   void* cross_vt;          // [B][H][64][Sp] T scratch: one layer's cross V transposed (batched pass)
@@ -191,6 +192,8 @@ struct AttnArgs {
   int tab_stride, tab_center;
   void* out;              // [B*Sq][H*64] T
   int B, H, Sq, Sk;
+  int bias_far;           // the table is constant from (key - query) <= -bias_far down and from >= +bias_far up (T5's last bucket of
+                          // either direction); 0 = not known.  attn_wide_kernel reads no table for tiles that far from their queries
 };
 int launch_attn(int precision, const AttnArgs& a, bool causal, hipStream_t st);
 int launch_transpose_v(int precision, const void* v, void* vt, int BH, int S, int Sp, hipStream_t st);

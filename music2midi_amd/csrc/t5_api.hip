@@ -265,6 +265,16 @@ extern "C" int m2m_session_create(const m2m_model* m, int max_batch, int max_enc
     const int bk = m2m_rel_bucket(-n, 0, g.num_buckets, g.max_distance);
     for (int h = 0; h < H; ++h) dt[(size_t)h * L + n] = m->dec_rel_bias_host[(size_t)bk * H + h];
   }
+  // distance from which on a table holds one value per side (the last bucket): the smallest D with bucket(-n) == bucket(-(len - 1))
+  // and bucket(+n) == bucket(len - 1) for every n >= D; 0 if the table is too short to get there
+  auto far_of = [&](int len, int bidir) {
+    int d = len - 1;
+    while (d > 0 && m2m_rel_bucket(-(d - 1), bidir, g.num_buckets, g.max_distance) == m2m_rel_bucket(-(len - 1), bidir, g.num_buckets, g.max_distance) &&
+           m2m_rel_bucket(d - 1, bidir, g.num_buckets, g.max_distance) == m2m_rel_bucket(len - 1, bidir, g.num_buckets, g.max_distance)) --d;
+    return d >= len - 1 ? 0 : d;
+  };
+  s->enc_bias_far = far_of(S, 1);
+  s->dec_bias_far = far_of(L, 0);      // (the future half of the causal table is masked, never read by a wide step)
   // the same decoder bias as a (key - query) table for the batched causal pass: entry L-1-n = bias(n), n = q - k >= 0;
   // the upper half (future keys) is masked by the kernel and stays 0
   std::vector<float> df((size_t)H * (2 * L - 1), 0.f);
@@ -333,7 +343,7 @@ extern "C" int m2m_encode(m2m_session* s, const float* inputs_embeds_dev, int B,
     if ((rc = launch_norm_gemm(P, EPI_HEADS, a, st))) return rc;
     AttnArgs at{};
     at.Q = s->qkv_enc; at.K = (const unsigned char*)s->qkv_enc + (size_t)M * m->inner * m->esize; at.Vt = s->vt_enc; at.Sp = Sp;
-    at.bias_tab = s->enc_bias_tab; at.tab_stride = 2 * s->max_enc - 1; at.tab_center = s->max_enc - 1;
+    at.bias_tab = s->enc_bias_tab; at.tab_stride = 2 * s->max_enc - 1; at.tab_center = s->max_enc - 1; at.bias_far = s->enc_bias_far;
     at.out = s->attn_enc; at.B = B; at.H = g.num_heads; at.Sq = S; at.Sk = S;
     if ((rc = launch_attn(P, at, false, st))) return rc;
     a = GemmArgs{}; a.vt_which = -1;
@@ -591,7 +601,7 @@ static int forward_batched(m2m_session* s, const int64_t* ids, int Ld, float* lo
     if ((rc = launch_norm_gemm(P, EPI_HEADS, a, st))) return rc;
     AttnArgs at{};
     at.Q = qkv; at.K = qkv + (size_t)M * m->inner * es; at.Vt = s->vt_enc; at.Sp = Lp;
-    at.bias_tab = s->dec_bias_full_tab; at.tab_stride = 2 * s->max_dec - 1; at.tab_center = s->max_dec - 1;
+    at.bias_tab = s->dec_bias_full_tab; at.tab_stride = 2 * s->max_dec - 1; at.tab_center = s->max_dec - 1; at.bias_far = s->dec_bias_far;
     at.out = s->attn_enc; at.B = B; at.H = H; at.Sq = Ld; at.Sk = Ld;
     if ((rc = launch_attn(P, at, true, st))) return rc;
     a = GemmArgs{}; a.vt_which = -1;
