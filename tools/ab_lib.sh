@@ -11,7 +11,7 @@ for t in "" $tag "" $tag; do
   python3 - $D/enc_kernel_stats.csv "$flt" <<'PY'
 import csv, re, sys
 for r in csv.DictReader(open(sys.argv[1])):
-    if "bf16" not in r["Name"] and "wide" not in r["Name"] and "resid_panel" not in r["Name"]: continue
+    if not any(t in r["Name"] for t in ("bf16", "wide", "resid_panel", "norm_gemm")): continue
     if re.search(sys.argv[2], r["Name"]) and float(r["Percentage"]) > 0.3:
         print(f"   {r['Name'][:72]:72s} n {r['Calls']:>4s}  avg {float(r['AverageNs']) / 1000:8.2f} us")
 PY
