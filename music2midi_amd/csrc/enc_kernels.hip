@@ -1636,9 +1636,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     }
     mx = fmaxf(mx, my) + cfar;
     if constexpr (AW_KEEP(6)) mx = fmaxf(mx, lane_xor<32>(mx));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * L2E);
-    const float mneg = (cfar - m_new) * L2E;
+    // m_run is the REFERENCE the exponentials are taken against, not necessarily the running maximum: it moves (and the 32 output
+    // accumulators and the row sum are rescaled) only when some row's new maximum exceeds its reference by more than AW_TAU — with
+    // 32 rows per wave SOME row sets a new maximum in almost every tile (1 - (12/13)^32 = 92 % at the 13th), so rescaling at every
+    // new maximum meant 16 packed multiplies + an exponential in nearly every step.  Until a row is re-referenced its weights may
+    // reach e^AW_TAU = 245: nothing to fp32 accumulators or to bf16's exponent, and the quotient o / l does not see the reference.
+#ifdef M2M_AW_EAGER
+    constexpr float AW_TAU = 0.f;
+#else
+    constexpr float AW_TAU = 5.5f;
+#endif
+    if (__ballot(mx > m_run + AW_TAU) != 0ull) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * L2E);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        o[0][i] *= alpha;
+        o[1][i] *= alpha;
+      }
+    }
+    const float mneg = (cfar - m_run) * L2E;
     AW_STAMP(kt >= 4 && kt < 8 ? 5 + (kt - 4) * 8 : -1);
     float ps0 = 0.f, ps1 = 0.f, ps2 = 0.f, ps3 = 0.f;
     float p[32];
@@ -1662,16 +1681,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     // (measured and dropped: the row sums from the matrix core — a block of ones times P^T, 4 more MFMAs per step instead of 32
     // adds: 88.7 against 86.6 us on the same box; the kernel is bound by a wave's dependent chain, which those MFMAs lengthen, not
     // by vector issue)
-    l_run = fmaf(l_run, alpha, (ps0 + ps1) + (ps2 + ps3));
-    m_run = m_new;
+    l_run += (ps0 + ps1) + (ps2 + ps3);
     AW_STAMP(kt >= 4 && kt < 8 ? 6 + (kt - 4) * 8 : -1);
-    if (__ballot(alpha != 1.0f) != 0ull) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        o[0][i] *= alpha;
-        o[1][i] *= alpha;
-      }
-    }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       float pp[8];

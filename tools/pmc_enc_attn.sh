@@ -15,7 +15,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 for f in sorted(glob.glob(f"{out}/p*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0]
-        if "bf16_t" not in k or not any(t in k for t in ("attn_kernel", "norm_gemm", "gemm_kernel")): continue
+        if not any(t in k for t in ("attn_kernel<m2m::bf16_t", "attn_wide", "norm_gemm", "gemm_kernel<m2m::bf16_t", "resid_panel")): continue
         a = agg[k][r["Counter_Name"]]; a[0] += 1; a[1] += float(r["Counter_Value"])
 for k, d in sorted(agg.items()):
     print(k[:70])

@@ -25,7 +25,7 @@ for r in csv.DictReader(open(f)):
 XCDS = 8   # the csv carries GRBM_GUI_ACTIVE summed over the 8 XCD instances; the formula takes their max
 lines = []
 for k in sorted(agg, key=lambda k: -dur[k]):
-    if not any(t in k for t in ("gemm_kernel", "attn_kernel", "resid_panel", "dec_ff", "logmel")): continue
+    if not any(t in k for t in ("gemm_kernel", "attn_kernel", "attn_wide", "resid_panel", "dec_ff", "logmel")): continue
     a = agg[k]; n = calls[k]
     busy, gui, mops = a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), a.get("GRBM_GUI_ACTIVE", 0.0), a.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0)
     util = 100.0 * busy / (gui / XCDS * 1024) if gui else 0.0

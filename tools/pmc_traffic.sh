@@ -33,7 +33,7 @@ with open(out + "/summary.txt", "w") as fh:
     head = f"# decode kernels: clips/launch = {min(rows, batch)}   (batch {batch} per GPU; FETCH_SIZE x2-corrected for gfx950; separate --pmc passes)"
     print(head); fh.write(head + "\n")
     for k in sorted(set(res.get("FETCH_SIZE", {})) | set(res.get("WRITE_SIZE", {}))):
-        if "dec_" not in k and "logmel" not in k and "gemm_kernel" not in k and "attn_kernel" not in k: continue
+        if "dec_" not in k and "logmel" not in k and "gemm_kernel" not in k and "attn_kernel" not in k and "attn_wide" not in k and "resid_panel" not in k: continue
         n, fs = res.get("FETCH_SIZE", {}).get(k, [0, 0.0]); _, ws = res.get("WRITE_SIZE", {}).get(k, [0, 0.0])
         n = max(n, 1)
         # counters are in KiB; gfx950 FETCH_SIZE counts wide coalesced reads at 1/2 -> x2 (MI355X_MICROARCH.md HBM)
