@@ -1678,9 +1678,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
       p[16 + i] = v0;
       p[16 + i + 1] = v1;
     }
-    // (measured and dropped: the row sums from the matrix core — a block of ones times P^T, 4 more MFMAs per step instead of 32
-    // adds: 88.7 against 86.6 us on the same box; the kernel is bound by a wave's dependent chain, which those MFMAs lengthen, not
-    // by vector issue)
+    // (measured and dropped, twice: the row sums from the matrix core — a block of ones times P^T, 4 more MFMAs per step instead of
+    // 32 adds: 88.7 against 86.6 us on the same box, and 77.5 against 76.6 on the final kernel)
     l_run += (ps0 + ps1) + (ps2 + ps3);
     AW_STAMP(kt >= 4 && kt < 8 ? 6 + (kt - 4) * 8 : -1);
 #pragma unroll
