@@ -1476,8 +1476,8 @@ __device__ unsigned long long g_aw_stamp[64];
 #endif
 
 #ifndef M2M_AW_CUT        // diagnostic builds only (tools/aw_variants.sh): bit i leaves a phase of the wide step out at COMPILE time
-#define M2M_AW_CUT 0      // (a run-time mask distorted the code: 177 registers, accumulator copies); results are garbage, times are not
-#endif
+#define M2M_AW_CUT 0      // (a run-time mask distorted the code: 177 registers, accumulator copies); results are garbage, times are not.
+#endif                    // bits: 1 exponentials, 2 P.V MFMAs + V reads, 8 the tile barrier, 16 staging, 64 the maximum's cross-half exchange
 #define AW_KEEP(bit) (!((M2M_AW_CUT) & (1 << (bit))))
 
 template <bool CAUSAL, bool BIAS>

@@ -2,8 +2,10 @@
 # Compile-time ablation of attn_wide_kernel's 64-key step: builds lib/libmusic2midi_amd_awcut<N>.so for each mask N (only
 # enc_kernels.hip is recompiled, with -DM2M_AW_CUT=N; the other objects come from the product build) — run HERE (no GPU), then
 # `gpurun -- tools/aw_variants.sh run` times every variant at B = 4 (one workgroup per CU: the lone-wave chain) and B = 32.
-#   bits: 1 exponentials  2 P.V MFMAs + V reads  4 Q.K MFMAs + K reads  8 tile barrier  16 staging  32 bias reads  64 max exchange
-MASKS="1 2 4 8 16 32 64 6 24 7 127"
+#   bits: 1 exponentials  2 P.V MFMAs + V reads  8 tile barrier  16 staging  64 max exchange
+#   (bits 4 = Q.K MFMAs + K reads and 32 = bias reads existed until the far-tile path restructured that phase; their figures — 17.6 / 19.4
+#   and 1.2 / 5.6 us of 92 / 90 — are in DESIGN.md 4.2)
+MASKS="1 2 8 16 64 3 24 27"
 cd "$(dirname "$0")/.."
 if [ "$1" != run ]; then
   for m in $MASKS; do
