@@ -119,6 +119,8 @@ __global__ __launch_bounds__(512, 2) void attn_head_fwd_kernel(HeadAttnArgs a) {
   const int nwaves = blockDim.x >> 6, split = a.key_split, nw = nwaves / split;
   ah_stage(Ks, Kg, a.ldk, a.Sk, Skp, wave, lane, nwaves);
   ah_stage(Vs, Vg, a.ldv, a.Sk, Skp, wave, lane, nwaves);
+  // (round 5, measured and dropped: this loop compiles to load -> s_waitcnt vmcnt(0) -> store per iteration, two or three round trips;
+  // four entries per thread requested before the K / V transfers instead: 21.0 / 13.8 against 20.7 / 13.2 us — no gain at these sizes)
   if (BIAS)
     for (int i = threadIdx.x; i < a.tab_stride + 32; i += blockDim.x) bias_s[i] = i < a.tab_stride ? a.bias_tab[(int64_t)hh * a.tab_stride + i] * AH_LOG2E : 0.f;
   // this wave's query block and its part of the key tiles
