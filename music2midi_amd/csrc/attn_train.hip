@@ -528,8 +528,9 @@ __global__ __launch_bounds__(256, 2) void attn_head_bwd_kernel(HeadAttnArgs a) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) vfr[s] = load_frag(Vg + (int64_t)vrow * a.ldv + 16 * s + 8 * h);
   }
-  auto tileB = [&](int j, auto masked) {
+  auto tileB = [&](int j, auto masked, auto with_diag) {
     constexpr bool MASK = decltype(masked)::value;              // the last key block (keys beyond Sk) and the causal diagonal
+    constexpr bool DIAG = decltype(with_diag)::value;           // == want_diag, as a compile-time fact of the loop the tile runs in
     f32x16 sacc = zero_acc(), pacc = zero_acc();
     const uint32_t kwq = kw_next >> (4 * h);                    // this query's keep bits against key block j
     const bf16_t* Kt = Xa + 32 * 64 * j;
@@ -569,7 +570,7 @@ __global__ __launch_bounds__(256, 2) void attn_head_bwd_kernel(HeadAttnArgs a) {
 #pragma unroll
       for (int db = 0; db < 2; ++db) mma16(dqT[db], ah_tr_frag_at(Kt, lo, s, db), df[s]);      // dQ^T += K^T dS^T
     }
-    if (want_diag) {
+    if (DIAG && (!CAUSAL || want_diag)) {                       // (causal: one loop with the run-time test — two loops there cost a spill)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const uint32_t w[4] = {df[s].v.x, df[s].v.y, df[s].v.z, df[s].v.w};
@@ -590,14 +591,32 @@ __global__ __launch_bounds__(256, 2) void attn_head_bwd_kernel(HeadAttnArgs a) {
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      if (h == 0) dout[32 * j + r] = c0[0];                    // (32 j + 31 <= Sk + 30: always inside the row)
+      // Stored by BOTH half-waves (the upper one repeats the lower one's value and address), in a loop compiled for want_diag: behind
+      // `if (want_diag)` / `if (h == 0)` the store sat in a branch, the compiler could not tell whether it had been issued, and the
+      // next tile's first use of a prefetched register (the keep word, the V rows) waited vmcnt(0) — for this store's
+      // acknowledgement, a memory write round trip in every tile of the bias variants (found in the ISA; vector-memory
+      // operations retire in order, stores included).  Now the wait is vmcnt(1).
+      // (The causal kernel keeps the branchy form: it is shorter-lived per tile and measured 26.6 us so against 26.9 - 27.5.)
+      if constexpr (CAUSAL) {
+        if (h == 0) dout[32 * j + r] = c0[0];                  // (32 j + 31 <= Sk + 30: always inside the row)
+      } else {
+        const float drow = c0[0];
+        dout[32 * j + r] = h == 0 ? drow : lane_xor<32>(drow);
+      }
       carry = c1;
     }
   };
   const bool ragged = (a.Sk & 31) != 0;
-  for (int j = 0; j < jend; ++j) {
-    if ((CAUSAL && j == blk) || (ragged && j == nk - 1)) tileB(j, std::true_type{});
-    else tileB(j, std::false_type{});
+  if (CAUSAL || want_diag) {
+    for (int j = 0; j < jend; ++j) {
+      if ((CAUSAL && j == blk) || (ragged && j == nk - 1)) tileB(j, std::true_type{}, std::true_type{});
+      else tileB(j, std::false_type{}, std::true_type{});
+    }
+  } else {
+    for (int j = 0; j < jend; ++j) {
+      if ((CAUSAL && j == blk) || (ragged && j == nk - 1)) tileB(j, std::true_type{}, std::false_type{});
+      else tileB(j, std::false_type{}, std::false_type{});
+    }
   }
   if (want_diag) {
     // the upper diagonals of the last tile visited, then zeros for what a causal block never reaches
