@@ -172,6 +172,9 @@ def host_cpu_share() -> dict:
     return out
 
 
+ENC_PASSES = 20      # encoder + cross-K/V passes timed for extras.encoder_plus_crosskv_ms
+
+
 def cpu_baseline(cfg, state, new_tokens: int, clips: int = 8, threads: int = 16):
     """Oracle on the host cores, fp32: `clips` clips batched (frontend + encoder + `new_tokens` greedy
     steps each) and ONE clip alone (BASELINE configs[0]).
@@ -866,8 +869,10 @@ def main():
         torch.cuda.synchronize(dev)
         fe_ms = ev[0].elapsed_time(ev[1])
         enc_first_ms = ev[1].elapsed_time(ev[2])          # one call, as rounds 1-4 reported it (host issue of ~60 launches included)
+        for _ in range(3):                                 # warm-up: the first passes after other work run ~10 % slower
+            model._encode(x, MAX_LENGTH)
         ev[1].record()
-        for _ in range(5):                                 # the figure of tools/enc_bench.py: mean of warm back-to-back passes
+        for _ in range(ENC_PASSES):                        # mean of warm back-to-back passes (tools/enc_sustained.py: 1.81 ms over 50-500)
             model._encode(x, MAX_LENGTH)
         ev[2].record()
         torch.cuda.synchronize(dev)
@@ -875,7 +880,7 @@ def main():
         model.generate_from_embeds(x, max_length=MAX_LENGTH)
         torch.cuda.synchronize(dev)
         t_dec = time.perf_counter() - t_dec
-        enc_ms = ev[1].elapsed_time(ev[2]) / 5
+        enc_ms = ev[1].elapsed_time(ev[2]) / ENC_PASSES
         # dominant kernel: decode cross-attention (6 launches per decode step, streams the
         # per-clip cross K/V: 2 * S * inner * esize bytes per clip per launch)
         t_mid = MAX_LENGTH // 2
