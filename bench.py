@@ -884,6 +884,7 @@ def main():
         # dominant kernel: decode cross-attention (6 launches per decode step, streams the
         # per-clip cross K/V: 2 * S * inner * esize bytes per clip per launch)
         t_mid = MAX_LENGTH // 2
+        model._encode(x, MAX_LENGTH)      # a greedy decode that re-packed its live rows has consumed the encode (m2m_generate_greedy)
         cross_us, cross_bytes = model.bench_kernel(native.KERNEL_DEC_CROSS_ATTN, t_mid, 600)
         self_us, self_bytes = model.bench_kernel(native.KERNEL_DEC_SELF_ATTN, t_mid, 600)
         step_us, _ = model.bench_kernel(native.KERNEL_DEC_STEP, t_mid, 200)

@@ -187,6 +187,12 @@ int m2m_encode(m2m_session* s, const float* inputs_embeds_dev, int B, int S, flo
  * Returns M2M_ERR_RANGE (tokens are still written) when an activation left the decoder's fixed-point range or
  * was not finite - where the fp32 reference would have produced Inf/NaN logits.  On every error return all
  * library-owned streams have been synchronised, so the caller may free or reuse the workspace at once.
+ *
+ * Session state afterwards: m2m_encode -> any number of m2m_decode_forced / m2m_generate_greedy / m2m_bench_kernel calls on the same
+ * encode is legal (HF's forward and generate share one encoder pass the same way, ref: music2midi/transformer.py:28-45) - EXCEPT
+ * that a greedy decode which re-packed its live rows (m2m_session_repack_stats reports rows_moved > 0, see below) has overwritten
+ * finished clips' cross K/V with live ones and thereby CONSUMED the encode: the next call that needs it returns M2M_ERR_STATE
+ * ("re-encode: ...") until m2m_encode runs again.  The token ids of the call itself are unaffected.
  */
 int m2m_generate_greedy(m2m_session* s, int max_length, int64_t* tokens_out_dev, int* out_len_host, void* stream);
 
@@ -194,8 +200,12 @@ int m2m_generate_greedy(m2m_session* s, int max_length, int64_t* tokens_out_dev,
  * Rows end at different steps (ref: music2midi/model.py:115-135 decodes chunks of inference.batch_size = 128 three-second
  * segments to max_length 1024; a trained checkpoint ends a segment after tens to hundreds of tokens).  Once a quarter of the
  * rows still being decoded have emitted EOS, m2m_generate_greedy re-packs the live rows into the first slots of the batch at its
- * next host poll (every 64 steps) and goes on with smaller launches; ids do not depend on it.  This returns how often that
- * happened in the last call and how many rows were moved (M2M_COMPACT=0 in the environment disables the re-packing).
+ * next host poll and goes on with smaller launches; ids do not depend on it.  The host polls after 16, 32, 64, 96 and 128 steps and
+ * then every 64 (without the re-packing: every 64); each poll drains every chain, and a poll at which a re-packing is possible (a
+ * chain still running, >= 64 steps left, >= 2 rows) also reads the finished flags back synchronously - so M2M_COMPACT=1 adds four
+ * early polls (about a decode step each) even to a batch that never emits EOS.  This returns how often rows were re-packed in the
+ * last call and how many were moved; rows_moved > 0 means that call consumed the session's encode (see m2m_generate_greedy).
+ * M2M_COMPACT=0 in the environment disables the re-packing.
  */
 int m2m_session_repack_stats(const m2m_session* s, int* repacks_out, int* rows_moved_out);
 

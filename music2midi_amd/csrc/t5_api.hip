@@ -450,9 +450,16 @@ static void quiesce(m2m_session* s, hipStream_t caller) {
 
 static int generate_greedy_impl(m2m_session* s, int max_length, int64_t* tokens_out_dev, int* out_len_host, hipStream_t caller);
 
+// why a call that needs the encoded state finds none: never encoded, or the last greedy decode re-packed its live rows over it
+static const char* encode_missing(const m2m_session* s) {
+  return s->rows_moved > 0 ? "re-encode: the last m2m_generate_greedy re-packed its live rows over the encoded state (it consumes the encode "
+                             "whenever m2m_session_repack_stats reports rows moved)"
+                           : "call m2m_encode first";
+}
+
 extern "C" int m2m_generate_greedy(m2m_session* s, int max_length, int64_t* tokens_out_dev, int* out_len_host, void* stream) {
   M2M_REQUIRE(s && tokens_out_dev && out_len_host, "m2m_generate_greedy: null argument");
-  if (!s->encoded) { set_error("m2m_generate_greedy: call m2m_encode first"); return M2M_ERR_STATE; }
+  if (!s->encoded) { set_error("m2m_generate_greedy: %s", encode_missing(s)); return M2M_ERR_STATE; }
   M2M_REQUIRE(max_length >= 1 && max_length <= s->max_dec, "m2m_generate_greedy: max_length %d outside [1, %d]", max_length, s->max_dec);
   const int rc = generate_greedy_impl(s, max_length, tokens_out_dev, out_len_host, (hipStream_t)stream);
   if (rc != M2M_OK) quiesce(s, (hipStream_t)stream);
@@ -489,7 +496,7 @@ static int generate_greedy_impl(m2m_session* s, int max_length, int64_t* tokens_
   bool all_done = steps == 0;
   std::vector<int> fin_host, mv_src, mv_dst;
   while (!all_done && launched < steps) {
-    // the first polls come sooner (after 16, 32, 64, 128 steps, then every 64): many rows of a real batch end within their first
+    // the first polls come sooner (after 16, 32, 64, 96, 128 steps, then every 64): many rows of a real batch end within their first
     // tens of tokens, and a poll costs one drained pipeline (~a step) while every step before a re-packing costs the full batch
     const int chunk = compact ? (launched < 32 ? 16 : (launched < 128 ? 32 : CHUNK)) : CHUNK;
     const int n = steps - launched < chunk ? steps - launched : chunk;
@@ -535,6 +542,11 @@ static int generate_greedy_impl(m2m_session* s, int max_length, int64_t* tokens_
           mv_src.push_back(tail++); mv_dst.push_back(hole);
         }
         hipStream_t st0 = s->groups[0].stream;
+        // Moving a row OVERWRITES the finished clip in its destination slot (cross K/V, self K/V, residual row): from here on the
+        // session no longer holds the encode of clips 0..B-1 in clip order, so this generate CONSUMES it.  A later
+        // m2m_decode_forced / m2m_generate_greedy / m2m_bench_kernel without a new m2m_encode returns M2M_ERR_STATE instead of
+        // decoding permuted / duplicated clips.
+        if (!mv_src.empty()) s->encoded = false;
         if (!mv_src.empty() && (rc = decode_move_rows(s, mv_src.data(), mv_dst.data(), (int)mv_src.size(), t_cur, st0))) return rc;
         M2M_CHECK_HIP(hipStreamSynchronize(st0));
         s->repacks += 1; s->rows_moved += (int)mv_src.size();
@@ -647,7 +659,7 @@ extern "C" int m2m_session_repack_stats(const m2m_session* s, int* repacks_out, 
 
 extern "C" int m2m_decode_forced(m2m_session* s, const int64_t* dec_input_ids_dev, int Ld, float* logits_out_dev, void* stream) {
   M2M_REQUIRE(s && dec_input_ids_dev && logits_out_dev, "m2m_decode_forced: null argument");
-  if (!s->encoded) { set_error("m2m_decode_forced: call m2m_encode first"); return M2M_ERR_STATE; }
+  if (!s->encoded) { set_error("m2m_decode_forced: %s", encode_missing(s)); return M2M_ERR_STATE; }
   M2M_REQUIRE(Ld >= 1 && Ld <= s->max_dec, "m2m_decode_forced: Ld %d outside [1, %d]", Ld, s->max_dec);
   hipStream_t st = (hipStream_t)stream;
   M2M_CHECK_HIP(hipMemcpyAsync(s->forced_ids, dec_input_ids_dev, (size_t)s->B * Ld * 8, hipMemcpyDeviceToDevice, st));
@@ -673,7 +685,7 @@ extern "C" int m2m_decode_forced(m2m_session* s, const int64_t* dec_input_ids_de
 extern "C" int m2m_bench_kernel(m2m_session* s, int which, int self_len, int iters, float* avg_us_host,
                                 int64_t* bytes_host, void* stream) {
   M2M_REQUIRE(s && avg_us_host && bytes_host && iters >= 1, "m2m_bench_kernel: bad argument");
-  if (!s->encoded) { set_error("m2m_bench_kernel: call m2m_encode first"); return M2M_ERR_STATE; }
+  if (!s->encoded) { set_error("m2m_bench_kernel: %s", encode_missing(s)); return M2M_ERR_STATE; }
   M2M_REQUIRE(self_len >= 1 && self_len <= s->max_dec, "m2m_bench_kernel: self_len out of range");
   M2M_REQUIRE(which == M2M_KERNEL_DEC_CROSS_ATTN || which == M2M_KERNEL_DEC_SELF_ATTN || which == M2M_KERNEL_DEC_STEP,
               "m2m_bench_kernel: unknown kernel id %d", which);
