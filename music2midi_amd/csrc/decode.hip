@@ -324,17 +324,15 @@ struct DecFfArgs {
   int check_done;        // headless greedy loop, layer 0: the carry workgroup of row block 0 turns "no row unfinished" into done
 };
 
-#ifndef M2M_FF_ROWS
-#define M2M_FF_ROWS 8
-#endif
-// residual rows per workgroup (<= 16, the MFMA tile height).  8 halves the fixed-point rows a workgroup
-// pulls (they were just written, so they come from HBM, not from a cache: tools/l2_persist.hip) at the
-// price of reading the weight slices twice from the Infinity Cache: 247.3 -> 244.6 ms per batch; 4 rows: 259.5
-constexpr int FF_R = M2M_FF_ROWS;
+// FF_R = residual rows per workgroup (<= 16, the MFMA tile height), a template parameter chosen per chain.  Small chains: 8 halves
+// the fixed-point rows a workgroup pulls (they were just written, so they come from HBM, not from a cache: tools/l2_persist.hip) at
+// the price of reading the weight slices twice from the Infinity Cache: 247.3 -> 244.6 ms per batch at 2 x 16 clips; 4 rows: 259.5.
+// Large chains (round 6): 16 rows halve the workgroups and the weight-slice reads of a launch (decode_ff_rows).  A row's arithmetic
+// does not depend on its tile (MFMA rows are independent): ids are bit-identical whichever is taken.
 constexpr int FF_C = 32;        // hidden columns per workgroup
 constexpr int FF_HP = FF_C + 8; // LDS row pitch of the activation slice (elements; keeps 16-byte alignment)
 
-template <typename T, int KS>
+template <typename T, int KS, int FF_R>
 __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(1, 2))) void dec_ff_kernel(DecFfArgs a) {
   M2M_STAMP_DECL
   __shared__ float ss_s[KS][16];
@@ -496,27 +494,29 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(1, 2)))
   M2M_STAMP(4, 2);
 }
 
-template <typename T>
+template <typename T, int FF_R>
 static int launch_dec_ff_t(const DecFfArgs& a, hipStream_t st) {
   const int nsl = a.d_ff / FF_C + 1;                                          // + 1: the residual-carry workgroup
   dim3 grid((unsigned)(ceil_div(nsl, 8) * 8 * ceil_div(a.B, FF_R)));
   switch (a.d / 64) {
-    case 2: hipLaunchKernelGGL((dec_ff_kernel<T, 2>), grid, dim3(128), 0, st, a); break;
-    case 4: hipLaunchKernelGGL((dec_ff_kernel<T, 4>), grid, dim3(256), 0, st, a); break;
-    case 6: hipLaunchKernelGGL((dec_ff_kernel<T, 6>), grid, dim3(384), 0, st, a); break;
-    case 8: hipLaunchKernelGGL((dec_ff_kernel<T, 8>), grid, dim3(512), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((dec_ff_kernel<T, 2, FF_R>), grid, dim3(128), 0, st, a); break;
+    case 4: hipLaunchKernelGGL((dec_ff_kernel<T, 4, FF_R>), grid, dim3(256), 0, st, a); break;
+    case 6: hipLaunchKernelGGL((dec_ff_kernel<T, 6, FF_R>), grid, dim3(384), 0, st, a); break;
+    case 8: hipLaunchKernelGGL((dec_ff_kernel<T, 8, FF_R>), grid, dim3(512), 0, st, a); break;
     default: set_error("dec_ff: d_model=%d not supported (128/256/384/512)", a.d); return M2M_ERR_INVALID;
   }
   M2M_CHECK_HIP(hipGetLastError());
   return M2M_OK;
 }
 
-static int launch_dec_ff(int precision, const DecFfArgs& a, hipStream_t st) {
+static int launch_dec_ff(int precision, const DecFfArgs& a, int rows, hipStream_t st) {
   if (a.d % 64 != 0 || a.d_ff % FF_C != 0) {
     set_error("dec_ff: d_model=%d must be a multiple of 64 and d_ff=%d of %d", a.d, a.d_ff, FF_C);
     return M2M_ERR_INVALID;
   }
-  return precision == M2M_PREC_BF16 ? launch_dec_ff_t<bf16_t>(a, st) : launch_dec_ff_t<float>(a, st);
+  const bool bf = precision == M2M_PREC_BF16;
+  if (rows == 16) return bf ? launch_dec_ff_t<bf16_t, 16>(a, st) : launch_dec_ff_t<float, 16>(a, st);
+  return bf ? launch_dec_ff_t<bf16_t, 8>(a, st) : launch_dec_ff_t<float, 8>(a, st);
 }
 
 // ======================================================= decode attention ====
@@ -1002,6 +1002,375 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
   M2M_STAMP(6 + (SELF ? 1 : 0), 3);
 }
 
+// ---- the same kernel for LARGE chains: C clips of one head per workgroup (round 6) ----
+// At the reference's own chunk (128 three-second segments, S = 190: ref music2midi/model.py:115-135, config.yaml inference.batch_size) a
+// chain launches 512 (clip, head) workgroups per attention kernel, one per CU at a time (16 waves x ~124 VGPRs), and each of them is the
+// same latency chain as at 16 clips: the row its predecessor wrote (~2.4 us), then its head's projection weights from L2 - 192 KB
+// (self) / 96 KB (cross) against a K/V stream of 131 KB (t = 512) / 49 KB: 1 024 workgroups pull more bytes from L2 as weights than
+// from HBM as K/V, and the regime is throughput-bound (12 attention launches x 2 rounds of workgroups per chain and step).  Here a
+// workgroup owns one head of C consecutive clips: ONE row round trip for all of them (wave pair c normalises clip c's row), the
+// head's weights fetched ONCE into the same registers and applied to the C rows, one bias row in LDS, then the clips' K/V streams
+// walked one after the other by all 16 waves - the next clip's first rounds requested before this clip's merge, so the stream
+// keeps running through the barriers - and the C output projections at the end.
+// Per row the arithmetic is the first kernel's, operation for operation (same lane -> element maps, same reduction trees, same
+// key -> lane-group partition, same rounding points): ids and logits are bit-identical whichever form a chain takes
+// (tests/test_t5_gpu.py::test_multi_clip_attention_is_bit_identical).  Chosen per chain by its clip count (decode_launch_attn).
+template <typename T, bool SELF, bool NT, bool FETCH, int C>
+__global__ __launch_bounds__(1024) void dec_attn_mc_kernel(DecAttnArgs a, int nb) {
+  static_assert(!FETCH || SELF, "only the layer-0 self-attention fetches its input row from the embedding table");
+  static_assert(C >= 2 && C <= 8, "a wave pair normalises one clip's row: at most 8 clips per 16-wave workgroup");
+  constexpr int E = 16 / sizeof(T);
+  constexpr int LPR = DK / E;
+  constexpr int KPW = 64 / LPR;
+  constexpr int KPB = 16 * KPW;
+  constexpr int NOUT = DK;
+  constexpr int LPO = 16;
+  constexpr int LPO2 = 8;
+  constexpr int WMAX2 = 6;
+  constexpr int PF = SELF ? M2M_DA_PF_SELF : M2M_DA_PF_CROSS;
+  constexpr int WMAX = 3;
+  constexpr int GPW = 64 / LPR;
+  using V16 = decltype(Vec16<T>().v);
+  extern __shared__ __align__(16) float hn[];   // [C][d] normalised input rows (already rounded to T), then (self) the bias row
+  __shared__ float redw[16], redl[16], redlf[16];
+  __shared__ float redo[16][DK];
+  __shared__ __align__(16) float redg[16 * GPW][DK];
+  __shared__ __align__(16) float qs[C][DK];
+  __shared__ __align__(16) float kn[DK];
+  __shared__ __align__(16) float vn[DK];
+  __shared__ __align__(16) float oh[C][DK];
+  __shared__ __align__(16) xq_t xrow[C][512];    // the fixed-point input rows (d_model <= 512): head 0 adds them into x_out at the end
+  const int st_t = a.state->t;
+  const int st_done = a.state->done | (st_t >= a.state->max_steps);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = blockIdx.x, b0 = blockIdx.y * C;      // linear id = 8 * block + h: a head's workgroups on one XCD, as in the first kernel
+  // finished-row flags of the C clips (scalar loads, requested with the loop state) as a bit mask; clips past the chain's end are
+  // clamped onto its last clip for every load and never stored
+  unsigned finmask = 0;
+#pragma unroll
+  for (int c = 0; c < C; ++c) finmask |= (a.fin_skip[(int64_t)min(b0 + c, nb - 1) * a.fin_stride] != 0 ? 1u : 0u) << c;
+  const int sub = lane % LPR;
+  const int kslot = wave * KPW + lane / LPR;
+  const int64_t kv_clip = (int64_t)a.H * a.kv_stride * DK;                       // elements between two clips' blocks
+  T* const Kb0 = reinterpret_cast<T*>(a.Kc) + ((int64_t)b0 * a.H + hh) * a.kv_stride * DK;
+  T* const Vb0 = reinterpret_cast<T*>(a.Vc) + ((int64_t)b0 * a.H + hh) * a.kv_stride * DK;
+
+  // ---- 0. requests for the prologue.  Wave pair cl = wave / 2 owns clip cl's row: wave 2 cl holds its elements 0..255, wave
+  //         2 cl + 1 the rest - the lane -> element map and the reduction tree of the first kernel's waves 0 and 1 ----
+  const int cl = wave >> 1, tin = (wave & 1) * 64 + lane;
+  const int xc = min(tin * 4, a.d - 4);
+  const int bx = min(b0 + min(cl, C - 1), nb - 1);
+  const bool own_wave = cl < C && (wave & 1) * 256 < a.d;      // wave-uniform
+  const bool own = cl < C && tin * 4 < a.d;
+  const int on_ = min(tid >> 1, a.d - 1), opart = tid & 1;
+  longlong2 xr0 = make_longlong2(0, 0), xr1 = make_longlong2(0, 0);
+  unsigned long long kraw = 0;
+  int fin0 = 0;
+  if constexpr (FETCH) {
+    kraw = a.keys[bx];
+    fin0 = a.finished[bx];
+  } else {
+    xr0 = *reinterpret_cast<const longlong2*>(a.x + (int64_t)bx * a.d + xc);
+    xr1 = *reinterpret_cast<const longlong2*>(a.x + (int64_t)bx * a.d + xc + 2);
+  }
+  const float4 gv = *reinterpret_cast<const float4*>(a.ln_w + xc);
+  __builtin_amdgcn_sched_barrier(0);               // the latency-critical rows go out FIRST (loads retire in order)
+  const int po = min(tid / LPO, NOUT - 1), part = tid % LPO;
+  const int which = po / DK, dd = po - which * DK;
+  const T* wrow = reinterpret_cast<const T*>(a.Wp) + ((int64_t)which * a.inner + hh * DK + dd) * a.d;
+  const int cnt = a.d / E / LPO;
+  Vec16<T> w[WMAX];
+#pragma unroll
+  for (int u = 0; u < WMAX; ++u) w[u].v = *reinterpret_cast<const V16*>(wrow + (min(u, cnt - 1) * LPO + part) * E);
+  float* const biasl = hn + C * a.d;                   // [kv_stride] (self only): ONE bias row serves the C clips
+  constexpr int BPT = 2;
+  float bv[SELF ? BPT : 1];
+  if (SELF) {
+#pragma unroll
+    for (int u = 0; u < BPT; ++u) bv[u] = a.bias[(int64_t)hh * a.bias_stride + min(tid + 1024 * u, a.bias_stride - 1)];
+  }
+  const int t = SELF ? (a.self_len_override > 0 ? a.self_len_override - 1 : st_t) : 0;
+  const int n_prev = SELF ? t : a.n_keys;
+  const int last = max(n_prev - 1, 0);
+
+  // the first clip's first PF rounds, right behind the prologue's own loads (clamped addresses, never predicated)
+  Vec16<T> kv[PF], vv[PF];
+#pragma unroll
+  for (int u = 0; u < PF; ++u) {
+    const int64_t off = (int64_t)min(kslot + u * KPB, last) * DK + sub * E;
+    kv[u].v = M2M_KV_LOAD(reinterpret_cast<const V16*>(Kb0 + off));
+    vv[u].v = M2M_KV_LOAD(reinterpret_cast<const V16*>(Vb0 + off));
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- 1. RMSNorm of the C rows -> hn[c] (rounded to the GEMM-input type T) ----
+  float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 e4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (FETCH) {
+    const int tok = amax_key_token(kraw, fin0, a.V, a.pad_id);
+    e4 = *reinterpret_cast<const float4*>(a.emb + (int64_t)tok * a.d + xc);
+  }
+  if (own_wave) {
+    if constexpr (FETCH) xv = e4;
+    else xv = make_float4(xq_flt(xr0.x), xq_flt(xr0.y), xq_flt(xr1.x), xq_flt(xr1.y));
+    float ss = own ? (xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w) : 0.f;
+    ss = wave_sum(ss);
+    if (lane == 0) redw[wave] = ss;
+  } else if (lane == 0) {
+    redw[wave] = 0.f;
+  }
+  __syncthreads();
+  if (own && hh == 0) {     // (hh: uniform) the raw row for head 0's residual carry; an embedding row is converted as the first kernel does
+    if constexpr (FETCH) {
+      if (!st_done) {
+        xr0 = make_longlong2(xq_fix_guarded(xv.x, a.state), xq_fix_guarded(xv.y, a.state));
+        xr1 = make_longlong2(xq_fix_guarded(xv.z, a.state), xq_fix_guarded(xv.w, a.state));
+      }
+    }
+    *reinterpret_cast<longlong2*>(&xrow[cl][xc]) = xr0;
+    *reinterpret_cast<longlong2*>(&xrow[cl][xc + 2]) = xr1;
+  }
+  if (own) {
+    // the first kernel sums its 16 wave slots in order, 14 of them zeros: 0 + r0 + r1 (+ 0 ...) - the same two adds
+    float tot = 0.f;
+    tot += redw[2 * cl];
+    tot += redw[2 * cl + 1];
+    const float rs = rsqrtf(tot / (float)a.d + a.eps);
+    float* const hc = hn + cl * a.d;
+    put_in<T>(hc, xc + 0, gv.x * (xv.x * rs));
+    put_in<T>(hc, xc + 1, gv.y * (xv.y * rs));
+    put_in<T>(hc, xc + 2, gv.z * (xv.z * rs));
+    put_in<T>(hc, xc + 3, gv.w * (xv.w * rs));
+  }
+  __syncthreads();
+
+  // ---- 2. this head's query projection of the C rows: the weights are in registers once ----
+  {
+    float acc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int u = 0; u < WMAX; ++u) {
+      if (u < cnt) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = chunk_dot<T>(w[u], hn + c * a.d, u * LPO + part, acc[c]);
+      }
+    }
+    for (int i = WMAX; i < cnt; i += 4) {   // d_model / dtype combinations beyond the register budget (fp32)
+      Vec16<T> w2[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) w2[u].v = *reinterpret_cast<const V16*>(wrow + (min(i + u, cnt - 1) * LPO + part) * E);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (i + u < cnt) {
+#pragma unroll
+          for (int c = 0; c < C; ++c) acc[c] = chunk_dot<T>(w2[u], hn + c * a.d, (i + u) * LPO + part, acc[c]);
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float q = group_sum<LPO>(acc[c]);
+      if (part == 0 && tid < NOUT * LPO) qs[c][dd] = q;      // q stays fp32
+    }
+  }
+  if (SELF) {
+#pragma unroll
+    for (int u = 0; u < BPT; ++u)
+      if (tid + 1024 * u < a.bias_stride) biasl[tid + 1024 * u] = bv[u];
+    for (int n = tid + 1024 * BPT; n < a.bias_stride; n += 1024) biasl[n] = a.bias[(int64_t)hh * a.bias_stride + n];
+  }
+  __syncthreads();
+
+  // output-projection slice and (self) the k,v weights of the rows this step appends: requested now, under the first stream
+  constexpr int OCH = 32 / E;
+  const T* worow = reinterpret_cast<const T*>(a.Wo) + (int64_t)on_ * a.inner + hh * DK + opart * 32;
+  Vec16<T> wo[OCH];
+#pragma unroll
+  for (int u = 0; u < OCH; ++u) wo[u].v = *reinterpret_cast<const V16*>(worow + u * E);
+  const int o2 = tid >> 3, part2 = tid & 7;
+  const int which2 = 1 + (o2 >> 6), dd2 = o2 & 63;
+  const T* wrow2 = reinterpret_cast<const T*>(a.Wp) + ((int64_t)which2 * a.inner + hh * DK + dd2) * a.d;
+  const int cnt2 = a.d / E / LPO2;
+  Vec16<T> wkv[SELF ? WMAX2 : 1];
+  if (SELF) {
+#pragma unroll
+    for (int u = 0; u < WMAX2; ++u) wkv[u].v = *reinterpret_cast<const V16*>(wrow2 + (min(u, cnt2 - 1) * LPO2 + part2) * E);
+  }
+
+  // ---- 3. the clips' streams, one after the other ----
+  for (int c = 0; c < C; ++c) {
+    const int bc = min(b0 + c, nb - 1);
+    const bool valid = b0 + c < nb;                              // uniform
+    T* const Kb = reinterpret_cast<T*>(a.Kc) + ((int64_t)bc * a.H + hh) * a.kv_stride * DK;
+    T* const Vb = reinterpret_cast<T*>(a.Vc) + ((int64_t)bc * a.H + hh) * a.kv_stride * DK;
+    const int n_live = ((finmask >> c) & 1u) ? 0 : n_prev;
+    float qv[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) qv[e] = qs[c][sub * E + e];
+    float m_run = -1e30f, l_run = 0.f;
+    float acc[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = 0.f;
+    auto visit = [&](float s, const float (&vrow)[E]) {
+      const bool up = s > m_run;
+      const float m_new = up ? s : m_run;
+      const float ex = m2m_exp<T>(up ? m_run - s : s - m_run);
+      const float alpha = up ? ex : 1.f;
+      const float p = up ? 1.f : ex;
+      l_run = fmaf(l_run, alpha, p);
+#pragma unroll
+      for (int e = 0; e < E; ++e) acc[e] = fmaf(acc[e], alpha, p * vrow[e]);
+      m_run = m_new;
+    };
+    auto round = [&](const int k0, const int u, Vec16<T>& ks, Vec16<T>& vs, const int reissue /*0 no, 1 yes, 2 if it exists*/) {
+      const int key = k0 + kslot + u * KPB;
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < E; ++e) s = fmaf(qv[e], ks.get(e), s);
+      s = group_sum<LPR>(s);
+      float vrow[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) vrow[e] = vs.get(e);
+      if (reissue == 1 || (reissue == 2 && k0 + (u + PF) * KPB < n_live)) {
+        const int64_t off = (int64_t)min(key + PF * KPB, last) * DK + sub * E;
+        ks.v = M2M_KV_LOAD(reinterpret_cast<const V16*>(Kb + off));
+        vs.v = M2M_KV_LOAD(reinterpret_cast<const V16*>(Vb + off));
+      }
+      if (key < n_live) {
+        if (SELF) s += biasl[t - key];
+        visit(s, vrow);
+      }
+    };
+    int k0 = 0;
+    for (; k0 + (2 * PF - 1) * KPB < n_live; k0 += PF * KPB) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) round(k0, u, kv[u], vv[u], 1);
+    }
+    for (; k0 < n_live; k0 += PF * KPB) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) round(k0, u, kv[u], vv[u], 2);
+    }
+    // the next clip's first rounds go out before this clip's merge (a finished clip walks no keys: nothing is requested for it)
+    if (c + 1 < C && !((finmask >> (c + 1)) & 1u)) {
+      const int64_t nxt = (int64_t)(min(b0 + c + 1, nb - 1) - bc) * kv_clip;
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int64_t off = nxt + (int64_t)min(kslot + u * KPB, last) * DK + sub * E;
+        kv[u].v = M2M_KV_LOAD(reinterpret_cast<const V16*>(Kb + off));
+        vv[u].v = M2M_KV_LOAD(reinterpret_cast<const V16*>(Vb + off));
+      }
+    }
+    if (SELF) {
+      const float* const hc = hn + c * a.d;
+      float acc2 = 0.f;
+#pragma unroll
+      for (int u = 0; u < WMAX2; ++u) {
+        if (u < cnt2) {
+          acc2 = chunk_dot<T>(wkv[u], hc, u * LPO2 + part2, acc2);
+        }
+      }
+      for (int i = WMAX2; i < cnt2; i += 4) {
+        Vec16<T> w2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w2[u].v = *reinterpret_cast<const V16*>(wrow2 + (min(i + u, cnt2 - 1) * LPO2 + part2) * E);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (i + u < cnt2) {
+            acc2 = chunk_dot<T>(w2[u], hc, (i + u) * LPO2 + part2, acc2);
+          }
+        }
+      }
+      acc2 = group_sum<LPO2>(acc2);
+      if (part2 == 0) {
+        const T r = from_f32<T>(acc2);
+        const int64_t slot = (int64_t)t * DK + dd2;
+        if (which2 == 1) { kn[dd2] = to_f32(r); if (!st_done && valid) Kb[slot] = r; }
+        else             { vn[dd2] = to_f32(r); if (!st_done && valid) Vb[slot] = r; }
+      }
+      __syncthreads();
+    }
+    if (SELF && wave == 0 && lane < LPR) {
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < E; ++e) s = fmaf(qv[e], kn[sub * E + e], s);
+      s = group_sum<LPR>(s);
+      s += biasl[0];
+      float vrow[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) vrow[e] = vn[sub * E + e];
+      visit(s, vrow);
+    }
+    // ---- merge of the 128 key groups (as in the first kernel) ----
+    {
+      const float mw = wave_max(m_run);
+      const float scale = m2m_exp<T>(m_run - mw);
+      float lsum = (sub == 0) ? l_run * scale : 0.f;
+      lsum = wave_sum(lsum);
+      float* gp = &redg[wave * GPW + lane / LPR][sub * E];
+#pragma unroll
+      for (int e = 0; e < E; e += 4)
+        *reinterpret_cast<float4*>(gp + e) = make_float4(acc[e] * scale, acc[e + 1] * scale, acc[e + 2] * scale, acc[e + 3] * scale);
+      if (lane == 0) { redw[wave] = mw; redl[wave] = lsum; }
+      __syncthreads();
+      {
+        float M = redw[lane & 15];
+        M = fmaxf(M, lane_xor<8>(M)); M = fmaxf(M, lane_xor<4>(M)); M = fmaxf(M, lane_xor<2>(M)); M = fmaxf(M, lane_xor<1>(M));
+        const float fw = m2m_exp<T>(redw[wave] - M);
+        float sw = redg[wave * GPW][lane];
+#pragma unroll
+        for (int j = 1; j < GPW; ++j) sw += redg[wave * GPW + j][lane];
+        redo[wave][lane] = sw * fw;
+        if (lane == 0) redlf[wave] = redl[wave] * fw;
+      }
+      __syncthreads();
+      if (tid < DK) {
+        float s = 0.f, L = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 16; ++wv) {
+          s += redo[wv][tid];
+          L += redlf[wv];
+        }
+        put_in<T>(oh[c], tid, L > 0.f ? s / L : 0.f);
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- 4. output projections of this head, accumulated into the C residual rows ----
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int bc = min(b0 + c, nb - 1);
+    float accp = 0.f;
+#pragma unroll
+    for (int u = 0; u < OCH; ++u) accp = chunk_dot<T>(wo[u], oh[c], opart * OCH + u, accp);
+    accp += lane_xor<1>(accp);
+    if (opart == 0 && tid < 2 * a.d && !st_done && b0 + c < nb) {
+      xq_t add = xq_fix_guarded(accp, a.state);
+      if (hh == 0) add += xrow[c][on_];                 // head 0 also carries the residual itself (kept in LDS since the prologue)
+      atomicAdd(reinterpret_cast<unsigned long long*>(a.x_out + (int64_t)bc * a.d + on_), (unsigned long long)add);
+      if (hh == a.H - 1) a.x_zero[(int64_t)bc * a.d + on_] = 0;
+    }
+  }
+  if (!SELF && a.book && hh == 0 && tid == 0) {
+    // headless bookkeeping of the C rows (see the first kernel)
+    for (int c = 0; c < C && b0 + c < nb; ++c) {
+      const int b = b0 + c;
+      if (!st_done) {
+        const int fin = a.finished[b];
+        const int next = amax_key_token(a.keys[b], fin, a.V, a.pad_id);
+        if (st_t < a.max_len) a.tokens[(int64_t)a.tok_row[b] * a.max_len + st_t] = next;
+        const int nf = fin | (next == a.eos_id);
+        a.finished[b] = nf;
+        if (!nf) atomicAdd(&a.state->n_unfinished, 1);
+        a.keys[b] = 0ull;
+      }
+      if (b == 0) a.state->t_copy = st_t;
+    }
+  }
+}
+
 template <typename T>
 static void launch_dec_attn_t(bool self, bool nt, const DecAttnArgs& a, dim3 grid, size_t smem, hipStream_t st) {
   if (self && a.emb) {
@@ -1016,14 +1385,41 @@ static void launch_dec_attn_t(bool self, bool nt, const DecAttnArgs& a, dim3 gri
   }
 }
 
-static int launch_dec_attn(int precision, bool self, bool nt, DecAttnArgs a, int B, int max_keys, hipStream_t st) {
-  (void)max_keys;
-  const size_t smem = ((size_t)a.d + (self ? (size_t)a.bias_stride : 0)) * sizeof(float);   // hn + (self) the bias row
+// several clips per workgroup (dec_attn_mc_kernel): C = 2 or 4
+template <typename T, int C>
+static void launch_dec_attn_mc_t(bool self, bool nt, const DecAttnArgs& a, int nb, size_t smem, hipStream_t st) {
+  const dim3 grid((unsigned)a.H, (unsigned)ceil_div(nb, C));
+  if (self && a.emb) {
+    if (nt) hipLaunchKernelGGL((dec_attn_mc_kernel<T, true, true, true, C>), grid, dim3(1024), smem, st, a, nb);
+    else hipLaunchKernelGGL((dec_attn_mc_kernel<T, true, false, true, C>), grid, dim3(1024), smem, st, a, nb);
+  } else if (self) {
+    if (nt) hipLaunchKernelGGL((dec_attn_mc_kernel<T, true, true, false, C>), grid, dim3(1024), smem, st, a, nb);
+    else hipLaunchKernelGGL((dec_attn_mc_kernel<T, true, false, false, C>), grid, dim3(1024), smem, st, a, nb);
+  } else {
+    if (nt) hipLaunchKernelGGL((dec_attn_mc_kernel<T, false, true, false, C>), grid, dim3(1024), smem, st, a, nb);
+    else hipLaunchKernelGGL((dec_attn_mc_kernel<T, false, false, false, C>), grid, dim3(1024), smem, st, a, nb);
+  }
+}
+
+static int launch_dec_attn(int precision, bool self, bool nt, DecAttnArgs a, int B, int clips, hipStream_t st) {
+  const size_t smem = ((size_t)a.d * (size_t)clips + (self ? (size_t)a.bias_stride : 0)) * sizeof(float);   // hn rows + (self) the bias row
   M2M_REQUIRE(smem <= 24 * 1024, "decode attention: max_dec_len=%d too long for the LDS bias row (<= %d)", a.bias_stride,
-              (24 * 1024 - a.d * 4) / 4);
-  dim3 grid((unsigned)a.H, (unsigned)B);
-  if (precision == M2M_PREC_BF16) launch_dec_attn_t<bf16_t>(self, nt, a, grid, smem, st);
-  else launch_dec_attn_t<float>(self, nt, a, grid, smem, st);
+              (24 * 1024 - a.d * 4 * clips) / 4);
+  const bool bf = precision == M2M_PREC_BF16;
+  if (clips == 1) {
+    dim3 grid((unsigned)a.H, (unsigned)B);
+    if (bf) launch_dec_attn_t<bf16_t>(self, nt, a, grid, smem, st);
+    else launch_dec_attn_t<float>(self, nt, a, grid, smem, st);
+  } else if (clips == 2) {
+    if (bf) launch_dec_attn_mc_t<bf16_t, 2>(self, nt, a, B, smem, st);
+    else launch_dec_attn_mc_t<float, 2>(self, nt, a, B, smem, st);
+  } else if (clips == 4) {
+    if (bf) launch_dec_attn_mc_t<bf16_t, 4>(self, nt, a, B, smem, st);
+    else launch_dec_attn_mc_t<float, 4>(self, nt, a, B, smem, st);
+  } else {
+    set_error("decode attention: %d clips per workgroup not instantiated (1, 2, 4)", clips);
+    return M2M_ERR_INVALID;
+  }
   M2M_CHECK_HIP(hipGetLastError());
   return M2M_OK;
 }
@@ -1308,6 +1704,20 @@ bool decode_finished_skip_on() {
   return !(v && v[0] == '0');
 }
 
+// Clips of one head per attention workgroup for a chain of nb clips: the multi-clip form (dec_attn_mc_kernel) from the chain sizes at
+// which the launches stop being single latency chains and become rounds of workgroups (measured: tools/native_chain_sweep.py, DESIGN
+// 4.3); s->attn_clips > 0 forces a value (M2M_DA_CLIPS, latched when the session is created; tests and A/B runs).
+int decode_attn_clips(const m2m_session* s, int nb) {
+  if (s->attn_clips > 0) return s->attn_clips;
+  return nb >= 48 ? 4 : (nb >= 24 ? 2 : 1);
+}
+
+// residual rows per feed-forward workgroup for a chain of nb clips (M2M_DEC_FF_ROWS forces 8 or 16, latched per session)
+int decode_ff_rows(const m2m_session* s, int nb) {
+  if (s->ff_rows > 0) return s->ff_rows;
+  return nb >= 48 ? 16 : 8;
+}
+
 int decode_launch_attn(m2m_session* s, const DecView& v, bool self, int layer, int self_len, hipStream_t st, bool headless, bool skip_finished) {
   const m2m_model* m = s->m;
   const m2m_t5_geometry& g = m->g;
@@ -1327,6 +1737,7 @@ int decode_launch_attn(m2m_session* s, const DecView& v, bool self, int layer, i
     const int resident = forced >= 0 ? forced : (int)(180e6 / per_layer);
     if (layer < resident) nt = false;
   }
+  const int clips = decode_attn_clips(s, v.nb);
   // self: A -> B (zero C); cross: B -> C (zero A)
   a.x = xbuf(s, v, self ? 0 : 1); a.x_out = xbuf(s, v, self ? 1 : 2); a.x_zero = xbuf(s, v, self ? 2 : 0);
   a.eps = g.layer_norm_eps; a.d = g.d_model;
@@ -1345,7 +1756,7 @@ int decode_launch_attn(m2m_session* s, const DecView& v, bool self, int layer, i
     a.Vc = (unsigned char*)s->self_v + off;
     a.kv_stride = s->max_dec; a.n_keys = 0; a.self_len_override = self_len;
     a.bias = s->dec_bias_tab; a.bias_stride = s->max_dec;
-    return launch_dec_attn(m->precision, true, nt, a, v.nb, s->max_dec, st);
+    return launch_dec_attn(m->precision, true, nt, a, v.nb, clips, st);
   }
   // cross K/V: [L][2][B][H][S][64] with B, S = the encoded problem
   const size_t per = (size_t)s->B * H * s->S * DK;
@@ -1354,7 +1765,7 @@ int decode_launch_attn(m2m_session* s, const DecView& v, bool self, int layer, i
   a.Kc = (unsigned char*)s->cross_kv + (((size_t)layer * 2 + 0) * per + voff) * es;
   a.Vc = (unsigned char*)s->cross_kv + (((size_t)layer * 2 + 1) * per + voff) * es;
   a.kv_stride = s->S; a.n_keys = s->S; a.self_len_override = 0; a.bias = nullptr; a.bias_stride = 0;
-  return launch_dec_attn(m->precision, false, nt, a, v.nb, s->S, st);
+  return launch_dec_attn(m->precision, false, nt, a, v.nb, clips, st);
 }
 
 int decode_launch_step(m2m_session* s, const DecView& v, bool forced, float* logits_out, int Ld, hipStream_t st) {
@@ -1380,7 +1791,7 @@ int decode_launch_step(m2m_session* s, const DecView& v, bool forced, float* log
     f.x = xC; f.x_out = xA; f.x_zero = xB; f.ln_w = L.ln2; f.eps = g.layer_norm_eps;
     f.Wi = L.wi; f.Wo = L.wo_ff; f.d = g.d_model; f.d_ff = g.d_ff; f.B = v.nb; f.state = v.state;
     f.check_done = (headless && l == 0) ? 1 : 0;
-    if ((rc = launch_dec_ff(P, f, st))) return rc;
+    if ((rc = launch_dec_ff(P, f, decode_ff_rows(s, v.nb), st))) return rc;
   }
   // final RMSNorm + lm_head (untied, no d_model**-0.5 scaling: transformers 4.34 semantics)
   DecGemmArgs a{};

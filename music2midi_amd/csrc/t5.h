@@ -123,6 +123,8 @@ struct m2m_session {
   int64_t* forced_ids;     // [B, max_dec]
   // current problem
   int B = 0, S = 0;
+  int attn_clips = 0;      // decode attention: clips per workgroup forced by M2M_DA_CLIPS when the session was created (0: by chain size)
+  int ff_rows = 0;         // decode feed-forward: residual rows per workgroup forced by M2M_DEC_FF_ROWS (0: by chain size)
   int repacks = 0, rows_moved = 0;   // live-row re-packings / rows moved by them in the last m2m_generate_greedy
   bool encoded = false;
   // decode chains
@@ -218,5 +220,7 @@ int decode_launch_attn(m2m_session* s, const DecView& v, bool self, int layer, i
 int decode_move_rows(m2m_session* s, const int* src, const int* dst, int n, int t, hipStream_t st);   // live-row re-packing (decode.hip)
 int decode_finalize(m2m_session* s, const DecView& v, hipStream_t st);   // headless greedy loop: write the last token, close the chain
 bool decode_headless();
+int decode_attn_clips(const m2m_session* s, int nb);
+int decode_ff_rows(const m2m_session* s, int nb);
 
 }  // namespace m2m

@@ -241,9 +241,18 @@ extern "C" int m2m_session_create(const m2m_model* m, int max_batch, int max_enc
               "m2m_session_create: max_enc_len=%d too long (attention bias table must fit LDS)", max_enc_len);
   M2M_REQUIRE((size_t)max_enc_len * 4 <= 60 * 1024 && (size_t)max_dec_len * 4 <= 60 * 1024,
               "m2m_session_create: sequence too long for the decode attention score buffer");
+  // switches of the decode path are read ONCE per session (graphs bake them in; getenv is not safe against a concurrent setenv)
+  const char* da_env = getenv("M2M_DA_CLIPS");
+  const int da_clips = (da_env && da_env[0]) ? atoi(da_env) : 0;
+  M2M_REQUIRE(da_clips == 0 || da_clips == 1 || da_clips == 2 || da_clips == 4,
+              "M2M_DA_CLIPS=%d: clips per decode-attention workgroup must be 0 (by chain size), 1, 2 or 4", da_clips);
+  const char* ff_env = getenv("M2M_DEC_FF_ROWS");
+  const int ff_rows = (ff_env && ff_env[0]) ? atoi(ff_env) : 0;
+  M2M_REQUIRE(ff_rows == 0 || ff_rows == 8 || ff_rows == 16, "M2M_DEC_FF_ROWS=%d: rows per decode feed-forward workgroup must be 0 (by chain size), 8 or 16", ff_rows);
   m2m_session* s = new m2m_session();
   s->m = m; s->max_batch = max_batch; s->max_enc = max_enc_len; s->max_dec = max_dec_len;
   s->ws = (unsigned char*)workspace_dev; s->ws_bytes = workspace_bytes;
+  s->attn_clips = da_clips; s->ff_rows = ff_rows;
   unsigned char* b = s->ws;
   s->x_enc = (float*)(b + w.x_enc); s->h_enc = b + w.h_enc; s->qkv_enc = b + w.qkv_enc; s->vt_enc = b + w.vt_enc; s->attn_enc = b + w.attn_enc;
   s->mid_enc = b + w.mid_enc; s->enc_bias_tab = (float*)(b + w.enc_bias); s->dec_bias_tab = (float*)(b + w.dec_bias);
