@@ -332,6 +332,10 @@ struct DecFfArgs {
 constexpr int FF_C = 32;        // hidden columns per workgroup
 constexpr int FF_HP = FF_C + 8; // LDS row pitch of the activation slice (elements; keeps 16-byte alignment)
 
+// diagnostic builds only (-DM2M_FF_ABL=mask, never the product): 1 = the slice workgroups add nothing (x passes through), 2 = they read no rows of x
+#ifndef M2M_FF_ABL
+#define M2M_FF_ABL 0
+#endif
 template <typename T, int KS, int FF_R>
 __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(1, 2))) void dec_ff_kernel(DecFfArgs a) {
   M2M_STAMP_DECL
@@ -386,7 +390,7 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(1, 2)))
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) xraw[s][q] = *reinterpret_cast<const longlong2*>(xr + 32 * s + 2 * q);
+    for (int q = 0; q < 4; ++q) xraw[s][q] = (M2M_FF_ABL & 2) ? make_longlong2(1 << 28, 1 << 27) : *reinterpret_cast<const longlong2*>(xr + 32 * s + 2 * q);
     g0[s] = *reinterpret_cast<const float4*>(a.ln_w + kbeg + 32 * s);
     g1[s] = *reinterpret_cast<const float4*>(a.ln_w + kbeg + 32 * s + 4);
   }
@@ -465,6 +469,7 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(1, 2)))
     o[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     mma32_16(o[j], fh, wo[j]);
   }
+  if (M2M_FF_ABL & 1) return;
   if constexpr (FF_R <= 8) {
     // Rows 8..15 of the MFMA tile are padding, i.e. lanes g >= 2 hold nothing to store.  They take over half
     // of their partner's rows (lane ^ 32 <-> g ^ 2) so that every lane issues 2 adds per tile instead of
@@ -1009,14 +1014,38 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
 // (self) / 96 KB (cross) against a K/V stream of 131 KB (t = 512) / 49 KB: 1 024 workgroups pull more bytes from L2 as weights than
 // from HBM as K/V, and the regime is throughput-bound (12 attention launches x 2 rounds of workgroups per chain and step).  Here a
 // workgroup owns one head of C consecutive clips: ONE row round trip for all of them (wave pair c normalises clip c's row), the
-// head's weights fetched ONCE into the same registers and applied to the C rows, one bias row in LDS, then the clips' K/V streams
-// walked one after the other by all 16 waves - the next clip's first rounds requested before this clip's merge, so the stream
-// keeps running through the barriers - and the C output projections at the end.
+// head's weights fetched ONCE into the same registers and applied to the C rows (self: q AND this step's k, v rows up front, so
+// the 24 weight registers are free again when the streams start), one bias row in LDS, then the clips' K/V streams walked one
+// after the other by all 16 waves as ONE continuous stream: a clip's rounds are padded to a multiple of the prefetch depth, and
+// its last rounds re-request into the NEXT live clip, so MC_PF rounds are in flight through every merge - and the C output
+// projections at the end.
 // Per row the arithmetic is the first kernel's, operation for operation (same lane -> element maps, same reduction trees, same
 // key -> lane-group partition, same rounding points): ids and logits are bit-identical whichever form a chain takes
-// (tests/test_t5_gpu.py::test_multi_clip_attention_is_bit_identical).  Chosen per chain by its clip count (decode_launch_attn).
+// (tests/test_t5_gpu.py::test_multi_clip_attention_and_wide_ff_tiles_are_bit_identical).  Chosen per chain by its clip count.
+// Prefetch depth (rounds in flight per workgroup).  Same-box A/B at 128 x S = 190, two chains of 64 clips, C = 2 (tools/r6_mc_ab.sh,
+// us per decode step): 2 rounds 370.0, 3 rounds 379.5, 4 rounds 394.0, 6 rounds 457.5 - as in the small-chain regime (the first
+// kernel's PF note) more bytes in flight per CU only lengthen every workgroup's latency-critical loads: the launches of a chain
+// start their streams together, the memory system is saturated in those bursts, and its loaded latency is bytes in flight / rate.
+#ifndef M2M_MC_PF_SELF
+#define M2M_MC_PF_SELF 2
+#endif
+#ifndef M2M_MC_PF_CROSS
+#define M2M_MC_PF_CROSS 2
+#endif
+// diagnostic builds only (-DM2M_MC_ABL=mask, never the product): 1 = no output-projection atomics, 2 = no K/V stream
+#ifndef M2M_MC_ABL
+#define M2M_MC_ABL 0
+#endif
+// Waves per SIMD the kernel is compiled for: 4 = the 128 registers of a 16-wave workgroup alone on its CU; 8 = 64 registers, TWO
+// workgroups per CU.  Same-box A/B (tools/r6_mc_ab.sh, 128 x S = 190, us per step): two chains of 64 clips, C = 4: 364.2 / 364.9 at
+// 4 waves against 409.4 / 411.4 at 8; C = 2: 379.2 / 382.5 against 384.8 / 387.5; only ONE chain of 128 clips with C = 2 (512
+// workgroups per launch) prefers 8 (411-417 against 437-440).  Co-resident workgroups of two chains stream at the same time, and
+// more streams in flight cost more than the latency phases they hide - the same finding as the prefetch depth.
+#ifndef M2M_MC_WAVES
+#define M2M_MC_WAVES 4
+#endif
 template <typename T, bool SELF, bool NT, bool FETCH, int C>
-__global__ __launch_bounds__(1024) void dec_attn_mc_kernel(DecAttnArgs a, int nb) {
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(M2M_MC_WAVES, M2M_MC_WAVES))) void dec_attn_mc_kernel(DecAttnArgs a, int nb) {
   static_assert(!FETCH || SELF, "only the layer-0 self-attention fetches its input row from the embedding table");
   static_assert(C >= 2 && C <= 8, "a wave pair normalises one clip's row: at most 8 clips per 16-wave workgroup");
   constexpr int E = 16 / sizeof(T);
@@ -1027,7 +1056,7 @@ __global__ __launch_bounds__(1024) void dec_attn_mc_kernel(DecAttnArgs a, int nb
   constexpr int LPO = 16;
   constexpr int LPO2 = 8;
   constexpr int WMAX2 = 6;
-  constexpr int PF = SELF ? M2M_DA_PF_SELF : M2M_DA_PF_CROSS;
+  constexpr int PF = SELF ? M2M_MC_PF_SELF : M2M_MC_PF_CROSS;
   constexpr int WMAX = 3;
   constexpr int GPW = 64 / LPR;
   using V16 = decltype(Vec16<T>().v);
@@ -1036,8 +1065,8 @@ __global__ __launch_bounds__(1024) void dec_attn_mc_kernel(DecAttnArgs a, int nb
   __shared__ float redo[16][DK];
   __shared__ __align__(16) float redg[16 * GPW][DK];
   __shared__ __align__(16) float qs[C][DK];
-  __shared__ __align__(16) float kn[DK];
-  __shared__ __align__(16) float vn[DK];
+  __shared__ __align__(16) float kn[SELF ? C : 1][DK];
+  __shared__ __align__(16) float vn[SELF ? C : 1][DK];
   __shared__ __align__(16) float oh[C][DK];
   __shared__ __align__(16) xq_t xrow[C][512];    // the fixed-point input rows (d_model <= 512): head 0 adds them into x_out at the end
   const int st_t = a.state->t;
@@ -1083,6 +1112,11 @@ __global__ __launch_bounds__(1024) void dec_attn_mc_kernel(DecAttnArgs a, int nb
   Vec16<T> w[WMAX];
 #pragma unroll
   for (int u = 0; u < WMAX; ++u) w[u].v = *reinterpret_cast<const V16*>(wrow + (min(u, cnt - 1) * LPO + part) * E);
+  // self: the weights of the k,v rows this step appends (128 outputs x 8 lanes) are part of the prologue here
+  const int o2 = tid >> 3, part2 = tid & 7;
+  const int which2 = 1 + (o2 >> 6), dd2 = o2 & 63;
+  const T* wrow2 = reinterpret_cast<const T*>(a.Wp) + ((int64_t)which2 * a.inner + hh * DK + dd2) * a.d;
+  const int cnt2 = a.d / E / LPO2;
   float* const biasl = hn + C * a.d;                   // [kv_stride] (self only): ONE bias row serves the C clips
   constexpr int BPT = 2;
   float bv[SELF ? BPT : 1];
@@ -1093,14 +1127,35 @@ __global__ __launch_bounds__(1024) void dec_attn_mc_kernel(DecAttnArgs a, int nb
   const int t = SELF ? (a.self_len_override > 0 ? a.self_len_override - 1 : st_t) : 0;
   const int n_prev = SELF ? t : a.n_keys;
   const int last = max(n_prev - 1, 0);
+  // a clip's rounds, padded to a multiple of the prefetch depth (the padding rounds re-read its last key row and visit nothing), so
+  // that a clip always starts in register slot 0 and its last PF rounds can re-request into the next clip slot for slot
+  const int rpc = ((n_prev + KPB - 1) / KPB + PF - 1) / PF * PF;
+  // clips that walk keys at all: live rows of this chain with at least one cached key
+  unsigned walk = 0;
+#pragma unroll
+  for (int c = 0; c < C; ++c) walk |= ((n_prev > 0 && !((finmask >> c) & 1u) && b0 + c < nb) ? 1u : 0u) << c;
+  if (M2M_MC_ABL & 2) walk = 0;
 
-  // the first clip's first PF rounds, right behind the prologue's own loads (clamped addresses, never predicated)
+  // The stream goes through buffer loads: one descriptor per operand for this workgroup's C clips (wave-uniform: built from the
+  // kernel arguments and blockIdx only), the clip as the scalar offset, a 32-bit byte offset per lane - one address register per
+  // slot serves K and V (with flat 64-bit addresses the compiler kept a register PAIR per load and slot alive across the loop:
+  // 2 x 2 x PF registers, which is what limited the depth of the window).
+  const unsigned clip_bytes = (unsigned)(kv_clip * (int64_t)sizeof(T));
+  const unsigned span_bytes = (unsigned)(min(C, nb - b0) - 1) * clip_bytes + (unsigned)(a.kv_stride * DK * (int)sizeof(T));
+  const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc(Kb0, 0, (int)span_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(Vb0, 0, (int)span_bytes, 0x00020000);
+  auto kvload = [](__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(V16, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, NT ? 2 : 0));   // aux 2 = nt
+  };
+  // the first walking clip's first PF rounds, right behind the prologue's own loads (clamped addresses, never predicated; when
+  // no clip walks this is clip 0's last row once more - dropped)
+  const int c_first = walk ? __builtin_ctz(walk) : 0;
   Vec16<T> kv[PF], vv[PF];
 #pragma unroll
   for (int u = 0; u < PF; ++u) {
-    const int64_t off = (int64_t)min(kslot + u * KPB, last) * DK + sub * E;
-    kv[u].v = M2M_KV_LOAD(reinterpret_cast<const V16*>(Kb0 + off));
-    vv[u].v = M2M_KV_LOAD(reinterpret_cast<const V16*>(Vb0 + off));
+    const unsigned off = (unsigned)((min(kslot + u * KPB, last) * DK + sub * E) * (int)sizeof(T));
+    kv[u].v = kvload(rK, off, (unsigned)c_first * clip_bytes);
+    vv[u].v = kvload(rV, off, (unsigned)c_first * clip_bytes);
   }
   __builtin_amdgcn_sched_barrier(0);
 
@@ -1145,7 +1200,7 @@ __global__ __launch_bounds__(1024) void dec_attn_mc_kernel(DecAttnArgs a, int nb
   }
   __syncthreads();
 
-  // ---- 2. this head's query projection of the C rows: the weights are in registers once ----
+  // ---- 2. this head's projections of the C rows: the weights are in registers once ----
   {
     float acc[C];
 #pragma unroll
@@ -1176,6 +1231,45 @@ __global__ __launch_bounds__(1024) void dec_attn_mc_kernel(DecAttnArgs a, int nb
     }
   }
   if (SELF) {
+    // the k,v rows of this step: projected, rounded to T, appended to the cache and kept in LDS for the clips' own-key visits.
+    // Their weights are requested only now, into the registers the q weights have left (one more L2 round trip in this workgroup's
+    // chain, which the co-resident workgroup fills: the kernel is held to 64 registers so that TWO workgroups share a CU)
+    Vec16<T> wkv[WMAX2];
+#pragma unroll
+    for (int u = 0; u < WMAX2; ++u) wkv[u].v = *reinterpret_cast<const V16*>(wrow2 + (min(u, cnt2 - 1) * LPO2 + part2) * E);
+    float acc2[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc2[c] = 0.f;
+#pragma unroll
+    for (int u = 0; u < WMAX2; ++u) {
+      if (u < cnt2) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc2[c] = chunk_dot<T>(wkv[u], hn + c * a.d, u * LPO2 + part2, acc2[c]);
+      }
+    }
+    for (int i = WMAX2; i < cnt2; i += 4) {
+      Vec16<T> w2[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) w2[u].v = *reinterpret_cast<const V16*>(wrow2 + (min(i + u, cnt2 - 1) * LPO2 + part2) * E);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (i + u < cnt2) {
+#pragma unroll
+          for (int c = 0; c < C; ++c) acc2[c] = chunk_dot<T>(w2[u], hn + c * a.d, (i + u) * LPO2 + part2, acc2[c]);
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float s2 = group_sum<LPO2>(acc2[c]);
+      if (part2 == 0) {
+        const T r = from_f32<T>(s2);                       // k, v are stored (and used) rounded to T
+        const int64_t slot = (int64_t)c * kv_clip + (int64_t)t * DK + dd2;
+        const bool st_ok = !st_done && b0 + c < nb;
+        if (which2 == 1) { kn[c][dd2] = to_f32(r); if (st_ok) Kb0[slot] = r; }
+        else             { vn[c][dd2] = to_f32(r); if (st_ok) Vb0[slot] = r; }
+      }
+    }
 #pragma unroll
     for (int u = 0; u < BPT; ++u)
       if (tid + 1024 * u < a.bias_stride) biasl[tid + 1024 * u] = bv[u];
@@ -1183,29 +1277,17 @@ __global__ __launch_bounds__(1024) void dec_attn_mc_kernel(DecAttnArgs a, int nb
   }
   __syncthreads();
 
-  // output-projection slice and (self) the k,v weights of the rows this step appends: requested now, under the first stream
-  constexpr int OCH = 32 / E;
-  const T* worow = reinterpret_cast<const T*>(a.Wo) + (int64_t)on_ * a.inner + hh * DK + opart * 32;
-  Vec16<T> wo[OCH];
-#pragma unroll
-  for (int u = 0; u < OCH; ++u) wo[u].v = *reinterpret_cast<const V16*>(worow + u * E);
-  const int o2 = tid >> 3, part2 = tid & 7;
-  const int which2 = 1 + (o2 >> 6), dd2 = o2 & 63;
-  const T* wrow2 = reinterpret_cast<const T*>(a.Wp) + ((int64_t)which2 * a.inner + hh * DK + dd2) * a.d;
-  const int cnt2 = a.d / E / LPO2;
-  Vec16<T> wkv[SELF ? WMAX2 : 1];
-  if (SELF) {
-#pragma unroll
-    for (int u = 0; u < WMAX2; ++u) wkv[u].v = *reinterpret_cast<const V16*>(wrow2 + (min(u, cnt2 - 1) * LPO2 + part2) * E);
-  }
-
   // ---- 3. the clips' streams, one after the other ----
+#pragma nounroll
   for (int c = 0; c < C; ++c) {
-    const int bc = min(b0 + c, nb - 1);
-    const bool valid = b0 + c < nb;                              // uniform
-    T* const Kb = reinterpret_cast<T*>(a.Kc) + ((int64_t)bc * a.H + hh) * a.kv_stride * DK;
-    T* const Vb = reinterpret_cast<T*>(a.Vc) + ((int64_t)bc * a.H + hh) * a.kv_stride * DK;
-    const int n_live = ((finmask >> c) & 1u) ? 0 : n_prev;
+    const bool walks = (walk >> c) & 1u;                                          // uniform
+    const unsigned cbase = (unsigned)c * clip_bytes;      // this clip inside the descriptors (an invalid tail clip walks nothing)
+    // per-clip OPAQUE copies of the lane's place in a round: derived from threadIdx the hand-over offsets below are loop invariants
+    // that the compiler keeps from the prologue, spills (64 registers), and reloads in the middle of the stream - and a scratch
+    // reload waits vmcnt(0), i.e. for every round in flight
+    int kslot_c = kslot, sub_c = sub;
+    asm volatile("" : "+v"(kslot_c), "+v"(sub_c));
+    const int n_live = walks ? n_prev : 0;
     float qv[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) qv[e] = qs[c][sub * E + e];
@@ -1224,82 +1306,64 @@ __global__ __launch_bounds__(1024) void dec_attn_mc_kernel(DecAttnArgs a, int nb
       for (int e = 0; e < E; ++e) acc[e] = fmaf(acc[e], alpha, p * vrow[e]);
       m_run = m_new;
     };
-    auto round = [&](const int k0, const int u, Vec16<T>& ks, Vec16<T>& vs, const int reissue /*0 no, 1 yes, 2 if it exists*/) {
-      const int key = k0 + kslot + u * KPB;
+    // consume slot u (round k0 / KPB + u of this clip); then re-request into it: mode 1 = this clip's round PF ahead, mode 2 = round u
+    // of the clip `nxt` elements further on (the next walking clip), mode 0 = nothing.  The mode is a compile-time constant per loop,
+    // so every load is unconditional and counted (s_waitcnt vmcnt(N) keeps the other slots in flight).
+    auto round = [&](const int k0, const int u, Vec16<T>& ks, Vec16<T>& vs, const int mode, const unsigned nxt) {
+      const int key = k0 + kslot_c + u * KPB;
       float s = 0.f;
 #pragma unroll
       for (int e = 0; e < E; ++e) s = fmaf(qv[e], ks.get(e), s);
       s = group_sum<LPR>(s);
-      float vrow[E];
+      if (key < n_live) {   // VALU-only predicate
+        float vrow[E];
 #pragma unroll
-      for (int e = 0; e < E; ++e) vrow[e] = vs.get(e);
-      if (reissue == 1 || (reissue == 2 && k0 + (u + PF) * KPB < n_live)) {
-        const int64_t off = (int64_t)min(key + PF * KPB, last) * DK + sub * E;
-        ks.v = M2M_KV_LOAD(reinterpret_cast<const V16*>(Kb + off));
-        vs.v = M2M_KV_LOAD(reinterpret_cast<const V16*>(Vb + off));
-      }
-      if (key < n_live) {
+        for (int e = 0; e < E; ++e) vrow[e] = vs.get(e);
         if (SELF) s += biasl[t - key];
         visit(s, vrow);
       }
+      // the slot is re-requested AFTER it has been consumed: with the request in front of the visit (the first kernel's order) the
+      // compiler sinks V's unpacking into the predicated block, keeps the packed V alive past the request, loads into a SECOND
+      // register set and copies it back behind a vmcnt(0) at the end of every iteration (seen in the ISA at PF = 4: the window
+      // became batches)
+      if (mode == 1) {
+        const unsigned off = (unsigned)((min(key + PF * KPB, last) * DK + sub_c * E) * (int)sizeof(T));
+        ks.v = kvload(rK, off, cbase);
+        vs.v = kvload(rV, off, cbase);
+      } else if (mode == 2) {
+        // (nxt < 2^31: a clip's byte offset goes into the scalar offset; otherwise it is the out-of-range marker and goes into the
+        // lane offset, the only part the range check looks at)
+        const unsigned off = (unsigned)((min(kslot_c + u * KPB, last) * DK + sub_c * E) * (int)sizeof(T));
+        const bool oob = nxt >= 0x7F000000u;                 // uniform
+        ks.v = kvload(rK, oob ? nxt : off, oob ? 0u : nxt);
+        vs.v = kvload(rV, oob ? nxt : off, oob ? 0u : nxt);
+      }
     };
-    int k0 = 0;
-    for (; k0 + (2 * PF - 1) * KPB < n_live; k0 += PF * KPB) {
+    if (walks) {
+      const int kend = rpc * KPB;
+      int k0 = 0;
+      for (; k0 + PF * KPB < kend; k0 += PF * KPB) {           // every re-request lies inside this clip's (padded) rounds
 #pragma unroll
-      for (int u = 0; u < PF; ++u) round(k0, u, kv[u], vv[u], 1);
-    }
-    for (; k0 < n_live; k0 += PF * KPB) {
-#pragma unroll
-      for (int u = 0; u < PF; ++u) round(k0, u, kv[u], vv[u], 2);
-    }
-    // the next clip's first rounds go out before this clip's merge (a finished clip walks no keys: nothing is requested for it)
-    if (c + 1 < C && !((finmask >> (c + 1)) & 1u)) {
-      const int64_t nxt = (int64_t)(min(b0 + c + 1, nb - 1) - bc) * kv_clip;
-#pragma unroll
-      for (int u = 0; u < PF; ++u) {
-        const int64_t off = nxt + (int64_t)min(kslot + u * KPB, last) * DK + sub * E;
-        kv[u].v = M2M_KV_LOAD(reinterpret_cast<const V16*>(Kb + off));
-        vv[u].v = M2M_KV_LOAD(reinterpret_cast<const V16*>(Vb + off));
+        for (int u = 0; u < PF; ++u) round(k0, u, kv[u], vv[u], 1, 0);
       }
+      // the clip's last PF rounds hand their slots to the next walking clip, so the stream runs through the merge below.  After the
+      // LAST walking clip the same loads are issued with a lane offset beyond the descriptor's range: the hardware's range check
+      // drops them (zeros, no memory access) - one code path, so the slots stay in ONE register set (with a second, load-free path
+      // for the last clip the register allocator kept a second set of 8 PF registers for the handed-over rounds and copied it back)
+      const unsigned rest = walk >> (c + 1);
+      const unsigned nxt = rest ? cbase + (unsigned)(__builtin_ctz(rest) + 1) * clip_bytes : 0x7F000000u;
+#pragma unroll
+      for (int u = 0; u < PF; ++u) round(k0, u, kv[u], vv[u], 2, nxt);
     }
-    if (SELF) {
-      const float* const hc = hn + c * a.d;
-      float acc2 = 0.f;
-#pragma unroll
-      for (int u = 0; u < WMAX2; ++u) {
-        if (u < cnt2) {
-          acc2 = chunk_dot<T>(wkv[u], hc, u * LPO2 + part2, acc2);
-        }
-      }
-      for (int i = WMAX2; i < cnt2; i += 4) {
-        Vec16<T> w2[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) w2[u].v = *reinterpret_cast<const V16*>(wrow2 + (min(i + u, cnt2 - 1) * LPO2 + part2) * E);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (i + u < cnt2) {
-            acc2 = chunk_dot<T>(w2[u], hc, (i + u) * LPO2 + part2, acc2);
-          }
-        }
-      }
-      acc2 = group_sum<LPO2>(acc2);
-      if (part2 == 0) {
-        const T r = from_f32<T>(acc2);
-        const int64_t slot = (int64_t)t * DK + dd2;
-        if (which2 == 1) { kn[dd2] = to_f32(r); if (!st_done && valid) Kb[slot] = r; }
-        else             { vn[dd2] = to_f32(r); if (!st_done && valid) Vb[slot] = r; }
-      }
-      __syncthreads();
-    }
-    if (SELF && wave == 0 && lane < LPR) {
+    if (SELF && wave == 0 && lane < LPR) {   // the key/value appended this step (relative position 0): group 0
       float s = 0.f;
 #pragma unroll
-      for (int e = 0; e < E; ++e) s = fmaf(qv[e], kn[sub * E + e], s);
+      for (int e = 0; e < E; ++e) s = fmaf(qv[e], kn[c][sub * E + e], s);
       s = group_sum<LPR>(s);
       s += biasl[0];
       float vrow[E];
 #pragma unroll
-      for (int e = 0; e < E; ++e) vrow[e] = vn[sub * E + e];
+      for (int e = 0; e < E; ++e) vrow[e] = vn[c][sub * E + e];
       visit(s, vrow);
     }
     // ---- merge of the 128 key groups (as in the first kernel) ----
@@ -1338,7 +1402,13 @@ __global__ __launch_bounds__(1024) void dec_attn_mc_kernel(DecAttnArgs a, int nb
     }
   }
 
-  // ---- 4. output projections of this head, accumulated into the C residual rows ----
+  // ---- 4. output projections of this head, accumulated into the C residual rows (the slice of wo is requested only here: 16 / 32
+  //         registers that would otherwise be held through every stream) ----
+  constexpr int OCH = 32 / E;
+  const T* worow = reinterpret_cast<const T*>(a.Wo) + (int64_t)on_ * a.inner + hh * DK + opart * 32;
+  Vec16<T> wo[OCH];
+#pragma unroll
+  for (int u = 0; u < OCH; ++u) wo[u].v = *reinterpret_cast<const V16*>(worow + u * E);
 #pragma unroll
   for (int c = 0; c < C; ++c) {
     const int bc = min(b0 + c, nb - 1);
@@ -1349,7 +1419,8 @@ __global__ __launch_bounds__(1024) void dec_attn_mc_kernel(DecAttnArgs a, int nb
     if (opart == 0 && tid < 2 * a.d && !st_done && b0 + c < nb) {
       xq_t add = xq_fix_guarded(accp, a.state);
       if (hh == 0) add += xrow[c][on_];                 // head 0 also carries the residual itself (kept in LDS since the prologue)
-      atomicAdd(reinterpret_cast<unsigned long long*>(a.x_out + (int64_t)bc * a.d + on_), (unsigned long long)add);
+      if (!(M2M_MC_ABL & 1) || hh == 0)
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.x_out + (int64_t)bc * a.d + on_), (unsigned long long)add);
       if (hh == a.H - 1) a.x_zero[(int64_t)bc * a.d + on_] = 0;
     }
   }
