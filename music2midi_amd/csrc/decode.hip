@@ -514,12 +514,195 @@ static int launch_dec_ff_t(const DecFfArgs& a, hipStream_t st) {
   return M2M_OK;
 }
 
-static int launch_dec_ff(int precision, const DecFfArgs& a, int rows, hipStream_t st) {
+// ---- the same sub-layer for LARGE chains: NSL consecutive hidden slices per workgroup (round 6) ----
+// At 64 clips per chain the kernel above is bound by its atomics: 36 slice workgroups + the carry add into every residual element
+// (885 K 64-bit atomics per launch; ablation build -DM2M_FF_ABL=1: 11.9 -> 7.6 us of kernel time, tools/r6_ablate.sh).  Here a
+// workgroup walks NSL consecutive slices of its row block with the SAME normalised rows (read and normalised once), converts each
+// slice's partial output to fixed point exactly as the first kernel does and sums the NSL integers in registers: ONE atomic per
+// element and workgroup.  Integer adds are associative, so the residual stream - and every id - is bit-identical to the first form
+// (tests/test_t5_gpu.py::test_multi_clip_attention_and_wide_ff_tiles_are_bit_identical); atomics and row reads per launch / NSL.
+// The next slice's up-projection weights are requested as soon as this slice's MFMAs have consumed theirs, its down-projection
+// weights once this slice's have been used.  FF_R <= 8 only (the lane pairing of the 8-row form).
+template <typename T, int KS, int NSL>
+__global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(1, 2))) void dec_ff_multi_kernel(DecFfArgs a) {
+  constexpr int FF_R = 8;
+  __shared__ float ss_s[KS][16];
+  __shared__ float red[KS][4][16 * 17];
+  __shared__ __align__(16) T hs[16 * FF_HP];
+  const int done = chain_done(a.state);
+  const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  // XCD-aware order as in the first kernel: the row blocks that share a group of slices run on the same XCD
+  const int nrb = (a.B + FF_R - 1) / FF_R, ngr = a.d_ff / (FF_C * NSL) + 1;   // row blocks; slice groups + the carry
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int c = xcd + 8 * (slot / nrb), b0 = (slot - (slot / nrb) * nrb) * FF_R;
+  const int K = a.d;
+  if (c >= ngr) return;   // padding workgroups (uniform)
+  if (c == ngr - 1) {     // the carry workgroup of the row block: as in the first kernel
+    xq_t v[FF_R];
+#pragma unroll
+    for (int i = 0; i < FF_R; ++i) v[i] = a.x[(int64_t)min(b0 + i, a.B - 1) * K + tid];
+    if (done) return;
+    if (a.check_done && b0 == 0 && tid == 0) {
+      if (a.state->n_unfinished == 0) { a.state->done = 1; a.state->out_len = a.state->t + 1; }
+      a.state->n_unfinished = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < FF_R; ++i) {
+      if (b0 + i < a.B) {
+        const int64_t at = (int64_t)(b0 + i) * K + tid;
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.x_out + at), (unsigned long long)v[i]);
+        a.x_zero[at] = 0;
+      }
+    }
+    return;
+  }
+  const int kbeg = ks * 64 + 8 * g;
+  const bool row_ok = r < FF_R && (b0 + r) < a.B;
+  const int arow = b0 + (row_ok ? r : 0);
+  const T* Wi = reinterpret_cast<const T*>(a.Wi);
+  const T* Wo = reinterpret_cast<const T*>(a.Wo);
+  const int s0 = c * NSL;                                   // first slice of this workgroup
+
+  const xq_t* xr = a.x + (int64_t)arow * K + kbeg;
+  longlong2 xraw[2][4];
+  float4 g0[2], g1[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) xraw[s][q] = *reinterpret_cast<const longlong2*>(xr + 32 * s + 2 * q);
+    g0[s] = *reinterpret_cast<const float4*>(a.ln_w + kbeg + 32 * s);
+    g1[s] = *reinterpret_cast<const float4*>(a.ln_w + kbeg + 32 * s + 4);
+  }
+  Frag<T> wf[4][2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) wf[j][s] = load_frag(Wi + (int64_t)(2 * FF_C * s0 + 16 * j + r) * K + kbeg + 32 * s);
+  Frag<T> wo[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wo[j] = load_frag(Wo + (int64_t)(16 * (4 * ks + j) + r) * a.d_ff + FF_C * s0 + 8 * g);
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("" ::"s"(done));
+  float4 x0[2], x1[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    x0[s] = make_float4(xq_flt(xraw[s][0].x), xq_flt(xraw[s][0].y), xq_flt(xraw[s][1].x), xq_flt(xraw[s][1].y));
+    x1[s] = make_float4(xq_flt(xraw[s][2].x), xq_flt(xraw[s][2].y), xq_flt(xraw[s][3].x), xq_flt(xraw[s][3].y));
+  }
+  // ---- RMSNorm once: the normalised fragments serve every slice ----
+  float ss = 0.f;
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+    ss += x0[s].x * x0[s].x + x0[s].y * x0[s].y + x0[s].z * x0[s].z + x0[s].w * x0[s].w +
+          x1[s].x * x1[s].x + x1[s].y * x1[s].y + x1[s].z * x1[s].z + x1[s].w * x1[s].w;
+  ss += lane_xor<16>(ss);
+  ss += lane_xor<32>(ss);
+  if (g == 0) ss_s[ks][r] = ss;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < KS; ++w) tot += ss_s[w][r];
+  const float rs = row_ok ? rsqrtf(tot / (float)K + a.eps) : 0.f;
+  Frag<T> fa[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const float xv[8] = {g0[s].x * (x0[s].x * rs), g0[s].y * (x0[s].y * rs), g0[s].z * (x0[s].z * rs),
+                         g0[s].w * (x0[s].w * rs), g1[s].x * (x1[s].x * rs), g1[s].y * (x1[s].y * rs),
+                         g1[s].z * (x1[s].z * rs), g1[s].w * (x1[s].w * rs)};
+    fa[s] = pack_frag<T>(xv);
+  }
+  // lane (r, g) stores tile rows 4 (g & 1) + 2 (g >> 1) + {0, 1} (the 8-row form's lane pairing)
+  const int rl = 4 * (g & 1) + 2 * (g >> 1);
+  xq_t sum0[4], sum1[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { sum0[j] = 0; sum1[j] = 0; }
+
+#pragma unroll
+  for (int i = 0; i < NSL; ++i) {
+    // ---- phase 1: up projection of slice s0 + i ----
+    f32x4_t acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mma32_16(acc[j], fa[s], wf[j][s]);
+    if (i + 1 < NSL) {   // the next slice's up-projection weights, into the registers just consumed
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) wf[j][s] = load_frag(Wi + (int64_t)(2 * FF_C * (s0 + i + 1) + 16 * j + r) * K + kbeg + 32 * s);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) red[ks][j][(4 * g + q) * 17 + r] = acc[j][q];
+    __syncthreads();
+    if (done) return;   // uniform
+    for (int idx = tid; idx < FF_R * FF_C; idx += 64 * KS) {
+      const int row = idx / FF_C, cc = idx % FF_C;
+      const int t = cc >> 3, q = row * 17 + (cc & 7);
+      float v0 = red[0][t][q], v1 = red[0][t][q + 8];
+#pragma unroll
+      for (int w = 1; w < KS; ++w) { v0 += red[w][t][q]; v1 += red[w][t][q + 8]; }
+      hs[row * FF_HP + cc] = from_f32<T>(gelu_new_t<T>(v0) * v1);
+    }
+    __syncthreads();
+    // ---- phase 2: down projection of the slice, converted to fixed point per slice, summed as integers ----
+    const Frag<T> fh = load_frag(hs + r * FF_HP + 8 * g);
+    f32x4_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      mma32_16(o[j], fh, wo[j]);
+    }
+    if (i + 1 < NSL) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wo[j] = load_frag(Wo + (int64_t)(16 * (4 * ks + j) + r) * a.d_ff + FF_C * (s0 + i + 1) + 8 * g);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float x2 = lane_xor<32>(o[j][2]), x3 = lane_xor<32>(o[j][3]);
+      const float v0 = g < 2 ? o[j][0] : x2, v1 = g < 2 ? o[j][1] : x3;
+      sum0[j] += xq_fix_guarded(v0, a.state);
+      sum1[j] += xq_fix_guarded(v1, a.state);
+    }
+  }
+  xq_t* const p0 = a.x_out + (int64_t)(b0 + rl) * K + 64 * ks + r;
+  const bool ok0 = rl < FF_R && b0 + rl < a.B, ok1 = rl + 1 < FF_R && b0 + rl + 1 < a.B;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (ok0) atomicAdd(reinterpret_cast<unsigned long long*>(p0 + 16 * j), (unsigned long long)sum0[j]);
+    if (ok1) atomicAdd(reinterpret_cast<unsigned long long*>(p0 + 16 * j + K), (unsigned long long)sum1[j]);
+  }
+}
+
+template <typename T, int NSL>
+static int launch_dec_ff_multi_t(const DecFfArgs& a, hipStream_t st) {
+  const int ngr = a.d_ff / (FF_C * NSL) + 1;
+  dim3 grid((unsigned)(ceil_div(ngr, 8) * 8 * ceil_div(a.B, 8)));
+  switch (a.d / 64) {
+    case 2: hipLaunchKernelGGL((dec_ff_multi_kernel<T, 2, NSL>), grid, dim3(128), 0, st, a); break;
+    case 4: hipLaunchKernelGGL((dec_ff_multi_kernel<T, 4, NSL>), grid, dim3(256), 0, st, a); break;
+    case 6: hipLaunchKernelGGL((dec_ff_multi_kernel<T, 6, NSL>), grid, dim3(384), 0, st, a); break;
+    case 8: hipLaunchKernelGGL((dec_ff_multi_kernel<T, 8, NSL>), grid, dim3(512), 0, st, a); break;
+    default: set_error("dec_ff: d_model=%d not supported (128/256/384/512)", a.d); return M2M_ERR_INVALID;
+  }
+  M2M_CHECK_HIP(hipGetLastError());
+  return M2M_OK;
+}
+
+static int launch_dec_ff(int precision, const DecFfArgs& a, int rows, int slices, hipStream_t st) {
   if (a.d % 64 != 0 || a.d_ff % FF_C != 0) {
     set_error("dec_ff: d_model=%d must be a multiple of 64 and d_ff=%d of %d", a.d, a.d_ff, FF_C);
     return M2M_ERR_INVALID;
   }
   const bool bf = precision == M2M_PREC_BF16;
+  if (slices > 1 && (a.d_ff / FF_C) % slices == 0) {        // several hidden slices per workgroup (large chains)
+    if (slices == 2) return bf ? launch_dec_ff_multi_t<bf16_t, 2>(a, st) : launch_dec_ff_multi_t<float, 2>(a, st);
+    if (slices == 4) return bf ? launch_dec_ff_multi_t<bf16_t, 4>(a, st) : launch_dec_ff_multi_t<float, 4>(a, st);
+  }
   if (rows == 16) return bf ? launch_dec_ff_t<bf16_t, 16>(a, st) : launch_dec_ff_t<float, 16>(a, st);
   return bf ? launch_dec_ff_t<bf16_t, 8>(a, st) : launch_dec_ff_t<float, 8>(a, st);
 }
@@ -1780,13 +1963,23 @@ bool decode_finished_skip_on() {
 // 4.3); s->attn_clips > 0 forces a value (M2M_DA_CLIPS, latched when the session is created; tests and A/B runs).
 int decode_attn_clips(const m2m_session* s, int nb) {
   if (s->attn_clips > 0) return s->attn_clips;
-  return nb >= 48 ? 4 : (nb >= 24 ? 2 : 1);
+  // same-box sweeps (tools/native_mc_sweep.py, us per step, C = 1 / 2 / 4): 2 x 16 clips, S = 864: 195 / 238 / -; 2 x 24: 264 / 266 / 363;
+  // 2 x 32: 329 / 300 / 386; 2 x 64, S = 864: 595 / 522 / 512; 2 x 64, S = 190 (the reference's chunk): 446 / 383 / 362
+  return nb >= 48 ? 4 : (nb >= 32 ? 2 : 1);
 }
 
-// residual rows per feed-forward workgroup for a chain of nb clips (M2M_DEC_FF_ROWS forces 8 or 16, latched per session)
+// residual rows per feed-forward workgroup for a chain of nb clips (M2M_DEC_FF_ROWS forces 8 or 16, latched per session).  16 rows
+// measured no different from 8 at 2 x 64 clips (365.5 / 366.3 us per step): 8 everywhere.
 int decode_ff_rows(const m2m_session* s, int nb) {
-  if (s->ff_rows > 0) return s->ff_rows;
-  return nb >= 48 ? 16 : 8;
+  (void)nb;
+  return s->ff_rows > 0 ? s->ff_rows : 8;
+}
+// hidden slices per feed-forward workgroup (dec_ff_multi_kernel from 2; M2M_DEC_FF_SLICES forces 1, 2 or 4, latched per session)
+int decode_ff_slices(const m2m_session* s, int nb) {
+  if (s->ff_slices > 0) return s->ff_slices;
+  // same-box sweeps (tools/native_mc_sweep.py, us per step, 1 / 2 / 4 slices): 2 x 16 clips 196 / 204 / -; 2 x 32: 301 / 292 / 312;
+  // 2 x 64 (the reference's chunk): 362 / 349-353 / 345-347
+  return nb >= 48 ? 4 : (nb >= 32 ? 2 : 1);
 }
 
 int decode_launch_attn(m2m_session* s, const DecView& v, bool self, int layer, int self_len, hipStream_t st, bool headless, bool skip_finished) {
@@ -1862,7 +2055,7 @@ int decode_launch_step(m2m_session* s, const DecView& v, bool forced, float* log
     f.x = xC; f.x_out = xA; f.x_zero = xB; f.ln_w = L.ln2; f.eps = g.layer_norm_eps;
     f.Wi = L.wi; f.Wo = L.wo_ff; f.d = g.d_model; f.d_ff = g.d_ff; f.B = v.nb; f.state = v.state;
     f.check_done = (headless && l == 0) ? 1 : 0;
-    if ((rc = launch_dec_ff(P, f, decode_ff_rows(s, v.nb), st))) return rc;
+    if ((rc = launch_dec_ff(P, f, decode_ff_rows(s, v.nb), decode_ff_slices(s, v.nb), st))) return rc;
   }
   // final RMSNorm + lm_head (untied, no d_model**-0.5 scaling: transformers 4.34 semantics)
   DecGemmArgs a{};

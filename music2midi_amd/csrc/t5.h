@@ -125,6 +125,7 @@ struct m2m_session {
   int B = 0, S = 0;
   int attn_clips = 0;      // decode attention: clips per workgroup forced by M2M_DA_CLIPS when the session was created (0: by chain size)
   int ff_rows = 0;         // decode feed-forward: residual rows per workgroup forced by M2M_DEC_FF_ROWS (0: by chain size)
+  int ff_slices = 0;       // decode feed-forward: hidden slices per workgroup forced by M2M_DEC_FF_SLICES (0: by chain size)
   int repacks = 0, rows_moved = 0;   // live-row re-packings / rows moved by them in the last m2m_generate_greedy
   bool encoded = false;
   // decode chains
@@ -222,5 +223,6 @@ int decode_finalize(m2m_session* s, const DecView& v, hipStream_t st);   // head
 bool decode_headless();
 int decode_attn_clips(const m2m_session* s, int nb);
 int decode_ff_rows(const m2m_session* s, int nb);
+int decode_ff_slices(const m2m_session* s, int nb);
 
 }  // namespace m2m

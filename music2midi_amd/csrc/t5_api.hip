@@ -249,10 +249,14 @@ extern "C" int m2m_session_create(const m2m_model* m, int max_batch, int max_enc
   const char* ff_env = getenv("M2M_DEC_FF_ROWS");
   const int ff_rows = (ff_env && ff_env[0]) ? atoi(ff_env) : 0;
   M2M_REQUIRE(ff_rows == 0 || ff_rows == 8 || ff_rows == 16, "M2M_DEC_FF_ROWS=%d: rows per decode feed-forward workgroup must be 0 (by chain size), 8 or 16", ff_rows);
+  const char* fs_env = getenv("M2M_DEC_FF_SLICES");
+  const int ff_slices = (fs_env && fs_env[0]) ? atoi(fs_env) : 0;
+  M2M_REQUIRE(ff_slices == 0 || ff_slices == 1 || ff_slices == 2 || ff_slices == 4,
+              "M2M_DEC_FF_SLICES=%d: hidden slices per decode feed-forward workgroup must be 0 (by chain size), 1, 2 or 4", ff_slices);
   m2m_session* s = new m2m_session();
   s->m = m; s->max_batch = max_batch; s->max_enc = max_enc_len; s->max_dec = max_dec_len;
   s->ws = (unsigned char*)workspace_dev; s->ws_bytes = workspace_bytes;
-  s->attn_clips = da_clips; s->ff_rows = ff_rows;
+  s->attn_clips = da_clips; s->ff_rows = ff_rows; s->ff_slices = ff_slices;
   unsigned char* b = s->ws;
   s->x_enc = (float*)(b + w.x_enc); s->h_enc = b + w.h_enc; s->qkv_enc = b + w.qkv_enc; s->vt_enc = b + w.vt_enc; s->attn_enc = b + w.attn_enc;
   s->mid_enc = b + w.mid_enc; s->enc_bias_tab = (float*)(b + w.enc_bias); s->dec_bias_tab = (float*)(b + w.dec_bias);

@@ -400,7 +400,8 @@ def test_live_row_repacking_without_graphs_and_with_small_chains(monkeypatch):
 def test_multi_clip_attention_and_wide_ff_tiles_are_bit_identical(monkeypatch, precision, B, S, L):
     """Round 6: large chains run the decode attention with C = 2 / 4 clips of one head per workgroup
     (dec_attn_mc_kernel: one row round trip and ONE fetch of the head's weights for C clips, the clips' K/V streams back to back)
-    and the feed-forward with 16 rows per workgroup.  Per row the arithmetic is the first kernels', operation for operation: ids,
+    and the feed-forward with 2 / 4 hidden slices per workgroup summed as integers before ONE atomic (dec_ff_multi_kernel; also
+    the 16-row tiles of the first form).  Per row the arithmetic is the first kernels', operation for operation: ids,
     output length and the teacher-forced step logits must be torch.equal whatever form a chain takes — with rows that end raggedly
     (early-out + re-packing on), chain sizes that are no multiple of C (clamped tail clips), one and two chains."""
     cfg = DEFAULT_CONFIG
@@ -410,22 +411,24 @@ def test_multi_clip_attention_and_wide_ff_tiles_are_bit_identical(monkeypatch, p
     synth.force_eos_head(sd, geom, active=340, eos_scale=1.6)
     x = embeds(B, S, geom.d_model, seed=33)
     ids, logits = {}, {}
-    for clips, rows in (("1", "8"), ("2", "16"), ("4", "8"), ("4", "16"), ("0", "0")):
+    base = ("1", "8", "1")
+    for leg in (base, ("2", "16", "2"), ("4", "8", "4"), ("4", "16", "1"), ("2", "8", "4"), ("0", "0", "0")):
+        clips, rows, slices = leg
         monkeypatch.setenv("M2M_DA_CLIPS", clips)           # latched when the session is created: a new model per leg
         monkeypatch.setenv("M2M_DEC_FF_ROWS", rows)
+        monkeypatch.setenv("M2M_DEC_FF_SLICES", slices)
         m = T5Transformer(cfg, precision=precision)
         load_t5_state(m, sd, strict=False)
         m = m.cuda().eval()
         monkeypatch.delenv("M2M_FORWARD", raising=False)
-        ids[clips, rows] = m.generate_from_embeds(x.cuda(), max_length=L).cpu()
+        ids[leg] = m.generate_from_embeds(x.cuda(), max_length=L).cpu()
         monkeypatch.setenv("M2M_FORWARD", "step")           # the same step kernels, teacher-forced along the ids just decoded
-        Ld = min(24, ids[clips, rows].shape[1])
-        logits[clips, rows] = m.logits_from_embeds(x.cuda(), ids["1", "8"][:, :Ld].cuda()).cpu()
+        Ld = min(24, ids[leg].shape[1])
+        logits[leg] = m.logits_from_embeds(x.cuda(), ids[base][:, :Ld].cuda()).cpu()
         del m
-    base = ("1", "8")
     for k in ids:
-        assert torch.equal(ids[k], ids[base]), f"ids differ with M2M_DA_CLIPS={k[0]} M2M_DEC_FF_ROWS={k[1]}"
-        assert torch.equal(logits[k], logits[base]), f"step logits differ with M2M_DA_CLIPS={k[0]} M2M_DEC_FF_ROWS={k[1]}"
+        assert torch.equal(ids[k], ids[base]), f"ids differ with M2M_DA_CLIPS={k[0]} M2M_DEC_FF_ROWS={k[1]} M2M_DEC_FF_SLICES={k[2]}"
+        assert torch.equal(logits[k], logits[base]), f"step logits differ with M2M_DA_CLIPS={k[0]} M2M_DEC_FF_ROWS={k[1]} M2M_DEC_FF_SLICES={k[2]}"
     a = ids[base]
     ends = [int((a[r] == geom.eos_token_id).float().argmax()) if (a[r] == geom.eos_token_id).any() else -1 for r in range(B)]
     print(f"multi-clip {precision} B={B} S={S}: {sum(1 for e in ends if e > 0)} of {B} rows end, length {a.shape[1]}")

@@ -1,7 +1,7 @@
 """Large-chain decode forms (round 6): tokens/s by clips per attention workgroup (M2M_DA_CLIPS), rows per feed-forward workgroup
 (M2M_DEC_FF_ROWS) and clips per chain (M2M_GROUP_ROWS), a child process per setting (the switches are latched per session).
 
-    python tools/native_mc_sweep.py B T precision max_length  "clips,ffrows,grouprows" ...
+    python tools/native_mc_sweep.py B T precision max_length  "clips,ffrows,grouprows[,ffslices]" ...
 """
 import os, subprocess, sys
 from pathlib import Path
@@ -27,9 +27,11 @@ print(f"{B * (t.shape[1] - 1) / dt / 1e3:.1f} k tok/s, {dt * 1e3:.1f} ms per bat
 ''' % str(ROOT)
 B, T, prec, L = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
 for spec in sys.argv[5:]:
-    clips, ffr, rows = spec.split(",")
+    clips, ffr, rows, *rest = spec.split(",")
     env = dict(os.environ, M2M_DA_CLIPS=clips, M2M_DEC_FF_ROWS=ffr)
+    if rest:
+        env["M2M_DEC_FF_SLICES"] = rest[0]
     if rows != "0":
         env["M2M_GROUP_ROWS"] = rows
     r = subprocess.run([sys.executable, "-c", CODE, str(B), str(T), prec, str(L)], env=env, capture_output=True, text=True, timeout=900)
-    print(f"B={B} T={T} {prec} L={L} clips/wg={clips} ff_rows={ffr} group_rows={rows}: {r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-400:]}", flush=True)
+    print(f"B={B} T={T} {prec} L={L} clips/wg={clips} ff_rows={ffr} group_rows={rows} ff_slices={rest[0] if rest else 'auto'}: {r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-400:]}", flush=True)
