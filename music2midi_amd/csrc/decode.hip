@@ -824,7 +824,13 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
 #ifndef M2M_DA_PF_SELF
 #define M2M_DA_PF_SELF 2
 #endif
-  constexpr int PF = SELF ? M2M_DA_PF_SELF : M2M_DA_PF_CROSS;
+  // fp32 (parity) mode, cross-attention: 4 rounds.  Its per-workgroup stream is 442 KB at S = 864 against a ~3 us prologue, and the
+  // same-box A/B (tools/r6_fp32_sweep.sh, 32 x S = 864, us per step incl. encoder) reads 345.1 / 345.5 / 345.9 with 2 rounds, 345.5
+  // with 3, 340.9 with 4; 3 rounds in the self-attention: 353.4.
+#ifndef M2M_DA_PF_CROSS_F32
+#define M2M_DA_PF_CROSS_F32 4
+#endif
+  constexpr int PF = SELF ? M2M_DA_PF_SELF : (sizeof(T) == 4 ? M2M_DA_PF_CROSS_F32 : M2M_DA_PF_CROSS);
   constexpr int WMAX = 3;                // q weight chunks per lane held in registers (d_model 384, bf16)
   using V16 = decltype(Vec16<T>().v);
   extern __shared__ __align__(16) float hn[];   // [d] normalised input row (already rounded to T)

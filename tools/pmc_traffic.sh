@@ -8,7 +8,7 @@ OUT=${PMC_OUT:-gpurun_out/pmc_traffic}
 mkdir -p $OUT
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT -o $C -- \
-    python3 bench.py --steps 1 --warmup 0 --no-roofline --no-parity --no-native --no-frontend --no-train --cpu-tokens 0 --max-length 49 > $OUT/$C.log 2>&1 || tail -5 $OUT/$C.log
+    python3 bench.py --precision ${PMC_PRECISION:-bf16} --steps 1 --warmup 0 --no-roofline --no-parity --no-native --no-frontend --no-train --cpu-tokens 0 --max-length 49 > $OUT/$C.log 2>&1 || tail -5 $OUT/$C.log
 done
 python3 - <<'PY'
 import csv, collections, glob
@@ -30,7 +30,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 batch = int(os.environ.get("PMC_BATCH", "32"))
 rows = int(os.environ.get("M2M_GROUP_ROWS") or (16 if batch >= 24 else batch))
 with open(out + "/summary.txt", "w") as fh:
-    head = f"# decode kernels: clips/launch = {min(rows, batch)}   (batch {batch} per GPU; FETCH_SIZE x2-corrected for gfx950; separate --pmc passes)"
+    head = f"# decode kernels: clips/launch = {min(rows, batch)}   (batch {batch} per GPU, precision {os.environ.get('PMC_PRECISION', 'bf16')}; FETCH_SIZE x2-corrected for gfx950; separate --pmc passes)"
     print(head); fh.write(head + "\n")
     for k in sorted(set(res.get("FETCH_SIZE", {})) | set(res.get("WRITE_SIZE", {}))):
         if "dec_" not in k and "logmel" not in k and "gemm_kernel" not in k and "attn_kernel" not in k and "attn_wide" not in k and "resid_panel" not in k: continue
