@@ -235,7 +235,7 @@ def cpu_frontend_baseline(cfg, clips: int = 64, threads: int = 16):
             "sample": f"torch.stft + dense [1025x384] mel matmul + clamp/log on {clips} x {N_SAMPLES} samples, fp32"}
 
 
-def pmc_traffic_bytes(kernel_substr: str, batch: int, n_chains: int = 1, profiles_dir=None):
+def pmc_traffic_bytes(kernel_substr: str, batch: int, n_chains: int = 1, profiles_dir=None, precision: str = "bf16"):
     """HBM bytes of one co-scheduled launch set (all `batch` clips) of a kernel from the newest committed PMC summary
     (profiles/*pmc_traffic_summary.txt, collected by tools/pmc_traffic.sh in separate FETCH_SIZE / WRITE_SIZE passes;
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  The summary lists bytes per KERNEL launch; a launch
@@ -245,7 +245,8 @@ def pmc_traffic_bytes(kernel_substr: str, batch: int, n_chains: int = 1, profile
     import re
     best = None
     files = sorted(Path(profiles_dir or ROOT / "profiles").glob("*pmc_traffic_summary.txt"), key=lambda f: (_round_of(f.name), f.name))
-    files = [f for f in files if "frontend" not in f.name]
+    # the fp32 mode has summaries of its own (tools/r6_fp32_profile.sh: *_fp32_pmc_traffic_summary.txt)
+    files = [f for f in files if "frontend" not in f.name and ("fp32" in f.name) == (precision == "fp32")]
     for f in files[-1:]:                       # the newest round's summary only: an older one describes older kernels
         text = f.read_text()
         m = re.search(r"clips/launch\s*=\s*(\d+)", text)
@@ -419,7 +420,7 @@ def ragged_eos_record(cfg, geom, dev, B: int, S: int, eos_scale: float = 1.6, re
                     "_skip_off = every row computed to the end (M2M_FINISHED_SKIP=0 M2M_COMPACT=0, HF's behaviour, rounds 1-3); speedup = _skip_off / product"}
 
 
-def reference_native_record(model, cfg, geom, dev, reps: int = 3) -> dict:
+def reference_native_record(model, cfg, geom, dev, reps: int = 3, esize: int = 2) -> dict:
     """The reference's own inference geometry (ref config.yaml:16,46-47, model.py:115-134): one `inference.batch_size` = 128 chunk of
     3 s segments at 16 kHz (48 000 samples -> S = 190), max_length 1024, bf16, same random-init weights (no EOS: 1 023 tokens per row)."""
     from music2midi_amd import synth
@@ -437,13 +438,50 @@ def reference_native_record(model, cfg, geom, dev, reps: int = 3) -> dict:
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / reps
     n_steps = toks.shape[1] - 1
-    step_bytes = decode_bytes_per_step(Bn, Sn, (1 + n_steps) / 2.0, 2)
+    step_bytes = decode_bytes_per_step(Bn, Sn, (1 + n_steps) / 2.0, esize)
     step_us = dt / n_steps * 1e6              # encoder + frontend included (an upper bound on the step: they are ~1 % of the batch)
-    return {"workload": f"reference-native geometry: {Bn} segments x {Tn} samples (3 s @ 16 kHz, S={Sn}), bf16, max_length {MAX_LENGTH}",
+    return {"workload": f"reference-native geometry: {Bn} segments x {Tn} samples (3 s @ 16 kHz, S={Sn}), {'bf16' if esize == 2 else 'fp32'}, max_length {MAX_LENGTH}",
             "tokens_per_s": Bn * n_steps / dt, "ms_per_batch": dt * 1e3, "new_tokens_per_clip": int(n_steps),
             "step_algorithmic_bytes": step_bytes, "step_mean_us": step_us, "step_achieved_GBs": step_bytes / (step_us * 1e-6) / 1e9,
             "step_frac": step_bytes / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-            "note": "step bytes = decoder weights 30.4 MB + 128 clips x 12 288 B x (190 + mean t) (SURVEY 8d formula at this geometry)"}
+            "note": f"step bytes = decoder weights {DEC_PARAMS_PER_STEP * esize / 1e6:.1f} MB + 128 clips x {6144 * esize} B x (190 + mean t) (SURVEY 8d formula at this geometry)"}
+
+
+def decode_roofline_record(model, x, B: int, S: int, es: int, precision: str, enc_ms: float) -> dict:
+    """`roofline` of the decode path of `model` (any precision) on the encoder inputs x: the dominant kernel (decode cross-attention)
+    timed live with hipEvents on the streams it runs on (m2m_bench_kernel: every chain's launch on its own stream, 600 launch sets
+    cycling the 6 layers), algorithmic bytes with the precision's element size (es = 2: bf16 weights and K/V; 4: fp32), traffic
+    from the newest committed PMC summary of that precision, and the whole path's fraction from one timed greedy decode."""
+    from music2midi_amd import native
+    dev = x.device
+    t_dec = time.perf_counter()
+    model.generate_from_embeds(x, max_length=MAX_LENGTH)
+    torch.cuda.synchronize(dev)
+    t_dec = time.perf_counter() - t_dec
+    t_mid = MAX_LENGTH // 2
+    model._encode(x, MAX_LENGTH)      # a greedy decode that re-packed its live rows has consumed the encode (m2m_generate_greedy)
+    cross_us, cross_bytes = model.bench_kernel(native.KERNEL_DEC_CROSS_ATTN, t_mid, 600)
+    self_us, self_bytes = model.bench_kernel(native.KERNEL_DEC_SELF_ATTN, t_mid, 600)
+    step_us, _ = model.bench_kernel(native.KERNEL_DEC_STEP, t_mid, 200)
+    achieved = cross_bytes / (cross_us * 1e-6) / 1e9
+    # whole decode loop: mean algorithmic bytes per step (t averaged over the run) / mean measured step
+    n_steps = MAX_LENGTH - 1
+    mean_step_us = (t_dec - enc_ms * 1e-3) / n_steps * 1e6
+    step_bytes = decode_bytes_per_step(B, S, (1 + n_steps) / 2.0, es)
+    step_gbs = step_bytes / (mean_step_us * 1e-6) / 1e9
+    n_chains = 2 if B >= 24 and not os.environ.get("M2M_GROUP_ROWS") else max(1, -(-B // int(os.environ.get("M2M_GROUP_ROWS") or B)))
+    tname = "m2m::bf16_t" if precision == "bf16" else "float"
+    return {"roofline": {"bound": "hbm", "kernel": f"dec_attn_kernel<{tname}> (cross-attention, decode step)",
+                         "launch": f"{n_chains} co-scheduled chain launches of {B // n_chains} clips each (as the decode loop issues them) = {B} clips",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic_bytes(f"dec_attn_kernel<{tname}, false,", B, precision=precision),
+                         "algorithmic_bytes_per_launch": cross_bytes, "avg_launch_us": cross_us,
+                         # the PATH's fraction (all 19 kernels of a decode step, averaged over the 1023 steps of a run):
+                         "step_frac": step_gbs / HBM_PEAK_GBS, "step_achieved": step_gbs,
+                         "step_algorithmic_bytes": step_bytes, "step_mean_us": mean_step_us},
+            "generate_from_embeds_s": t_dec, "self_attn_us_at_t512": self_us, "self_attn_GBs": self_bytes / (self_us * 1e-6) / 1e9,
+            "decode_step_us_at_t512": step_us}
 
 
 def decode_bytes_per_step(B: int, S: int, t_mean: float, esize: int) -> float:
@@ -533,12 +571,20 @@ def dry_run_train(args, rank: int, world: int) -> int:
     logged = D.reduce_logged({"train/loss": torch.tensor(1.0 + rank), "train/score": 0.25 * rank, "batch_size": 16})
     ok = ok and abs(logged["train/loss"] - (1.0 + (world - 1) / 2)) < 1e-12 and logged["batch_size"] == 16 * world
     D.barrier()
-    dt = D.all_reduce_max(time.perf_counter() - t0, "cpu")
+    dt_local = time.perf_counter() - t0
+    per_rank = D.all_gather_floats(dt_local, "cpu")
+    dt = D.all_reduce_max(dt_local, "cpu")
+    # the N > 1 fields of the real line: the averaged "parameters" must checksum alike on every rank (a test hook spoils one rank's)
+    if os.environ.get("M2M_BENCH_CORRUPT_RANK") == str(rank):
+        flat[0] += 1.0
+    after = D.verify_replicas({"params_after_steps": D.tensor_checksum(flat)}, "cpu")
     if rank == 0:
         print(json.dumps({"metric": "training clips/sec/node (forward+backward+Adafactor step)", "value": 0.0, "unit": "clips/s", "n_gpus": world,
                           "dry_run": True, "mode": "train", "backend": torch.distributed.get_backend() if world > 1 else "none",
                           "world": torch.distributed.get_world_size() if world > 1 else 1, "grad_allreduce_bytes": b1,
                           "grad_average_ok": bool(ok), "logged": logged, "host_threads": torch.get_num_threads(), "wall_s": dt,
+                          "ranks_seen": after["ranks_seen"], "replica_checksums": after["checksums"], "per_rank_ms_per_step": [e * 1e3 for e in per_rank],
+                          "grad_allreduce_bytes_per_step": b1,
                           "config": {"global_batch": 16 * world, "parallelism": f"data-parallel x{world}"}}), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
@@ -632,7 +678,11 @@ def train_step_record(model_module, cfg, geom, dev, B: int, precision: str, step
         loss, nbytes = step()
     torch.cuda.synchronize(dev)
     D.barrier()
-    dt = D.all_reduce_max(time.perf_counter() - t0, dev) / steps
+    dt_local = time.perf_counter() - t0
+    per_rank_ms = [e / steps * 1e3 for e in D.all_gather_floats(dt_local, dev)]
+    dt = D.all_reduce_max(dt_local, dev) / steps
+    # every rank trained on ITS clips: after these steps the replicas are identical only if the gradient average reached every rank
+    after = D.verify_replicas({"params_after_steps": D.tensor_checksum(tr.params)}, dev) if world > 1 else None
     S = F + 2
     enc = 6 * (4227072 * S + 2048 * S * S) + 4718592 * S
     dec = TRAIN_LABELS * (6 * (2 * 384 * 512 * 6 + 3 * 2 * 384 * 1152) + 2 * 384 * 400) + 6 * (4 * TRAIN_LABELS * TRAIN_LABELS * 512 + 4 * TRAIN_LABELS * S * 512)
@@ -652,6 +702,9 @@ def train_step_record(model_module, cfg, geom, dev, B: int, precision: str, step
                              ("none (split pass forced)" if overlap else "none")}
     if world == 1 and profile_launches:
         rec["roofline"].update(train_profile_summary())
+    if world > 1:
+        rec["per_rank_ms_per_step"] = per_rank_ms
+        rec["replicas_after_steps"] = after
     tr.close()
     return rec
 
@@ -784,11 +837,17 @@ def main():
         Bt = 16 if args.batch == 32 else args.batch
         rec = train_step_record(model, cfg, geom, dev, Bt, args.precision, args.steps, args.warmup, world, dropout=args.dropout)
         if rank == 0:
-            print(json.dumps({"metric": "training clips/sec/node (forward+backward+Adafactor step)", "value": rec["clips_per_s"], "unit": "clips/s",
-                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"],
-                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-                              "config": {"workload": rec["workload"], "global_batch": Bt * world, "parallelism": f"data-parallel x{world}",
-                                         "grad_allreduce_bytes": rec["grad_allreduce_bytes"]}, "extras": rec}), flush=True)
+            line = {"metric": "training clips/sec/node (forward+backward+Adafactor step)", "value": rec["clips_per_s"], "unit": "clips/s",
+                    "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"],
+                    "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+                    "config": {"workload": rec["workload"], "global_batch": Bt * world, "parallelism": f"data-parallel x{world}",
+                               "grad_allreduce_bytes": rec["grad_allreduce_bytes"]}, "extras": rec}
+            if world > 1:     # as the generate line: proof that the collectives saw N ranks, with identical replicas before AND after the steps
+                line["ranks_seen"] = replicas["ranks_seen"]
+                line["replica_checksums"] = dict(replicas["checksums"], **rec["replicas_after_steps"]["checksums"])
+                line["per_rank_ms_per_step"] = rec["per_rank_ms_per_step"]
+                line["grad_allreduce_bytes_per_step"] = rec["grad_allreduce_bytes"]
+            print(json.dumps(line), flush=True)
         if world > 1:
             torch.distributed.destroy_process_group()
         return
@@ -842,7 +901,8 @@ def main():
                                    f"{args.precision}, batch {B} clips/GPU x {N_SAMPLES} samples, S={S}, max_length {args.max_length}"
                                    + (f"; configs[3] sharding over {world} GPUs" if world > 1 else ""),
                        "precision_note": ("throughput mode: bf16 GEMM inputs and K/V caches; its ids follow a bf16-emulating oracle and equal the "
-                                          "fp32 CPU reference's on about half of the tokens (parity_mode.bf16_vs_fp32_id_agreement); the mode with "
+                                          "fp32 CPU reference's on 54-61 % of the tokens (rounds 4-5; this run's figure replaces this text when the "
+                                          "parity-mode record runs: parity_mode.bf16_vs_fp32_id_agreement); the mode with "
                                           "bit-exact greedy ids is fp32: parity_mode.tokens_per_s") if args.precision == "bf16" else
                                          "fp32 parity mode: greedy ids bit-identical to the fp32 CPU reference",
                        "global_batch": B * world, "clips_per_gpu": B, "new_tokens_per_clip": toks.shape[1] - 1,
@@ -876,41 +936,17 @@ def main():
             model._encode(x, MAX_LENGTH)
         ev[2].record()
         torch.cuda.synchronize(dev)
-        t_dec = time.perf_counter()
-        model.generate_from_embeds(x, max_length=MAX_LENGTH)
-        torch.cuda.synchronize(dev)
-        t_dec = time.perf_counter() - t_dec
         enc_ms = ev[1].elapsed_time(ev[2]) / ENC_PASSES
         # dominant kernel: decode cross-attention (6 launches per decode step, streams the
         # per-clip cross K/V: 2 * S * inner * esize bytes per clip per launch)
-        t_mid = MAX_LENGTH // 2
-        model._encode(x, MAX_LENGTH)      # a greedy decode that re-packed its live rows has consumed the encode (m2m_generate_greedy)
-        cross_us, cross_bytes = model.bench_kernel(native.KERNEL_DEC_CROSS_ATTN, t_mid, 600)
-        self_us, self_bytes = model.bench_kernel(native.KERNEL_DEC_SELF_ATTN, t_mid, 600)
-        step_us, _ = model.bench_kernel(native.KERNEL_DEC_STEP, t_mid, 200)
-        achieved = cross_bytes / (cross_us * 1e-6) / 1e9
-        # whole decode loop: mean algorithmic bytes per step (t averaged over the run) / mean measured step
-        n_steps = MAX_LENGTH - 1
-        mean_step_us = (t_dec - enc_ms * 1e-3) / n_steps * 1e6
-        step_bytes = decode_bytes_per_step(B, S, (1 + n_steps) / 2.0, es)
-        step_gbs = step_bytes / (mean_step_us * 1e-6) / 1e9
-        n_chains = 2 if B >= 24 and not os.environ.get("M2M_GROUP_ROWS") else max(1, -(-B // int(os.environ.get("M2M_GROUP_ROWS") or B)))
-        out["roofline"] = {"bound": "hbm", "kernel": "dec_attn_kernel (cross-attention, decode step)",
-                           "launch": f"{n_chains} co-scheduled chain launches of {B // n_chains} clips each (as the decode loop issues them) = {B} clips",
-                           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS,
-                           "traffic": pmc_traffic_bytes("dec_attn_kernel<m2m::bf16_t, false,", B)
-                           if args.precision == "bf16" else None,
-                           "algorithmic_bytes_per_launch": cross_bytes, "avg_launch_us": cross_us,
-                           # the PATH's fraction (all 20 kernels of a decode step, averaged over the 1023 steps of a run):
-                           "step_frac": step_gbs / HBM_PEAK_GBS, "step_achieved": step_gbs,
-                           "step_algorithmic_bytes": step_bytes, "step_mean_us": mean_step_us}
+        rr = decode_roofline_record(model, x, B, S, es, args.precision, enc_ms)
+        out["roofline"] = rr["roofline"]
         out["extras"] = {
             "frontend_ms": fe_ms, "encoder_plus_crosskv_ms": enc_ms, "encoder_plus_crosskv_single_call_ms": enc_first_ms,
             "encoder_TFLOPs": B * 35.17e9 / (enc_ms * 1e-3) / 1e12,
-            "generate_from_embeds_s": t_dec,
-            "self_attn_us_at_t512": self_us, "self_attn_GBs": self_bytes / (self_us * 1e-6) / 1e9,
-            "decode_step_us_at_t512": step_us,
+            "generate_from_embeds_s": rr["generate_from_embeds_s"],
+            "self_attn_us_at_t512": rr["self_attn_us_at_t512"], "self_attn_GBs": rr["self_attn_GBs"],
+            "decode_step_us_at_t512": rr["decode_step_us_at_t512"],
             "frontend_GBs": B * (4 * N_SAMPLES + 4 * N_FRAMES * 384) / (fe_ms * 1e-3) / 1e9,
         }
 
@@ -973,6 +1009,30 @@ def main():
             "bf16_vs_fp32_first_divergence_step": first_div,
             "bf16_vs_fp32_mean_identical_prefix": float(np.mean(prefix)),
         }
+        # the DEFAULT mode of the Python classes (what evaluate.py gets) against its own roofline: fp32 byte counts (4-byte K/V and weights)
+        if not args.no_roofline:
+            x32 = m32.encoder_inputs(inputs)
+            for _ in range(2):
+                m32._encode(x32, MAX_LENGTH)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                m32._encode(x32, MAX_LENGTH)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            enc32_ms = e0.elapsed_time(e1) / 5
+            rr32 = decode_roofline_record(m32, x32, B, S, 4, "fp32", enc32_ms)
+            out["parity_mode"]["roofline"] = rr32["roofline"]
+            out["parity_mode"]["encoder_plus_crosskv_ms"] = enc32_ms
+            out["parity_mode"]["encoder_fp32_mfma_frac_of_157TF"] = B * 35.17e9 / (enc32_ms * 1e-3) / 157e12
+            del x32
+        if not args.no_native:      # the reference's precision at the reference's geometry: the number a user of evaluate.py sees
+            nat32 = reference_native_record(m32, cfg, geom, dev, reps=2, esize=4)
+            out["parity_mode"]["reference_native"] = {k: nat32[k] for k in ("workload", "tokens_per_s", "ms_per_batch", "step_mean_us", "step_frac")}
+        out["config"]["precision_note"] = (
+            f"throughput mode: bf16 GEMM inputs and K/V caches; its ids follow a bf16-emulating oracle and equal the fp32 CPU reference's on "
+            f"{100 * float(same.float().mean()):.0f} % of the tokens of this run (parity_mode.bf16_vs_fp32_id_agreement; {int(sum(1 for d in first_div if d < 0))} of {B} "
+            f"rows identical to the end); the mode with bit-exact greedy ids is fp32: parity_mode.tokens_per_s = {B * (ids_fp32.shape[1] - 1) / dt32:.0f}")
         out["parity_mode"].update(golden_divergence(ids_bf16, ids_fp32))
         if B >= 2 and (ROOT / "tests" / "golden" / "t5_forced.npz").exists():
             try:

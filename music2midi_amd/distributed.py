@@ -132,6 +132,15 @@ def module_checksum(module: torch.nn.Module, gemm_dtype: Optional[torch.dtype] =
     return total
 
 
+def tensor_checksum(t: torch.Tensor) -> int:
+    """The same position-weighted 64-bit checksum over ONE tensor's 32-bit words (the trainer's flat fp32 parameter buffer): after K
+    data-parallel steps every rank must hold the same bytes — its clips differ, so only a correct gradient average keeps them so."""
+    x = t.detach().reshape(-1)
+    words = (x.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF) if x.dtype == torch.float32 else x.to(torch.float64).contiguous().view(torch.int64)
+    idx = torch.arange(words.numel(), dtype=torch.int64, device=words.device)
+    return int((words * (2 * idx + 1)).sum().item()) & ((1 << 64) - 1)
+
+
 def verify_replicas(checksums: Dict[str, int], device) -> Dict[str, object]:
     """All-reduce MIN and MAX of every named 64-bit checksum over the ranks and raise when a pair differs: a rank whose weights
     are not rank 0's (a broadcast that did not reach it, a different repack) must stop the run, not decode different tokens.

@@ -83,6 +83,20 @@ def test_bench_train_mode_dry_run_averages_gradients_and_metrics_over_the_ranks(
     assert rec["grad_allreduce_bytes"] > 30_000_000 * 4
     assert rec["logged"]["train/loss"] == 1.5 and rec["logged"]["train/score"] == 0.125 and rec["logged"]["batch_size"] == 32
     assert 1 <= rec["host_threads"] <= max(1, (os.cpu_count() or 2) // 2)
+    # round 6: the training line carries at N > 1 what the generate line does, so the first 8-GPU run of configs[4]
+    # proves by itself that the collectives saw N ranks and left identical replicas behind
+    assert rec["ranks_seen"] == 2 and len(rec["per_rank_ms_per_step"]) == 2 and all(t > 0 for t in rec["per_rank_ms_per_step"])
+    assert rec["grad_allreduce_bytes_per_step"] == rec["grad_allreduce_bytes"]
+    assert rec["replica_checksums"]["params_after_steps"].startswith("0x")
+
+
+def test_bench_train_mode_catches_replicas_that_differ_after_the_steps(tmp_path):
+    """One rank's parameters changed after the averaged step (test hook): the MIN / MAX all-reduce of the after-steps checksum differs,
+    every rank stops, no line is printed."""
+    r = _run({"M2M_BENCH_LOG_DIR": str(tmp_path), "M2M_BENCH_CORRUPT_RANK": "1"}, extra_args=("--mode", "train"))
+    assert r.returncode != 0
+    assert "replicas differ between ranks" in r.stderr and "params_after_steps" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
 def test_pmc_summary_without_the_launch_width_header_is_refused(tmp_path, capsys):
