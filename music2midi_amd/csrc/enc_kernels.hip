@@ -795,11 +795,10 @@ __global__ __launch_bounds__(RP_THREADS) void resid_panel_kernel(GemmArgs g) {
 static bool resid_panel_takes(int precision, int epi, const GemmArgs& a) {
   if (precision != M2M_PREC_BF16 || epi != EPI_RESID || a.resid || a.drop_thresh) return false;
   if (!(a.N == 128 || a.N == 256 || a.N == 384) || a.K % 64 != 0 || a.K < 128 || a.ldo != a.N) return false;
-  const char* v = getenv("M2M_RESID_PANEL");
-  if (v && v[0] == '0') return false;
-  if (v && v[0] == 'f') return true;
-  static const int min_blocks = [] { const char* e = getenv("M2M_NORM_GEMM_MIN_BLOCKS"); return e ? atoi(e) : 160; }();
-  return ceil_div(a.M, RP_BM) >= min_blocks;
+  const EncSwitches sw = enc_switches_now();
+  if (sw.resid_panel == 1) return false;
+  if (sw.resid_panel == 2) return true;
+  return ceil_div(a.M, RP_BM) >= sw.min_blocks;
 }
 
 static int launch_resid_panel(const GemmArgs& a, hipStream_t st) {
@@ -1134,14 +1133,28 @@ __global__ __launch_bounds__(NG_THREADS) void norm_gemm_kernel(GemmArgs g) {
 // One workgroup per 128 rows and no second workgroup per CU: the fused kernel needs about a chip's worth of row blocks to beat the
 // 128 x 128 tiling (which spreads a small problem over rows AND columns).  B = 32 x S = 864 gives 216, the reference-native 128 x 190
 // gives 190; below M2M_NORM_GEMM_MIN_BLOCKS (default 160) the two-kernel path runs.  M2M_NORM_GEMM: "0" never, "force" whatever the
-// size (the parity tests), "e<digits>" not for the listed epilogue ids (diagnostic).  Read per launch: a dozen launches per pass.
+// size (the parity tests), "e<digits>" not for the listed epilogue ids (diagnostic).  Latched per session (t5.h EncSwitches).
 static bool norm_gemm_on(int epi, int M) {
-  const char* v = getenv("M2M_NORM_GEMM");
-  if (v && v[0] == '0') return false;
-  if (v && v[0] == 'e') { for (const char* c = v + 1; *c; ++c) if (*c - '0' == epi) return false; return true; }
-  if (v && v[0] == 'f') return true;
-  static const int min_blocks = [] { const char* e = getenv("M2M_NORM_GEMM_MIN_BLOCKS"); return e ? atoi(e) : 160; }();
-  return ceil_div(M, 128) >= min_blocks;
+  const EncSwitches sw = enc_switches_now();
+  if (sw.norm_gemm == 1) return false;
+  if (sw.norm_gemm_skip) return !((sw.norm_gemm_skip >> epi) & 1u);
+  if (sw.norm_gemm == 2) return true;
+  return ceil_div(M, 128) >= sw.min_blocks;
+}
+
+// the switches as the environment has them now (a session latches the result when it is created: t5.h EncSwitches)
+thread_local const EncSwitches* tl_enc_switches = nullptr;
+EncSwitches read_enc_switches() {
+  EncSwitches sw;
+  auto tri = [](const char* name) { const char* v = getenv(name); return !v ? 0 : v[0] == '0' ? 1 : v[0] == 'f' ? 2 : 0; };
+  sw.norm_gemm = tri("M2M_NORM_GEMM");
+  if (const char* v = getenv("M2M_NORM_GEMM"))
+    if (v[0] == 'e') for (const char* c = v + 1; *c; ++c) if (*c >= '0' && *c <= '9') sw.norm_gemm_skip |= 1u << (*c - '0');
+  sw.resid_panel = tri("M2M_RESID_PANEL");
+  if (const char* e = getenv("M2M_ATTN_WIDE")) sw.attn_wide = e[0] == '0' ? 0 : 1;
+  if (const char* e = getenv("M2M_NORM_GEMM_MIN_BLOCKS")) sw.min_blocks = atoi(e);
+  sw.norm_gemm_hout = getenv("M2M_NORM_GEMM_HOUT") ? 1 : 0;
+  return sw;
 }
 
 int launch_norm_gemm(int precision, int epi, const GemmArgs& a_in, hipStream_t st) {
@@ -1162,7 +1175,7 @@ int launch_norm_gemm(int precision, int epi, const GemmArgs& a_in, hipStream_t s
   M2M_REQUIRE(a.M >= 1 && a.N >= 1, "norm_gemm: empty problem");
   }
   GemmArgs a2 = a_in;
-  if (!a2.h_out && getenv("M2M_NORM_GEMM_HOUT")) a2.h_out = const_cast<void*>(a2.A);      // diagnostic: the panel also goes to the fallback's h buffer
+  if (!a2.h_out && enc_switches_now().norm_gemm_hout) a2.h_out = const_cast<void*>(a2.A);      // diagnostic: the panel also goes to the fallback's h buffer
   const GemmArgs& a = a2;
   const size_t smem = ng_lds_bytes(a.K);
   dim3 grid((unsigned)ceil_div(a.M, NG_BM));
@@ -1871,10 +1884,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
 }
 
 // M2M_ATTN_WIDE=0: the bf16 mode runs the first kernel as well (A/B, and the test that holds the two forms to each other)
-static bool attn_wide_on() {
-  const char* e = getenv("M2M_ATTN_WIDE");
-  return !(e && e[0] == '0');
-}
+static bool attn_wide_on() { return enc_switches_now().attn_wide != 0; }
 
 template <typename T, bool CAUSAL, bool BIAS>
 static int launch_attn_tt(const AttnArgs& a, hipStream_t st) {

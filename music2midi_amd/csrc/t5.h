@@ -70,6 +70,28 @@ struct DecState {
 }  // namespace m2m
 
 namespace m2m {
+// Environment switches of the encoder-side kernel families (enc_kernels.hip), read ONCE when a session is created: they choose
+// between kernels that are not all bit-identical (the two attention forms differ in the last bits), so a session keeps the forms
+// it started with whatever the environment does later, and no launch calls getenv (not safe against a concurrent setenv).
+// The public entry points of a session put theirs in scope (EncSwitchScope); launches outside any scope (tools, the trainer's
+// products) read the environment themselves, as before.
+struct EncSwitches {
+  int norm_gemm = 0;            // M2M_NORM_GEMM: 0 by size, 1 never ("0"), 2 always ("force")
+  unsigned norm_gemm_skip = 0;  // "e<digits>": not for the listed epilogue ids (diagnostic)
+  int resid_panel = 0;          // M2M_RESID_PANEL: as norm_gemm
+  int attn_wide = 1;            // M2M_ATTN_WIDE=0: the first attention kernel in the bf16 mode as well
+  int min_blocks = 160;         // M2M_NORM_GEMM_MIN_BLOCKS: row blocks from which the row-panel kernels run
+  int norm_gemm_hout = 0;       // M2M_NORM_GEMM_HOUT (diagnostic)
+};
+EncSwitches read_enc_switches();
+extern thread_local const EncSwitches* tl_enc_switches;
+struct EncSwitchScope {
+  const EncSwitches* prev;
+  explicit EncSwitchScope(const EncSwitches* s) : prev(tl_enc_switches) { tl_enc_switches = s; }
+  ~EncSwitchScope() { tl_enc_switches = prev; }
+};
+inline EncSwitches enc_switches_now() { return tl_enc_switches ? *tl_enc_switches : read_enc_switches(); }
+
 constexpr int MAX_GROUPS = 8;
 
 // A contiguous range of clips decoded as one independent chain (own step counter/stream/graph).
@@ -123,6 +145,7 @@ struct m2m_session {
   int64_t* forced_ids;     // [B, max_dec]
   // current problem
   int B = 0, S = 0;
+  m2m::EncSwitches enc_sw;  // encoder-side kernel switches, latched at creation
   int attn_clips = 0;      // decode attention: clips per workgroup forced by M2M_DA_CLIPS when the session was created (0: by chain size)
   int ff_rows = 0;         // decode feed-forward: residual rows per workgroup forced by M2M_DEC_FF_ROWS (0: by chain size)
   int ff_slices = 0;       // decode feed-forward: hidden slices per workgroup forced by M2M_DEC_FF_SLICES (0: by chain size)

@@ -257,6 +257,7 @@ extern "C" int m2m_session_create(const m2m_model* m, int max_batch, int max_enc
   s->m = m; s->max_batch = max_batch; s->max_enc = max_enc_len; s->max_dec = max_dec_len;
   s->ws = (unsigned char*)workspace_dev; s->ws_bytes = workspace_bytes;
   s->attn_clips = da_clips; s->ff_rows = ff_rows; s->ff_slices = ff_slices;
+  s->enc_sw = read_enc_switches();
   unsigned char* b = s->ws;
   s->x_enc = (float*)(b + w.x_enc); s->h_enc = b + w.h_enc; s->qkv_enc = b + w.qkv_enc; s->vt_enc = b + w.vt_enc; s->attn_enc = b + w.attn_enc;
   s->mid_enc = b + w.mid_enc; s->enc_bias_tab = (float*)(b + w.enc_bias); s->dec_bias_tab = (float*)(b + w.dec_bias);
@@ -341,6 +342,7 @@ extern "C" int m2m_encode(m2m_session* s, const float* inputs_embeds_dev, int B,
   const int P = m->precision;
   hipStream_t st = (hipStream_t)stream;
   const int M = B * S, d = g.d_model;
+  const EncSwitchScope sw_scope(&s->enc_sw);
   s->encoded = false;
   M2M_CHECK_HIP(hipMemcpyAsync(s->x_enc, inputs_embeds_dev, (size_t)M * d * 4, hipMemcpyDeviceToDevice, st));
   int rc;
@@ -675,6 +677,7 @@ extern "C" int m2m_decode_forced(m2m_session* s, const int64_t* dec_input_ids_de
   if (!s->encoded) { set_error("m2m_decode_forced: %s", encode_missing(s)); return M2M_ERR_STATE; }
   M2M_REQUIRE(Ld >= 1 && Ld <= s->max_dec, "m2m_decode_forced: Ld %d outside [1, %d]", Ld, s->max_dec);
   hipStream_t st = (hipStream_t)stream;
+  const EncSwitchScope sw_scope(&s->enc_sw);
   M2M_CHECK_HIP(hipMemcpyAsync(s->forced_ids, dec_input_ids_dev, (size_t)s->B * Ld * 8, hipMemcpyDeviceToDevice, st));
   const char* fwd = getenv("M2M_FORWARD");          // "step": Ld KV-cached decode steps instead (read per call: tests toggle it)
   const bool stepwise = fwd && strcmp(fwd, "step") == 0;

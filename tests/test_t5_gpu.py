@@ -277,7 +277,7 @@ def test_norm_gemm_fused_kernel_is_bit_identical_to_the_two_kernel_path(monkeypa
     fused kernel (head-major q/k, transposed V, gated GELU in both weight interleaves, cross-q, cross-K/V with the final encoder norm
     as its prologue, fp32 lm_head): its logits and the greedy ids must be bit-identical with the switch on and off."""
     cfg = tiny_config() if cfg_name == "tiny" else DEFAULT_CONFIG
-    model, _, g = build(cfg, "bf16")
+    g = T5Geometry(load_config(cfg).model.t5)
     x = embeds(B, S, g.d_model).cuda()
     dec = torch.from_numpy((synth.uniform01(11, "dec", B * Ld) * (g.vocab_size - 3)).astype(np.int64).reshape(B, Ld) + 3).cuda()
     dec[:, 0] = g.decoder_start_token_id
@@ -285,7 +285,9 @@ def test_norm_gemm_fused_kernel_is_bit_identical_to_the_two_kernel_path(monkeypa
     for flag in ("force", "0"):          # "force": the fused kernel whatever the size (by default problems under 160 row blocks keep the two-kernel path)
         monkeypatch.setenv("M2M_NORM_GEMM", flag)
         monkeypatch.setenv("M2M_RESID_PANEL", flag)      # the row-panel residual products (attention output / feed-forward down projection) likewise
+        model, _, _ = build(cfg, "bf16")                 # the switches are latched when a session is created (round 6): a model per leg
         out[flag] = (model.logits_from_embeds(x, dec).cpu(), model.generate_from_embeds(x, max_length=min(Ld, 24)).cpu())
+        del model
     assert torch.isfinite(out["force"][0]).all()
     assert torch.equal(out["force"][0], out["0"][0]), f"fused norm+GEMM logits differ: max |d| {(out['force'][0] - out['0'][0]).abs().max():.3e}"
     assert torch.equal(out["force"][1], out["0"][1])
@@ -301,14 +303,16 @@ def test_attention_wide_form_against_the_first_form(monkeypatch, cfg_name, B, S,
     the logits may differ by bf16 re-rounding only (measured 4e-3 .. 7e-3 relative l2, the size of the bf16 mode's own noise floor against
     the emulating oracle) — bar 2 %; the fp32 mode must not change at all."""
     cfg = tiny_config() if cfg_name == "tiny" else DEFAULT_CONFIG
-    model, _, g = build(cfg, "bf16")
+    g = T5Geometry(load_config(cfg).model.t5)
     x = embeds(B, S, g.d_model).cuda()
     dec = torch.from_numpy((synth.uniform01(12, "dec", B * Ld) * (g.vocab_size - 3)).astype(np.int64).reshape(B, Ld) + 3).cuda()
     dec[:, 0] = g.decoder_start_token_id
     out = {}
     for flag in ("1", "0"):
         monkeypatch.setenv("M2M_ATTN_WIDE", flag)
+        model, _, _ = build(cfg, "bf16")                 # latched per session: a model per leg
         out[flag] = model.logits_from_embeds(x, dec).float().cpu()
+        del model
     assert torch.isfinite(out["1"]).all()
     d = (out["1"] - out["0"]).double()
     rel = float(d.norm() / out["0"].double().norm())
@@ -316,11 +320,12 @@ def test_attention_wide_form_against_the_first_form(monkeypatch, cfg_name, B, S,
     if S >= 128:           # at least one 64-key step (shorter inputs take the masked 32-key steps in both forms)
         assert not torch.equal(out["1"], out["0"]), "the switch did not change the kernel"
     assert rel < 2e-2
-    m32, _, _ = build(cfg, "fp32")
     o32 = {}
     for flag in ("1", "0"):
         monkeypatch.setenv("M2M_ATTN_WIDE", flag)
+        m32, _, _ = build(cfg, "fp32")
         o32[flag] = m32.logits_from_embeds(x, dec).cpu()
+        del m32
     assert torch.equal(o32["1"], o32["0"])
 
 
@@ -435,3 +440,24 @@ def test_multi_clip_attention_and_wide_ff_tiles_are_bit_identical(monkeypatch, p
     if precision == "fp32":
         from oracle.t5 import T5Oracle
         assert torch.equal(a, T5Oracle(geom, sd).generate(x, L))
+
+
+def test_encoder_switches_are_latched_when_the_session_is_created(monkeypatch):
+    """M2M_NORM_GEMM / M2M_RESID_PANEL / M2M_ATTN_WIDE / M2M_NORM_GEMM_MIN_BLOCKS choose between kernel forms that are not
+    all bit-identical; they are read ONCE per session, so an existing session keeps its kernels when the environment changes under it
+    (and no launch calls getenv).  The attention forms differ in the last bits: an existing model must not notice the flip."""
+    cfg = DEFAULT_CONFIG
+    g = T5Geometry(load_config(cfg).model.t5)
+    B, S, Ld = 2, 190, 40
+    x = embeds(B, S, g.d_model).cuda()
+    dec = torch.from_numpy((synth.uniform01(12, "dec", B * Ld) * (g.vocab_size - 3)).astype(np.int64).reshape(B, Ld) + 3).cuda()
+    dec[:, 0] = g.decoder_start_token_id
+    monkeypatch.setenv("M2M_ATTN_WIDE", "1")
+    model, _, _ = build(cfg, "bf16")
+    a = model.logits_from_embeds(x, dec).cpu()
+    monkeypatch.setenv("M2M_ATTN_WIDE", "0")
+    b = model.logits_from_embeds(x, dec).cpu()          # same session: still the wide form
+    assert torch.equal(a, b)
+    other, _, _ = build(cfg, "bf16")                    # a new session reads the environment again
+    c = other.logits_from_embeds(x, dec).cpu()
+    assert not torch.equal(a, c)
