@@ -2007,7 +2007,8 @@ int decode_launch_attn(m2m_session* s, const DecView& v, bool self, int layer, i
     const int resident = forced >= 0 ? forced : (int)(180e6 / per_layer);
     if (layer < resident) nt = false;
   }
-  const int clips = decode_attn_clips(s, v.nb);
+  int clips = decode_attn_clips(s, v.nb);
+  if (self && s->attn_clips_self > 0) clips = s->attn_clips_self;      // diagnostic: another width for the self-attention launches
   // self: A -> B (zero C); cross: B -> C (zero A)
   a.x = xbuf(s, v, self ? 0 : 1); a.x_out = xbuf(s, v, self ? 1 : 2); a.x_zero = xbuf(s, v, self ? 2 : 0);
   a.eps = g.layer_norm_eps; a.d = g.d_model;

@@ -884,7 +884,14 @@ __global__ __launch_bounds__(NG_THREADS) void norm_gemm_kernel(GemmArgs g) {
                                                                  // a lone wave per SIMD does not hide its own LDS / barrier latencies.)
   const int r = lane & 31, h = lane >> 5;
   const int m0 = blockIdx.x * NG_BM;
-  const int ntn = (g.N + NG_BN - 1) / NG_BN;
+  // Column groups (round 6, small problems): gridDim.y workgroups share a row block, each normalises the panel for itself (the rows
+  // come from L2 again, the arithmetic is the same) and sweeps ITS share of the column tiles - so a problem of a few row blocks still
+  // spreads over the chip without a separate norm launch.  nt_lo = first tile of this group; everything below counts tiles locally.
+  const int ntn_all = (g.N + NG_BN - 1) / NG_BN;
+  const int tpg = (ntn_all + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int nt_lo = (int)blockIdx.y * tpg;
+  const int ntn = min(tpg, ntn_all - nt_lo);
+  if (ntn <= 0) return;                                          // (uniform: a trailing group without tiles)
   const T* W = reinterpret_cast<const T*>(g.W);
   // (Measured and dropped: every workgroup starting its sweep at a different column tile, so that the 216 of them do not ask the L2
   // for the same 16 KB of weights at the same moment — encoder + cross-K/V 1.912 / 1.937 against 1.917 / 1.932 ms on the same box:
@@ -901,7 +908,7 @@ __global__ __launch_bounds__(NG_THREADS) void norm_gemm_kernel(GemmArgs g) {
 #define NG_LOADB(set_, t_)                                                                                         \
   {                                                                                                                \
     const int tt_ = (M2M_NG_SKIP & 2) ? min((t_), 2) : (t_);                                                       \
-    const int n0_ = (tt_ / NK) * NG_BN, k0_ = (tt_ % NK) * NG_BK;                                                  \
+    const int n0_ = (nt_lo + tt_ / NK) * NG_BN, k0_ = (tt_ % NK) * NG_BK;                                          \
     r##set_##0 = *reinterpret_cast<const uint4*>(W + (int64_t)min(n0_ + br0, g.N - 1) * K + k0_ + bc0);           \
     r##set_##1 = *reinterpret_cast<const uint4*>(W + (int64_t)min(n0_ + br1, g.N - 1) * K + k0_ + bc1);           \
   }
@@ -946,14 +953,14 @@ __global__ __launch_bounds__(NG_THREADS) void norm_gemm_kernel(GemmArgs g) {
           const float y0 = gw0.x * (v.x * rstd), y1 = gw0.y * (v.y * rstd), y2 = gw0.z * (v.z * rstd), y3 = gw0.w * (v.w * rstd);
           const uint2 pk = make_uint2(pack2_bf16(y0, y1), pack2_bf16(y2, y3));
           *reinterpret_cast<uint2*>(panel + rl * PP + lane * 4) = pk;
-          if (g.h_out && m0 + rl < g.M) *reinterpret_cast<uint2*>(reinterpret_cast<T*>(g.h_out) + (int64_t)(m0 + rl) * K + lane * 4) = pk;
+          if (g.h_out && blockIdx.y == 0 && m0 + rl < g.M) *reinterpret_cast<uint2*>(reinterpret_cast<T*>(g.h_out) + (int64_t)(m0 + rl) * K + lane * 4) = pk;
         }
         if (two) {
           const float4 v = v1[i];
           const float y0 = gw1.x * (v.x * rstd), y1 = gw1.y * (v.y * rstd), y2 = gw1.z * (v.z * rstd), y3 = gw1.w * (v.w * rstd);
           const uint2 pk = make_uint2(pack2_bf16(y0, y1), pack2_bf16(y2, y3));
           *reinterpret_cast<uint2*>(panel + rl * PP + lane * 4 + 256) = pk;
-          if (g.h_out && m0 + rl < g.M) *reinterpret_cast<uint2*>(reinterpret_cast<T*>(g.h_out) + (int64_t)(m0 + rl) * K + lane * 4 + 256) = pk;
+          if (g.h_out && blockIdx.y == 0 && m0 + rl < g.M) *reinterpret_cast<uint2*>(reinterpret_cast<T*>(g.h_out) + (int64_t)(m0 + rl) * K + lane * 4 + 256) = pk;
         }
       }
     }
@@ -1016,7 +1023,7 @@ __global__ __launch_bounds__(NG_THREADS) void norm_gemm_kernel(GemmArgs g) {
   for (int ti = 0; ti < TPT; ++ti) {
     const int nt = nt0 + ti;
     if (nt >= ntn) break;                                         // uniform
-    const int n0 = nt * NG_BN;
+    const int n0 = (nt_lo + nt) * NG_BN;
     f32x16 acc0 = zero_acc(), acc1 = zero_acc();
     // ---- epilogue of this tile follows its k loop (Cs is its own buffer: the stores overlap the next tile's first k steps; the
     //      next write of Cs is a whole k loop of barriers away).  Measured alternative: the staged tile leaving in pieces, one per
@@ -1139,7 +1146,17 @@ static bool norm_gemm_on(int epi, int M) {
   if (sw.norm_gemm == 1) return false;
   if (sw.norm_gemm_skip) return !((sw.norm_gemm_skip >> epi) & 1u);
   if (sw.norm_gemm == 2) return true;
-  return ceil_div(M, 128) >= sw.min_blocks;
+  return ceil_div(M, 128) >= sw.min_blocks || sw.norm_gemm_split;
+}
+// column groups per row block: one from a chip's worth of row blocks on (the round-5 form), else as many as keep the launch at about
+// one workgroup per CU - down to one column tile per workgroup (M2M_NORM_GEMM_SPLIT=0: never split, the two-kernel path below the gate)
+static int norm_gemm_groups(int M, int N) {
+  const EncSwitches sw = enc_switches_now();
+  const int rb = ceil_div(M, NG_BM), ntn = ceil_div(N, NG_BN);
+  if (rb >= sw.min_blocks || !sw.norm_gemm_split) return 1;
+  int gq = 256 / rb;
+  if (gq < 1) gq = 1;
+  return gq > ntn ? ntn : gq;
 }
 
 // the switches as the environment has them now (a session latches the result when it is created: t5.h EncSwitches)
@@ -1154,6 +1171,7 @@ EncSwitches read_enc_switches() {
   if (const char* e = getenv("M2M_ATTN_WIDE")) sw.attn_wide = e[0] == '0' ? 0 : 1;
   if (const char* e = getenv("M2M_NORM_GEMM_MIN_BLOCKS")) sw.min_blocks = atoi(e);
   sw.norm_gemm_hout = getenv("M2M_NORM_GEMM_HOUT") ? 1 : 0;
+  if (const char* e = getenv("M2M_NORM_GEMM_SPLIT")) sw.norm_gemm_split = e[0] == '0' ? 0 : 1;
   return sw;
 }
 
@@ -1178,7 +1196,7 @@ int launch_norm_gemm(int precision, int epi, const GemmArgs& a_in, hipStream_t s
   if (!a2.h_out && enc_switches_now().norm_gemm_hout) a2.h_out = const_cast<void*>(a2.A);      // diagnostic: the panel also goes to the fallback's h buffer
   const GemmArgs& a = a2;
   const size_t smem = ng_lds_bytes(a.K);
-  dim3 grid((unsigned)ceil_div(a.M, NG_BM));
+  dim3 grid((unsigned)ceil_div(a.M, NG_BM), (unsigned)norm_gemm_groups(a.M, a.N));
 #define NG_GO_K(E_, NK_)                                                                     \
   do {                                                                                       \
     M2M_OPT_IN_LDS((norm_gemm_kernel<E_, NK_>), 160 * 1024);                                 \

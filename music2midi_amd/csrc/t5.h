@@ -82,6 +82,7 @@ struct EncSwitches {
   int attn_wide = 1;            // M2M_ATTN_WIDE=0: the first attention kernel in the bf16 mode as well
   int min_blocks = 160;         // M2M_NORM_GEMM_MIN_BLOCKS: row blocks from which the row-panel kernels run
   int norm_gemm_hout = 0;       // M2M_NORM_GEMM_HOUT (diagnostic)
+  int norm_gemm_split = 1;      // M2M_NORM_GEMM_SPLIT=0: below min_blocks the two-kernel path instead of the column-group form (round 6)
 };
 EncSwitches read_enc_switches();
 extern thread_local const EncSwitches* tl_enc_switches;
@@ -147,6 +148,7 @@ struct m2m_session {
   int B = 0, S = 0;
   m2m::EncSwitches enc_sw;  // encoder-side kernel switches, latched at creation
   int attn_clips = 0;      // decode attention: clips per workgroup forced by M2M_DA_CLIPS when the session was created (0: by chain size)
+  int attn_clips_self = 0; // M2M_DA_CLIPS_SELF (diagnostic): clips per self-attention workgroup when it should differ from the cross kernels
   int ff_rows = 0;         // decode feed-forward: residual rows per workgroup forced by M2M_DEC_FF_ROWS (0: by chain size)
   int ff_slices = 0;       // decode feed-forward: hidden slices per workgroup forced by M2M_DEC_FF_SLICES (0: by chain size)
   int repacks = 0, rows_moved = 0;   // live-row re-packings / rows moved by them in the last m2m_generate_greedy

@@ -258,6 +258,7 @@ extern "C" int m2m_session_create(const m2m_model* m, int max_batch, int max_enc
   s->ws = (unsigned char*)workspace_dev; s->ws_bytes = workspace_bytes;
   s->attn_clips = da_clips; s->ff_rows = ff_rows; s->ff_slices = ff_slices;
   s->enc_sw = read_enc_switches();
+  { const char* v = getenv("M2M_DA_CLIPS_SELF"); const int c = (v && v[0]) ? atoi(v) : 0; s->attn_clips_self = (c == 1 || c == 2 || c == 4) ? c : 0; }
   unsigned char* b = s->ws;
   s->x_enc = (float*)(b + w.x_enc); s->h_enc = b + w.h_enc; s->qkv_enc = b + w.qkv_enc; s->vt_enc = b + w.vt_enc; s->attn_enc = b + w.attn_enc;
   s->mid_enc = b + w.mid_enc; s->enc_bias_tab = (float*)(b + w.enc_bias); s->dec_bias_tab = (float*)(b + w.dec_bias);
