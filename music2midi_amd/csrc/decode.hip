@@ -1970,7 +1970,8 @@ bool decode_finished_skip_on() {
 int decode_attn_clips(const m2m_session* s, int nb) {
   if (s->attn_clips > 0) return s->attn_clips;
   // same-box sweeps (tools/native_mc_sweep.py, us per step, C = 1 / 2 / 4): 2 x 16 clips, S = 864: 195 / 238 / -; 2 x 24: 264 / 266 / 363;
-  // 2 x 32: 329 / 300 / 386; 2 x 64, S = 864: 595 / 522 / 512; 2 x 64, S = 190 (the reference's chunk): 446 / 383 / 362
+  // 2 x 32: 329 / 300 / 386; 2 x 64, S = 864: 595 / 522 / 512; 2 x 64, S = 190 (the reference's chunk): 446 / 383 / 362;
+  // S = 190: 2 x 32: 256 / 226 / 289; 2 x 40: - / 276 / 299; 2 x 48: - / 316 / 313
   return nb >= 48 ? 4 : (nb >= 32 ? 2 : 1);
 }
 
@@ -1984,8 +1985,8 @@ int decode_ff_rows(const m2m_session* s, int nb) {
 int decode_ff_slices(const m2m_session* s, int nb) {
   if (s->ff_slices > 0) return s->ff_slices;
   // same-box sweeps (tools/native_mc_sweep.py, us per step, 1 / 2 / 4 slices): 2 x 16 clips 196 / 204 / -; 2 x 32: 301 / 292 / 312;
-  // 2 x 64 (the reference's chunk): 362 / 349-353 / 345-347
-  return nb >= 48 ? 4 : (nb >= 32 ? 2 : 1);
+  // 2 x 48, S = 190: - / 313 / 326; 2 x 64 (the reference's chunk): 362 / 349-353 / 345-347
+  return nb >= 56 ? 4 : (nb >= 32 ? 2 : 1);
 }
 
 int decode_launch_attn(m2m_session* s, const DecView& v, bool self, int layer, int self_len, hipStream_t st, bool headless, bool skip_finished) {

@@ -19,8 +19,12 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 torch.set_num_threads(16)
 tiny = copy.deepcopy(DEFAULT_CONFIG); tiny["model"]["t5"].update(d_model=128, d_ff=256, num_layers=2, num_decoder_layers=2, num_heads=2)
 models = {}
-def get(cfg_name, eos_kind):
-    key = (cfg_name, eos_kind)
+# kernel forms of the decode step (round 6): (clips per attention workgroup, hidden slices per feed-forward workgroup), latched when a
+# model's session is created - 0 = by chain size.  Every form must give the oracle's ids at every shape, however small the chain.
+FORMS = [(0, 0), (2, 2), (4, 4), (4, 1), (2, 4), (1, 1)]
+def get(cfg_name, eos_kind, form=(0, 0)):
+    key = (cfg_name, eos_kind, form)
+    os.environ["M2M_DA_CLIPS"], os.environ["M2M_DEC_FF_SLICES"] = str(form[0]), str(form[1])     # read by the session this model creates on first use
     if key not in models:
         cfg = tiny if cfg_name == "tiny" else DEFAULT_CONFIG
         g = T5Geometry(load_config(cfg).model.t5)
@@ -43,7 +47,8 @@ for i, r in enumerate(u):
     os.environ.pop("M2M_GROUP_ROWS", None)
     if rows: os.environ["M2M_GROUP_ROWS"] = str(rows)
     os.environ["M2M_GRAPH_STEPS"] = str([1, 3, 8][int(r[6] * 3)])
-    m, orc, g = get(cfg_name, eos_kind)
+    form = FORMS[int(r[7] * len(FORMS))]
+    m, orc, g = get(cfg_name, eos_kind, form)
     x = torch.from_numpy(synth.normal(1000 + i, "x", (B, S, g.d_model), 3.0))
     want, margins = orc.generate(x, L, return_margins=True)
     got = m.generate_from_embeds(x.cuda(), max_length=L).cpu()
@@ -64,8 +69,8 @@ for i, r in enumerate(u):
             print(f"near-tie case {i}: {cfg_name} eos={eos_kind} B={B} S={S} L={L} rows={rows}: first differences at oracle margin <= {worst:.2e}", flush=True)
             continue
         bad += 1
-        print(f"MISMATCH case {i}: {cfg_name} eos={eos_kind} B={B} S={S} L={L} rows={rows} graph={os.environ['M2M_GRAPH_STEPS']} got {tuple(got.shape)} want {tuple(want.shape)}", flush=True)
+        print(f"MISMATCH case {i}: {cfg_name} eos={eos_kind} form={form} B={B} S={S} L={L} rows={rows} graph={os.environ['M2M_GRAPH_STEPS']} got {tuple(got.shape)} want {tuple(want.shape)}", flush=True)
     elif i % 10 == 0:
-        print(f"case {i}: {cfg_name} eos={eos_kind} B={B} S={S} L={L} rows={rows} -> ids {tuple(got.shape)} identical ({time.time() - t0:.0f} s)", flush=True)
+        print(f"case {i}: {cfg_name} eos={eos_kind} form={form} B={B} S={S} L={L} rows={rows} -> ids {tuple(got.shape)} identical ({time.time() - t0:.0f} s)", flush=True)
 print("FUZZ", "FAILED" if bad else "OK", f"{n_cases} cases, {bad} mismatches, {near} excused near-ties (oracle top-2 margin < {NEAR_TIE:g})")
 sys.exit(1 if bad else 0)
