@@ -461,3 +461,30 @@ def test_encoder_switches_are_latched_when_the_session_is_created(monkeypatch):
     other, _, _ = build(cfg, "bf16")                    # a new session reads the environment again
     c = other.logits_from_embeds(x, dec).cpu()
     assert not torch.equal(a, c)
+
+
+@pytest.mark.parametrize("d_model,d_ff,heads", [(512, 1024, 8), (256, 512, 4), (128, 256, 2)])
+def test_other_model_widths_through_every_decode_form(monkeypatch, d_model, d_ff, heads):
+    """m2m_model_create accepts d_model 128 / 256 / 384 / 512: the widths the reference never uses go through the same kernel forms
+    (the multi-clip attention normalises a row with a wave PAIR — one wave at d_model <= 256 —, keeps 512 fixed-point columns per
+    row in LDS, and the multi-slice feed-forward needs d_ff / 32 divisible by its slice count).  fp32 ids == oracle for the first
+    forms and for C = 2 / 4 clips per workgroup with 2 / 4 slices, on a ragged-EOS batch that is no multiple of C."""
+    cfg = copy.deepcopy(DEFAULT_CONFIG)
+    cfg["model"]["t5"].update(d_model=d_model, d_ff=d_ff, num_layers=2, num_decoder_layers=2, num_heads=heads)
+    geom = T5Geometry(load_config(cfg).model.t5)
+    sd = synth.t5_state_dict(geom, seed=3)
+    synth.perturb_layer_norms(sd, 3)
+    synth.force_eos_head(sd, geom)
+    B, S, L = 11, 70, 48
+    x = embeds(B, S, geom.d_model, seed=41)
+    from oracle.t5 import T5Oracle
+    want = T5Oracle(geom, sd).generate(x, L)
+    for clips, slices in (("1", "1"), ("2", "2"), ("4", "4"), ("0", "0")):
+        monkeypatch.setenv("M2M_DA_CLIPS", clips)
+        monkeypatch.setenv("M2M_DEC_FF_SLICES", slices)
+        m = T5Transformer(cfg, precision="fp32")
+        load_t5_state(m, sd, strict=False)
+        m = m.cuda().eval()
+        got = m.generate_from_embeds(x.cuda(), max_length=L).cpu()
+        assert torch.equal(got, want), f"d_model={d_model}: ids differ from the oracle with M2M_DA_CLIPS={clips} M2M_DEC_FF_SLICES={slices}"
+        del m
