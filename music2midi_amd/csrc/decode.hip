@@ -332,7 +332,8 @@ struct DecFfArgs {
 constexpr int FF_C = 32;        // hidden columns per workgroup
 constexpr int FF_HP = FF_C + 8; // LDS row pitch of the activation slice (elements; keeps 16-byte alignment)
 
-// diagnostic builds only (-DM2M_FF_ABL=mask, never the product): 1 = the slice workgroups add nothing (x passes through), 2 = they read no rows of x
+// diagnostic builds only (-DM2M_FF_ABL=mask, never the product): 1 = the slice workgroups add nothing (x passes through), 2 = they read no rows of x,
+// 4 (multi-slice form) = the later slices re-use the first slice's weights
 #ifndef M2M_FF_ABL
 #define M2M_FF_ABL 0
 #endif
@@ -570,18 +571,30 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(1, 2)))
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) xraw[s][q] = *reinterpret_cast<const longlong2*>(xr + 32 * s + 2 * q);
+    for (int q = 0; q < 4; ++q) xraw[s][q] = (M2M_FF_ABL & 2) ? make_longlong2(1 << 28, 1 << 27) : *reinterpret_cast<const longlong2*>(xr + 32 * s + 2 * q);
     g0[s] = *reinterpret_cast<const float4*>(a.ln_w + kbeg + 32 * s);
     g1[s] = *reinterpret_cast<const float4*>(a.ln_w + kbeg + 32 * s + 4);
   }
-  Frag<T> wf[4][2];
+  // NB register sets of slice weights (slice i in set i % NB, the slice NB ahead requested into the set just consumed).  The ablation
+  // build prices the later slices' fetches at 2.9 of the kernel's 12.2 us with NB = 1 (-DM2M_FF_ABL=4: the later slices re-use the
+  // first slice's weights), but TWO sets in flight measured SLOWER on the same box (tools/native_mc_sweep.py, us per step): 2 x 64
+  // clips 351.7 / 352.7 against 344-348, with 2 slices 365.7 against 349-353, 2 x 32 clips 301.1 against 291.9 - as with the K/V
+  // prefetch, bytes requested earlier delay everybody's latency-critical rows.  NB = 1.
+#ifndef M2M_FF_MULTI_SETS
+#define M2M_FF_MULTI_SETS 1
+#endif
+  constexpr int NB = (NSL > 1 && sizeof(T) == 2) ? M2M_FF_MULTI_SETS : 1;
+  Frag<T> wf[NB][4][2];
+  Frag<T> wo[NB][4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int b = 0; b < NB; ++b) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) wf[j][s] = load_frag(Wi + (int64_t)(2 * FF_C * s0 + 16 * j + r) * K + kbeg + 32 * s);
-  Frag<T> wo[4];
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) wo[j] = load_frag(Wo + (int64_t)(16 * (4 * ks + j) + r) * a.d_ff + FF_C * s0 + 8 * g);
+      for (int s = 0; s < 2; ++s) wf[b][j][s] = load_frag(Wi + (int64_t)(2 * FF_C * (s0 + b) + 16 * j + r) * K + kbeg + 32 * s);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wo[b][j] = load_frag(Wo + (int64_t)(16 * (4 * ks + j) + r) * a.d_ff + FF_C * (s0 + b) + 8 * g);
+  }
   __builtin_amdgcn_sched_barrier(0);
   asm volatile("" ::"s"(done));
   float4 x0[2], x1[2];
@@ -627,12 +640,12 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(1, 2)))
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) mma32_16(acc[j], fa[s], wf[j][s]);
-    if (i + 1 < NSL) {   // the next slice's up-projection weights, into the registers just consumed
+      for (int j = 0; j < 4; ++j) mma32_16(acc[j], fa[s], wf[i % NB][j][s]);
+    if (i + NB < NSL && !(M2M_FF_ABL & 4)) {   // the up-projection weights of the slice NB ahead, into the set just consumed
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) wf[j][s] = load_frag(Wi + (int64_t)(2 * FF_C * (s0 + i + 1) + 16 * j + r) * K + kbeg + 32 * s);
+        for (int s = 0; s < 2; ++s) wf[i % NB][j][s] = load_frag(Wi + (int64_t)(2 * FF_C * (s0 + i + NB) + 16 * j + r) * K + kbeg + 32 * s);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -655,11 +668,11 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(1, 2)))
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       o[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      mma32_16(o[j], fh, wo[j]);
+      mma32_16(o[j], fh, wo[i % NB][j]);
     }
-    if (i + 1 < NSL) {
+    if (i + NB < NSL && !(M2M_FF_ABL & 4)) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) wo[j] = load_frag(Wo + (int64_t)(16 * (4 * ks + j) + r) * a.d_ff + FF_C * (s0 + i + 1) + 8 * g);
+      for (int j = 0; j < 4; ++j) wo[i % NB][j] = load_frag(Wo + (int64_t)(16 * (4 * ks + j) + r) * a.d_ff + FF_C * (s0 + i + NB) + 8 * g);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -669,6 +682,7 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(1, 2)))
       sum1[j] += xq_fix_guarded(v1, a.state);
     }
   }
+  if (M2M_FF_ABL & 1) return;
   xq_t* const p0 = a.x_out + (int64_t)(b0 + rl) * K + 64 * ks + r;
   const bool ok0 = rl < FF_R && b0 + rl < a.B, ok1 = rl + 1 < FF_R && b0 + rl + 1 < a.B;
 #pragma unroll

@@ -303,7 +303,27 @@ extern "C" int m2m_session_create(const m2m_model* m, int max_batch, int max_enc
   for (int i = 0; i < MAX_GROUPS && e == hipSuccess; ++i) {
     DecGroup& gr = s->groups[i];
     gr.view.state = s->states + i;
-    e = hipStreamCreateWithFlags(&gr.stream, hipStreamNonBlocking);
+    // M2M_CHAIN_CU_MASK=<n> (diagnostic, round 6): chain i may only use the CUs whose index within their XCD satisfies
+    // (cu * n / 32) % n == i % n, i.e. n disjoint slices of every XCD - to see whether two chains of 128-workgroup launches already
+    // land side by side on their own (they do: DESIGN 4.3)
+    const char* cm = getenv("M2M_CHAIN_CU_MASK");
+    const int nmask = (cm && cm[0]) ? atoi(cm) : 0;
+    if (nmask >= 2 && nmask <= 8) {
+      uint32_t mask[8];                                   // 256 CUs = 8 XCDs x 32; bit index = the runtime's CU numbering
+      const int mode = getenv("M2M_CHAIN_CU_MASK_MODE") ? atoi(getenv("M2M_CHAIN_CU_MASK_MODE")) : 0;
+      for (int w = 0; w < 8; ++w) {
+        mask[w] = 0;
+        for (int b = 0; b < 32; ++b) {
+          const int cu = w * 32 + b;
+          // mode 0: contiguous slices of each 32-CU group; mode 1: interleaved CUs
+          const int owner = mode == 0 ? ((b * nmask) / 32) % nmask : cu % nmask;
+          if (owner == i % nmask) mask[w] |= 1u << b;
+        }
+      }
+      e = hipExtStreamCreateWithCUMask(&gr.stream, 8, mask);
+    } else {
+      e = hipStreamCreateWithFlags(&gr.stream, hipStreamNonBlocking);
+    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&gr.ev_done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc((void**)&gr.state_host, sizeof(DecState), hipHostMallocDefault);
   }
