@@ -838,6 +838,9 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
 #ifndef M2M_DA_PF_SELF
 #define M2M_DA_PF_SELF 2
 #endif
+#ifndef M2M_DA_REQUEST_FIRST
+#define M2M_DA_REQUEST_FIRST 0
+#endif
   // fp32 (parity) mode, cross-attention: 4 rounds.  Its per-workgroup stream is 442 KB at S = 864 against a ~3 us prologue, and the
   // same-box A/B (tools/r6_fp32_sweep.sh, 32 x S = 864, us per step incl. encoder) reads 345.1 / 345.5 / 345.9 with 2 rounds, 345.5
   // with 3, 340.9 with 4; 3 rounds in the self-attention: 353.4.
@@ -1064,6 +1067,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
 #pragma unroll
     for (int e = 0; e < E; ++e) s = fmaf(qv[e], ks.get(e), s);
     s = group_sum<LPR>(s);                                                   // every lane of the group gets the sum
+#if M2M_DA_REQUEST_FIRST       // rounds 1-5: the slot re-requested BEFORE its visit (see below)
     float vrow[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) vrow[e] = vs.get(e);
@@ -1076,6 +1080,24 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
       if (SELF) s += biasl[t - key];
       visit(s, vrow);
     }
+#else
+    // The slot is re-requested AFTER it has been consumed (round 6).  With the request in front of the visit the compiler sinks V's
+    // unpacking into the predicated block, keeps the packed V alive past the request, loads into a SECOND register set and copies
+    // it back behind s_waitcnt vmcnt(0) at the end of EVERY iteration (ISA of rounds 1-5: vmcnt(2), 4 v_mov, vmcnt(0), 4 v_mov at
+    // the back edge): the "rolling window" drained once per iteration - two rounds per memory round trip and CU.
+    if (key < n_live) {   // VALU-only predicate
+      float vrow[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) vrow[e] = vs.get(e);
+      if (SELF) s += biasl[t - key];
+      visit(s, vrow);
+    }
+    if (reissue == 1 || (reissue == 2 && k0 + (u + PF) * KPB < n_live)) {   // workgroup-uniform, no lane is predicated
+      const int64_t off = (int64_t)min(key + PF * KPB, last) * DK + sub * E;
+      ks.v = M2M_KV_LOAD(reinterpret_cast<const V16*>(Kb + off));
+      vs.v = M2M_KV_LOAD(reinterpret_cast<const V16*>(Vb + off));
+    }
+#endif
   };
   int k0 = 0;
   // main loop: all PF re-requests of the iteration exist (the last one targets round k0 / KPB + 2 PF - 1)
