@@ -440,7 +440,19 @@ def reference_native_record(model, cfg, geom, dev, reps: int = 3, esize: int = 2
     n_steps = toks.shape[1] - 1
     step_bytes = decode_bytes_per_step(Bn, Sn, (1 + n_steps) / 2.0, esize)
     step_us = dt / n_steps * 1e6              # encoder + frontend included (an upper bound on the step: they are ~1 % of the batch)
-    return {"workload": f"reference-native geometry: {Bn} segments x {Tn} samples (3 s @ 16 kHz, S={Sn}), {'bf16' if esize == 2 else 'fp32'}, max_length {MAX_LENGTH}",
+    # the attention launch sets of this geometry, live (m2m_bench_kernel: both 64-clip chains' launches on their own streams, cycling the layers)
+    from music2midi_amd import native
+    x = model.encoder_inputs(inputs)
+    model._encode(x, MAX_LENGTH)
+    cross_us, cross_bytes = model.bench_kernel(native.KERNEL_DEC_CROSS_ATTN, MAX_LENGTH // 2, 300)
+    self_us, self_bytes = model.bench_kernel(native.KERNEL_DEC_SELF_ATTN, MAX_LENGTH // 2, 300)
+    kernels = {"cross_attn_launch_set_us": cross_us, "cross_attn_GBs": cross_bytes / (cross_us * 1e-6) / 1e9,
+               "cross_attn_frac": cross_bytes / (cross_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+               "self_attn_launch_set_us_at_t512": self_us, "self_attn_GBs": self_bytes / (self_us * 1e-6) / 1e9,
+               "self_attn_frac": self_bytes / (self_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+               "launch_set": f"{Bn} clips = 2 co-scheduled chain launches of {Bn // 2} clips (dec_attn_mc_kernel, 4 clips of one head per workgroup)"}
+    del x
+    return {"kernels": kernels, "workload": f"reference-native geometry: {Bn} segments x {Tn} samples (3 s @ 16 kHz, S={Sn}), {'bf16' if esize == 2 else 'fp32'}, max_length {MAX_LENGTH}",
             "tokens_per_s": Bn * n_steps / dt, "ms_per_batch": dt * 1e3, "new_tokens_per_clip": int(n_steps),
             "step_algorithmic_bytes": step_bytes, "step_mean_us": step_us, "step_achieved_GBs": step_bytes / (step_us * 1e-6) / 1e9,
             "step_frac": step_bytes / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
