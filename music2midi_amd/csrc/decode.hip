@@ -1269,8 +1269,11 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(DecAttnArgs a) {
 #ifndef M2M_MC_WAVES
 #define M2M_MC_WAVES 4
 #endif
-template <typename T, bool SELF, bool NT, bool FETCH, int C>
+// CIF = clips in flight: register-slot sets, clip c in set c % CIF, a clip's last rounds handed to the next walking clip OF ITS SET.
+// 1: one stream, clip after clip (the product).  2 (cross-attention, M2M_MC_CIF=2): measured slower, see launch_dec_attn_mc_t.
+template <typename T, bool SELF, bool NT, bool FETCH, int C, int CIF = 1>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(M2M_MC_WAVES, M2M_MC_WAVES))) void dec_attn_mc_kernel(DecAttnArgs a, int nb) {
+  static_assert(CIF == 1 || (CIF == 2 && !SELF && C % 2 == 0), "two clips in flight: cross-attention, an even clip count");
   static_assert(!FETCH || SELF, "only the layer-0 self-attention fetches its input row from the embedding table");
   static_assert(C >= 2 && C <= 8, "a wave pair normalises one clip's row: at most 8 clips per 16-wave workgroup");
   constexpr int E = 16 / sizeof(T);
@@ -1374,13 +1377,18 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(M2M_MC_WAV
   };
   // the first walking clip's first PF rounds, right behind the prologue's own loads (clamped addresses, never predicated; when
   // no clip walks this is clip 0's last row once more - dropped)
-  const int c_first = walk ? __builtin_ctz(walk) : 0;
-  Vec16<T> kv[PF], vv[PF];
+  constexpr unsigned SETBITS = CIF == 1 ? 0xFFFFFFFFu : 0x55555555u;      // the clips of set 0
+  Vec16<T> kv[CIF][PF], vv[CIF][PF];
 #pragma unroll
-  for (int u = 0; u < PF; ++u) {
-    const unsigned off = (unsigned)((min(kslot + u * KPB, last) * DK + sub * E) * (int)sizeof(T));
-    kv[u].v = kvload(rK, off, (unsigned)c_first * clip_bytes);
-    vv[u].v = kvload(rV, off, (unsigned)c_first * clip_bytes);
+  for (int st = 0; st < CIF; ++st) {
+    const unsigned mine = walk & (SETBITS << st);
+    const int c_first = mine ? __builtin_ctz(mine) : st;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const unsigned off = (unsigned)((min(kslot + u * KPB, last) * DK + sub * E) * (int)sizeof(T));
+      kv[st][u].v = kvload(rK, off, (unsigned)c_first * clip_bytes);
+      vv[st][u].v = kvload(rV, off, (unsigned)c_first * clip_bytes);
+    }
   }
   __builtin_amdgcn_sched_barrier(0);
 
@@ -1504,7 +1512,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(M2M_MC_WAV
 
   // ---- 3. the clips' streams, one after the other ----
 #pragma nounroll
-  for (int c = 0; c < C; ++c) {
+  for (int c0 = 0; c0 < C; c0 += CIF) {
+#pragma unroll
+  for (int st = 0; st < CIF; ++st) {
+    const int c = c0 + st;
     const bool walks = (walk >> c) & 1u;                                          // uniform
     const unsigned cbase = (unsigned)c * clip_bytes;      // this clip inside the descriptors (an invalid tail clip walks nothing)
     // per-clip OPAQUE copies of the lane's place in a round: derived from threadIdx the hand-over offsets below are loop invariants
@@ -1569,16 +1580,16 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(M2M_MC_WAV
       int k0 = 0;
       for (; k0 + PF * KPB < kend; k0 += PF * KPB) {           // every re-request lies inside this clip's (padded) rounds
 #pragma unroll
-        for (int u = 0; u < PF; ++u) round(k0, u, kv[u], vv[u], 1, 0);
+        for (int u = 0; u < PF; ++u) round(k0, u, kv[st][u], vv[st][u], 1, 0);
       }
       // the clip's last PF rounds hand their slots to the next walking clip, so the stream runs through the merge below.  After the
       // LAST walking clip the same loads are issued with a lane offset beyond the descriptor's range: the hardware's range check
       // drops them (zeros, no memory access) - one code path, so the slots stay in ONE register set (with a second, load-free path
       // for the last clip the register allocator kept a second set of 8 PF registers for the handed-over rounds and copied it back)
-      const unsigned rest = walk >> (c + 1);
-      const unsigned nxt = rest ? cbase + (unsigned)(__builtin_ctz(rest) + 1) * clip_bytes : 0x7F000000u;
+      const unsigned rest = (walk >> (c + CIF)) & SETBITS;                     // later walking clips of this set
+      const unsigned nxt = rest ? cbase + (unsigned)(__builtin_ctz(rest) + CIF) * clip_bytes : 0x7F000000u;
 #pragma unroll
-      for (int u = 0; u < PF; ++u) round(k0, u, kv[u], vv[u], 2, nxt);
+      for (int u = 0; u < PF; ++u) round(k0, u, kv[st][u], vv[st][u], 2, nxt);
     }
     if (SELF && wave == 0 && lane < LPR) {   // the key/value appended this step (relative position 0): group 0
       float s = 0.f;
@@ -1625,6 +1636,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(M2M_MC_WAV
       }
       __syncthreads();
     }
+  }   // clips of a trip (sets)
   }
 
   // ---- 4. output projections of this head, accumulated into the C residual rows (the slice of wo is requested only here: 16 / 32
@@ -1685,12 +1697,21 @@ static void launch_dec_attn_t(bool self, bool nt, const DecAttnArgs& a, dim3 gri
 template <typename T, int C>
 static void launch_dec_attn_mc_t(bool self, bool nt, const DecAttnArgs& a, int nb, size_t smem, hipStream_t st) {
   const dim3 grid((unsigned)a.H, (unsigned)ceil_div(nb, C));
+  // M2M_MC_CIF=2 (diagnostic): two clips in flight in the cross-attention.  At S = 190 a clip's whole stream is one round trip, so the
+  // kernel is C dependent round trips long and two register-slot sets overlap them - on paper 14 -> ~10.5 us per launch; measured on
+  // one box (tools/native_mc_sweep.py, us per step, one / two in flight): 2 x 64 clips bf16 340.6 / 338.9 against 351.4 / 350.9,
+  // fp32 577.2 against 591.9, 2 x 32 clips 220.4 against 226.6, 2 x 64 at S = 864 480.9 against 485.0.  One in flight.
+  static const int cif_env = [] { const char* v = getenv("M2M_MC_CIF"); return v ? atoi(v) : -1; }();
+  const bool two_in_flight = !self && cif_env == 2;
   if (self && a.emb) {
     if (nt) hipLaunchKernelGGL((dec_attn_mc_kernel<T, true, true, true, C>), grid, dim3(1024), smem, st, a, nb);
     else hipLaunchKernelGGL((dec_attn_mc_kernel<T, true, false, true, C>), grid, dim3(1024), smem, st, a, nb);
   } else if (self) {
     if (nt) hipLaunchKernelGGL((dec_attn_mc_kernel<T, true, true, false, C>), grid, dim3(1024), smem, st, a, nb);
     else hipLaunchKernelGGL((dec_attn_mc_kernel<T, true, false, false, C>), grid, dim3(1024), smem, st, a, nb);
+  } else if (two_in_flight) {     // short cross streams (a clip's keys fit the prefetch window): two clips in flight
+    if (nt) hipLaunchKernelGGL((dec_attn_mc_kernel<T, false, true, false, C, 2>), grid, dim3(1024), smem, st, a, nb);
+    else hipLaunchKernelGGL((dec_attn_mc_kernel<T, false, false, false, C, 2>), grid, dim3(1024), smem, st, a, nb);
   } else {
     if (nt) hipLaunchKernelGGL((dec_attn_mc_kernel<T, false, true, false, C>), grid, dim3(1024), smem, st, a, nb);
     else hipLaunchKernelGGL((dec_attn_mc_kernel<T, false, false, false, C>), grid, dim3(1024), smem, st, a, nb);
